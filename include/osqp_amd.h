@@ -1,0 +1,310 @@
+/*
+ * osqp_amd.h -- C ABI of the MI355X-native OSQP ADMM engine (libosqp_amd.so).
+ *
+ * This header is the drop-in boundary.  Part 1 declares exactly the symbols and
+ * struct layouts that the reference wrapper osqp/OSQP.jl v0.8.1 binds with
+ * `ccall` (every entry cites the reference call site as [REF file:line], paths
+ * relative to the reference checkout).  An unmodified OSQP.jl pointed at
+ * libosqp_amd.so instead of OSQP_jll's libosqp therefore keeps working
+ * (see INTEGRATION.md).  Part 2 declares the extension entry points that have
+ * no counterpart in the reference (device-resident problem generation, the
+ * batched small-QP path, introspection for measurement).
+ *
+ * Conventions (same as the reference's FFI): plain pointers and sizes, no C++
+ * or torch types; c_int is 64-bit [REF src/types.jl:5-9]; c_float is double;
+ * return value 0 means success, anything else is an error that the Julia side
+ * turns into `error(...)` [REF src/interface.jl:157-159].
+ *
+ * All pointers passed IN are borrowed for the duration of the call only (the
+ * Julia side holds them under `@preserve` [REF src/interface.jl:132-155]); the
+ * library deep-copies.  Everything reachable from an OSQPWorkspace* is owned
+ * by the library and released by osqp_cleanup().
+ */
+#ifndef OSQP_AMD_H
+#define OSQP_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef long long c_int;   /* [REF src/types.jl:5-9]  Cc_int = Clonglong */
+typedef double    c_float; /* Cdouble everywhere in [REF src/types.jl]   */
+
+/* ------------------------------------------------------------------------- */
+/* Part 1a: constants  [REF src/constants.jl:1-21]                            */
+/* ------------------------------------------------------------------------- */
+#define OSQP_INFTY 1e30 /* [REF src/constants.jl:5] */
+
+enum osqp_linsys_solver_type {
+  QDLDL_SOLVER       = 0, /* [REF src/constants.jl:1]  direct LDL^T (default; "auto" here: falls back to PCG when the factor cannot fit) */
+  MKL_PARDISO_SOLVER = 1, /* [REF src/constants.jl:2]  accepted, served by the same direct LDL^T back-end */
+  AMD_PCG_SOLVER     = 2, /* extension: force the indirect (preconditioned CG) back-end */
+  AMD_DIRECT_SOLVER  = 3  /* extension: force the direct back-end (never fall back) */
+};
+
+/* status_val codes [REF src/constants.jl:9-21] */
+#define OSQP_DUAL_INFEASIBLE_INACCURATE    (4)
+#define OSQP_PRIMAL_INFEASIBLE_INACCURATE  (3)
+#define OSQP_SOLVED_INACCURATE             (2)
+#define OSQP_SOLVED                        (1)
+#define OSQP_MAX_ITER_REACHED             (-2)
+#define OSQP_PRIMAL_INFEASIBLE            (-3)
+#define OSQP_DUAL_INFEASIBLE              (-4)
+#define OSQP_SIGINT                       (-5)
+#define OSQP_TIME_LIMIT_REACHED           (-6)
+#define OSQP_NON_CVX                      (-7)
+#define OSQP_UNSOLVED                    (-10)
+
+/* ------------------------------------------------------------------------- */
+/* Part 1b: struct layouts read across the boundary                           */
+/* ------------------------------------------------------------------------- */
+
+/* Compressed-sparse-column matrix, 56 bytes. [REF src/types.jl:11-19]
+ * nz == -1 marks compressed-column form [REF src/types.jl:46]; indices are
+ * 0-based [REF src/types.jl:39-43]. */
+typedef struct {
+  c_int    nzmax;
+  c_int    m;
+  c_int    n;
+  c_int   *p;
+  c_int   *i;
+  c_float *x;
+  c_int    nz;
+} csc;
+
+/* 56 bytes. [REF src/types.jl:101-109] */
+typedef struct {
+  c_int    n;
+  c_int    m;
+  csc     *P; /* upper triangle only [REF src/interface.jl:102-104] */
+  csc     *A;
+  c_float *q;
+  c_float *l;
+  c_float *u;
+} OSQPData;
+
+/* 176 bytes, linsys_solver is a 32-bit enum followed by 4 bytes of padding.
+ * [REF src/types.jl:111-134] */
+typedef struct {
+  c_float rho;
+  c_float sigma;
+  c_int   scaling;
+  c_int   adaptive_rho;
+  c_int   adaptive_rho_interval;
+  c_float adaptive_rho_tolerance;
+  c_float adaptive_rho_fraction;
+  c_int   max_iter;
+  c_float eps_abs;
+  c_float eps_rel;
+  c_float eps_prim_inf;
+  c_float eps_dual_inf;
+  c_float alpha;
+  int     linsys_solver; /* enum osqp_linsys_solver_type */
+  c_float delta;
+  c_int   polish;
+  c_int   polish_refine_iter;
+  c_int   verbose;
+  c_int   scaled_termination;
+  c_int   check_termination;
+  c_int   warm_start;
+  c_float time_limit;
+} OSQPSettings;
+
+/* 136 bytes. [REF src/types.jl:81-99] */
+typedef struct {
+  c_int   iter;
+  char    status[32];
+  c_int   status_val;
+  c_int   status_polish;
+  c_float obj_val;
+  c_float pri_res;
+  c_float dua_res;
+  c_float setup_time;
+  c_float solve_time;
+  c_float update_time;
+  c_float polish_time;
+  c_float run_time;
+  c_int   rho_updates;
+  c_float rho_estimate;
+} OSQPInfo;
+
+/* 16 bytes. [REF src/types.jl:74-77] */
+typedef struct {
+  c_float *x;
+  c_float *y;
+} OSQPSolution;
+
+/* 30-field mirror. [REF src/types.jl:173-217]
+ * The Julia side dereferences `data`, `solution`, `info`, `delta_y`, `delta_x`
+ * as HOST pointers after osqp_solve [REF src/interface.jl:176-205, 744-746].
+ * The iterates live in HBM; those five are host mirrors refreshed before
+ * osqp_solve returns.  `rho_vec` .. `E_temp` other than delta_x/delta_y are
+ * NULL in libosqp_amd.so (device-resident; no reference code reads them). */
+typedef struct OSQPWorkspace {
+  OSQPData     *data;          /*   0 */
+  void         *linsys_solver; /*   8 */
+  void         *pol;           /*  16 */
+  c_float      *rho_vec;       /*  24 */
+  c_float      *rho_inv_vec;   /*  32 */
+  c_int        *constr_type;   /*  40 */
+  c_float      *x;             /*  48 */
+  c_float      *y;             /*  56 */
+  c_float      *z;             /*  64 */
+  c_float      *xz_tilde;      /*  72 */
+  c_float      *x_prev;        /*  80 */
+  c_float      *z_prev;        /*  88 */
+  c_float      *Ax;            /*  96 */
+  c_float      *Px;            /* 104 */
+  c_float      *Aty;           /* 112 */
+  c_float      *delta_y;       /* 120  host mirror: primal-infeasibility certificate */
+  c_float      *Atdelta_y;     /* 128 */
+  c_float      *delta_x;       /* 136  host mirror: dual-infeasibility certificate */
+  c_float      *Pdelta_x;      /* 144 */
+  c_float      *Adelta_x;      /* 152 */
+  c_float      *D_temp;        /* 160 */
+  c_float      *D_temp_A;      /* 168 */
+  c_float      *E_temp;        /* 176 */
+  OSQPSettings *settings;      /* 184 */
+  void         *scaling;       /* 192 */
+  OSQPSolution *solution;      /* 200  host mirror */
+  OSQPInfo     *info;          /* 208  host mirror */
+  void         *timer;         /* 216 */
+  c_int         first_run;     /* 224 */
+  c_int         summary_printed; /* 232 */
+  void         *impl;          /* 240  library-private (engine handle) */
+} OSQPWorkspace;
+
+/* ------------------------------------------------------------------------- */
+/* Part 1c: the 30 symbols OSQP.jl binds                                      */
+/* ------------------------------------------------------------------------- */
+
+/* [REF src/types.jl:139] */
+void osqp_set_default_settings(OSQPSettings *settings);
+
+/* [REF src/interface.jl:147]  0 on success; non-zero (1 data, 2 settings,
+ * 4 linsys init, 5 non-convex, 6 alloc) makes setup! throw. */
+c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings);
+
+/* [REF src/interface.jl:171]  return value ignored by the caller; the outcome
+ * is info->status_val. */
+c_int osqp_solve(OSQPWorkspace *work);
+
+/* [REF src/interface.jl:220] */
+const char *osqp_version(void);
+
+/* [REF src/interface.jl:225]  must accept NULL (finalizer of a never-set-up
+ * Model [REF src/interface.jl:24-25]). */
+c_int osqp_cleanup(OSQPWorkspace *work);
+
+/* [REF src/interface.jl:241, 259, 277, 303] */
+c_int osqp_update_lin_cost(OSQPWorkspace *work, const c_float *q_new);
+c_int osqp_update_lower_bound(OSQPWorkspace *work, const c_float *l_new);
+c_int osqp_update_upper_bound(OSQPWorkspace *work, const c_float *u_new);
+c_int osqp_update_bounds(OSQPWorkspace *work, const c_float *l_new, const c_float *u_new);
+
+/* [REF src/interface.jl:337, 358, 382]  idx are 0-based positions into the
+ * setup-time nnz order (P: upper-triangular nnz order); NULL = all nnz. */
+c_int osqp_update_P(OSQPWorkspace *work, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n);
+c_int osqp_update_A(OSQPWorkspace *work, const c_float *Ax_new, const c_int *Ax_new_idx, c_int A_new_n);
+c_int osqp_update_P_A(OSQPWorkspace *work, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n,
+                      const c_float *Ax_new, const c_int *Ax_new_idx, c_int A_new_n);
+
+/* [REF src/interface.jl:476, 580, 593, 606, 619, 632, 645] */
+c_int osqp_update_max_iter(OSQPWorkspace *work, c_int max_iter_new);
+c_int osqp_update_polish(OSQPWorkspace *work, c_int polish_new);
+c_int osqp_update_polish_refine_iter(OSQPWorkspace *work, c_int polish_refine_iter_new);
+c_int osqp_update_verbose(OSQPWorkspace *work, c_int verbose_new);
+c_int osqp_update_scaled_termination(OSQPWorkspace *work, c_int scaled_termination_new);
+c_int osqp_update_check_termination(OSQPWorkspace *work, c_int check_termination_new);
+c_int osqp_update_warm_start(OSQPWorkspace *work, c_int warm_start_new);
+
+/* [REF src/interface.jl:489, 502, 515, 528, 541, 554, 567, 658] */
+c_int osqp_update_eps_abs(OSQPWorkspace *work, c_float eps_abs_new);
+c_int osqp_update_eps_rel(OSQPWorkspace *work, c_float eps_rel_new);
+c_int osqp_update_eps_prim_inf(OSQPWorkspace *work, c_float eps_prim_inf_new);
+c_int osqp_update_eps_dual_inf(OSQPWorkspace *work, c_float eps_dual_inf_new);
+c_int osqp_update_rho(OSQPWorkspace *work, c_float rho_new);
+c_int osqp_update_alpha(OSQPWorkspace *work, c_float alpha_new);
+c_int osqp_update_delta(OSQPWorkspace *work, c_float delta_new);
+c_int osqp_update_time_limit(OSQPWorkspace *work, c_float time_limit_new);
+
+/* [REF src/interface.jl:676, 690, 709] */
+c_int osqp_warm_start_x(OSQPWorkspace *work, const c_float *x);
+c_int osqp_warm_start_y(OSQPWorkspace *work, const c_float *y);
+c_int osqp_warm_start(OSQPWorkspace *work, const c_float *x, const c_float *y);
+
+/* ------------------------------------------------------------------------- */
+/* Part 2: extensions (no counterpart in the reference)                       */
+/* ------------------------------------------------------------------------- */
+
+/* Synthetic problem families of SURVEY.md section 8d; generated by a
+ * counter-based SplitMix64 stream keyed by (seed, stream, index), so the host
+ * generator (oracle/gen.c) and the device generator produce identical bits. */
+enum osqp_amd_problem_kind {
+  OSQP_AMD_GEN_RANDOM_QP = 0, /* n=m, `per_row` nnz per row of A, P = M + M' + diag */
+  OSQP_AMD_GEN_LASSO     = 1, /* P diagonal, A = [I; -I], m = 2n */
+  OSQP_AMD_GEN_MPC       = 2  /* nx=6, nu=4, T=10: n=100, m=200 */
+};
+
+/* Build the problem directly in HBM (no host copy, no PCIe) and run setup on
+ * it.  `n` is the number of variables, `per_row` the nnz per row of A (random
+ * QP only), `seed` the generator key.  Same return codes as osqp_setup. */
+c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row,
+                               unsigned long long seed, const OSQPSettings *settings);
+
+/* Introspection for measurement (bench.py, tests).  Fills `out[0..count)`:
+ *  0 back-end in use (0 direct, 2 pcg)      1 nnz(A)          2 nnz(P full symmetric)
+ *  3 nnz(triu P)                             4 nnz(L) (direct) 5 levels of the trisolve schedule
+ *  6 total CG iterations so far              7 total ADMM iterations so far
+ *  8 numeric factorisations so far           9 device bytes allocated
+ * 10 algorithmic bytes of one SpMV with A   11 algorithmic bytes of one forward+backward trisolve
+ * Returns the number of entries written. */
+c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
+
+/* Time `reps` launches of one hot-path kernel with HIP events on the engine's
+ * own stream; returns the mean milliseconds per launch, <0 on error.
+ * which: 0 SpMV A*x, 1 SpMV A'*y, 2 SpMV P*x, 3 forward+backward trisolve,
+ *        4 fused ADMM vector update, 5 one full ADMM iteration. */
+c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
+
+/* Run exactly `iters` ADMM iterations from the current iterate (no
+ * termination test inside, residuals refreshed at the end); used by bench.py
+ * to time K steps.  Returns 0 on success. */
+c_int osqp_amd_iterate(OSQPWorkspace *work, c_int iters);
+
+/* Element-wise kernel parity hooks (tests only): run one device kernel on
+ * host-provided vectors and copy the result back.
+ *  op 0: y = A*x (len n -> m)   op 1: y = A'*x (m -> n)   op 2: y = P*x (n -> n)
+ *  op 3: y = K^{-1} x through the linear-system back-end (n+m -> n+m)        */
+c_int osqp_amd_apply(OSQPWorkspace *work, c_int op, const c_float *in, c_float *out);
+
+/* Batched path: `count` independent QPs that
+ * share one sparsity pattern.  P (upper triangle) and A are given once as
+ * patterns; values are [count x nnz] row-major; q,l,u are [count x n|m].
+ * Outputs: x [count x n], y [count x m], info [count] (host pointers).
+ * The instances are solved one per workgroup with the reduced KKT system
+ * factorised in LDS.  `device` selects the HIP device (one process per GPU). */
+c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m,
+                           const c_int *Pp, const c_int *Pi, const c_float *Px_all,
+                           const c_int *Ap, const c_int *Ai, const c_float *Ax_all,
+                           const c_float *q_all, const c_float *l_all, const c_float *u_all,
+                           const OSQPSettings *settings,
+                           c_float *x_out, c_float *y_out, OSQPInfo *info_out, c_int device);
+
+/* Generate `count` MPC instances [first, first+count) of the mpc-batch family
+ * on the device and solve them there; outputs as above but DEVICE pointers
+ * (so that the caller can hand them to an RCCL gather without a host hop).
+ * info_out is [count x 4] doubles: iter, status_val, pri_res, dua_res. */
+c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long long seed,
+                                     const OSQPSettings *settings,
+                                     c_float *x_dev, c_float *y_dev, c_float *info_dev, c_int device);
+
+/* Last error message of the calling thread ("" if none). */
+const char *osqp_amd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSQP_AMD_H */

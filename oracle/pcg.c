@@ -1,0 +1,130 @@
+/*
+ * oracle/pcg.c -- TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * Indirect back-end of the KKT solve (row K9 of SURVEY.md section 8a; not part
+ * of libosqp v0.6.2, needed because a direct factor of the random-sparsity
+ * configs cannot fit in any memory -- SURVEY.md section 0.3).  Eliminating nu
+ * from   [P + sigma I, A'; A, -diag(rho)^-1] [x~; nu] = [r_x; r_z]   gives
+ *     (P + sigma I + A' diag(rho) A) x~ = r_x + A' (rho .* r_z),   z~ = A x~,
+ * solved by Jacobi-preconditioned conjugate gradients, warm-started from the
+ * previous x~.  This is the CPU statement the HIP PCG path is checked against.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+struct pcg_solver {
+  c_int n, m;
+  c_float sigma;
+  const csc *P, *A;       /* borrowed: the workspace's scaled matrices */
+  c_float *rho;           /* copy of rho_vec */
+  c_float *dinv;          /* inverse Jacobi diagonal */
+  c_float *x, *r, *z, *p, *w, *t, *b1;
+  c_int total_iters, max_iter;
+};
+
+static void build_precond(pcg_solver *s) {
+  c_int n = s->n, j, k;
+  for (j = 0; j < n; j++) {
+    c_float d = s->sigma;
+    for (k = s->P->p[j]; k < s->P->p[j + 1]; k++) if (s->P->i[k] == j) d += s->P->x[k];
+    for (k = s->A->p[j]; k < s->A->p[j + 1]; k++) d += s->rho[s->A->i[k]] * s->A->x[k] * s->A->x[k];
+    s->dinv[j] = 1.0 / d;
+  }
+}
+
+pcg_solver *pcg_init(const csc *P, const csc *A, c_float sigma, const c_float *rho_vec) {
+  pcg_solver *s = (pcg_solver *)calloc(1, sizeof(pcg_solver));
+  c_int n = P->n, m = A->m;
+  size_t nn = (size_t)(n > 0 ? n : 1), mm = (size_t)(m > 0 ? m : 1);
+  s->n = n; s->m = m; s->sigma = sigma; s->P = P; s->A = A;
+  s->rho = (c_float *)malloc(sizeof(c_float) * mm);
+  memcpy(s->rho, rho_vec, sizeof(c_float) * (size_t)m);
+  s->dinv = (c_float *)malloc(sizeof(c_float) * nn);
+  s->x = (c_float *)calloc(nn, sizeof(c_float));
+  s->r = (c_float *)calloc(nn, sizeof(c_float));
+  s->z = (c_float *)calloc(nn, sizeof(c_float));
+  s->p = (c_float *)calloc(nn, sizeof(c_float));
+  s->w = (c_float *)calloc(nn, sizeof(c_float));
+  s->b1 = (c_float *)calloc(nn, sizeof(c_float));
+  s->t = (c_float *)calloc(mm, sizeof(c_float));
+  s->max_iter = 20000;
+  build_precond(s);
+  return s;
+}
+
+/* w = (P + sigma I + A' rho A) v */
+static void apply_M(pcg_solver *s, const c_float *v, c_float *w) {
+  c_int j;
+  mat_vec(s->A, v, s->t, 0);
+  for (j = 0; j < s->m; j++) s->t[j] *= s->rho[j];
+  mat_vec(s->P, v, w, 0);
+  mat_tpose_vec(s->P, v, w, 1, 1);
+  for (j = 0; j < s->n; j++) w[j] += s->sigma * v[j];
+  mat_tpose_vec(s->A, s->t, w, 1, 0);
+}
+
+c_int pcg_solve(pcg_solver *s, c_float *b, c_float tol_abs) {
+  c_int n = s->n, m = s->m, j, it = 0;
+  /* b1 = r_x + A' (rho .* r_z) */
+  for (j = 0; j < m; j++) s->t[j] = s->rho[j] * b[n + j];
+  for (j = 0; j < n; j++) s->b1[j] = b[j];
+  mat_tpose_vec(s->A, s->t, s->b1, 1, 0);
+  /* r = b1 - M x0 */
+  apply_M(s, s->x, s->w);
+  c_float rz = 0.0;
+  for (j = 0; j < n; j++) {
+    s->r[j] = s->b1[j] - s->w[j];
+    s->z[j] = s->dinv[j] * s->r[j];
+    s->p[j] = s->z[j];
+    rz += s->r[j] * s->z[j];
+  }
+  c_int status = 0;
+  while (it < s->max_iter) {
+    if (vec_norm_inf(s->r, n) <= tol_abs) break;
+    apply_M(s, s->p, s->w);
+    c_float pw = vec_prod(s->p, s->w, n);
+    if (!(pw > 0.0)) { status = -1; break; }
+    c_float alpha = rz / pw;
+    c_float rz_new = 0.0;
+    for (j = 0; j < n; j++) {
+      s->x[j] += alpha * s->p[j];
+      s->r[j] -= alpha * s->w[j];
+      s->z[j] = s->dinv[j] * s->r[j];
+      rz_new += s->r[j] * s->z[j];
+    }
+    c_float beta = rz_new / rz;
+    rz = rz_new;
+    for (j = 0; j < n; j++) s->p[j] = s->z[j] + beta * s->p[j];
+    it++;
+  }
+  s->total_iters += it;
+  for (j = 0; j < n; j++) b[j] = s->x[j];
+  mat_vec(s->A, s->x, b + n, 0);
+  return status < 0 ? -1 - it : it;
+}
+
+void pcg_update_matrices(pcg_solver *s, const csc *P, const csc *A) {
+  s->P = P; s->A = A;
+  build_precond(s);
+}
+
+void pcg_update_rho(pcg_solver *s, const c_float *rho_vec) {
+  memcpy(s->rho, rho_vec, sizeof(c_float) * (size_t)s->m);
+  build_precond(s);
+}
+
+c_int pcg_total_iters(const pcg_solver *s) { return s->total_iters; }
+
+/* the CG start vector of the next solve (the ADMM loop sets it to the current x
+ * at the start of every osqp_solve so that a solve depends on (x, z, y) only) */
+void pcg_set_guess(pcg_solver *s, const c_float *x) {
+  memcpy(s->x, x, sizeof(c_float) * (size_t)s->n);
+}
+
+void pcg_free(pcg_solver *s) {
+  if (!s) return;
+  free(s->rho); free(s->dinv); free(s->x); free(s->r); free(s->z); free(s->p); free(s->w); free(s->t); free(s->b1);
+  free(s);
+}
