@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/sec of the HIP engine on BASELINE.json's workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rand-1e6|rand-1e5|lasso-5e5]
+
+A "step" is one ADMM iteration of the hot path (rhs build, KKT solve by the
+back-end the workload needs, fused x/z/y update, residual evaluation every
+`check_termination`=25 iterations) on a synthetic QP generated in HBM before the
+timed region.  Each rank (one process per GPU) owns an independent QP instance
+(seed = 1 + rank): the path shards over instances with no data-path collective;
+the only exchange is the final RCCL gather of per-instance results (weak scaling).
+
+The JSON line carries `roofline` for the dominant kernel (CSR SpMV y = A x,
+measured live with HIP events on the engine's stream) and `cpu_baseline` (the
+CPU oracle timed on rank 0's host core on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (kind, n, per_row, linsys)
+    "rand-1e6": (0, 1_000_000, 1000, "pcg"),
+    "rand-1e5": (0, 100_000, 100, "pcg"),
+    "rand-2e4": (0, 20_000, 20, "pcg"),
+    "lasso-5e5": (1, 500_000, 0, "qdldl"),
+}
+
+SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25, adaptive_rho_interval=50,
+                polish=False, max_iter=4000)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--workload", default=os.environ.get("OSQP_AMD_BENCH_WORKLOAD", "rand-1e6"))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import osqp_jl_amd as oq
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    lib = oq.load_library()  # HIP engine; hard error if missing
+    assert lib.osqp_amd_set_device(local_rank) == 0
+
+    kind, n, per_row, linsys = WORKLOADS[args.workload]
+    model = oq.Model(lib)
+    t0 = time.time()
+    oq.setup_generated(model, kind, n, per_row, 1 + rank, linsys_solver=linsys, **SETTINGS)
+    setup_s = time.time() - t0
+    ws = model.workspace
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: W untimed ADMM iterations from the cold start
+    if args.warmup > 0:
+        assert lib.osqp_amd_iterate(ws, args.warmup) == 0
+    st0 = oq.stats(model)
+    barrier()
+    t0 = time.perf_counter()
+    assert lib.osqp_amd_iterate(ws, args.steps) == 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st1 = oq.stats(model)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    cg_per_admm = (st1[6] - st0[6]) / max(args.steps, 1)
+
+    # time-to-eps: a full cold-start solve to eps_abs = eps_rel = 1e-4
+    oq.update_settings(model, warm_start=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = oq.solve(model)
+    torch.cuda.synchronize()
+    solve_s = time.perf_counter() - t0
+
+    # roofline of the dominant kernel, measured live with HIP events on the engine's stream
+    st = oq.stats(model)
+    nnzA, nnzPf = st[1], st[2]
+    if st[0] == 2:   # indirect back-end: CSR SpMV y = A x
+        kname, which, abytes = "k_spmv (y = A x)", 0, st[10]
+    else:            # direct back-end: forward+backward triangular solve
+        kname, which, abytes = "sptrsv forward+backward", 3, st[11]
+    ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
+    achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                "algorithmic_bytes_per_launch": abytes}
+
+    # final gather of per-instance results over RCCL (the only collective of the path)
+    summary = torch.tensor([float(res.info.iter), float(res.info.status_val), res.info.pri_res, res.info.dua_res,
+                            res.info.obj_val, solve_s], dtype=torch.float64, device="cuda")
+    if world > 1:
+        gathered = [torch.zeros_like(summary) for _ in range(world)]
+        dist.all_gather(gathered, summary)
+        summaries = [g.cpu().tolist() for g in gathered]
+    else:
+        summaries = [summary.cpu().tolist()]
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu:
+        cpu_baseline = cpu_leg(oq, args)
+
+    if rank == 0:
+        its_per_s = args.steps * world / elapsed
+        out = {
+            "metric": "ADMM iterations/sec", "value": round(its_per_s, 3), "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "n": n, "m": int(oq.dimensions(model)[1]), "nnz_A": int(nnzA),
+                       "nnz_P_full": int(nnzPf), "backend": "pcg" if st[0] == 2 else "direct-ldl",
+                       "eps_abs": 1e-4, "eps_rel": 1e-4, "check_termination": 25, "adaptive_rho_interval": 50,
+                       "instances": world, "sharding": "one independent QP per GPU, final RCCL all_gather of results"},
+            "cg_iters_per_admm_iter": round(cg_per_admm, 3),
+            "time_to_eps_s": round(solve_s, 4), "iters_to_eps": int(res.info.iter), "status": res.info.status,
+            "pri_res": res.info.pri_res, "dua_res": res.info.dua_res, "rho_updates": int(res.info.rho_updates),
+            "setup_s": round(setup_s, 3), "device_gb": round(st[9] / 1e9, 2),
+            "per_rank": summaries,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_leg(oq, args):
+    """CPU oracle (oracle/, a port of the published algorithm; libosqp itself is not
+    available in this image) on a bounded sample: the rand-1e5 member of the same
+    family when the workload is rand-1e6 (whose 2.5e9 non-zeros do not fit a
+    bounded CPU run), the workload itself otherwise."""
+    import subprocess
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    ora = oq.load_library(oq.ORACLE_LIB_PATH)
+    name = args.workload
+    sample = name
+    if name == "rand-1e6":
+        sample = "rand-1e5"
+    kind, n, per_row, linsys = WORKLOADS[sample]
+    m = oq.Model(ora)
+    t0 = time.perf_counter()
+    oq.setup_generated(m, kind, n, per_row, 1, linsys_solver=linsys, **SETTINGS)
+    setup_s = time.perf_counter() - t0
+    ws = m.workspace
+    ora.osqp_amd_iterate(ws, 5)  # warm the caches
+    iters, spent = 0, 0.0
+    chunk = 5
+    while spent < args.cpu_seconds and iters < 2000:
+        t0 = time.perf_counter()
+        ora.osqp_amd_iterate(ws, chunk)
+        spent += time.perf_counter() - t0
+        iters += chunk
+    st = oq.stats(m)
+    v = iters / spent
+    out = {"value": round(v, 4), "unit": "iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+           "sample": f"{sample}: {iters} ADMM iterations of the CPU oracle ({'PCG' if st[0] == 2 else 'LDL'} back-end, 1 thread) "
+                     f"in {spent:.1f} s after a {setup_s:.1f} s setup",
+           "nnz_A": int(st[1])}
+    if sample != name:
+        kindw, nw, kw, _ = WORKLOADS[name]
+        scale = (nw * kw) / (n * per_row)
+        out["value_scaled_to_workload"] = round(v / scale, 5)
+        out["scaling_note"] = f"per-iteration work of {name} is {scale:.0f}x that of {sample} (nnz ratio); value_scaled_to_workload = value / {scale:.0f}"
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -301,6 +301,10 @@ c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long lon
                                      const OSQPSettings *settings,
                                      c_float *x_dev, c_float *y_dev, c_float *info_dev, c_int device);
 
+/* Select the HIP device for workspaces created afterwards by this process
+ * (one process per GPU: pass LOCAL_RANK). */
+c_int osqp_amd_set_device(c_int device);
+
 /* Last error message of the calling thread ("" if none). */
 const char *osqp_amd_last_error(void);
 

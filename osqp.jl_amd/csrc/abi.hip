@@ -1,0 +1,375 @@
+// abi.hip -- the C-ABI of libosqp_amd.so (include/osqp_amd.h): the 30 symbols
+// osqp/OSQP.jl binds [REF src/interface.jl:147-709, src/types.jl:139] plus the
+// extension entry points.  Exceptions stop here and become the integer exit
+// flags the Julia side tests with `!= 0` [REF src/interface.jl:157-159].
+#include "engine.hpp"
+
+#include <cmath>
+
+using namespace oq;
+
+namespace {
+
+struct Impl {
+  Engine eng;
+  OSQPData data;
+  OSQPSettings settings;
+  OSQPSolution solution;
+  OSQPInfo info;
+};
+
+Engine *E(OSQPWorkspace *w) { return &((Impl *)w->impl)->eng; }
+const Engine *E(const OSQPWorkspace *w) { return &((const Impl *)w->impl)->eng; }
+
+int validate_data(const OSQPData *d) {
+  if (!d || !d->P || !d->A || !d->q) return 1;
+  if (d->n <= 0 || d->m < 0) return 1;
+  if (d->n >= 2147483647LL || d->m >= 2147483647LL) return 1;
+  if (d->P->m != d->n || d->P->n != d->n) return 1;
+  for (c_int j = 0; j < d->n; j++)
+    for (c_int k = d->P->p[j]; k < d->P->p[j + 1]; k++)
+      if (d->P->i[k] > j || d->P->i[k] < 0) return 1;  // P must be upper triangular
+  if (d->A->m != d->m || d->A->n != d->n) return 1;
+  for (c_int j = 0; j < d->m; j++)
+    if (d->l[j] > d->u[j]) return 1;
+  return 0;
+}
+
+int validate_settings(const OSQPSettings *s) {
+  if (!s) return 1;
+  if (s->scaling < 0) return 1;
+  if (s->adaptive_rho != 0 && s->adaptive_rho != 1) return 1;
+  if (s->adaptive_rho_interval < 0) return 1;
+  if (s->adaptive_rho_fraction <= 0) return 1;
+  if (s->adaptive_rho_tolerance < 1.0) return 1;
+  if (s->polish_refine_iter < 0) return 1;
+  if (s->rho <= 0.0 || s->sigma <= 0.0 || s->delta <= 0.0) return 1;
+  if (s->max_iter <= 0) return 1;
+  if (s->eps_abs < 0.0 || s->eps_rel < 0.0) return 1;
+  if (s->eps_abs == 0.0 && s->eps_rel == 0.0) return 1;
+  if (s->eps_prim_inf <= 0.0 || s->eps_dual_inf <= 0.0) return 1;
+  if (s->alpha <= 0.0 || s->alpha >= 2.0) return 1;
+  if (s->linsys_solver < 0 || s->linsys_solver > 3) return 1;
+  if (s->verbose != 0 && s->verbose != 1) return 1;
+  if (s->scaled_termination != 0 && s->scaled_termination != 1) return 1;
+  if (s->check_termination < 0) return 1;
+  if (s->warm_start != 0 && s->warm_start != 1) return 1;
+  if (s->time_limit < 0.0) return 1;
+  return 0;
+}
+
+OSQPWorkspace *new_workspace() {
+  OSQPWorkspace *w = (OSQPWorkspace *)calloc(1, sizeof(OSQPWorkspace));
+  Impl *im = new Impl();
+  memset(&im->data, 0, sizeof(OSQPData));
+  memset(&im->info, 0, sizeof(OSQPInfo));
+  w->impl = im;
+  w->data = &im->data;
+  w->settings = &im->settings;
+  w->solution = &im->solution;
+  w->info = &im->info;
+  im->eng.ws = w;
+  return w;
+}
+
+void finish_setup(OSQPWorkspace *w) {
+  Impl *im = (Impl *)w->impl;
+  Engine &e = im->eng;
+  im->data.n = e.n; im->data.m = e.m;
+  im->settings = e.st;
+  im->solution.x = e.h_x.data(); im->solution.y = e.h_y.data();
+  w->delta_x = e.h_dx.data(); w->delta_y = e.h_dy.data();
+  update_status(w->info, OSQP_UNSOLVED);
+  w->info->status_polish = 0;
+  w->info->rho_estimate = e.st.rho;
+  w->first_run = 1;
+  w->summary_printed = 0;
+  if (e.st.verbose)
+    printf("[osqp-amd] n = %d, m = %d, nnz(triu P) = %lld, nnz(A) = %lld, linsys = %s, device %d\n", e.n, e.m,
+           (long long)e.nnzPtriu, (long long)e.nnzA, e.lin->kind() == 0 ? "direct LDL' (HIP)" : "PCG (HIP)", e.device);
+}
+
+void destroy(OSQPWorkspace *w) {
+  if (!w) return;
+  delete (Impl *)w->impl;
+  free(w);
+}
+
+template <typename F>
+c_int guarded(F &&f) {
+  try {
+    return (c_int)f();
+  } catch (const Error &er) {
+    set_last_error(er.what());
+    return er.code ? er.code : 6;
+  } catch (const std::exception &ex) {
+    set_last_error(ex.what());
+    return 6;
+  }
+}
+
+void require_device() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    throw Error(6, "libosqp_amd: no HIP device available (this library has no CPU fallback)");
+}
+
+}  // namespace
+
+extern "C" {
+
+void osqp_set_default_settings(OSQPSettings *s) {
+  s->rho = 0.1; s->sigma = 1e-6; s->scaling = 10;
+  s->adaptive_rho = 1; s->adaptive_rho_interval = 0;
+  s->adaptive_rho_tolerance = 5.0; s->adaptive_rho_fraction = 0.4;
+  s->max_iter = 4000; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->alpha = 1.6;
+  s->linsys_solver = QDLDL_SOLVER; s->delta = 1e-6; s->polish = 0;
+  s->polish_refine_iter = 3; s->verbose = 1; s->scaled_termination = 0;
+  s->check_termination = 25; s->warm_start = 1; s->time_limit = 0.0;
+}
+
+const char *osqp_version(void) { return "0.6.2"; }
+
+c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings) {
+  if (!workp) return 1;
+  *workp = nullptr;
+  if (validate_data(data)) { set_last_error("invalid problem data"); return 1; }
+  if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
+  OSQPWorkspace *w = nullptr;
+  c_int rc = guarded([&]() {
+    require_device();
+    w = new_workspace();
+    Engine &e = *E(w);
+    e.tic();
+    e.setup_host(data, *settings);
+    finish_setup(w);
+    w->info->setup_time = e.toc();
+    return 0;
+  });
+  if (rc != 0) { destroy(w); return rc; }
+  *workp = w;
+  return 0;
+}
+
+c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row, unsigned long long seed,
+                               const OSQPSettings *settings) {
+  if (!workp) return 1;
+  *workp = nullptr;
+  if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
+  if (n <= 0 || n >= 2147483647LL) return 1;
+  OSQPWorkspace *w = nullptr;
+  c_int rc = guarded([&]() {
+    require_device();
+    w = new_workspace();
+    Engine &e = *E(w);
+    DevBuf<int64_t> Pp, Ap;
+    DevBuf<int> Pi, Ai;
+    DevBuf<double> Px, Ax, q, l, u;
+    int nn = 0, mm = 0;
+    generate_problem((int)kind, (int)n, (int)per_row, seed, nullptr, nn, mm, Pp, Pi, Px, Ap, Ai, Ax, q, l, u);
+    HIP_CHECK(hipDeviceSynchronize());
+    e.tic();  // setup_time covers setup only; generation stands in for the caller's own data
+    e.setup_device(nn, mm, Pp, Pi, Px, Ap, Ai, Ax, q, l, u, *settings);
+    finish_setup(w);
+    w->info->setup_time = e.toc();
+    return 0;
+  });
+  if (rc != 0) { destroy(w); return rc; }
+  *workp = w;
+  return 0;
+}
+
+c_int osqp_solve(OSQPWorkspace *w) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->solve(); });
+}
+
+c_int osqp_cleanup(OSQPWorkspace *w) {
+  if (!w) return 0;  // finalizer of a never-set-up Model [REF src/interface.jl:24-25, 223-229]
+  try { destroy(w); } catch (...) { return 1; }
+  return 0;
+}
+
+c_int osqp_update_lin_cost(OSQPWorkspace *w, const c_float *q_new) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_lin_cost(q_new); });
+}
+c_int osqp_update_bounds(OSQPWorkspace *w, const c_float *l_new, const c_float *u_new) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_bounds(l_new, u_new); });
+}
+c_int osqp_update_lower_bound(OSQPWorkspace *w, const c_float *l_new) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_bounds(l_new, nullptr); });
+}
+c_int osqp_update_upper_bound(OSQPWorkspace *w, const c_float *u_new) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_bounds(nullptr, u_new); });
+}
+c_int osqp_update_P(OSQPWorkspace *w, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_PA(Px_new, Px_new_idx, P_new_n, nullptr, nullptr, 0, true, false); });
+}
+c_int osqp_update_A(OSQPWorkspace *w, const c_float *Ax_new, const c_int *Ax_new_idx, c_int A_new_n) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_PA(nullptr, nullptr, 0, Ax_new, Ax_new_idx, A_new_n, false, true); });
+}
+c_int osqp_update_P_A(OSQPWorkspace *w, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n, const c_float *Ax_new,
+                      const c_int *Ax_new_idx, c_int A_new_n) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->update_PA(Px_new, Px_new_idx, P_new_n, Ax_new, Ax_new_idx, A_new_n, true, true); });
+}
+
+c_int osqp_update_rho(OSQPWorkspace *w, c_float rho_new) {
+  if (!w) return 7;
+  if (rho_new <= 0) return 1;
+  return guarded([&]() {
+    Engine &e = *E(w);
+    e.begin_update();
+    int rc = e.update_rho(rho_new);
+    w->settings->rho = e.st.rho;
+    e.end_update();
+    return rc;
+  });
+}
+
+#define OQ_SETTING(fn, type, field, cond)                 \
+  c_int fn(OSQPWorkspace *w, type v) {                    \
+    if (!w) return 7;                                     \
+    if (!(cond)) return 1;                                \
+    E(w)->st.field = v;                                   \
+    w->settings->field = v;                               \
+    return 0;                                             \
+  }
+OQ_SETTING(osqp_update_max_iter, c_int, max_iter, v > 0)
+OQ_SETTING(osqp_update_eps_abs, c_float, eps_abs, v >= 0.)
+OQ_SETTING(osqp_update_eps_rel, c_float, eps_rel, v >= 0.)
+OQ_SETTING(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v >= 0.)
+OQ_SETTING(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v >= 0.)
+OQ_SETTING(osqp_update_alpha, c_float, alpha, v > 0. && v < 2.)
+OQ_SETTING(osqp_update_delta, c_float, delta, v > 0.)
+OQ_SETTING(osqp_update_polish_refine_iter, c_int, polish_refine_iter, v >= 0)
+OQ_SETTING(osqp_update_verbose, c_int, verbose, v == 0 || v == 1)
+OQ_SETTING(osqp_update_scaled_termination, c_int, scaled_termination, v == 0 || v == 1)
+OQ_SETTING(osqp_update_check_termination, c_int, check_termination, v >= 0)
+OQ_SETTING(osqp_update_warm_start, c_int, warm_start, v == 0 || v == 1)
+OQ_SETTING(osqp_update_time_limit, c_float, time_limit, v >= 0.)
+
+c_int osqp_update_polish(OSQPWorkspace *w, c_int v) {
+  if (!w) return 7;
+  if (v != 0 && v != 1) return 1;
+  E(w)->st.polish = v;
+  w->settings->polish = v;
+  w->info->polish_time = 0.0;
+  return 0;
+}
+
+c_int osqp_warm_start(OSQPWorkspace *w, const c_float *x, const c_float *y) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->warm_start(x, y); });
+}
+c_int osqp_warm_start_x(OSQPWorkspace *w, const c_float *x) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->warm_start(x, nullptr); });
+}
+c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->warm_start(nullptr, y); });
+}
+
+// ---------------------------------------------------------------- extensions
+c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
+  if (!w || !out) return 0;
+  const Engine &e = *E(w);
+  c_float v[12] = {0};
+  v[0] = (c_float)e.lin->kind();
+  v[1] = (c_float)e.nnzA;
+  v[2] = (c_float)e.Pf.nnz;
+  v[3] = (c_float)e.nnzPtriu;
+  v[4] = e.lin->nnzL();
+  v[5] = e.lin->levels();
+  v[6] = e.lin->cg_iters();
+  v[7] = (c_float)e.admm_iters_total;
+  v[8] = e.lin->factorizations();
+  v[9] = (c_float)g_device_bytes;
+  v[10] = e.A.spmv_bytes();
+  v[11] = e.lin->trisolve_bytes();
+  c_int k = 0;
+  for (; k < count && k < 12; k++) out[k] = v[k];
+  return k;
+}
+
+c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
+  if (!w || reps <= 0) return -1.0;
+  c_float result = -1.0;
+  guarded([&]() {
+    Engine &e = *E(w);
+    hipStream_t s = e.stream;
+    if (which == 3) { result = e.lin->time_solve((int)reps); return 0; }
+    auto run = [&]() {
+      switch (which) {
+      case 0: spmv(e.A, e.x.get(), e.tm2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 1: spmv(e.At, e.y.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 2: spmv(e.Pf, e.x.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 4:
+        admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.x_prev.get(), e.z_prev.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
+                    e.u.get(), e.tn.get(), e.tm.get(), e.tm2.get(), e.tn2.get(), e.Ax.get(), s);
+        break;
+      default: throw Error(1, "unknown kernel id");
+      }
+    };
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    run();  // warm
+    HIP_CHECK(hipEventRecord(a, s));
+    for (c_int i = 0; i < reps; i++) run();
+    HIP_CHECK(hipEventRecord(b, s));
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    result = ms / (float)reps;
+    return 0;
+  });
+  return result;
+}
+
+c_int osqp_amd_iterate(OSQPWorkspace *w, c_int iters) {
+  if (!w) return 7;
+  return guarded([&]() { return E(w)->iterate(iters); });
+}
+
+c_int osqp_amd_apply(OSQPWorkspace *w, c_int op, const c_float *in, c_float *out) {
+  if (!w) return 7;
+  return guarded([&]() {
+    Engine &e = *E(w);
+    hipStream_t s = e.stream;
+    int nin = op == 0 || op == 2 ? e.n : (op == 1 ? e.m : e.n + e.m);
+    int nout = op == 0 ? e.m : (op == 3 ? e.n + e.m : e.n);
+    DevBuf<double> di((size_t)nin), dout((size_t)nout);
+    di.upload(in, nin, s);
+    if (op == 0) spmv(e.A, di.get(), dout.get(), nullptr, 0.0, 0.0, nullptr, s);
+    else if (op == 1) spmv(e.At, di.get(), dout.get(), nullptr, 0.0, 0.0, nullptr, s);
+    else if (op == 2) spmv(e.Pf, di.get(), dout.get(), nullptr, 0.0, 0.0, nullptr, s);
+    else if (op == 3) {
+      vec_copy(dout.get(), di.get(), nin, s);
+      e.tn.zero(s);
+      e.lin->set_guess(e.tn.get());
+      int rc = e.lin->solve(dout.get(), 0.0);
+      if (rc) return rc;
+    } else return 1;
+    dout.download(out, nout, s);
+    e.sync();
+    return 0;
+  });
+}
+
+c_int osqp_amd_set_device(c_int device) {
+  return guarded([&]() { HIP_CHECK(hipSetDevice((int)device)); return 0; });
+}
+
+const char *osqp_amd_last_error(void) { return last_error_cstr(); }
+
+}  // extern "C"

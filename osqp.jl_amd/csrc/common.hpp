@@ -1,0 +1,106 @@
+// common.hpp -- shared declarations of the HIP engine (libosqp_amd.so).
+// MI355X / gfx950 only: 64-lane wavefronts, 256 CUs in 8 XCDs, HBM3E.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/osqp_amd.h"
+
+namespace oq {
+
+// ---- error handling: exceptions inside, return codes at the C boundary ----
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string &m);
+
+#define HIP_CHECK(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      throw oq::Error(6, std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ +   \
+                             ":" + std::to_string(__LINE__));                                       \
+  } while (0)
+
+// ---- device buffers -------------------------------------------------------
+extern size_t g_device_bytes;  // bytes currently allocated through DevBuf
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_CHECK(hipMalloc((void **)&p, bytes));
+    g_device_bytes += bytes;
+  }
+  void release() {
+    if (p) {
+      (void)hipFree(p);
+      g_device_bytes -= (n ? n : 1) * sizeof(T);
+      p = nullptr;
+      n = 0;
+    }
+  }
+  void zero(hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), s)); }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void download(T *h, size_t count, hipStream_t s) const {
+    if (count) HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+  T *get() const { return p; }
+};
+
+// ---- device CSR matrix: 64-bit row pointers, 32-bit column indices, fp64 values
+struct DevCsr {
+  int rows = 0, cols = 0;
+  int64_t nnz = 0;
+  DevBuf<int64_t> rowptr;
+  DevBuf<int> col;
+  DevBuf<double> val;
+  int group = 64;  // lanes per row chosen for the SpMV kernel (1..64)
+  double spmv_bytes() const {  // algorithmic bytes of one y = M x
+    return 12.0 * (double)nnz + 4.0 * ((double)rows + 1.0) + 8.0 * ((double)rows + (double)cols);
+  }
+};
+
+// scalar slots written by the reduction kernels (device array of doubles)
+enum Slot {
+  S_PRI = 0, S_PRI_UNS, S_Z, S_AX, S_Z_UNS, S_AX_UNS,
+  S_DUA, S_DUA_UNS, S_Q, S_ATY, S_PX, S_Q_UNS, S_ATY_UNS, S_PX_UNS,
+  S_XPX, S_QX,
+  S_T0, S_T1, S_T2, S_T3, S_T4, S_T5,   // scratch slots (infeasibility tests, scaling, PCG)
+  S_COUNT = 32
+};
+
+constexpr int kBlock = 256;
+constexpr int kReduceBlocks = 1024;  // fixed grid of the two-stage (deterministic) sum reductions
+
+inline int blocks_for(int64_t n, int per_block = kBlock) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2147483647LL) throw Error(6, "grid too large");
+  return (int)b;
+}
+
+}  // namespace oq

@@ -1,0 +1,717 @@
+// engine.hip -- host control of the device-resident ADMM loop.
+//
+// Mirrors, step for step, the algorithm behind osqp_setup / osqp_solve /
+// osqp_update_* [REF src/interface.jl:147, 171, 241-382, 476-709] as laid out
+// in SURVEY.md Appendix A; all arithmetic runs in the kernels of kernels.hip,
+// the host only sequences launches and reads back a handful of scalars every
+// `check_termination` iterations.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace oq {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &m) { g_last_error = m; }
+const char *last_error_cstr() { return g_last_error.c_str(); }
+
+#define RHO_MIN 1e-6
+#define RHO_MAX 1e6
+#define MIN_SCALING 1e-4
+#define MAX_SCALING 1e4
+
+void update_status(OSQPInfo *info, c_int status_val) {
+  const char *s = "unsolved";
+  info->status_val = status_val;
+  switch (status_val) {
+  case OSQP_SOLVED: s = "solved"; break;
+  case OSQP_SOLVED_INACCURATE: s = "solved inaccurate"; break;
+  case OSQP_PRIMAL_INFEASIBLE: s = "primal infeasible"; break;
+  case OSQP_PRIMAL_INFEASIBLE_INACCURATE: s = "primal infeasible inaccurate"; break;
+  case OSQP_DUAL_INFEASIBLE: s = "dual infeasible"; break;
+  case OSQP_DUAL_INFEASIBLE_INACCURATE: s = "dual infeasible inaccurate"; break;
+  case OSQP_MAX_ITER_REACHED: s = "maximum iterations reached"; break;
+  case OSQP_TIME_LIMIT_REACHED: s = "run time limit reached"; break;
+  case OSQP_SIGINT: s = "interrupted"; break;
+  case OSQP_NON_CVX: s = "problem non convex"; break;
+  default: break;
+  }
+  memset(info->status, 0, sizeof(info->status));
+  strncpy(info->status, s, sizeof(info->status) - 1);
+}
+
+static void reset_info(OSQPInfo *info) {
+  info->solve_time = 0.0;
+  info->polish_time = 0.0;
+  update_status(info, OSQP_UNSOLVED);
+  info->rho_updates = 0;
+}
+
+static double limit_scaling(double v) {
+  v = v < MIN_SCALING ? 1.0 : v;
+  return v > MAX_SCALING ? MAX_SCALING : v;
+}
+
+Engine::Engine() {}
+Engine::~Engine() {
+  lin.reset();
+  if (h_slots) (void)hipHostFree(h_slots);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::fetch_slots(int count) {
+  HIP_CHECK(hipMemcpyAsync(h_slots, slots.get(), sizeof(double) * count, hipMemcpyDeviceToHost, stream));
+  sync();
+}
+
+// --------------------------------------------------------------------------
+// setup
+// --------------------------------------------------------------------------
+// coordinate list of the full symmetric P from its upper triangle (CSC): entry k = (i, j), i <= j
+//   e = k          -> (row j, col i)   (the CSC arrays read as CSR of the lower triangle)
+//   e = nnz + k    -> (row i, col j)   (mirror; dropped on the diagonal)
+__global__ __launch_bounds__(kBlock) void k_sym_coo(int64_t nnz, const int *__restrict__ Pi, const int *__restrict__ colid,
+                                                    int *__restrict__ erow, int *__restrict__ ecol, int *__restrict__ bad) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  int i = Pi[k], j = colid[k];
+  if (i > j) *bad = 1;  // not upper triangular
+  erow[k] = j; ecol[k] = i;
+  erow[nnz + k] = (i == j) ? -1 : i;
+  ecol[nnz + k] = j;
+}
+__global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int *p, int v) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) p[k] = v;
+}
+
+void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
+                          DevBuf<int> &Ai, DevBuf<double> &Ax, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
+                          const OSQPSettings &s) {
+  n = n_; m = m_; st = s;
+  HIP_CHECK(hipGetDevice(&device));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIP_CHECK(hipHostMalloc((void **)&h_slots, sizeof(double) * S_COUNT));
+  slots.alloc(S_COUNT); slots.zero(stream);
+  partials.alloc(2 * kReduceBlocks);
+  flag.alloc(4); flag.zero(stream);
+
+  int64_t ends[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(&ends[0], Pp.get() + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(&ends[1], Ap.get() + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  sync();
+  nnzPtriu = ends[0]; nnzA = ends[1];
+  if (nnzA >= 2147483647LL || 2 * nnzPtriu >= 2147483647LL) throw Error(6, "matrix too large: more than 2^31-1 non-zeros");
+
+  // ---- A' is the caller's CSC as it comes; A (CSR) is its transpose ----
+  At.rows = n; At.cols = m; At.nnz = nnzA;
+  At.rowptr = std::move(Ap); At.col = std::move(Ai); At.val = std::move(Ax);
+  At.group = pick_group(n, nnzA);
+  {
+    DevBuf<int> colid((size_t)nnzA), src;
+    expand_colptr(n, At.rowptr.get(), nnzA, colid.get(), stream);
+    csr_from_coo(m, n, nnzA, At.col.get(), colid.get(), A, src, stream);
+    gather_values(A.nnz, src.get(), At.val.get(), A.val.get(), 0, stream);
+    A_k2pos.alloc((size_t)nnzA);
+    invert_map(A.nnz, src.get(), 0, nnzA, A_k2pos.get(), stream);
+    sync();
+  }
+  // ---- full symmetric P from the upper triangle ----
+  {
+    DevBuf<int> colid((size_t)nnzPtriu), erow((size_t)(2 * nnzPtriu)), ecol((size_t)(2 * nnzPtriu)), src;
+    expand_colptr(n, Pp.get(), nnzPtriu, colid.get(), stream);
+    if (nnzPtriu > 0)
+      hipLaunchKernelGGL(k_sym_coo, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, Pi.get(), colid.get(),
+                         erow.get(), ecol.get(), flag.get());
+    int bad = 0;
+    flag.download(&bad, 1, stream);
+    sync();
+    if (bad) throw Error(1, "P is not upper triangular");
+    csr_from_coo(n, n, 2 * nnzPtriu, erow.get(), ecol.get(), Pf, src, stream);
+    gather_values(Pf.nnz, src.get(), Px.get(), Pf.val.get(), nnzPtriu, stream);
+    P_k2lo.alloc((size_t)nnzPtriu); P_k2up.alloc((size_t)nnzPtriu);
+    if (nnzPtriu > 0) {
+      hipLaunchKernelGGL(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
+      invert_map(Pf.nnz, src.get(), 0, nnzPtriu, P_k2lo.get(), stream);
+      invert_map(Pf.nnz, src.get(), nnzPtriu, 2 * nnzPtriu, P_k2up.get(), stream);
+    }
+    sync();
+  }
+  // keep the patterns reachable for the direct back-end's symbolic phase
+  Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
+  Px.release();
+
+  q = std::move(q_); l = std::move(l_); u = std::move(u_);
+  auto alloc0 = [&](DevBuf<double> &b, size_t cnt) { b.alloc(cnt); b.zero(stream); };
+  alloc0(D, n); alloc0(Dinv, n); alloc0(E, m); alloc0(Einv, m); alloc0(rho, m); alloc0(rho_inv, m);
+  ctype.alloc(m); ctype.zero(stream);
+  alloc0(x, n); alloc0(z, m); alloc0(y, m); alloc0(x_prev, n); alloc0(z_prev, m); alloc0(xz, (size_t)n + m);
+  alloc0(dx, n); alloc0(dy, m); alloc0(Ax, m); alloc0(Px_, n); alloc0(Aty, n);
+  alloc0(tn, n); alloc0(tm, m); alloc0(tn2, n); alloc0(tm2, m);
+  vec_set(D.get(), 1.0, n, stream); vec_set(Dinv.get(), 1.0, n, stream);
+  vec_set(E.get(), 1.0, m, stream); vec_set(Einv.get(), 1.0, m, stream);
+  c = 1.0; cinv = 1.0;
+  // host copies of the unscaled bounds (validation of single-sided bound updates)
+  h_l.resize(m); h_u.resize(m);
+  l.download(h_l.data(), m, stream); u.download(h_u.data(), m, stream);
+  sync();
+  for (int i = 0; i < m; i++) if (h_l[i] > h_u[i]) throw Error(1, "lower bound greater than upper bound");
+
+  if (st.scaling) scale_data();
+  set_rho_vec();
+  h_x.assign(n, 0.0); h_y.assign(m, 0.0); h_dx.assign(n, 0.0); h_dy.assign(m, 0.0);
+  lambda0 = 0.15;
+  if (const char *e = getenv("OSQP_AMD_PCG_LAMBDA")) lambda0 = atof(e);
+  lambda = lambda0;
+  select_linsys();
+  sync();
+}
+
+void Engine::setup_host(const OSQPData *d, const OSQPSettings &s) {
+  const int n_ = (int)d->n, m_ = (int)d->m;
+  hipStream_t s0 = nullptr;  // uploads on the null stream, synchronous
+  const int64_t nzP = d->P->p[n_], nzA = d->A->p[n_];
+  if (nzA >= 2147483647LL || 2 * nzP >= 2147483647LL) throw Error(6, "matrix too large: more than 2^31-1 non-zeros");
+  // host patterns (32-bit row indices) are kept for the direct back-end
+  hP.rows = n_; hP.cols = n_; hP.p.assign(d->P->p, d->P->p + n_ + 1); hP.i.resize(nzP);
+  for (int64_t k = 0; k < nzP; k++) hP.i[k] = (int)d->P->i[k];
+  hA.rows = m_; hA.cols = n_; hA.p.assign(d->A->p, d->A->p + n_ + 1); hA.i.resize(nzA);
+  for (int64_t k = 0; k < nzA; k++) hA.i[k] = (int)d->A->i[k];
+  for (int64_t k = 0; k < nzA; k++) if (hA.i[k] < 0 || hA.i[k] >= m_) throw Error(1, "row index of A out of range");
+  have_host_pattern = true;
+  DevBuf<int64_t> Pp((size_t)n_ + 1), Ap((size_t)n_ + 1);
+  DevBuf<int> Pi((size_t)nzP), Ai((size_t)nzA);
+  DevBuf<double> Px((size_t)nzP), Ax_((size_t)nzA), q_((size_t)n_), l_((size_t)m_), u_((size_t)m_);
+  Pp.upload((const int64_t *)hP.p.data(), (size_t)n_ + 1, s0); Ap.upload((const int64_t *)hA.p.data(), (size_t)n_ + 1, s0);
+  Pi.upload(hP.i.data(), nzP, s0); Ai.upload(hA.i.data(), nzA, s0);
+  Px.upload(d->P->x, nzP, s0); Ax_.upload(d->A->x, nzA, s0);
+  q_.upload(d->q, n_, s0); l_.upload(d->l, m_, s0); u_.upload(d->u, m_, s0);
+  HIP_CHECK(hipDeviceSynchronize());
+  setup_device(n_, m_, Pp, Pi, Px, Ap, Ai, Ax_, q_, l_, u_, s);
+}
+
+void Engine::fetch_host_pattern() {
+  if (have_host_pattern) return;
+  hP.rows = n; hP.cols = n; hP.p.resize((size_t)n + 1); hP.i.resize(nnzPtriu);
+  Pp_keep.download(hP.p.data(), (size_t)n + 1, stream);
+  Pi_keep.download(hP.i.data(), nnzPtriu, stream);
+  hA.rows = m; hA.cols = n; hA.p.resize((size_t)n + 1); hA.i.resize(nnzA);
+  At.rowptr.download(hA.p.data(), (size_t)n + 1, stream);
+  At.col.download(hA.i.data(), nnzA, stream);
+  sync();
+  have_host_pattern = true;
+}
+
+// --------------------------------------------------------------------------
+// K0: Ruiz equilibration + cost scaling
+// --------------------------------------------------------------------------
+void Engine::scale_data() {
+  c = 1.0;
+  vec_set(D.get(), 1.0, n, stream); vec_set(E.get(), 1.0, m, stream);
+  double *Dt = tn.get(), *Et = tm.get();
+  for (int it = 0; it < st.scaling; it++) {
+    csr_row_absmax(Pf, Dt, false, stream);             // ||P[:,j]||inf (P symmetric: row = column)
+    if (m > 0) csr_row_absmax(At, Dt, true, stream);   // max with ||A[:,j]||inf
+    if (m > 0) csr_row_absmax(A, Et, false, stream);   // ||A[i,:]||inf
+    vec_limit_rsqrt(Dt, n, stream);
+    vec_limit_rsqrt(Et, m, stream);
+    csr_scale_rows_cols(Pf, Dt, Dt, 1, 1.0, stream);
+    if (m > 0) {
+      csr_scale_rows_cols(A, Et, Dt, 0, 1.0, stream);
+      csr_scale_rows_cols(At, Dt, Et, 2, 1.0, stream);
+    }
+    vec_ew_prod(q.get(), q.get(), Dt, n, stream);
+    vec_ew_prod(D.get(), D.get(), Dt, n, stream);
+    vec_ew_prod(E.get(), E.get(), Et, m, stream);
+    // cost scaling
+    csr_row_absmax(Pf, Dt, false, stream);
+    HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double) * 2, stream));
+    reduce_sum(Dt, n, partials.get(), slots.get() + S_T0, stream);
+    reduce_absmax(q.get(), nullptr, n, slots.get() + S_T1, stream);
+    fetch_slots();
+    double c_temp = h_slots[S_T0] / (double)n;
+    double qn = limit_scaling(h_slots[S_T1]);
+    c_temp = limit_scaling(std::max(c_temp, qn));
+    c_temp = 1.0 / c_temp;
+    csr_scale_rows_cols(Pf, nullptr, nullptr, 0, c_temp, stream);
+    vec_scale(q.get(), c_temp, n, stream);
+    c *= c_temp;
+  }
+  cinv = 1.0 / c;
+  vec_ew_recip(Dinv.get(), D.get(), n, stream);
+  vec_ew_recip(Einv.get(), E.get(), m, stream);
+  vec_ew_prod(l.get(), l.get(), E.get(), m, stream);
+  vec_ew_prod(u.get(), u.get(), E.get(), m, stream);
+}
+
+void Engine::unscale_data() {
+  csr_scale_rows_cols(Pf, nullptr, nullptr, 0, cinv, stream);
+  csr_scale_rows_cols(Pf, Dinv.get(), Dinv.get(), 1, 1.0, stream);
+  vec_scale_by_vec_scalar(q.get(), Dinv.get(), cinv, n, stream);
+  if (m > 0) {
+    csr_scale_rows_cols(A, Einv.get(), Dinv.get(), 0, 1.0, stream);
+    csr_scale_rows_cols(At, Dinv.get(), Einv.get(), 2, 1.0, stream);
+    vec_ew_prod(l.get(), l.get(), Einv.get(), m, stream);
+    vec_ew_prod(u.get(), u.get(), Einv.get(), m, stream);
+  }
+}
+
+// --------------------------------------------------------------------------
+// K1: rho vector
+// --------------------------------------------------------------------------
+void Engine::set_rho_vec() {
+  st.rho = std::min(std::max(st.rho, RHO_MIN), RHO_MAX);
+  rho_vec_update(m, l.get(), u.get(), ctype.get(), rho.get(), rho_inv.get(), st.rho, 0, flag.get(), stream);
+}
+
+int Engine::update_rho_vec_from_bounds() {
+  if (m == 0) return 0;
+  flag.zero(stream);
+  rho_vec_update(m, l.get(), u.get(), ctype.get(), rho.get(), rho_inv.get(), st.rho, 1, flag.get(), stream);
+  int changed = 0;
+  flag.download(&changed, 1, stream);
+  sync();
+  if (changed && lin) return lin->update_rho();
+  return 0;
+}
+
+int Engine::update_rho(double rho_new) {
+  if (rho_new <= 0) return 1;
+  st.rho = std::min(std::max(rho_new, RHO_MIN), RHO_MAX);
+  rho_vec_update(m, l.get(), u.get(), ctype.get(), rho.get(), rho_inv.get(), st.rho, 2, flag.get(), stream);
+  return lin ? lin->update_rho() : 0;
+}
+
+void Engine::cold_start() {
+  x.zero(stream); z.zero(stream); y.zero(stream);
+}
+
+// --------------------------------------------------------------------------
+// ADMM iteration (K5 + KKT back-end)
+// --------------------------------------------------------------------------
+int Engine::kkt_solve() {
+  double cand = -1.0;
+  if (have_res) cand = lambda * std::sqrt(sc_pri * sc_dua);
+  return lin->solve(xz.get(), cand);
+}
+
+// one iteration; x/x_prev and z/z_prev have been swapped by the caller
+int Engine::admm_step() {
+  admm_rhs(n, m, st.sigma, x_prev.get(), q.get(), z_prev.get(), rho_inv.get(), y.get(), xz.get(), stream);
+  int rc = kkt_solve();
+  admm_update(n, m, st.alpha, xz.get(), x_prev.get(), z_prev.get(), rho.get(), rho_inv.get(), l.get(), u.get(), x.get(),
+              z.get(), y.get(), dx.get(), dy.get(), stream);
+  admm_iters_total++;
+  return rc;
+}
+
+// --------------------------------------------------------------------------
+// K8: residuals, objective
+// --------------------------------------------------------------------------
+void Engine::update_info(long long iter, bool compute_objective) {
+  OSQPInfo *info = ws->info;
+  spmv(A, x.get(), Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  if (m > 0) spmv(At, y.get(), Aty.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  residual_norms(n, m, x.get(), z.get(), Ax.get(), Px_.get(), Aty.get(), q.get(), Dinv.get(), Einv.get(), slots.get(),
+                 partials.get(), stream);
+  fetch_slots(16);
+  memcpy(res, h_slots, sizeof(double) * 16);
+  const bool uns = st.scaling && !st.scaled_termination;
+  info->iter = iter;
+  if (compute_objective) info->obj_val = obj_from_slots();
+  info->pri_res = m == 0 ? 0.0 : (uns ? res[S_PRI_UNS] : res[S_PRI]);
+  info->dua_res = uns ? cinv * res[S_DUA_UNS] : res[S_DUA];
+  sc_pri = m == 0 ? 0.0 : res[S_PRI];
+  sc_dua = res[S_DUA];
+  // progress monitor of the PCG tolerance rule (same statement as oracle/osqp_oracle.c)
+  double g = std::sqrt(sc_pri * sc_dua);
+  have_res = true;
+  if (!have_ref) { g_ref = g; it_ref = iter; have_ref = true; }
+  else if (iter - it_ref >= 25) {
+    if (g > 0.5 * g_ref) lambda = std::max(0.25 * lambda, 1e-6);
+    g_ref = g; it_ref = iter;
+  }
+  info->solve_time = toc();
+}
+
+double Engine::obj_from_slots() const {
+  double obj = 0.5 * res[S_XPX] + res[S_QX];
+  if (st.scaling) obj *= cinv;
+  return obj;
+}
+
+bool Engine::is_primal_infeasible(double eps) {
+  const bool uns = st.scaling && !st.scaled_termination;
+  prim_infeas_prep(m, dy.get(), l.get(), u.get(), uns ? E.get() : nullptr, slots.get(), partials.get(), stream);
+  fetch_slots();
+  double norm_dy = h_slots[S_T0], ineq_lhs = h_slots[S_T1];
+  if (norm_dy > eps) {
+    if (ineq_lhs < -eps * norm_dy) {
+      spmv(At, dy.get(), tn.get(), nullptr, 0.0, 0.0, nullptr, stream);
+      HIP_CHECK(hipMemsetAsync(slots.get() + S_T3, 0, sizeof(double), stream));
+      reduce_absmax(tn.get(), uns ? Dinv.get() : nullptr, n, slots.get() + S_T3, stream);
+      fetch_slots();
+      return h_slots[S_T3] < eps * norm_dy;
+    }
+  }
+  return false;
+}
+
+bool Engine::is_dual_infeasible(double eps) {
+  const bool uns = st.scaling && !st.scaled_termination;
+  HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double) * 6, stream));
+  reduce_absmax(dx.get(), uns ? D.get() : nullptr, n, slots.get() + S_T0, stream);
+  reduce_dot(q.get(), dx.get(), n, partials.get(), slots.get() + S_T1, stream);
+  fetch_slots();
+  double norm_dx = h_slots[S_T0], qdx = h_slots[S_T1];
+  double cost_scaling = uns ? c : 1.0;
+  if (norm_dx > eps) {
+    if (qdx < -cost_scaling * eps * norm_dx) {
+      spmv(Pf, dx.get(), tn2.get(), nullptr, 0.0, 0.0, nullptr, stream);
+      HIP_CHECK(hipMemsetAsync(slots.get() + S_T3, 0, sizeof(double), stream));
+      reduce_absmax(tn2.get(), uns ? Dinv.get() : nullptr, n, slots.get() + S_T3, stream);
+      fetch_slots();
+      if (h_slots[S_T3] < cost_scaling * eps * norm_dx) {
+        spmv(A, dx.get(), tm.get(), nullptr, 0.0, 0.0, nullptr, stream);
+        dual_infeas_rows(m, tm.get(), uns ? Einv.get() : nullptr, l.get(), u.get(), eps * norm_dx, slots.get(), stream);
+        fetch_slots();
+        return h_slots[S_T2] == 0.0;
+      }
+    }
+  }
+  return false;
+}
+
+int Engine::check_termination(bool approximate) {
+  OSQPInfo *info = ws->info;
+  double eps_abs = st.eps_abs, eps_rel = st.eps_rel, eps_prim_inf = st.eps_prim_inf, eps_dual_inf = st.eps_dual_inf;
+  const bool uns = st.scaling && !st.scaled_termination;
+  if (!(info->pri_res <= OSQP_INFTY) || !(info->dua_res <= OSQP_INFTY)) {  // also catches NaN
+    update_status(info, OSQP_NON_CVX);
+    info->obj_val = NAN;
+    return 1;
+  }
+  if (approximate) { eps_abs *= 10; eps_rel *= 10; eps_prim_inf *= 10; eps_dual_inf *= 10; }
+  bool prim_res_check = false, dual_res_check = false, prim_inf_check = false, dual_inf_check = false;
+  if (m == 0) prim_res_check = true;
+  else {
+    double mx = uns ? std::max(res[S_Z_UNS], res[S_AX_UNS]) : std::max(res[S_Z], res[S_AX]);
+    double eps_prim = eps_abs + eps_rel * mx;
+    if (info->pri_res < eps_prim) prim_res_check = true;
+    else prim_inf_check = is_primal_infeasible(eps_prim_inf);
+  }
+  double mxd = uns ? cinv * std::max(res[S_Q_UNS], std::max(res[S_ATY_UNS], res[S_PX_UNS]))
+                   : std::max(res[S_Q], std::max(res[S_ATY], res[S_PX]));
+  double eps_dual = eps_abs + eps_rel * mxd;
+  if (info->dua_res < eps_dual) dual_res_check = true;
+  else dual_inf_check = is_dual_infeasible(eps_dual_inf);
+
+  if (prim_res_check && dual_res_check) {
+    update_status(info, approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED);
+    return 1;
+  } else if (prim_inf_check) {
+    update_status(info, approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE);
+    if (uns) vec_ew_prod(dy.get(), dy.get(), E.get(), m, stream);
+    info->obj_val = OSQP_INFTY;
+    return 1;
+  } else if (dual_inf_check) {
+    update_status(info, approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE);
+    if (uns) vec_ew_prod(dx.get(), dx.get(), D.get(), n, stream);
+    info->obj_val = -OSQP_INFTY;
+    return 1;
+  }
+  return 0;
+}
+
+// A.4: on scaled quantities, from the norms of the last residual evaluation
+double Engine::compute_rho_estimate() {
+  double pri = m == 0 ? 0.0 : res[S_PRI], dua = res[S_DUA];
+  double pri_norm = m == 0 ? 0.0 : std::max(res[S_Z], res[S_AX]);
+  pri /= (pri_norm + 1e-10);
+  double dua_norm = std::max(std::max(res[S_Q], m == 0 ? 0.0 : res[S_ATY]), res[S_PX]);
+  dua /= (dua_norm + 1e-10);
+  double est = st.rho * std::sqrt(pri / (dua + 1e-10));
+  return std::min(std::max(est, RHO_MIN), RHO_MAX);
+}
+
+int Engine::adapt_rho() {
+  double rho_new = compute_rho_estimate();
+  ws->info->rho_estimate = rho_new;
+  if (rho_new > st.rho * st.adaptive_rho_tolerance || rho_new < st.rho / st.adaptive_rho_tolerance) {
+    int e = update_rho(rho_new);
+    ws->info->rho_updates += 1;
+    return e;
+  }
+  return 0;
+}
+
+static bool has_solution(const OSQPInfo *info) {
+  return info->status_val != OSQP_PRIMAL_INFEASIBLE && info->status_val != OSQP_PRIMAL_INFEASIBLE_INACCURATE &&
+         info->status_val != OSQP_DUAL_INFEASIBLE && info->status_val != OSQP_DUAL_INFEASIBLE_INACCURATE &&
+         info->status_val != OSQP_NON_CVX;
+}
+
+// A.5: host mirrors refreshed here (the Julia side reads solution->x/y, delta_x, delta_y as host pointers)
+void Engine::store_solution() {
+  OSQPInfo *info = ws->info;
+  if (has_solution(info)) {
+    if (st.scaling) {
+      vec_ew_prod(tn.get(), x.get(), D.get(), n, stream);
+      vec_ew_prod(tm.get(), y.get(), E.get(), m, stream);
+      vec_scale(tm.get(), cinv, m, stream);
+      tn.download(h_x.data(), n, stream); tm.download(h_y.data(), m, stream);
+    } else {
+      x.download(h_x.data(), n, stream); y.download(h_y.data(), m, stream);
+    }
+    sync();
+  } else {
+    std::fill(h_x.begin(), h_x.end(), NAN);
+    std::fill(h_y.begin(), h_y.end(), NAN);
+    if (info->status_val == OSQP_PRIMAL_INFEASIBLE || info->status_val == OSQP_PRIMAL_INFEASIBLE_INACCURATE) {
+      HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double), stream));
+      reduce_absmax(dy.get(), nullptr, m, slots.get() + S_T0, stream);
+      fetch_slots();
+      vec_scale(dy.get(), 1.0 / h_slots[S_T0], m, stream);
+      dy.download(h_dy.data(), m, stream);
+    }
+    if (info->status_val == OSQP_DUAL_INFEASIBLE || info->status_val == OSQP_DUAL_INFEASIBLE_INACCURATE) {
+      HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double), stream));
+      reduce_absmax(dx.get(), nullptr, n, slots.get() + S_T0, stream);
+      fetch_slots();
+      vec_scale(dx.get(), 1.0 / h_slots[S_T0], n, stream);
+      dx.download(h_dx.data(), n, stream);
+    }
+    cold_start();
+    sync();
+  }
+}
+
+// --------------------------------------------------------------------------
+// osqp_solve [REF src/interface.jl:171]
+// --------------------------------------------------------------------------
+int Engine::solve() {
+  OSQPInfo *info = ws->info;
+  long long iter, max_iter = st.max_iter;
+  bool can_check_termination = false, can_print = st.verbose != 0;
+  const bool compute_cost_function = st.verbose != 0;
+  double temp_run_time;
+  if (clear_update_time) info->update_time = 0.0;
+  rho_update_from_solve = true;
+  tic();
+  if (st.verbose) printf("iter   objective    pri res    dua res    rho\n");
+  if (!st.warm_start) cold_start();
+  lin->set_guess(x.get());
+  have_res = false; have_ref = false; lambda = lambda0;
+
+  for (iter = 1; iter <= max_iter; iter++) {
+    if (ws->first_run) temp_run_time = info->setup_time + toc();
+    else temp_run_time = info->update_time + toc();
+    if (st.time_limit && temp_run_time >= st.time_limit) {
+      update_status(info, OSQP_TIME_LIMIT_REACHED);
+      can_check_termination = false;
+      break;
+    }
+    std::swap(x, x_prev);
+    std::swap(z, z_prev);
+    if (admm_step()) {  // negative curvature in the indirect solve
+      update_status(info, OSQP_NON_CVX); info->obj_val = NAN; info->iter = iter;
+      break;
+    }
+    can_check_termination = st.check_termination && (iter % st.check_termination == 0);
+    can_print = st.verbose && ((iter % 200 == 0) || iter == 1);
+    if (can_check_termination || can_print) {
+      update_info(iter, compute_cost_function);
+      if (can_print) printf("%4lld  %11.4e  %9.2e  %9.2e  %9.2e\n", iter, info->obj_val, info->pri_res, info->dua_res, st.rho);
+      if (can_check_termination && check_termination(false)) break;
+    }
+    if (st.adaptive_rho && !st.adaptive_rho_interval) {
+      sync();  // the automatic interval is defined on elapsed solve time (nondeterministic, as in the reference)
+      if (toc() > st.adaptive_rho_fraction * info->setup_time) {
+        long long base = st.check_termination ? st.check_termination : 25;
+        long long rounded = base * (long long)std::floor((double)iter / (double)base + 0.5);
+        if (rounded < base) rounded = base;
+        st.adaptive_rho_interval = rounded;
+        if (st.adaptive_rho_interval < st.check_termination) st.adaptive_rho_interval = st.check_termination;
+      }
+    }
+    if (st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0)) {
+      if (!can_check_termination && !can_print) update_info(iter, compute_cost_function);
+      if (adapt_rho()) { update_status(info, OSQP_NON_CVX); break; }
+    }
+  }
+
+  if (!can_check_termination && info->status_val != OSQP_NON_CVX) {
+    if (!can_print) update_info(iter - 1, compute_cost_function);
+    check_termination(false);
+  }
+  if (!compute_cost_function && has_solution(info)) info->obj_val = obj_from_slots_fresh();
+  if (info->status_val == OSQP_UNSOLVED) {
+    if (!check_termination(true)) update_status(info, OSQP_MAX_ITER_REACHED);
+  }
+  if (info->status_val == OSQP_TIME_LIMIT_REACHED) {
+    if (!check_termination(true)) update_status(info, OSQP_TIME_LIMIT_REACHED);
+  }
+  info->rho_estimate = compute_rho_estimate();
+  sync();
+  info->solve_time = toc();
+  if (st.polish && info->status_val == OSQP_SOLVED) polish();
+  if (ws->first_run) info->run_time = info->setup_time + info->solve_time + info->polish_time;
+  else info->run_time = info->update_time + info->solve_time + info->polish_time;
+  ws->first_run = 0;
+  clear_update_time = true;
+  rho_update_from_solve = false;
+  if (st.verbose)
+    printf("status: %s, iterations: %lld, objective: %.6e, run time: %.3es\n", info->status, (long long)info->iter,
+           info->obj_val, info->run_time);
+  store_solution();
+  *ws->settings = st;
+  return 0;
+}
+
+// objective at the current x (Px recomputed: the last residual evaluation may be older than x)
+double Engine::obj_from_slots_fresh() {
+  spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  reduce_dot(x.get(), Px_.get(), n, partials.get(), slots.get() + S_T4, stream);
+  reduce_dot(q.get(), x.get(), n, partials.get(), slots.get() + S_T5, stream);
+  fetch_slots();
+  double obj = 0.5 * h_slots[S_T4] + h_slots[S_T5];
+  if (st.scaling) obj *= cinv;
+  return obj;
+}
+
+int Engine::iterate(long long iters) {
+  tic();
+  lin->set_guess(x.get());
+  for (long long it = 1; it <= iters; it++) {
+    std::swap(x, x_prev);
+    std::swap(z, z_prev);
+    admm_step();
+    if (st.check_termination && (it % st.check_termination == 0)) update_info(it, false);
+  }
+  update_info(iters, true);
+  sync();
+  return 0;
+}
+
+// polish (row N1) needs a reduced-KKT factorisation; provided by the direct back-end (direct.hip)
+void Engine::polish() {
+  tic();
+  ws->info->status_polish = polish_run(*this);
+  sync();
+  ws->info->polish_time = toc();
+}
+
+// --------------------------------------------------------------------------
+// updates
+// --------------------------------------------------------------------------
+void Engine::begin_update() {
+  if (clear_update_time) { clear_update_time = false; ws->info->update_time = 0.0; }
+  tic();
+}
+void Engine::end_update() { sync(); ws->info->update_time += toc(); }
+
+int Engine::update_lin_cost(const double *q_new) {
+  begin_update();
+  q.upload(q_new, n, stream);
+  sync();
+  if (st.scaling) vec_scale_by_vec_scalar(q.get(), D.get(), c, n, stream);
+  reset_info(ws->info);
+  end_update();
+  return 0;
+}
+
+int Engine::update_bounds(const double *l_new, const double *u_new) {
+  begin_update();
+  std::vector<double> nl(h_l), nu(h_u);
+  if (l_new) nl.assign(l_new, l_new + m);
+  if (u_new) nu.assign(u_new, u_new + m);
+  for (int i = 0; i < m; i++) if (nl[i] > nu[i]) return 1;
+  h_l.swap(nl); h_u.swap(nu);
+  if (l_new) { l.upload(h_l.data(), m, stream); sync(); if (st.scaling) vec_ew_prod(l.get(), l.get(), E.get(), m, stream); }
+  if (u_new) { u.upload(h_u.data(), m, stream); sync(); if (st.scaling) vec_ew_prod(u.get(), u.get(), E.get(), m, stream); }
+  reset_info(ws->info);
+  int e = update_rho_vec_from_bounds();
+  end_update();
+  return e;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_vals(int64_t k, const long long *__restrict__ idx, const double *__restrict__ v,
+                                                         double *__restrict__ t1, const int *__restrict__ map1,
+                                                         double *__restrict__ t2, const int *__restrict__ map2) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= k) return;
+  int64_t e = idx ? idx[i] : i;
+  double val = v[i];
+  if (map1) { int p = map1[e]; if (p >= 0) t1[p] = val; } else t1[e] = val;
+  if (t2) { int p = map2[e]; if (p >= 0) t2[p] = val; }
+}
+
+int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const double *Ax_new, const c_int *Aidx, c_int An,
+                      bool doP, bool doA) {
+  begin_update();
+  if (doP) { if (Pidx) { if (Pn > nnzPtriu) return 1; } else if (Pn != nnzPtriu && Pn != 0) return 1; }
+  if (doA) { if (Aidx) { if (An > nnzA) return 2; } else if (An != nnzA && An != 0) return 2; }
+  if (doP && Pidx) for (c_int i = 0; i < Pn; i++) if (Pidx[i] < 0 || Pidx[i] >= nnzPtriu) return 1;
+  if (doA && Aidx) for (c_int i = 0; i < An; i++) if (Aidx[i] < 0 || Aidx[i] >= nnzA) return 2;
+  if (st.scaling) unscale_data();
+  auto scatter = [&](const double *vals, const c_int *idx, c_int k, double *t1, const int *map1, double *t2, const int *map2) {
+    if (k <= 0) return;
+    DevBuf<double> dv((size_t)k);
+    DevBuf<long long> di;
+    dv.upload(vals, (size_t)k, stream);
+    if (idx) { di.alloc((size_t)k); di.upload((const long long *)idx, (size_t)k, stream); }
+    hipLaunchKernelGGL(k_scatter_vals, dim3(blocks_for(k)), dim3(kBlock), 0, stream, (int64_t)k, idx ? di.get() : (const long long *)nullptr,
+                       dv.get(), t1, map1, t2, map2);
+    sync();
+  };
+  if (doP) scatter(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
+  if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
+  if (st.scaling) scale_data();
+  int e = lin->update_matrices();
+  reset_info(ws->info);
+  end_update();
+  return e;
+}
+
+int Engine::warm_start(const double *xw, const double *yw) {
+  st.warm_start = 1;
+  ws->settings->warm_start = 1;
+  if (xw) {
+    x.upload(xw, n, stream); sync();
+    if (st.scaling) vec_ew_prod(x.get(), x.get(), Dinv.get(), n, stream);
+    if (m > 0) spmv(A, x.get(), z.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  } else {
+    x.zero(stream); z.zero(stream);
+  }
+  if (yw) {
+    y.upload(yw, m, stream); sync();
+    if (st.scaling) vec_scale_by_vec_scalar(y.get(), Einv.get(), c, m, stream);
+  } else {
+    y.zero(stream);
+  }
+  sync();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// back-end selection: the reference's `linsys_solver` setting
+// [REF src/constants.jl:1-2, src/interface.jl:749-773] plus two extension values
+// --------------------------------------------------------------------------
+void Engine::select_linsys() {
+  int want = st.linsys_solver;
+  if (want == AMD_PCG_SOLVER) { lin = make_pcg(*this); return; }
+  // QDLDL / MKL Pardiso / AMD_DIRECT: direct LDL'.  For QDLDL ("auto") fall back to PCG when the
+  // KKT matrix is too large for a host symbolic analysis or its factor cannot fit.
+  const double nnzK = (double)nnzPtriu + (double)nnzA + (double)n + (double)m;
+  if (want != AMD_DIRECT_SOLVER && nnzK > 4e7) { lin = make_pcg(*this); return; }
+  int err = 0;
+  lin = make_direct(*this, &err);
+  if (!lin) {
+    if (err == -1 && want != AMD_DIRECT_SOLVER) { lin = make_pcg(*this); return; }  // predicted fill too large
+    throw Error(err > 0 ? err : 4, err == 5 ? "KKT matrix has the wrong inertia: problem non-convex" : "direct back-end failed to initialise");
+  }
+}
+
+}  // namespace oq

@@ -1,0 +1,152 @@
+// engine.hpp -- device-resident OSQP ADMM engine (one per OSQPWorkspace).
+//
+// Data layout in HBM (all fp64 values, 32-bit column indices, 64-bit row pointers):
+//   A   CSR m x n   (rows of A, for z~ = A x, A dx, residual A x)
+//   At  CSR n x m   (rows of A' = the caller's CSC arrays as they come, for A'y)
+//   Pf  CSR n x n   (full symmetric P expanded from the caller's upper triangle)
+//   k2pos maps from the caller's nnz order (CSC of A, CSC of triu P) into A / Pf,
+//   so that osqp_update_P / osqp_update_A are O(k) scatters.
+// Iterates x, z, y, x_prev, z_prev, xz_tilde, delta_x, delta_y, Ax, Px, Aty stay
+// in HBM for the whole solve; every check_termination iterations 16 scalars
+// come back to the host.
+#pragma once
+#include <chrono>
+#include <memory>
+
+#include "kernels.hpp"
+
+namespace oq {
+
+struct Engine;
+
+// KKT back-end interface (the reference's `linsys_solver` plug-in point,
+// [REF src/constants.jl:1-2, src/interface.jl:749-773]).
+struct Linsys {
+  virtual ~Linsys() {}
+  virtual int kind() const = 0;  // 0 direct LDL', 2 PCG
+  // xz = [sigma x_prev - q ; z_prev - rho^-1 y] on entry, [x~ ; z~] on exit.
+  // tol_candidate: lambda*sqrt(pri*dua) of the last residual evaluation (<0: none yet).
+  // Returns 0, or 5 when negative curvature is met (problem non-convex).
+  virtual int solve(double *xz, double tol_candidate) = 0;
+  virtual int update_rho() = 0;       // engine.rho / rho_inv changed
+  virtual int update_matrices() = 0;  // engine.A / At / Pf values changed
+  virtual void set_guess(const double *x) {}
+  virtual double nnzL() const { return 0.0; }
+  virtual double levels() const { return 0.0; }
+  virtual double trisolve_bytes() const { return 0.0; }
+  virtual double factorizations() const { return 0.0; }
+  virtual double cg_iters() const { return 0.0; }
+  virtual float time_solve(int reps) { return -1.f; }
+};
+
+struct HostCsc {  // host copy of a sparsity pattern (for the symbolic phase of the direct back-end)
+  int rows = 0, cols = 0;
+  std::vector<int64_t> p;
+  std::vector<int> i;
+};
+
+struct Engine {
+  int n = 0, m = 0;
+  OSQPSettings st;
+  hipStream_t stream = nullptr;
+  int device = 0;
+
+  DevCsr A, At, Pf;
+  DevBuf<int> A_k2pos, P_k2lo, P_k2up;
+  DevBuf<int64_t> Pp_keep;  // caller's triu(P) CSC pattern, kept for the direct back-end's symbolic phase
+  DevBuf<int> Pi_keep;
+  int64_t nnzA = 0, nnzPtriu = 0;
+  HostCsc hP, hA;           // patterns on the host (filled lazily)
+  bool have_host_pattern = false;
+
+  DevBuf<double> q, l, u, D, Dinv, E, Einv, rho, rho_inv;
+  DevBuf<int> ctype, flag;
+  DevBuf<double> x, z, y, x_prev, z_prev, xz, dx, dy, Ax, Px_, Aty, tn, tm, tn2, tm2;
+  DevBuf<double> slots, partials;
+  double *h_slots = nullptr;  // pinned
+  double res[16] = {0};       // norms of the last residual evaluation (Slot order)
+  double c = 1.0, cinv = 1.0;
+  std::vector<double> h_l, h_u;  // unscaled bounds on the host (validation of bound updates)
+
+  std::unique_ptr<Linsys> lin;
+
+  // PCG tolerance rule state
+  double sc_pri = 0, sc_dua = 0, lambda0 = 0.15, lambda = 0.15, g_ref = 0;
+  long long it_ref = 0;
+  bool have_res = false, have_ref = false;
+
+  // statistics
+  long long admm_iters_total = 0;
+  // timers
+  std::chrono::steady_clock::time_point t0;
+  bool clear_update_time = false, rho_update_from_solve = false;
+
+  // host mirrors (ABI-visible)
+  OSQPWorkspace *ws = nullptr;
+  std::vector<double> h_x, h_y, h_dx, h_dy;
+
+  Engine();
+  ~Engine();
+
+  // ---- setup ----
+  // device-resident CSC inputs (ownership of the buffers moves into the engine)
+  void setup_device(int n, int m, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
+                    DevBuf<int> &Ai, DevBuf<double> &Ax, DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u,
+                    const OSQPSettings &s);
+  void setup_host(const OSQPData *data, const OSQPSettings &s);
+  void fetch_host_pattern();
+
+  // ---- algorithm ----
+  void scale_data();
+  void unscale_data();
+  void set_rho_vec();
+  int update_rho_vec_from_bounds();
+  void cold_start();
+  int solve();
+  int iterate(long long iters);
+  int admm_step();
+  int kkt_solve();
+  void update_info(long long iter, bool compute_objective);
+  double obj_from_slots_fresh();
+  void polish();
+  void begin_update();
+  void end_update();
+  int check_termination(bool approximate);
+  bool is_primal_infeasible(double eps);
+  bool is_dual_infeasible(double eps);
+  double compute_rho_estimate();
+  int adapt_rho();
+  int update_rho(double rho_new);
+  void store_solution();
+  double obj_from_slots() const;
+
+  // ---- updates ----
+  int update_lin_cost(const double *q_new);
+  int update_bounds(const double *l_new, const double *u_new);
+  int update_PA(const double *Px, const c_int *Pidx, c_int Pn, const double *Ax, const c_int *Aidx, c_int An, bool doP, bool doA);
+  int warm_start(const double *x, const double *y);
+
+  // ---- helpers ----
+  void tic() { t0 = std::chrono::steady_clock::now(); }
+  double toc() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+  void fetch_slots(int count = S_COUNT);
+  void select_linsys();
+};
+
+std::unique_ptr<Linsys> make_pcg(Engine &e);
+// returns nullptr with *err = -1 when the predicted factor is too large (caller may fall back to PCG),
+// 4 on a numeric failure, 5 on wrong inertia (non-convex)
+std::unique_ptr<Linsys> make_direct(Engine &e, int *err);
+// polish: returns status_polish (1 success, -1 failed, 0 not attempted)
+int polish_run(Engine &e);
+const char *last_error_cstr();
+
+// device generators (gen.hip)
+void generate_problem(int kind, int n, int per_row, unsigned long long seed, hipStream_t s, int &n_out, int &m_out,
+                      DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap, DevBuf<int> &Ai,
+                      DevBuf<double> &Ax, DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u);
+
+void update_status(OSQPInfo *info, c_int status_val);
+
+}  // namespace oq

@@ -1,0 +1,726 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4, wave64).
+//
+// Everything on the ADMM hot path is HBM-bandwidth bound (<= 0.25 flop/byte), so
+// the rules that matter are: coalesced 8-byte value / 4-byte index streams, one
+// sub-wave group of lanes per CSR row sized to the row length, wavefront
+// shuffle reductions, no atomics on fp64 sums (two-stage fixed-order
+// reductions keep every solve bit-reproducible), max-norms through integer
+// atomicMax on the bit pattern of non-negative doubles (order independent).
+#include "kernels.hpp"
+#include <algorithm>
+
+namespace oq {
+
+size_t g_device_bytes = 0;
+
+// --------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// all threads of a 256-thread block get the block total (fixed order -> deterministic)
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double sm[4];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__device__ __forceinline__ double block_max(double v) {
+  __shared__ double smx[4];
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return nanmax(nanmax(smx[0], smx[1]), nanmax(smx[2], smx[3]));
+}
+// max of non-negative doubles through their (monotone) bit pattern; NaN sorts above +inf
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
+  atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+// sum of the kReduceBlocks partials, same order in every block
+__device__ __forceinline__ double sum_partials(const double *partials) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < kReduceBlocks; i += kBlock) v += partials[i];
+  return block_sum(v);
+}
+
+// --------------------------------------------------------------------------
+// sparse structure
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_expand_colptr(int cols, const int64_t *__restrict__ colptr, int64_t nnz,
+                                                          int *__restrict__ out) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  int lo = 0, hi = cols;  // find largest j with colptr[j] <= k
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (colptr[mid] <= k) lo = mid; else hi = mid;
+  }
+  out[k] = lo;
+}
+void expand_colptr(int cols, const int64_t *colptr, int64_t nnz, int *out, hipStream_t s) {
+  if (nnz == 0) return;
+  hipLaunchKernelGGL(k_expand_colptr, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, cols, colptr, nnz, out);
+}
+
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kBlock * kScanItems;
+// per-tile exclusive scan; tile totals to sums[]
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const int64_t *__restrict__ in, int64_t *__restrict__ out,
+                                                       int64_t n, int64_t *__restrict__ sums) {
+  __shared__ int64_t sm[kBlock];
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int64_t v[kScanItems], tot = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) { v[i] = (base + i < n) ? in[base + i] : 0; tot += v[i]; }
+  sm[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {
+    int64_t t = (threadIdx.x >= off) ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t excl = sm[threadIdx.x] - tot;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) { if (base + i < n) out[base + i] = excl; excl += v[i]; }
+  if (threadIdx.x == kBlock - 1 && sums) sums[blockIdx.x] = sm[kBlock - 1];
+}
+__global__ __launch_bounds__(kBlock) void k_scan_add(int64_t *__restrict__ out, int64_t n, const int64_t *__restrict__ offs) {
+  int64_t i = (int64_t)blockIdx.x * kScanTile + threadIdx.x;
+  int64_t o = offs[blockIdx.x];
+  for (int k = 0; k < kScanItems; k++, i += kBlock) if (i < n) out[i] += o;
+}
+__global__ void k_set_i64(int64_t *p, const int64_t *a, const int64_t *b) { *p = *a + *b; }
+
+static void scan_rec(const int64_t *in, int64_t *out, int64_t n, hipStream_t s) {
+  int tiles = blocks_for(n, kScanTile);
+  if (tiles == 1) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, s, in, out, n, (int64_t *)nullptr);
+    return;
+  }
+  DevBuf<int64_t> sums(tiles), offs(tiles);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, s, in, out, n, sums.get());
+  scan_rec(sums.get(), offs.get(), tiles, s);
+  hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBlock), 0, s, out, n, offs.get());
+  HIP_CHECK(hipStreamSynchronize(s));  // sums/offs are freed on return
+}
+void exclusive_scan(const int64_t *counts, int64_t *out, int64_t n, hipStream_t s) {
+  // out has n+1 entries; scan the n counts, then out[n] = out[n-1] + counts[n-1]
+  if (n == 0) { HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int64_t), s)); return; }
+  scan_rec(counts, out, n, s);
+  hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, out + n, out + n - 1, counts + n - 1);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_rows(int64_t E, const int *__restrict__ erow, int64_t *__restrict__ counts) {
+  int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  int r = erow[e];
+  if (r >= 0) atomicAdd((unsigned long long *)&counts[r], 1ULL);
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_coo(int64_t E, const int *__restrict__ erow, const int *__restrict__ ecol,
+                                                        int64_t *__restrict__ cursor, int *__restrict__ col, int *__restrict__ src) {
+  int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  int r = erow[e];
+  if (r < 0) return;
+  int64_t pos = (int64_t)atomicAdd((unsigned long long *)&cursor[r], 1ULL);
+  col[pos] = ecol[e];
+  src[pos] = (int)e;
+}
+// rows of length <= kSmallRow: one thread per row, insertion sort on (col, src)
+constexpr int kSmallRow = 16;
+constexpr int kLdsRow = 4096;
+__global__ __launch_bounds__(kBlock) void k_sort_rows_small(int rows, const int64_t *__restrict__ rp, int *__restrict__ col,
+                                                            int *__restrict__ src) {
+  int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  int64_t s = rp[r];
+  int len = (int)(rp[r + 1] - s);
+  if (len > kSmallRow || len < 2) return;
+  for (int i = 1; i < len; i++) {
+    int c = col[s + i], q = src[s + i];
+    int j = i - 1;
+    while (j >= 0 && (col[s + j] > c || (col[s + j] == c && src[s + j] > q))) {
+      col[s + j + 1] = col[s + j]; src[s + j + 1] = src[s + j]; j--;
+    }
+    col[s + j + 1] = c; src[s + j + 1] = q;
+  }
+}
+// rows of kSmallRow < length <= kLdsRow: one workgroup per row, bitonic sort of 64-bit keys in LDS
+__global__ __launch_bounds__(kBlock) void k_sort_rows_lds(int rows, const int64_t *__restrict__ rp, int *__restrict__ col,
+                                                          int *__restrict__ src, int *__restrict__ n_long) {
+  __shared__ unsigned long long key[kLdsRow];
+  int r = blockIdx.x;
+  int64_t s = rp[r];
+  int64_t len64 = rp[r + 1] - s;
+  if (len64 <= kSmallRow) return;
+  if (len64 > kLdsRow) { if (threadIdx.x == 0) atomicAdd(n_long, 1); return; }
+  int len = (int)len64, N = 1;
+  while (N < len) N <<= 1;
+  for (int i = threadIdx.x; i < N; i += kBlock)
+    key[i] = (i < len) ? (((unsigned long long)(unsigned)col[s + i] << 32) | (unsigned)src[s + i]) : ~0ULL;
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < N; i += kBlock) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = key[i], b = key[ixj];
+          bool up = ((i & k) == 0);
+          if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < len; i += kBlock) { col[s + i] = (int)(key[i] >> 32); src[s + i] = (int)(key[i] & 0xFFFFFFFFu); }
+}
+
+void csr_from_coo(int rows, int cols, int64_t E, const int *erow, const int *ecol, DevCsr &out, DevBuf<int> &src,
+                  hipStream_t s) {
+  if (E >= 2147483647LL) throw Error(6, "more than 2^31-1 entries in one matrix are not supported");
+  out.rows = rows; out.cols = cols;
+  DevBuf<int64_t> counts((size_t)rows + 1);
+  counts.zero(s);
+  out.rowptr.alloc((size_t)rows + 1);
+  if (E > 0) hipLaunchKernelGGL(k_count_rows, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, counts.get());
+  exclusive_scan(counts.get(), out.rowptr.get(), rows, s);
+  int64_t nnz = 0;
+  HIP_CHECK(hipMemcpyAsync(&nnz, out.rowptr.get() + rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  out.nnz = nnz;
+  out.col.alloc((size_t)nnz);
+  out.val.alloc((size_t)nnz);
+  src.alloc((size_t)nnz);
+  if (nnz > 0) {
+    HIP_CHECK(hipMemcpyAsync(counts.get(), out.rowptr.get(), sizeof(int64_t) * (size_t)rows, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_scatter_coo, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, ecol, counts.get(), out.col.get(), src.get());
+    hipLaunchKernelGGL(k_sort_rows_small, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get());
+    DevBuf<int> n_long(1);
+    n_long.zero(s);
+    hipLaunchKernelGGL(k_sort_rows_lds, dim3(rows), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get(), n_long.get());
+    int h_long = 0;
+    n_long.download(&h_long, 1, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (h_long > 0) {  // rare: rows longer than the LDS tile are ordered on the host
+      std::vector<int64_t> rp((size_t)rows + 1);
+      out.rowptr.download(rp.data(), rp.size(), s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      std::vector<unsigned long long> keys;
+      std::vector<int> hc, hs;
+      for (int r = 0; r < rows; r++) {
+        int64_t len = rp[r + 1] - rp[r];
+        if (len <= kLdsRow) continue;
+        hc.resize(len); hs.resize(len); keys.resize(len);
+        HIP_CHECK(hipMemcpy(hc.data(), out.col.get() + rp[r], sizeof(int) * len, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hs.data(), src.get() + rp[r], sizeof(int) * len, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < len; i++) keys[i] = ((unsigned long long)(unsigned)hc[i] << 32) | (unsigned)hs[i];
+        std::sort(keys.begin(), keys.end());
+        for (int64_t i = 0; i < len; i++) { hc[i] = (int)(keys[i] >> 32); hs[i] = (int)(keys[i] & 0xFFFFFFFFu); }
+        HIP_CHECK(hipMemcpy(out.col.get() + rp[r], hc.data(), sizeof(int) * len, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(src.get() + rp[r], hs.data(), sizeof(int) * len, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  out.group = pick_group(rows, nnz);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_values(int64_t nnz, const int *__restrict__ src, const double *__restrict__ in,
+                                                          double *__restrict__ out, int64_t modulo) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t e = src[k];
+  if (modulo > 0 && e >= modulo) e -= modulo;
+  out[k] = in[e];
+}
+void gather_values(int64_t nnz, const int *src, const double *in, double *out, int64_t modulo, hipStream_t s) {
+  if (nnz == 0) return;
+  hipLaunchKernelGGL(k_gather_values, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, in, out, modulo);
+}
+__global__ __launch_bounds__(kBlock) void k_invert_map(int64_t nnz, const int *__restrict__ src, int64_t lo, int64_t hi,
+                                                       int *__restrict__ k2pos) {
+  int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= nnz) return;
+  int64_t e = src[pos];
+  if (e >= lo && e < hi) k2pos[e - lo] = (int)pos;
+}
+void invert_map(int64_t nnz, const int *src, int64_t lo, int64_t hi, int *k2pos, hipStream_t s) {
+  if (nnz == 0) return;
+  hipLaunchKernelGGL(k_invert_map, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, lo, hi, k2pos);
+}
+__global__ __launch_bounds__(kBlock) void k_convert_i64_i32(int64_t n, const int64_t *__restrict__ in, int *__restrict__ out) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) out[k] = (int)in[k];
+}
+void convert_i64_i32(int64_t n, const int64_t *in, int *out, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_convert_i64_i32, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, in, out);
+}
+
+int pick_group(int rows, int64_t nnz) {
+  double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
+  if (mean <= 1.5) return 1;
+  if (mean <= 3.0) return 2;
+  if (mean <= 6.0) return 4;
+  if (mean <= 12.0) return 8;
+  if (mean <= 24.0) return 16;
+  if (mean <= 48.0) return 32;
+  return 64;
+}
+
+// --------------------------------------------------------------------------
+// K6 / K7: CSR SpMV.  G lanes cooperate on one row (G | 64): coalesced streams of
+// 8-byte values and 4-byte column indices, 4 independent accumulators per lane to
+// keep >= 4 gathers of x in flight, xor-shuffle reduction inside the group.
+// --------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_spmv(int rows, const int64_t *__restrict__ rp, const int *__restrict__ ci,
+                                                 const double *__restrict__ va, const double *__restrict__ x,
+                                                 double *__restrict__ y, const double *__restrict__ rscale, double beta,
+                                                 double gamma, const double *__restrict__ v) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  if (row >= rows) return;
+  const int64_t s = rp[row], e = rp[row + 1];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t k = s + lane;
+  for (; k + 3 * G < e; k += 4 * G) {
+    const int c0 = ci[k], c1 = ci[k + G], c2 = ci[k + 2 * G], c3 = ci[k + 3 * G];
+    const double v0 = va[k], v1 = va[k + G], v2 = va[k + 2 * G], v3 = va[k + 3 * G];
+    a0 += v0 * x[c0]; a1 += v1 * x[c1]; a2 += v2 * x[c2]; a3 += v3 * x[c3];
+  }
+  for (; k < e; k += G) a0 += va[k] * x[ci[k]];
+  double acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    if (rscale) acc *= rscale[row];
+    if (beta != 0.0) acc += beta * y[row];
+    if (v) acc += gamma * v[row];
+    y[row] = acc;
+  }
+}
+
+void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
+          hipStream_t s) {
+  if (M.rows == 0) return;
+  const int G = M.group;
+  dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
+#define OQ_SPMV(GG) \
+  hipLaunchKernelGGL(k_spmv<GG>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), x, y, rscale, beta, gamma, v)
+  switch (G) {
+  case 1: OQ_SPMV(1); break;
+  case 2: OQ_SPMV(2); break;
+  case 4: OQ_SPMV(4); break;
+  case 8: OQ_SPMV(8); break;
+  case 16: OQ_SPMV(16); break;
+  case 32: OQ_SPMV(32); break;
+  default: OQ_SPMV(64); break;
+  }
+#undef OQ_SPMV
+}
+
+// --------------------------------------------------------------------------
+// K0: Ruiz equilibration pieces
+// --------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_row_absmax(int rows, const int64_t *__restrict__ rp, const double *__restrict__ va,
+                                                       double *__restrict__ out, int accumulate) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  if (row >= rows) return;
+  const int64_t s = rp[row], e = rp[row + 1];
+  double m = 0.0;
+  for (int64_t k = s + lane; k < e; k += G) m = fmax(m, fabs(va[k]));
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if (lane == 0) out[row] = accumulate ? fmax(out[row], m) : m;
+}
+void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s) {
+  if (M.rows == 0) return;
+  const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
+  dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
+  if (G == 64) hipLaunchKernelGGL(k_row_absmax<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+  else if (G == 8) hipLaunchKernelGGL(k_row_absmax<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+  else hipLaunchKernelGGL(k_row_absmax<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+}
+
+// val[k] = ((val[k] * a) * b) * scalar.  order 0: a = r[row], b = c[col];  order 2: a = c[col], b = r[row]
+// (so that A and its transposed copy A' round identically);  order 1: a = r[min(row,col)], b = r[max(row,col)]
+// (the order in which the CPU statement multiplies an upper-triangular entry, so P stays bit-symmetric)
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int64_t *__restrict__ rp, const int *__restrict__ ci,
+                                                            double *__restrict__ va, const double *__restrict__ r,
+                                                            const double *__restrict__ c, int symmetric_order, double scalar) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  if (row >= rows) return;
+  const int64_t s = rp[row], e = rp[row + 1];
+  for (int64_t k = s + lane; k < e; k += G) {
+    double x = va[k];
+    if (r) {
+      const int col = ci[k];
+      double a, b;
+      if (symmetric_order == 1) { int lo = col < (int)row ? col : (int)row, hi = col < (int)row ? (int)row : col; a = r[lo]; b = r[hi]; }
+      else if (symmetric_order == 2) { a = c[col]; b = r[row]; }
+      else { a = r[row]; b = c[col]; }
+      x = (x * a) * b;
+    }
+    if (scalar != 1.0) x *= scalar;
+    va[k] = x;
+  }
+}
+void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmetric_order, double scalar, hipStream_t s) {
+  if (M.rows == 0 || M.nnz == 0) return;
+  const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
+  dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
+  if (G == 64) hipLaunchKernelGGL(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  else if (G == 8) hipLaunchKernelGGL(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  else hipLaunchKernelGGL(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+}
+
+#define MIN_SCALING 1e-4
+#define MAX_SCALING 1e4
+__global__ __launch_bounds__(kBlock) void k_vec_op(int op, double *__restrict__ out, const double *__restrict__ a,
+                                                   const double *__restrict__ b, double sc, double sc2, int n) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  switch (op) {
+  case 0: { double d = out[i]; d = d < MIN_SCALING ? 1.0 : d; d = d > MAX_SCALING ? MAX_SCALING : d; out[i] = 1.0 / sqrt(d); break; }
+  case 1: { double d = out[i]; d = d < MIN_SCALING ? 1.0 : d; d = d > MAX_SCALING ? MAX_SCALING : d; out[i] = d; break; }
+  case 2: out[i] = a[i] * b[i]; break;
+  case 3: out[i] = 1.0 / a[i]; break;
+  case 4: out[i] *= sc; break;
+  case 5: out[i] = sc; break;
+  case 6: out[i] = a[i]; break;
+  case 7: out[i] = (out[i] * a[i]) * sc; break;
+  case 8: out[i] += sc * a[i]; break;
+  case 9: out[i] = fmin(fmax(out[i], sc), sc2); break;
+  }
+}
+static void vec_op(int op, double *out, const double *a, const double *b, double sc, double sc2, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n);
+}
+void vec_limit_rsqrt(double *d, int n, hipStream_t s) { vec_op(0, d, nullptr, nullptr, 0, 0, n, s); }
+void vec_limit(double *d, int n, hipStream_t s) { vec_op(1, d, nullptr, nullptr, 0, 0, n, s); }
+void vec_ew_prod(double *out, const double *a, const double *b, int n, hipStream_t s) { vec_op(2, out, a, b, 0, 0, n, s); }
+void vec_ew_recip(double *out, const double *a, int n, hipStream_t s) { vec_op(3, out, a, nullptr, 0, 0, n, s); }
+void vec_scale(double *x, double a, int n, hipStream_t s) { vec_op(4, x, nullptr, nullptr, a, 0, n, s); }
+void vec_set(double *x, double a, int n, hipStream_t s) { vec_op(5, x, nullptr, nullptr, a, 0, n, s); }
+void vec_copy(double *dst, const double *src, int n, hipStream_t s) { vec_op(6, dst, src, nullptr, 0, 0, n, s); }
+void vec_scale_by_vec_scalar(double *x, const double *d, double a, int n, hipStream_t s) { vec_op(7, x, d, nullptr, a, 0, n, s); }
+void vec_axpy(double *y, double a, const double *x, int n, hipStream_t s) { vec_op(8, y, x, nullptr, a, 0, n, s); }
+void vec_clamp(double *x, double lo, double hi, int n, hipStream_t s) { vec_op(9, x, nullptr, nullptr, lo, hi, n, s); }
+
+// --------------------------------------------------------------------------
+// reductions
+// --------------------------------------------------------------------------
+void zero_slots(double *slots, hipStream_t s) { HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(double) * S_COUNT, s)); }
+
+__global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ x, const double *__restrict__ scale, int n,
+                                                   double *__restrict__ slot) {
+  double m = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    m = nanmax(m, fabs(scale ? scale[i] * x[i] : x[i]));
+  m = block_max(m);
+  if (threadIdx.x == 0) atomic_max_nonneg(slot, m);
+}
+void reduce_absmax(const double *x, const double *scale, int n, double *slot, hipStream_t s) {
+  if (n <= 0) return;
+  int grid = blocks_for(n); if (grid > kReduceBlocks) grid = kReduceBlocks;
+  hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, s, x, scale, n, slot);
+}
+__global__ __launch_bounds__(kBlock) void k_dot_partial(const double *__restrict__ a, const double *__restrict__ b, int n,
+                                                        double *__restrict__ partials) {
+  double v = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v += b ? a[i] * b[i] : a[i];
+  v = block_sum(v);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const double *__restrict__ partials, double *__restrict__ slot) {
+  double v = sum_partials(partials);
+  if (threadIdx.x == 0) *slot = v;
+}
+void reduce_dot(const double *a, const double *b, int n, double *partials, double *slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_dot_partial, dim3(kReduceBlocks), dim3(kBlock), 0, s, a, b, n, partials);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot);
+}
+void reduce_sum(const double *x, int n, double *partials, double *slot, hipStream_t s) { reduce_dot(x, nullptr, n, partials, slot, s); }
+
+// --------------------------------------------------------------------------
+// K1: constraint classification + rho vector
+// --------------------------------------------------------------------------
+#define RHO_MIN 1e-6
+#define RHO_EQ_OVER_RHO_INEQ 1e3
+#define RHO_TOL 1e-4
+#define INF_SCALED (OSQP_INFTY * MIN_SCALING)
+__global__ __launch_bounds__(kBlock) void k_rho_vec(int m, const double *__restrict__ l, const double *__restrict__ u,
+                                                    int *__restrict__ ctype, double *__restrict__ rho, double *__restrict__ rho_inv,
+                                                    double rho_s, int mode, int *__restrict__ flag) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  int t = ctype[i];
+  if (mode != 2) {
+    int tn;
+    if (l[i] < -INF_SCALED && u[i] > INF_SCALED) tn = -1;
+    else if (u[i] - l[i] < RHO_TOL) tn = 1;
+    else tn = 0;
+    if (mode == 1) { if (tn == t) return; *flag = 1; }
+    t = tn;
+    ctype[i] = t;
+  } else if (t == -1) return;
+  double r = t == -1 ? RHO_MIN : (t == 1 ? RHO_EQ_OVER_RHO_INEQ * rho_s : rho_s);
+  rho[i] = r;
+  rho_inv[i] = 1.0 / r;
+}
+void rho_vec_update(int m, const double *l, const double *u, int *ctype, double *rho, double *rho_inv, double rho_scalar,
+                    int mode, int *flag, hipStream_t s) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(k_rho_vec, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, l, u, ctype, rho, rho_inv, rho_scalar, mode, flag);
+}
+
+// --------------------------------------------------------------------------
+// K5: ADMM vector updates
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_admm_rhs(int n, int m, double sigma, const double *__restrict__ x_prev,
+                                                     const double *__restrict__ q, const double *__restrict__ z_prev,
+                                                     const double *__restrict__ rho_inv, const double *__restrict__ y,
+                                                     double *__restrict__ xz) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) xz[i] = sigma * x_prev[i] - q[i];
+  else if (i < n + m) { int j = i - n; xz[i] = z_prev[j] - rho_inv[j] * y[j]; }
+}
+void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q, const double *z_prev, const double *rho_inv,
+              const double *y, double *xz, hipStream_t s) {
+  hipLaunchKernelGGL(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz);
+}
+__global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alpha, const double *__restrict__ xz,
+                                                        const double *__restrict__ x_prev, const double *__restrict__ z_prev,
+                                                        const double *__restrict__ rho, const double *__restrict__ rho_inv,
+                                                        const double *__restrict__ l, const double *__restrict__ u,
+                                                        double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
+                                                        double *__restrict__ delta_x, double *__restrict__ delta_y) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    double xp = x_prev[i];
+    double xn = alpha * xz[i] + (1.0 - alpha) * xp;
+    x[i] = xn;
+    delta_x[i] = xn - xp;
+  } else if (i < n + m) {
+    int j = i - n;
+    double zt = xz[i], zp = z_prev[j], yj = y[j];
+    double zh = alpha * zt + (1.0 - alpha) * zp;
+    double zn = zh + rho_inv[j] * yj;
+    zn = fmin(fmax(zn, l[j]), u[j]);
+    z[j] = zn;
+    double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    y[j] = yj + dy;
+  }
+}
+void admm_update(int n, int m, double alpha, const double *xz, const double *x_prev, const double *z_prev, const double *rho,
+                 const double *rho_inv, const double *l, const double *u, double *x, double *z, double *y, double *delta_x,
+                 double *delta_y, hipStream_t s) {
+  hipLaunchKernelGGL(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, x_prev, z_prev, rho,
+                     rho_inv, l, u, x, z, y, delta_x, delta_y);
+}
+
+// --------------------------------------------------------------------------
+// K8: residual norms + objective pieces, one pass over the n- and m-vectors
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_residual_norms(int n, int m, const double *__restrict__ x, const double *__restrict__ z,
+                                                           const double *__restrict__ Ax, const double *__restrict__ Px,
+                                                           const double *__restrict__ Aty, const double *__restrict__ q,
+                                                           const double *__restrict__ Dinv, const double *__restrict__ Einv,
+                                                           double *__restrict__ slots, double *__restrict__ partials) {
+  double v[14];
+#pragma unroll
+  for (int k = 0; k < 14; k++) v[k] = 0.0;
+  double xpx = 0.0, qx = 0.0;
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    double ax = Ax[i], zi = z[i], e = Einv[i], r = ax - zi;
+    v[S_PRI] = nanmax(v[S_PRI], fabs(r));   v[S_PRI_UNS] = nanmax(v[S_PRI_UNS], fabs(e * r));
+    v[S_Z] = nanmax(v[S_Z], fabs(zi));      v[S_AX] = nanmax(v[S_AX], fabs(ax));
+    v[S_Z_UNS] = nanmax(v[S_Z_UNS], fabs(e * zi)); v[S_AX_UNS] = nanmax(v[S_AX_UNS], fabs(e * ax));
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    double px = Px[i], qi = q[i], at = m > 0 ? Aty[i] : 0.0, d = Dinv[i], xi = x[i];
+    double r = (qi + px) + at;
+    v[S_DUA] = nanmax(v[S_DUA], fabs(r));   v[S_DUA_UNS] = nanmax(v[S_DUA_UNS], fabs(d * r));
+    v[S_Q] = nanmax(v[S_Q], fabs(qi));      v[S_ATY] = nanmax(v[S_ATY], fabs(at));   v[S_PX] = nanmax(v[S_PX], fabs(px));
+    v[S_Q_UNS] = nanmax(v[S_Q_UNS], fabs(d * qi)); v[S_ATY_UNS] = nanmax(v[S_ATY_UNS], fabs(d * at));
+    v[S_PX_UNS] = nanmax(v[S_PX_UNS], fabs(d * px));
+    xpx += xi * px; qx += qi * xi;
+  }
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    double b = block_max(v[k]);
+    if (threadIdx.x == 0) atomic_max_nonneg(&slots[k], b);
+  }
+  xpx = block_sum(xpx);
+  qx = block_sum(qx);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = xpx; partials[kReduceBlocks + blockIdx.x] = qx; }
+}
+__global__ __launch_bounds__(kBlock) void k_sum_partials2(const double *__restrict__ partials, double *__restrict__ s0, double *__restrict__ s1) {
+  double a = sum_partials(partials);
+  double b = sum_partials(partials + kReduceBlocks);
+  if (threadIdx.x == 0) { *s0 = a; *s1 = b; }
+}
+void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px, const double *Aty,
+                    const double *q, const double *Dinv, const double *Einv, double *slots, double *partials, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(double) * 16, s));
+  hipLaunchKernelGGL(k_residual_norms, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, x, z, Ax, Px, Aty, q, Dinv, Einv, slots, partials);
+  hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slots + S_XPX, slots + S_QX);
+}
+
+// --------------------------------------------------------------------------
+// K10: infeasibility tests
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_prim_infeas_prep(int m, double *__restrict__ dy, const double *__restrict__ l,
+                                                             const double *__restrict__ u, const double *__restrict__ E,
+                                                             double *__restrict__ slots, double *__restrict__ partials) {
+  double mx = 0.0, sum = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+    double d = dy[i], li = l[i], ui = u[i];
+    if (ui > INF_SCALED) { if (li < -INF_SCALED) d = 0.0; else d = fmin(d, 0.0); }
+    else if (li < -INF_SCALED) d = fmax(d, 0.0);
+    dy[i] = d;
+    mx = nanmax(mx, fabs(E ? E[i] * d : d));
+    sum += ui * fmax(d, 0.0) + li * fmin(d, 0.0);
+  }
+  mx = block_max(mx);
+  sum = block_sum(sum);
+  if (threadIdx.x == 0) { atomic_max_nonneg(&slots[S_T0], mx); partials[blockIdx.x] = sum; }
+}
+void prim_infeas_prep(int m, double *dy, const double *l, const double *u, const double *E, double *slots, double *partials,
+                      hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
+  hipLaunchKernelGGL(k_prim_infeas_prep, dim3(kReduceBlocks), dim3(kBlock), 0, s, m, dy, l, u, E, slots, partials);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slots + S_T1);
+}
+__global__ __launch_bounds__(kBlock) void k_dual_infeas_rows(int m, const double *__restrict__ Adx, const double *__restrict__ Einv,
+                                                             const double *__restrict__ l, const double *__restrict__ u, double thr,
+                                                             double *__restrict__ slots) {
+  double bad = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+    double a = Einv ? Einv[i] * Adx[i] : Adx[i];
+    if ((u[i] < INF_SCALED && a > thr) || (l[i] > -INF_SCALED && a < -thr) || a != a) bad = 1.0;
+  }
+  bad = block_max(bad);
+  if (threadIdx.x == 0 && bad > 0.0) atomic_max_nonneg(&slots[S_T2], bad);
+}
+void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double *l, const double *u, double thr, double *slots,
+                      hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(slots + S_T2, 0, sizeof(double), s));
+  if (m <= 0) return;
+  int grid = blocks_for(m); if (grid > kReduceBlocks) grid = kReduceBlocks;
+  hipLaunchKernelGGL(k_dual_infeas_rows, dim3(grid), dim3(kBlock), 0, s, m, Adx, Einv, l, u, thr, slots);
+}
+
+// --------------------------------------------------------------------------
+// K9: PCG pieces
+// --------------------------------------------------------------------------
+// one 8-lane group per row j of A' (column j of A): d = sigma + P_jj + sum rho_i A_ij^2
+__global__ __launch_bounds__(kBlock) void k_pcg_precond(int n, const int64_t *__restrict__ atp, const int *__restrict__ ati,
+                                                        const double *__restrict__ atx, const int64_t *__restrict__ pp,
+                                                        const int *__restrict__ pi, const double *__restrict__ px,
+                                                        const double *__restrict__ rho, double sigma, double *__restrict__ dinv) {
+  constexpr int G = 8;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  if (j >= n) return;
+  double acc = 0.0;
+  if (atp) for (int64_t k = atp[j] + lane; k < atp[j + 1]; k += G) { double a = atx[k]; acc += rho[ati[k]] * a * a; }
+  for (int64_t k = pp[j] + lane; k < pp[j + 1]; k += G) if (pi[k] == (int)j) acc += px[k];
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) dinv[j] = 1.0 / (sigma + acc);
+}
+void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s) {
+  int n = Pf.rows;
+  hipLaunchKernelGGL(k_pcg_precond, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n,
+                     At.cols > 0 && At.rows > 0 ? At.rowptr.get() : (const int64_t *)nullptr, At.col.get(), At.val.get(),
+                     Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, sigma, dinv);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ w,
+                                                     const double *__restrict__ dinv, double *__restrict__ r, double *__restrict__ zz,
+                                                     double *__restrict__ p, double *__restrict__ partials, double *__restrict__ slot_rn) {
+  double rz = 0.0, mx = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double ri = b[i] - w[i];
+    double zi = dinv[i] * ri;
+    r[i] = ri; zz[i] = zi; p[i] = zi;
+    rz += ri * zi;
+    mx = nanmax(mx, fabs(ri));
+  }
+  rz = block_sum(rz);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = rz; atomic_max_nonneg(slot_rn, mx); }
+}
+void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
+                       double *partials, double *slot_rz, double *slot_rn, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz);
+}
+__global__ __launch_bounds__(kBlock) void k_pcg_update_xr(int n, const double *__restrict__ slot_rz, const double *__restrict__ slot_pw,
+                                                          double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
+                                                          const double *__restrict__ w, const double *__restrict__ dinv,
+                                                          double *__restrict__ zz, double *__restrict__ partials,
+                                                          double *__restrict__ slot_rn) {
+  const double alpha = *slot_rz / *slot_pw;
+  double rz = 0.0, mx = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    x[i] += alpha * p[i];
+    double ri = r[i] - alpha * w[i];
+    double zi = dinv[i] * ri;
+    r[i] = ri; zz[i] = zi;
+    rz += ri * zi;
+    mx = nanmax(mx, fabs(ri));
+  }
+  rz = block_sum(rz);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = rz; atomic_max_nonneg(slot_rn, mx); }
+}
+void pcg_update_xr(int n, const double *slot_rz, const double *slot_pw, double *x, const double *p, double *r, const double *w,
+                   const double *dinv, double *zz, double *partials, double *slot_rz_new, double *slot_rn, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_pcg_update_xr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, slot_rz, slot_pw, x, p, r, w, dinv, zz, partials, slot_rn);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz_new);
+}
+__global__ __launch_bounds__(kBlock) void k_pcg_update_p(int n, const double *__restrict__ slot_rz_new, const double *__restrict__ slot_rz,
+                                                         const double *__restrict__ zz, double *__restrict__ p) {
+  const double beta = *slot_rz_new / *slot_rz;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) p[i] = zz[i] + beta * p[i];
+}
+void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s) {
+  hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p);
+}
+__global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, const double *__restrict__ num, const double *__restrict__ den,
+                                                     const double *__restrict__ x, int n) {
+  const double a = *num / *den;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_axpy_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, y, slot_num, slot_den, x, n);
+}
+
+}  // namespace oq

@@ -1,0 +1,91 @@
+// kernels.hpp -- launchers of the hand-written gfx950 kernels (kernels.hip).
+// Rows K0-K10 of SURVEY.md section 8a; each launcher names its row.
+#pragma once
+#include "common.hpp"
+
+namespace oq {
+
+// ---------------- sparse structure (setup only) ----------------
+// out[k] = column id of CSC entry k (binary search in colptr)
+void expand_colptr(int cols, const int64_t *colptr, int64_t nnz, int *out, hipStream_t s);
+// exclusive scan of counts[0..n) into out[0..n] (out[n] = total), 64-bit
+void exclusive_scan(const int64_t *counts, int64_t *out, int64_t n, hipStream_t s);
+// Build CSR (rowptr/col/src) from E coordinate entries; entries with erow < 0 are dropped.
+// src[pos] = index e of the entry stored at pos.  Rows come out sorted by (col, e).
+void csr_from_coo(int rows, int cols, int64_t E, const int *erow, const int *ecol, DevCsr &out,
+                  DevBuf<int> &src, hipStream_t s);
+void gather_values(int64_t nnz, const int *src, const double *in, double *out, int64_t modulo, hipStream_t s);
+void invert_map(int64_t nnz, const int *src, int64_t lo, int64_t hi, int *k2pos, hipStream_t s);
+void convert_i64_i32(int64_t n, const int64_t *in, int *out, hipStream_t s);
+// choose lanes-per-row for the SpMV kernel from the mean row length
+int pick_group(int rows, int64_t nnz);
+
+// ---------------- K6 / K7: CSR SpMV ----------------
+// y[i] = (rscale ? rscale[i] : 1) * sum_k val[k] x[col[k]] + beta * y[i] + gamma * v[i]
+void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
+          const double *v, hipStream_t s);
+
+// ---------------- K0: Ruiz equilibration pieces ----------------
+void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);  // out[i] = max(|row i|) (or max with old)
+// order 0: (v*r[row])*c[col]; 1: symmetric (v*r[min])*r[max]; 2: (v*c[col])*r[row]; then *scalar
+void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s);
+void vec_limit_rsqrt(double *d, int n, hipStream_t s);  // d <- 1/sqrt(limit(d))
+void vec_limit(double *d, int n, hipStream_t s);
+void vec_ew_prod(double *out, const double *a, const double *b, int n, hipStream_t s);       // out = a.*b
+void vec_ew_recip(double *out, const double *a, int n, hipStream_t s);                       // out = 1./a
+void vec_scale(double *x, double a, int n, hipStream_t s);                                   // x *= a
+void vec_set(double *x, double a, int n, hipStream_t s);
+void vec_copy(double *dst, const double *src, int n, hipStream_t s);
+void vec_scale_by_vec_scalar(double *x, const double *d, double a, int n, hipStream_t s);    // x = (x.*d)*a
+void vec_axpy(double *y, double a, const double *x, int n, hipStream_t s);                   // y += a x
+void vec_clamp(double *x, double lo, double hi, int n, hipStream_t s);
+
+// ---------------- reductions ----------------
+void zero_slots(double *slots, hipStream_t s);
+void reduce_absmax(const double *x, const double *scale, int n, double *slot, hipStream_t s);  // slot = max(slot, |scale.*x|)
+void reduce_sum(const double *x, int n, double *partials, double *slot, hipStream_t s);        // deterministic two-stage
+void reduce_dot(const double *a, const double *b, int n, double *partials, double *slot, hipStream_t s);
+
+// ---------------- K1: constraint classification + rho vector ----------------
+// mode 0: set types from bounds and fill rho (setup); mode 1: re-classify, flag[0] set if any type changed;
+// mode 2: keep types, refresh rho / rho_inv from the new scalar rho.
+void rho_vec_update(int m, const double *l, const double *u, int *ctype, double *rho, double *rho_inv,
+                    double rho_scalar, int mode, int *flag, hipStream_t s);
+
+// ---------------- K5: ADMM vector updates ----------------
+void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q, const double *z_prev,
+              const double *rho_inv, const double *y, double *xz, hipStream_t s);
+void admm_update(int n, int m, double alpha, const double *xz, const double *x_prev, const double *z_prev,
+                 const double *rho, const double *rho_inv, const double *l, const double *u, double *x, double *z,
+                 double *y, double *delta_x, double *delta_y, hipStream_t s);
+
+// ---------------- K8: residual norms + objective pieces ----------------
+void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px,
+                    const double *Aty, const double *q, const double *Dinv, const double *Einv, double *slots,
+                    double *partials, hipStream_t s);
+
+// ---------------- K10: infeasibility tests ----------------
+// projects delta_y onto the polar of the recession cone of [l,u] (in place), then
+// slots[S_T0] = ||E.*dy||inf (E may be null), slots[S_T1] = u'max(dy,0) + l'min(dy,0)
+void prim_infeas_prep(int m, double *dy, const double *l, const double *u, const double *E, double *slots,
+                      double *partials, hipStream_t s);
+// slots[S_T2] = number of rows violating the dual-infeasibility sign conditions
+void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double *l, const double *u, double thr,
+                      double *slots, hipStream_t s);
+
+// ---------------- K9: PCG pieces ----------------
+// dinv[j] = 1 / (sigma + Pdiag[j] + sum_i rho[i] A[i,j]^2) with At = CSR of A'
+void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s);
+// r = b - w; zz = dinv.*r; p = zz; partials -> slot rz = r'zz ; slot rn = ||r||inf
+void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
+                       double *partials, double *slot_rz, double *slot_rn, hipStream_t s);
+// alpha = rz / pw (read from slots); x += alpha p; Ax += alpha t...; r -= alpha w; zz = dinv r; -> rz_new, ||r||inf
+void pcg_update_xr(int n, const double *slot_rz, const double *slot_pw, double *x, const double *p, double *r,
+                   const double *w, const double *dinv, double *zz, double *partials, double *slot_rz_new,
+                   double *slot_rn, hipStream_t s);
+// beta = rz_new / rz ; p = zz + beta p
+void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s);
+// y += (slot_num/slot_den) * x   (device-side scalar)
+void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s);
+
+}  // namespace oq

@@ -1,0 +1,116 @@
+// pcg.hip -- indirect KKT back-end (row K9 of SURVEY.md section 8a).
+//
+// Eliminating nu from [P + sigma I, A'; A, -diag(rho)^-1] [x~; nu] = [r_x; r_z] gives
+//     M x~ = r_x + A'(rho .* r_z),   M = P + sigma I + A' diag(rho) A,   z~ = A x~,
+// solved by Jacobi-preconditioned CG warm-started from the previous x~.  Needed for
+// the random-sparsity configs, whose LDL' factor cannot fit in any memory
+// (SURVEY.md section 0.3).  CPU statement: oracle/pcg.c.
+//
+// Per CG iteration: 3 SpMV (A p, P p, A' t) + 2 fused vector kernels; the scalars
+// alpha and beta never leave the device (read from reduction slots by the next
+// kernel); the host reads back ||r||inf and p'Mp once per iteration for the
+// stopping test.
+#include "engine.hpp"
+
+#include <cmath>
+
+namespace oq {
+
+namespace {
+
+struct Pcg : Linsys {
+  Engine &e;
+  DevBuf<double> xs, r, zz, p, w, t, b1, dinv;
+  long long total_iters = 0;
+  int max_iter = 20000;
+  // slots: S_T0 rz (ping), S_T1 rz (pong), S_T2 pw, S_T3 ||r||inf, S_T4 ||b1||inf
+  explicit Pcg(Engine &en) : e(en) {
+    size_t n = e.n, m = e.m;
+    xs.alloc(n); r.alloc(n); zz.alloc(n); p.alloc(n); w.alloc(n); b1.alloc(n); dinv.alloc(n); t.alloc(m);
+    xs.zero(e.stream);
+    precond();
+  }
+  int kind() const override { return 2; }
+  double cg_iters() const override { return (double)total_iters; }
+
+  void precond() { pcg_precond(e.At, e.Pf, e.rho.get(), e.st.sigma, dinv.get(), e.stream); }
+
+  // out = (P + sigma I + A' rho A) v
+  void apply_M(const double *v, double *out) {
+    hipStream_t s = e.stream;
+    if (e.m > 0) spmv(e.A, v, t.get(), e.rho.get(), 0.0, 0.0, nullptr, s);   // t = rho .* (A v)
+    spmv(e.Pf, v, out, nullptr, 0.0, e.st.sigma, v, s);                      // out = P v + sigma v
+    if (e.m > 0) spmv(e.At, t.get(), out, nullptr, 1.0, 0.0, nullptr, s);     // out += A' t
+  }
+
+  int solve(double *xz, double cand) override {
+    hipStream_t s = e.stream;
+    const int n = e.n, m = e.m;
+    double *slots = e.slots.get();
+    // b1 = r_x + A'(rho .* r_z)
+    if (m > 0) {
+      vec_ew_prod(t.get(), e.rho.get(), xz + n, m, s);
+      spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s);
+    } else {
+      vec_copy(b1.get(), xz, n, s);
+    }
+    HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
+    reduce_absmax(b1.get(), nullptr, n, slots + S_T4, s);
+    // r = b1 - M x0 ; zz = dinv r ; p = zz
+    apply_M(xs.get(), w.get());
+    pcg_init_residual(n, b1.get(), w.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0,
+                      slots + S_T3, s);
+    e.fetch_slots();
+    const double bnorm = e.h_slots[S_T4];
+    // tolerance rule (same statement as oracle/osqp_oracle.c pcg_tolerance)
+    const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
+    double tol = hi;
+    if (cand >= 0.0) tol = cand;
+    if (!(tol < hi)) tol = hi;
+    if (tol < lo) tol = lo;
+    double rn = e.h_slots[S_T3];
+    int it = 0, cur = 0;  // cur: which of S_T0/S_T1 holds the current r'z
+    int status = 0;
+    while (it < max_iter) {
+      if (rn <= tol) break;
+      if (rn != rn) { status = 5; break; }
+      apply_M(p.get(), w.get());
+      reduce_dot(p.get(), w.get(), n, e.partials.get(), slots + S_T2, s);
+      pcg_update_xr(n, slots + S_T0 + cur, slots + S_T2, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(),
+                    e.partials.get(), slots + S_T0 + (1 - cur), slots + S_T3, s);
+      pcg_update_p(n, slots + S_T0 + (1 - cur), slots + S_T0 + cur, zz.get(), p.get(), s);
+      e.fetch_slots();
+      if (!(e.h_slots[S_T2] > 0.0)) { status = 5; break; }  // p'Mp <= 0: M is not positive definite
+      rn = e.h_slots[S_T3];
+      cur = 1 - cur;
+      it++;
+    }
+    total_iters += it;
+    vec_copy(xz, xs.get(), n, s);
+    if (m > 0) spmv(e.A, xs.get(), xz + n, nullptr, 0.0, 0.0, nullptr, s);
+    return status;
+  }
+  int update_rho() override { precond(); return 0; }
+  int update_matrices() override { precond(); return 0; }
+  void set_guess(const double *x) override { vec_copy(xs.get(), x, e.n, e.stream); }
+  float time_solve(int reps) override {
+    // one operator application (3 SpMV) as the unit of the indirect back-end
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    apply_M(p.get(), w.get());
+    HIP_CHECK(hipEventRecord(a, e.stream));
+    for (int i = 0; i < reps; i++) apply_M(p.get(), w.get());
+    HIP_CHECK(hipEventRecord(b, e.stream));
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ms / (float)reps;
+  }
+};
+
+}  // namespace
+
+std::unique_ptr<Linsys> make_pcg(Engine &e) { return std::unique_ptr<Linsys>(new Pcg(e)); }
+
+}  // namespace oq
