@@ -29,6 +29,27 @@ void set_last_error(const std::string &m);
                              ":" + std::to_string(__LINE__));                                       \
   } while (0)
 
+// Every kernel launch goes through OQ_LAUNCH: launch errors are always checked;
+// with OSQP_AMD_DEBUG=1 each launch is announced on stderr and synchronised, so a
+// faulting kernel is the last name printed.
+extern int g_debug_sync;
+inline void post_launch(const char *name, hipStream_t s) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw Error(6, std::string("launch of ") + name + " failed: " + hipGetErrorString(e));
+  if (g_debug_sync) {
+    fprintf(stderr, "[osqp-amd] %s ... ", name);
+    fflush(stderr);
+    e = hipStreamSynchronize(s);
+    fprintf(stderr, "%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+    if (e != hipSuccess) throw Error(6, std::string("kernel ") + name + " failed: " + hipGetErrorString(e));
+  }
+}
+#define OQ_LAUNCH(kern, grid, block, shmem, stream, ...)                    \
+  do {                                                                      \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);      \
+    oq::post_launch(#kern, stream);                                         \
+  } while (0)
+
 // ---- device buffers -------------------------------------------------------
 extern size_t g_device_bytes;  // bytes currently allocated through DevBuf
 

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int *p, int v) {
 }
 
 void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
-                          DevBuf<int> &Ai, DevBuf<double> &Ax, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
+                          DevBuf<int> &Ai, DevBuf<double> &Ax_in, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
                           const OSQPSettings &s) {
   n = n_; m = m_; st = s;
   HIP_CHECK(hipGetDevice(&device));
@@ -106,7 +106,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
 
   // ---- A' is the caller's CSC as it comes; A (CSR) is its transpose ----
   At.rows = n; At.cols = m; At.nnz = nnzA;
-  At.rowptr = std::move(Ap); At.col = std::move(Ai); At.val = std::move(Ax);
+  At.rowptr = std::move(Ap); At.col = std::move(Ai); At.val = std::move(Ax_in);
   At.group = pick_group(n, nnzA);
   {
     DevBuf<int> colid((size_t)nnzA), src;
@@ -122,7 +122,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     DevBuf<int> colid((size_t)nnzPtriu), erow((size_t)(2 * nnzPtriu)), ecol((size_t)(2 * nnzPtriu)), src;
     expand_colptr(n, Pp.get(), nnzPtriu, colid.get(), stream);
     if (nnzPtriu > 0)
-      hipLaunchKernelGGL(k_sym_coo, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, Pi.get(), colid.get(),
+      OQ_LAUNCH(k_sym_coo, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, Pi.get(), colid.get(),
                          erow.get(), ecol.get(), flag.get());
     int bad = 0;
     flag.download(&bad, 1, stream);
@@ -132,7 +132,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     gather_values(Pf.nnz, src.get(), Px.get(), Pf.val.get(), nnzPtriu, stream);
     P_k2lo.alloc((size_t)nnzPtriu); P_k2up.alloc((size_t)nnzPtriu);
     if (nnzPtriu > 0) {
-      hipLaunchKernelGGL(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
+      OQ_LAUNCH(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
       invert_map(Pf.nnz, src.get(), 0, nnzPtriu, P_k2lo.get(), stream);
       invert_map(Pf.nnz, src.get(), nnzPtriu, 2 * nnzPtriu, P_k2up.get(), stream);
     }
@@ -662,7 +662,7 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
     DevBuf<long long> di;
     dv.upload(vals, (size_t)k, stream);
     if (idx) { di.alloc((size_t)k); di.upload((const long long *)idx, (size_t)k, stream); }
-    hipLaunchKernelGGL(k_scatter_vals, dim3(blocks_for(k)), dim3(kBlock), 0, stream, (int64_t)k, idx ? di.get() : (const long long *)nullptr,
+    OQ_LAUNCH(k_scatter_vals, dim3(blocks_for(k)), dim3(kBlock), 0, stream, (int64_t)k, idx ? di.get() : (const long long *)nullptr,
                        dv.get(), t1, map1, t2, map2);
     sync();
   };

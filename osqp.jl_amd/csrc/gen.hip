@@ -130,12 +130,12 @@ void generate_problem(int kind, int n, int per_row, unsigned long long seed, hip
     q.alloc(n); l.alloc(m); u.alloc(m);
     DevBuf<unsigned long long> S((size_t)n);
     S.zero(s);
-    hipLaunchKernelGGL(k_gen_A, dim3(blocks_for(std::max<long long>(nnzA, n + 1))), dim3(kBlock), 0, s, (long long)n, m, k, seed,
+    OQ_LAUNCH(k_gen_A, dim3(blocks_for(std::max<long long>(nnzA, n + 1))), dim3(kBlock), 0, s, (long long)n, m, k, seed,
                        Ap.get(), Ai.get(), Ax.get());
-    hipLaunchKernelGGL(k_gen_U, dim3(blocks_for(((long long)n + 1) * 64)), dim3(kBlock), 0, s, (long long)n, kp, seed, Pp.get(),
+    OQ_LAUNCH(k_gen_U, dim3(blocks_for(((long long)n + 1) * 64)), dim3(kBlock), 0, s, (long long)n, kp, seed, Pp.get(),
                        Pi.get(), Px.get(), S.get());
-    hipLaunchKernelGGL(k_gen_diag, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, Pp.get(), Px.get(), S.get());
-    hipLaunchKernelGGL(k_gen_vecs, dim3(blocks_for(std::max<long long>(n, m))), dim3(kBlock), 0, s, (long long)n, m, seed, q.get(),
+    OQ_LAUNCH(k_gen_diag, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, Pp.get(), Px.get(), S.get());
+    OQ_LAUNCH(k_gen_vecs, dim3(blocks_for(std::max<long long>(n, m))), dim3(kBlock), 0, s, (long long)n, m, seed, q.get(),
                        l.get(), u.get());
     HIP_CHECK(hipStreamSynchronize(s));
     return;
@@ -146,7 +146,7 @@ void generate_problem(int kind, int n, int per_row, unsigned long long seed, hip
     Pp.alloc((size_t)n + 1); Pi.alloc(n); Px.alloc(n);
     Ap.alloc((size_t)n + 1); Ai.alloc(2 * (size_t)n); Ax.alloc(2 * (size_t)n);
     q.alloc(n); l.alloc(m); u.alloc(m);
-    hipLaunchKernelGGL(k_gen_lasso, dim3(blocks_for((long long)n + 1)), dim3(kBlock), 0, s, (long long)n, seed, Pp.get(), Pi.get(),
+    OQ_LAUNCH(k_gen_lasso, dim3(blocks_for((long long)n + 1)), dim3(kBlock), 0, s, (long long)n, seed, Pp.get(), Pi.get(),
                        Px.get(), Ap.get(), Ai.get(), Ax.get(), q.get(), l.get(), u.get());
     HIP_CHECK(hipStreamSynchronize(s));
     return;

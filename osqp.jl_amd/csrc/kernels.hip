@@ -12,6 +12,7 @@
 namespace oq {
 
 size_t g_device_bytes = 0;
+int g_debug_sync = getenv("OSQP_AMD_DEBUG") ? atoi(getenv("OSQP_AMD_DEBUG")) : 0;
 
 // --------------------------------------------------------------------------
 // device helpers
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_colptr(int cols, const int64_
 }
 void expand_colptr(int cols, const int64_t *colptr, int64_t nnz, int *out, hipStream_t s) {
   if (nnz == 0) return;
-  hipLaunchKernelGGL(k_expand_colptr, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, cols, colptr, nnz, out);
+  OQ_LAUNCH(k_expand_colptr, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, cols, colptr, nnz, out);
 }
 
 constexpr int kScanItems = 4;
@@ -108,20 +109,20 @@ __global__ void k_set_i64(int64_t *p, const int64_t *a, const int64_t *b) { *p =
 static void scan_rec(const int64_t *in, int64_t *out, int64_t n, hipStream_t s) {
   int tiles = blocks_for(n, kScanTile);
   if (tiles == 1) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, s, in, out, n, (int64_t *)nullptr);
+    OQ_LAUNCH(k_scan_tiles, dim3(1), dim3(kBlock), 0, s, in, out, n, (int64_t *)nullptr);
     return;
   }
   DevBuf<int64_t> sums(tiles), offs(tiles);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, s, in, out, n, sums.get());
+  OQ_LAUNCH(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, s, in, out, n, sums.get());
   scan_rec(sums.get(), offs.get(), tiles, s);
-  hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBlock), 0, s, out, n, offs.get());
+  OQ_LAUNCH(k_scan_add, dim3(tiles), dim3(kBlock), 0, s, out, n, offs.get());
   HIP_CHECK(hipStreamSynchronize(s));  // sums/offs are freed on return
 }
 void exclusive_scan(const int64_t *counts, int64_t *out, int64_t n, hipStream_t s) {
   // out has n+1 entries; scan the n counts, then out[n] = out[n-1] + counts[n-1]
   if (n == 0) { HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int64_t), s)); return; }
   scan_rec(counts, out, n, s);
-  hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, s, out + n, out + n - 1, counts + n - 1);
+  OQ_LAUNCH(k_set_i64, dim3(1), dim3(1), 0, s, out + n, out + n - 1, counts + n - 1);
 }
 
 __global__ __launch_bounds__(kBlock) void k_count_rows(int64_t E, const int *__restrict__ erow, int64_t *__restrict__ counts) {
@@ -195,7 +196,7 @@ void csr_from_coo(int rows, int cols, int64_t E, const int *erow, const int *eco
   DevBuf<int64_t> counts((size_t)rows + 1);
   counts.zero(s);
   out.rowptr.alloc((size_t)rows + 1);
-  if (E > 0) hipLaunchKernelGGL(k_count_rows, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, counts.get());
+  if (E > 0) OQ_LAUNCH(k_count_rows, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, counts.get());
   exclusive_scan(counts.get(), out.rowptr.get(), rows, s);
   int64_t nnz = 0;
   HIP_CHECK(hipMemcpyAsync(&nnz, out.rowptr.get() + rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -206,11 +207,11 @@ void csr_from_coo(int rows, int cols, int64_t E, const int *erow, const int *eco
   src.alloc((size_t)nnz);
   if (nnz > 0) {
     HIP_CHECK(hipMemcpyAsync(counts.get(), out.rowptr.get(), sizeof(int64_t) * (size_t)rows, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_scatter_coo, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, ecol, counts.get(), out.col.get(), src.get());
-    hipLaunchKernelGGL(k_sort_rows_small, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get());
+    OQ_LAUNCH(k_scatter_coo, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, ecol, counts.get(), out.col.get(), src.get());
+    OQ_LAUNCH(k_sort_rows_small, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get());
     DevBuf<int> n_long(1);
     n_long.zero(s);
-    hipLaunchKernelGGL(k_sort_rows_lds, dim3(rows), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get(), n_long.get());
+    OQ_LAUNCH(k_sort_rows_lds, dim3(rows), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get(), n_long.get());
     int h_long = 0;
     n_long.download(&h_long, 1, s);
     HIP_CHECK(hipStreamSynchronize(s));
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_values(int64_t nnz, const int
 }
 void gather_values(int64_t nnz, const int *src, const double *in, double *out, int64_t modulo, hipStream_t s) {
   if (nnz == 0) return;
-  hipLaunchKernelGGL(k_gather_values, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, in, out, modulo);
+  OQ_LAUNCH(k_gather_values, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, in, out, modulo);
 }
 __global__ __launch_bounds__(kBlock) void k_invert_map(int64_t nnz, const int *__restrict__ src, int64_t lo, int64_t hi,
                                                        int *__restrict__ k2pos) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_invert_map(int64_t nnz, const int *_
 }
 void invert_map(int64_t nnz, const int *src, int64_t lo, int64_t hi, int *k2pos, hipStream_t s) {
   if (nnz == 0) return;
-  hipLaunchKernelGGL(k_invert_map, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, lo, hi, k2pos);
+  OQ_LAUNCH(k_invert_map, dim3(blocks_for(nnz)), dim3(kBlock), 0, s, nnz, src, lo, hi, k2pos);
 }
 __global__ __launch_bounds__(kBlock) void k_convert_i64_i32(int64_t n, const int64_t *__restrict__ in, int *__restrict__ out) {
   int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_convert_i64_i32(int64_t n, const int
 }
 void convert_i64_i32(int64_t n, const int64_t *in, int *out, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_convert_i64_i32, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, in, out);
+  OQ_LAUNCH(k_convert_i64_i32, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, in, out);
 }
 
 int pick_group(int rows, int64_t nnz) {
@@ -319,7 +320,7 @@ void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, dou
   const int G = M.group;
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
 #define OQ_SPMV(GG) \
-  hipLaunchKernelGGL(k_spmv<GG>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), x, y, rscale, beta, gamma, v)
+  OQ_LAUNCH(k_spmv<GG>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), x, y, rscale, beta, gamma, v)
   switch (G) {
   case 1: OQ_SPMV(1); break;
   case 2: OQ_SPMV(2); break;
@@ -352,9 +353,9 @@ void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s
   if (M.rows == 0) return;
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
-  if (G == 64) hipLaunchKernelGGL(k_row_absmax<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
-  else if (G == 8) hipLaunchKernelGGL(k_row_absmax<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
-  else hipLaunchKernelGGL(k_row_absmax<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+  if (G == 64) OQ_LAUNCH(k_row_absmax<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+  else if (G == 8) OQ_LAUNCH(k_row_absmax<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
+  else OQ_LAUNCH(k_row_absmax<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
 }
 
 // val[k] = ((val[k] * a) * b) * scalar.  order 0: a = r[row], b = c[col];  order 2: a = c[col], b = r[row]
@@ -386,9 +387,9 @@ void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmet
   if (M.rows == 0 || M.nnz == 0) return;
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
-  if (G == 64) hipLaunchKernelGGL(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
-  else if (G == 8) hipLaunchKernelGGL(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
-  else hipLaunchKernelGGL(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  else if (G == 8) OQ_LAUNCH(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  else OQ_LAUNCH(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
 }
 
 #define MIN_SCALING 1e-4
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_vec_op(int op, double *__restrict__ 
 }
 static void vec_op(int op, double *out, const double *a, const double *b, double sc, double sc2, int n, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n);
+  OQ_LAUNCH(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n);
 }
 void vec_limit_rsqrt(double *d, int n, hipStream_t s) { vec_op(0, d, nullptr, nullptr, 0, 0, n, s); }
 void vec_limit(double *d, int n, hipStream_t s) { vec_op(1, d, nullptr, nullptr, 0, 0, n, s); }
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ x,
 void reduce_absmax(const double *x, const double *scale, int n, double *slot, hipStream_t s) {
   if (n <= 0) return;
   int grid = blocks_for(n); if (grid > kReduceBlocks) grid = kReduceBlocks;
-  hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(kBlock), 0, s, x, scale, n, slot);
+  OQ_LAUNCH(k_absmax, dim3(grid), dim3(kBlock), 0, s, x, scale, n, slot);
 }
 __global__ __launch_bounds__(kBlock) void k_dot_partial(const double *__restrict__ a, const double *__restrict__ b, int n,
                                                         double *__restrict__ partials) {
@@ -455,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_sum_partials(const double *__restric
   if (threadIdx.x == 0) *slot = v;
 }
 void reduce_dot(const double *a, const double *b, int n, double *partials, double *slot, hipStream_t s) {
-  hipLaunchKernelGGL(k_dot_partial, dim3(kReduceBlocks), dim3(kBlock), 0, s, a, b, n, partials);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot);
+  OQ_LAUNCH(k_dot_partial, dim3(kReduceBlocks), dim3(kBlock), 0, s, a, b, n, partials);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot);
 }
 void reduce_sum(const double *x, int n, double *partials, double *slot, hipStream_t s) { reduce_dot(x, nullptr, n, partials, slot, s); }
 
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_rho_vec(int m, const double *__restr
 void rho_vec_update(int m, const double *l, const double *u, int *ctype, double *rho, double *rho_inv, double rho_scalar,
                     int mode, int *flag, hipStream_t s) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(k_rho_vec, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, l, u, ctype, rho, rho_inv, rho_scalar, mode, flag);
+  OQ_LAUNCH(k_rho_vec, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, l, u, ctype, rho, rho_inv, rho_scalar, mode, flag);
 }
 
 // --------------------------------------------------------------------------
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_admm_rhs(int n, int m, double sigma,
 }
 void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q, const double *z_prev, const double *rho_inv,
               const double *y, double *xz, hipStream_t s) {
-  hipLaunchKernelGGL(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz);
+  OQ_LAUNCH(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz);
 }
 __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alpha, const double *__restrict__ xz,
                                                         const double *__restrict__ x_prev, const double *__restrict__ z_prev,
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
 void admm_update(int n, int m, double alpha, const double *xz, const double *x_prev, const double *z_prev, const double *rho,
                  const double *rho_inv, const double *l, const double *u, double *x, double *z, double *y, double *delta_x,
                  double *delta_y, hipStream_t s) {
-  hipLaunchKernelGGL(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, x_prev, z_prev, rho,
+  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, x_prev, z_prev, rho,
                      rho_inv, l, u, x, z, y, delta_x, delta_y);
 }
 
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(kBlock) void k_sum_partials2(const double *__restri
 void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px, const double *Aty,
                     const double *q, const double *Dinv, const double *Einv, double *slots, double *partials, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(double) * 16, s));
-  hipLaunchKernelGGL(k_residual_norms, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, x, z, Ax, Px, Aty, q, Dinv, Einv, slots, partials);
-  hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slots + S_XPX, slots + S_QX);
+  OQ_LAUNCH(k_residual_norms, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, x, z, Ax, Px, Aty, q, Dinv, Einv, slots, partials);
+  OQ_LAUNCH(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slots + S_XPX, slots + S_QX);
 }
 
 // --------------------------------------------------------------------------
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(kBlock) void k_prim_infeas_prep(int m, double *__re
 void prim_infeas_prep(int m, double *dy, const double *l, const double *u, const double *E, double *slots, double *partials,
                       hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
-  hipLaunchKernelGGL(k_prim_infeas_prep, dim3(kReduceBlocks), dim3(kBlock), 0, s, m, dy, l, u, E, slots, partials);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slots + S_T1);
+  OQ_LAUNCH(k_prim_infeas_prep, dim3(kReduceBlocks), dim3(kBlock), 0, s, m, dy, l, u, E, slots, partials);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slots + S_T1);
 }
 __global__ __launch_bounds__(kBlock) void k_dual_infeas_rows(int m, const double *__restrict__ Adx, const double *__restrict__ Einv,
                                                              const double *__restrict__ l, const double *__restrict__ u, double thr,
@@ -628,7 +629,7 @@ void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double
   HIP_CHECK(hipMemsetAsync(slots + S_T2, 0, sizeof(double), s));
   if (m <= 0) return;
   int grid = blocks_for(m); if (grid > kReduceBlocks) grid = kReduceBlocks;
-  hipLaunchKernelGGL(k_dual_infeas_rows, dim3(grid), dim3(kBlock), 0, s, m, Adx, Einv, l, u, thr, slots);
+  OQ_LAUNCH(k_dual_infeas_rows, dim3(grid), dim3(kBlock), 0, s, m, Adx, Einv, l, u, thr, slots);
 }
 
 // --------------------------------------------------------------------------
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_precond(int n, const int64_t *__
 }
 void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s) {
   int n = Pf.rows;
-  hipLaunchKernelGGL(k_pcg_precond, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n,
+  OQ_LAUNCH(k_pcg_precond, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n,
                      At.cols > 0 && At.rows > 0 ? At.rowptr.get() : (const int64_t *)nullptr, At.col.get(), At.val.get(),
                      Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, sigma, dinv);
 }
@@ -675,8 +676,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__rest
 void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
                        double *partials, double *slot_rz, double *slot_rn, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz);
+  OQ_LAUNCH(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz);
 }
 __global__ __launch_bounds__(kBlock) void k_pcg_update_xr(int n, const double *__restrict__ slot_rz, const double *__restrict__ slot_pw,
                                                           double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
@@ -700,8 +701,8 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_xr(int n, const double *_
 void pcg_update_xr(int n, const double *slot_rz, const double *slot_pw, double *x, const double *p, double *r, const double *w,
                    const double *dinv, double *zz, double *partials, double *slot_rz_new, double *slot_rn, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_pcg_update_xr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, slot_rz, slot_pw, x, p, r, w, dinv, zz, partials, slot_rn);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz_new);
+  OQ_LAUNCH(k_pcg_update_xr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, slot_rz, slot_pw, x, p, r, w, dinv, zz, partials, slot_rn);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz_new);
 }
 __global__ __launch_bounds__(kBlock) void k_pcg_update_p(int n, const double *__restrict__ slot_rz_new, const double *__restrict__ slot_rz,
                                                          const double *__restrict__ zz, double *__restrict__ p) {
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_p(int n, const double *__
   if (i < n) p[i] = zz[i] + beta * p[i];
 }
 void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p);
+  OQ_LAUNCH(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p);
 }
 __global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, const double *__restrict__ num, const double *__restrict__ den,
                                                      const double *__restrict__ x, int n) {
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, con
 }
 void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_axpy_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, y, slot_num, slot_den, x, n);
+  OQ_LAUNCH(k_axpy_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, y, slot_num, slot_den, x, n);
 }
 
 }  // namespace oq
