@@ -44,6 +44,7 @@ typedef struct {
   /* scaled residuals of the last update_info (feed the PCG tolerance rule) */
   c_float sc_pri_res, sc_dua_res;
   int have_res;
+  c_float g_seed; int have_seed; /* max(pri, dua) at the start point of the solve */
   c_float pcg_lambda0;  /* initial lambda of the PCG tolerance rule */
   c_float pcg_lambda;   /* current lambda (quartered whenever 25+ iterations gained < 2x) */
   c_float g_ref; c_int it_ref; int have_ref;
@@ -269,6 +270,7 @@ static c_float pcg_tolerance(OSQPWorkspace *w, c_float rhs_norm) {
   c_float hi = 1e-2 * rhs_norm, lo = 1e-13 * rhs_norm + 1e-300;
   c_float t = hi;
   if (pv->have_res) t = pv->pcg_lambda * sqrt(pv->sc_pri_res * pv->sc_dua_res);
+  else if (pv->have_seed) t = pv->pcg_lambda * pv->g_seed;
   if (!(t < hi)) t = hi;
   if (t < lo) t = lo;
   return t;
@@ -735,6 +737,14 @@ c_int osqp_solve(OSQPWorkspace *w) {
   if (!w->settings->warm_start) cold_start(w);
   if (LIN(w)->kind == 2) pcg_set_guess(LIN(w)->pcg, w->x);
   PRIV(w)->have_res = 0; PRIV(w)->have_ref = 0; PRIV(w)->pcg_lambda = PRIV(w)->pcg_lambda0;
+  PRIV(w)->have_seed = 0;
+  if (LIN(w)->kind == 2) { /* seed the PCG tolerance rule with the residuals of the start point */
+    c_float p0 = w->data->m ? compute_pri_res(w, w->x, w->z) : 0.0;
+    c_float d0 = compute_dua_res(w, w->x, w->y);
+    (void)p0; (void)d0;
+    PRIV(w)->g_seed = c_maxf(w->data->m ? PRIV(w)->sc_pri_res : 0.0, PRIV(w)->sc_dua_res);
+    PRIV(w)->have_seed = 1;
+  }
 
   for (iter = 1; iter <= max_iter; iter++) {
     /* time limit (A.3 last bullet) */

@@ -1,6 +1,441 @@
-// direct.hip -- direct KKT back-end (rows K2-K4): placeholder until the LDL' path lands.
+// direct.hip -- direct KKT back-end: numeric LDL' factorisation and sparse
+// triangular solves on the device (rows K2, K3, K4 of SURVEY.md section 8a), and
+// polish (row N1) on top of the same machinery.
+//
+//   K = [P + sigma I, A'; A, -diag(rho)^-1]  =  Pm' L D L' Pm      (quasi-definite: exactly n positive pivots)
+//
+// Host (symbolic.hip): ordering, elimination tree, pattern of L, level schedule.
+// Pivots are numbered level by level (level = height in the elimination tree), so
+// that level l is the contiguous index range [level_ptr[l], level_ptr[l+1]):
+//   * numeric factorisation: left-looking, one wavefront per column, levels in
+//     ascending order (a column only needs columns of lower levels);
+//   * forward solve  L v = b: row-oriented over the CSR copy of L, ascending levels;
+//   * backward solve L' w = D^-1 v: row-oriented over the CSC arrays, descending levels.
+// Runs of narrow levels (the top of the tree) are chained inside one workgroup
+// with barriers instead of one launch per level.
+// Per solve the kernels stream L twice: 2 * (12 nnz(L) + 4 (N+1)) + ~40 N bytes.
+#include <climits>
+#include <cmath>
+
 #include "engine.hpp"
+#include "symbolic.hpp"
+
 namespace oq {
-std::unique_ptr<Linsys> make_direct(Engine &e, int *err) { *err = -1; return nullptr; }
-int polish_run(Engine &e) { return 0; }
+
+namespace {
+
+constexpr int kChainRows = 512;   // levels at most this wide are chained in one workgroup
+constexpr int kChainThreads = 1024;
+
+// ------------------------------------------------------------------ assembly
+__global__ __launch_bounds__(kBlock) void k_diag_init(int N, int n, double sigma, const int *__restrict__ pinv,
+                                                      const double *__restrict__ cdiag, double cconst, double *__restrict__ D) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= N) return;
+  D[pinv[o]] = o < n ? sigma : (cdiag ? -cdiag[o - n] : cconst);
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_P(int64_t nnz, const int64_t *__restrict__ PtoL, const int *__restrict__ k2lo,
+                                                      const double *__restrict__ Pfval, double *__restrict__ Lx, double *__restrict__ D) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t t = PtoL[k];
+  double v = Pfval[k2lo[k]];
+  if (t >= 0) Lx[t] = v; else D[-t - 1] += v;
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_A(int64_t nnz, const int64_t *__restrict__ AtoL, const double *__restrict__ Atval,
+                                                      double *__restrict__ Lx) {
+  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t t = AtoL[k];
+  if (t != INT64_MIN) Lx[t] = Atval[k];
+}
+
+// ------------------------------------------------------------------ K2: numeric LDL'
+// One wavefront per column k of the level.  On entry Lx[col k] and D[k] hold the entries of K
+// (lower part), on exit the column of L and the pivot.  For every j in the row pattern of k
+// (CSR row k, ascending j; column j is final):  c[i] -= L_ij * (L_kj d_j) for the rows i > k of
+// column j, located in column k by binary search; d_k -= L_kj^2 d_j.
+__global__ __launch_bounds__(kBlock) void k_ldl_level(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                      double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                      const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
+                                                      double *__restrict__ D, double *__restrict__ Dinv, int *__restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int k = c0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (k >= c1) return;
+  const int64_t cs = Lp[k], ce = Lp[k + 1];
+  double dk = D[k];
+  for (int64_t q = Rp[k]; q < Rp[k + 1]; q++) {
+    const int j = Rj[q];
+    const int64_t pos = Rmap[q];
+    const double lkj = Lx[pos];
+    const double f = lkj * D[j];
+    dk -= lkj * f;
+    const int64_t je = Lp[j + 1];
+    for (int64_t t = pos + 1 + lane; t < je; t += 64) {
+      const int i = Li[t];
+      const double v = Lx[t] * f;
+      int64_t lo = cs, hi = ce;  // first position in column k with row >= i (it is there: struct(L_j) below k is inside struct(L_k))
+      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (Li[mid] < i) lo = mid + 1; else hi = mid; }
+      Lx[lo] -= v;
+    }
+    __threadfence_block();  // the next j may touch the same entries from other lanes
+  }
+  const bool bad = (dk == 0.0) || (dk != dk);
+  const double dinv = 1.0 / dk;
+  for (int64_t t = cs + lane; t < ce; t += 64) Lx[t] *= dinv;
+  if (lane == 0) {
+    D[k] = dk; Dinv[k] = dinv;
+    if (bad) atomicOr(&status[0], 1);
+    else if (dk > 0.0) atomicAdd(&status[1], 1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
+                                                       double *__restrict__ Rx) {
+  int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q < nnz) Rx[q] = Lx[Rmap[q]];
+}
+
+// ------------------------------------------------------------------ K3 / K4: level-scheduled triangular solves
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_fwd_level(int r0, int r1, const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                      const double *__restrict__ Rx, double *__restrict__ b) {
+  const int lane = threadIdx.x & (G - 1);
+  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
+  if (row >= r1) return;
+  double acc = 0.0;
+  for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) b[row] -= acc;
+}
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                      const double *__restrict__ Lx, const double *__restrict__ Dinv,
+                                                      double *__restrict__ b) {
+  const int lane = threadIdx.x & (G - 1);
+  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
+  if (row >= r1) return;
+  double acc = 0.0;
+  for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += G) acc += Lx[t] * b[Li[t]];
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
+}
+// chains of narrow levels inside one workgroup (4 lanes per row, barrier between levels)
+__global__ __launch_bounds__(kChainThreads) void k_fwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
+                                                             const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                             const double *__restrict__ Rx, double *__restrict__ b) {
+  const int lane = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  for (int l = l0; l < l1; l++) {
+    const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
+    for (int row = r0 + grp; row < r1; row += kChainThreads / 4) {
+      double acc = 0.0;
+      for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += 4) acc += Rx[q] * b[Rj[q]];
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+      if (lane == 0) b[row] -= acc;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kChainThreads) void k_bwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
+                                                             const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                             const double *__restrict__ Lx, const double *__restrict__ Dinv,
+                                                             double *__restrict__ b) {
+  const int lane = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  for (int l = l1 - 1; l >= l0; l--) {
+    const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
+    for (int row = r0 + grp; row < r1; row += kChainThreads / 4) {
+      double acc = 0.0;
+      for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += 4) acc += Lx[t] * b[Li[t]];
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+      if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_perm_in(int N, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ bp) {
+  int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < N) bp[k] = in[perm[k]];
+}
+// ADMM form: x~ = sol_x ; z~ = rhs_z + rho^-1 nu   (SURVEY.md A.2).  plain form: out = sol
+__global__ __launch_bounds__(kBlock) void k_perm_out(int N, int n, const int *__restrict__ pinv, const double *__restrict__ bp,
+                                                     const double *__restrict__ rho_inv, double *__restrict__ out) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= N) return;
+  double v = bp[pinv[o]];
+  if (rho_inv && o >= n) out[o] += rho_inv[o - n] * v; else out[o] = v;
+}
+
+struct Step { int kind; int a, b, G; };  // kind 0: single level [a,b) rows; 1: chain of levels [a,b)
+
+// ------------------------------------------------------------------ factor object
+struct LdlFactor {
+  Engine &e;
+  Symbolic S;
+  int N = 0, n = 0, mr = 0, nlev = 0;
+  double sigma = 0, cconst = 0;
+  DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL;
+  DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
+  DevBuf<double> Lx, Rx, D, Dinv, bp;
+  std::vector<Step> fwd, bwd;
+  long long factorizations = 0;
+
+  LdlFactor(Engine &en, const std::vector<int> &row_map, int mr_, double sigma_, double cconst_, int64_t limit)
+      : e(en), sigma(sigma_), cconst(cconst_) {
+    e.fetch_host_pattern();
+    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, S);
+    if (S.too_large) return;
+    hipStream_t s = e.stream;
+    N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
+    auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
+    up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
+    Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
+    e.sync();
+    build_schedule();
+    // the big index arrays are only needed on the device from here on
+    std::vector<int>().swap(S.Li); std::vector<int>().swap(S.Rj); std::vector<int64_t>().swap(S.Rmap);
+    std::vector<int64_t>().swap(S.PtoL); std::vector<int64_t>().swap(S.AtoL);
+  }
+
+  static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
+
+  void build_schedule() {
+    const auto &lp = S.level_ptr;
+    // forward: level 0 rows have no predecessors (nothing to do); backward: every level (D^-1 applies everywhere)
+    auto make = [&](bool forward) {
+      std::vector<Step> steps;
+      int l = forward ? 1 : 0;
+      while (l < nlev) {
+        int width = lp[l + 1] - lp[l];
+        if (width <= kChainRows) {
+          int l2 = l;
+          while (l2 < nlev && lp[l2 + 1] - lp[l2] <= kChainRows) l2++;
+          steps.push_back({1, l, l2, 4});
+          l = l2;
+        } else {
+          const std::vector<int64_t> &ptr = forward ? S.Rp : S.Lp;
+          double mean = (double)(ptr[lp[l + 1]] - ptr[lp[l]]) / (double)width;
+          steps.push_back({0, lp[l], lp[l + 1], pick(mean)});
+          l++;
+        }
+      }
+      return steps;
+    };
+    fwd = make(true);
+    bwd = make(false);
+    std::reverse(bwd.begin(), bwd.end());
+  }
+
+  // returns 0 ok, 4 zero pivot, 5 wrong inertia
+  int refactor(const double *cdiag) {
+    hipStream_t s = e.stream;
+    Lx.zero(s);
+    status.zero(s);
+    OQ_LAUNCH(k_diag_init, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, n, sigma, pinv.get(), cdiag, cconst, D.get());
+    if (e.nnzPtriu > 0)
+      OQ_LAUNCH(k_scatter_P, dim3(blocks_for(e.nnzPtriu)), dim3(kBlock), 0, s, e.nnzPtriu, PtoL.get(), e.P_k2lo.get(),
+                e.Pf.val.get(), Lx.get(), D.get());
+    if (e.nnzA > 0)
+      OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
+    for (int l = 0; l < nlev; l++) {
+      int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
+      OQ_LAUNCH(k_ldl_level, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(),
+                Rp.get(), Rj.get(), Rmap.get(), D.get(), Dinv.get(), status.get());
+    }
+    if (S.nnzL > 0) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
+    int st[2] = {0, 0};
+    status.download(st, 2, s);
+    e.sync();
+    factorizations++;
+    if (st[0]) return 4;
+    if (st[1] != n) return 5;
+    return 0;
+  }
+
+  void run_steps() {
+    hipStream_t s = e.stream;
+    for (const Step &t : fwd) {
+      if (t.kind == 1) { OQ_LAUNCH(k_fwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rp.get(), Rj.get(), Rx.get(), bp.get()); continue; }
+      dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
+      switch (t.G) {
+      case 1: OQ_LAUNCH(k_fwd_level<1>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
+      case 4: OQ_LAUNCH(k_fwd_level<4>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
+      case 16: OQ_LAUNCH(k_fwd_level<16>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
+      default: OQ_LAUNCH(k_fwd_level<64>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
+      }
+    }
+    for (const Step &t : bwd) {
+      if (t.kind == 1) { OQ_LAUNCH(k_bwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get()); continue; }
+      dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
+      switch (t.G) {
+      case 1: OQ_LAUNCH(k_bwd_level<1>, grid, block, 0, s, t.a, t.b, Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get()); break;
+      case 4: OQ_LAUNCH(k_bwd_level<4>, grid, block, 0, s, t.a, t.b, Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get()); break;
+      case 16: OQ_LAUNCH(k_bwd_level<16>, grid, block, 0, s, t.a, t.b, Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get()); break;
+      default: OQ_LAUNCH(k_bwd_level<64>, grid, block, 0, s, t.a, t.b, Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get()); break;
+      }
+    }
+  }
+
+  // in place on b (length N, KKT order).  rho_inv != nullptr: the ADMM form with the z~ fix-up.
+  void solve(double *b, const double *rho_inv) {
+    hipStream_t s = e.stream;
+    OQ_LAUNCH(k_perm_in, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, perm.get(), b, bp.get());
+    run_steps();
+    OQ_LAUNCH(k_perm_out, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, n, pinv.get(), bp.get(), rho_inv, b);
+  }
+
+  double trisolve_bytes() const { return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N; }
+};
+
+struct Direct : Linsys {
+  Engine &e;
+  std::unique_ptr<LdlFactor> F;
+  explicit Direct(Engine &en) : e(en) {}
+  int kind() const override { return 0; }
+  int solve(double *xz, double) override { F->solve(xz, e.rho_inv.get()); return 0; }
+  int update_rho() override { return F->refactor(e.rho_inv.get()); }
+  int update_matrices() override { return F->refactor(e.rho_inv.get()); }
+  double nnzL() const override { return (double)F->S.nnzL; }
+  double levels() const override { return (double)F->nlev; }
+  double trisolve_bytes() const override { return F->trisolve_bytes(); }
+  double factorizations() const override { return (double)F->factorizations; }
+  float time_solve(int reps) override {
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    F->run_steps();
+    HIP_CHECK(hipEventRecord(a, e.stream));
+    for (int i = 0; i < reps; i++) F->run_steps();
+    HIP_CHECK(hipEventRecord(b, e.stream));
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ms / (float)reps;
+  }
+};
+
+int64_t factor_limit(const Engine &e, bool forced) {
+  if (const char *v = getenv("OSQP_AMD_NNZL_LIMIT")) return atoll(v);
+  (void)e;
+  return forced ? (int64_t)2000000000LL : (int64_t)400000000LL;  // 4e8 entries = 9.6 GB of L (both copies)
+}
+
+}  // namespace
+
+std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
+  *err = 0;
+  std::vector<int> ident(e.m);
+  for (int i = 0; i < e.m; i++) ident[i] = i;
+  std::unique_ptr<Direct> d(new Direct(e));
+  d->F.reset(new LdlFactor(e, ident, e.m, e.st.sigma, 0.0, factor_limit(e, e.st.linsys_solver == AMD_DIRECT_SOLVER)));
+  if (d->F->S.too_large) { *err = -1; return nullptr; }
+  int rc = d->F->refactor(e.rho_inv.get());
+  if (rc) { *err = rc; return nullptr; }
+  return std::unique_ptr<Linsys>(d.release());
+}
+
+// ---------------------------------------------------------------------------
+// Polish: guess the active constraints from (z, y), solve the
+// equality-constrained QP on them through a delta-regularised KKT system with
+// iterative refinement, accept if the residuals improve.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gather_idx(int k, const int *__restrict__ idx, const double *__restrict__ in, double *__restrict__ out) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < k) out[i] = in[idx[i]];
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_idx(int k, const int *__restrict__ idx, const double *__restrict__ in, double *__restrict__ out) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < k) out[idx[i]] = in[i];
+}
+__global__ __launch_bounds__(kBlock) void k_normal_cone(int m, double *__restrict__ z, double *__restrict__ y, const double *__restrict__ l,
+                                                        const double *__restrict__ u) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  double s = z[i] + y[i];
+  double zn = fmin(fmax(s, l[i]), u[i]);
+  z[i] = zn; y[i] = s - zn;
+}
+
+int polish_run(Engine &e) {
+  hipStream_t s = e.stream;
+  const int n = e.n, m = e.m;
+  OSQPInfo *info = e.ws->info;
+  // active sets from the ADMM solution (host decides; m doubles x 4 come back once)
+  std::vector<double> hz(m), hy(m), hl(m), hu(m);
+  e.z.download(hz.data(), m, s); e.y.download(hy.data(), m, s); e.l.download(hl.data(), m, s); e.u.download(hu.data(), m, s);
+  e.sync();
+  std::vector<int> ind_low, ind_upp, row_map(m, -1);
+  for (int i = 0; i < m; i++) if (hz[i] - hl[i] < -hy[i]) ind_low.push_back(i);
+  for (int i = 0; i < m; i++) if (hu[i] - hz[i] < hy[i]) ind_upp.push_back(i);
+  const int n_low = (int)ind_low.size(), n_upp = (int)ind_upp.size(), mr = n_low + n_upp;
+  // rows that are both lower- and upper-active keep their lower slot in the reduced matrix (as the CPU statement does)
+  for (int k = 0; k < n_upp; k++) row_map[ind_upp[k]] = n_low + k;
+  for (int k = 0; k < n_low; k++) row_map[ind_low[k]] = k;
+  std::vector<int> act(mr);
+  for (int k = 0; k < n_low; k++) act[k] = ind_low[k];
+  for (int k = 0; k < n_upp; k++) act[n_low + k] = ind_upp[k];
+
+  LdlFactor F(e, row_map, mr, e.st.delta, -e.st.delta, 400000000LL);
+  if (F.S.too_large) return -1;
+  if (F.refactor(nullptr) != 0) return -1;
+  const int nr = n + mr;
+  DevBuf<double> rhs_red(nr), sol(nr), rhs(nr), yfull(m), Axv(m), px(n), pz(m), py(m);
+  DevBuf<int> dact(mr ? mr : 1);
+  dact.upload(act.data(), mr, s);
+  // rhs_red = [-q ; l_low ; u_upp]
+  vec_copy(rhs_red.get(), e.q.get(), n, s);
+  vec_scale(rhs_red.get(), -1.0, n, s);
+  if (n_low) OQ_LAUNCH(k_gather_idx, dim3(blocks_for(n_low)), dim3(kBlock), 0, s, n_low, dact.get(), e.l.get(), rhs_red.get() + n);
+  if (n_upp) OQ_LAUNCH(k_gather_idx, dim3(blocks_for(n_upp)), dim3(kBlock), 0, s, n_upp, dact.get() + n_low, e.u.get(), rhs_red.get() + n + n_low);
+  // solve, then iterative refinement against the unregularised matrix: rhs = rhs_red - [P x + Ared' y ; Ared x]
+  DevBuf<double> ared_x(mr ? mr : 1);
+  vec_copy(sol.get(), rhs_red.get(), nr, s);
+  F.solve(sol.get(), nullptr);
+  for (int it = 0; it < e.st.polish_refine_iter; it++) {
+    vec_copy(rhs.get(), rhs_red.get(), nr, s);
+    spmv(e.Pf, sol.get(), px.get(), nullptr, 0.0, 0.0, nullptr, s);
+    vec_axpy(rhs.get(), -1.0, px.get(), n, s);
+    if (mr > 0) {
+      yfull.zero(s);
+      OQ_LAUNCH(k_scatter_idx, dim3(blocks_for(mr)), dim3(kBlock), 0, s, mr, dact.get(), sol.get() + n, yfull.get());
+      spmv(e.At, yfull.get(), px.get(), nullptr, 0.0, 0.0, nullptr, s);
+      vec_axpy(rhs.get(), -1.0, px.get(), n, s);
+      spmv(e.A, sol.get(), Axv.get(), nullptr, 0.0, 0.0, nullptr, s);
+      OQ_LAUNCH(k_gather_idx, dim3(blocks_for(mr)), dim3(kBlock), 0, s, mr, dact.get(), Axv.get(), ared_x.get());
+      vec_axpy(rhs.get() + n, -1.0, ared_x.get(), mr, s);
+    }
+    F.solve(rhs.get(), nullptr);
+    vec_axpy(sol.get(), 1.0, rhs.get(), nr, s);
+  }
+  // polished (x, z, y)
+  vec_copy(px.get(), sol.get(), n, s);
+  if (m > 0) spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+  py.zero(s);
+  if (mr > 0) OQ_LAUNCH(k_scatter_idx, dim3(blocks_for(mr)), dim3(kBlock), 0, s, mr, dact.get(), sol.get() + n, py.get());
+  if (m > 0) OQ_LAUNCH(k_normal_cone, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, pz.get(), py.get(), e.l.get(), e.u.get());
+  // residuals at the polished point (same kernels as update_info)
+  spmv(e.A, px.get(), e.Ax.get(), nullptr, 0.0, 0.0, nullptr, s);
+  spmv(e.Pf, px.get(), e.Px_.get(), nullptr, 0.0, 0.0, nullptr, s);
+  if (m > 0) spmv(e.At, py.get(), e.Aty.get(), nullptr, 0.0, 0.0, nullptr, s);
+  residual_norms(n, m, px.get(), pz.get(), e.Ax.get(), e.Px_.get(), e.Aty.get(), e.q.get(), e.Dinv.get(), e.Einv.get(),
+                 e.slots.get(), e.partials.get(), s);
+  e.fetch_slots(16);
+  const double *r = e.h_slots;
+  const bool uns = e.st.scaling && !e.st.scaled_termination;
+  double pol_pri = m == 0 ? 0.0 : (uns ? r[S_PRI_UNS] : r[S_PRI]);
+  double pol_dua = uns ? e.cinv * r[S_DUA_UNS] : r[S_DUA];
+  double pol_obj = 0.5 * r[S_XPX] + r[S_QX];
+  if (e.st.scaling) pol_obj *= e.cinv;
+  bool ok = (pol_pri < info->pri_res && pol_dua < info->dua_res) || (pol_pri < info->pri_res && info->dua_res < 1e-10) ||
+            (pol_dua < info->dua_res && info->pri_res < 1e-10);
+  if (!ok) return -1;
+  info->obj_val = pol_obj; info->pri_res = pol_pri; info->dua_res = pol_dua;
+  vec_copy(e.x.get(), px.get(), n, s);
+  vec_copy(e.z.get(), pz.get(), m, s);
+  vec_copy(e.y.get(), py.get(), m, s);
+  return 1;
+}
+
 }  // namespace oq

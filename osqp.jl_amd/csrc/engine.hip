@@ -293,6 +293,7 @@ void Engine::cold_start() {
 int Engine::kkt_solve() {
   double cand = -1.0;
   if (have_res) cand = lambda * std::sqrt(sc_pri * sc_dua);
+  else if (have_seed) cand = lambda * g_seed;
   return lin->solve(xz.get(), cand);
 }
 
@@ -503,7 +504,17 @@ int Engine::solve() {
   if (st.verbose) printf("iter   objective    pri res    dua res    rho\n");
   if (!st.warm_start) cold_start();
   lin->set_guess(x.get());
-  have_res = false; have_ref = false; lambda = lambda0;
+  have_res = false; have_ref = false; lambda = lambda0; have_seed = false;
+  if (lin->kind() == 2) {  // seed the PCG tolerance rule with the residuals of the start point (as oracle/osqp_oracle.c)
+    spmv(A, x.get(), Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
+    spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
+    if (m > 0) spmv(At, y.get(), Aty.get(), nullptr, 0.0, 0.0, nullptr, stream);
+    residual_norms(n, m, x.get(), z.get(), Ax.get(), Px_.get(), Aty.get(), q.get(), Dinv.get(), Einv.get(), slots.get(),
+                   partials.get(), stream);
+    fetch_slots(16);
+    g_seed = std::max(m == 0 ? 0.0 : h_slots[S_PRI], h_slots[S_DUA]);
+    have_seed = true;
+  }
 
   for (iter = 1; iter <= max_iter; iter++) {
     if (ws->first_run) temp_run_time = info->setup_time + toc();

@@ -73,7 +73,8 @@ struct Engine {
   // PCG tolerance rule state
   double sc_pri = 0, sc_dua = 0, lambda0 = 0.15, lambda = 0.15, g_ref = 0;
   long long it_ref = 0;
-  bool have_res = false, have_ref = false;
+  bool have_res = false, have_ref = false, have_seed = false;
+  double g_seed = 0;
 
   // statistics
   long long admm_iters_total = 0;

@@ -1,0 +1,284 @@
+// symbolic.hip -- host-side symbolic analysis for the direct KKT back-end (see symbolic.hpp).
+// Plain C++ (no device code): ordering + elimination tree + level schedule + pattern of L + scatter maps.
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <numeric>
+
+#include "engine.hpp"
+
+namespace oq {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Fill-reducing ordering: approximate minimum degree on a quotient graph.
+// Nodes are variables until eliminated; an eliminated node becomes an "element"
+// whose member list is the clique it created.  Degrees are the usual upper bound
+// |A_i| + |L_p \ i| + sum_e |L_e \ L_p|; elements swallowed by a new one are dropped.
+// ---------------------------------------------------------------------------
+struct MinDegree {
+  int N;
+  std::vector<std::vector<int>> var_adj, elem_adj, members;
+  std::vector<char> state;  // 0 variable, 1 element, 2 dead
+  std::vector<int> degree, bucket_head, next, prev, stamp, wstamp, wcount;
+  int min_bucket = 0;
+
+  explicit MinDegree(int n) : N(n), var_adj(n), elem_adj(n), members(n), state(n, 0), degree(n, 0), bucket_head(n + 1, -1),
+                              next(n, -1), prev(n, -1), stamp(n, 0), wstamp(n, 0), wcount(n, 0) {}
+
+  void unlink(int i) {
+    if (prev[i] >= 0) next[prev[i]] = next[i]; else bucket_head[degree[i]] = next[i];
+    if (next[i] >= 0) prev[next[i]] = prev[i];
+    next[i] = prev[i] = -1;
+  }
+  void link(int i) {
+    int d = degree[i];
+    prev[i] = -1; next[i] = bucket_head[d];
+    if (bucket_head[d] >= 0) prev[bucket_head[d]] = i;
+    bucket_head[d] = i;
+  }
+
+  void run(std::vector<int> &order) {
+    order.resize(N);
+    for (int i = 0; i < N; i++) degree[i] = (int)var_adj[i].size();
+    for (int i = N - 1; i >= 0; i--) link(i);
+    std::vector<int> clique;
+    int tag = 0;
+    for (int k = 0; k < N; k++) {
+      while (min_bucket < N && bucket_head[min_bucket] < 0) min_bucket++;
+      const int p = bucket_head[min_bucket];
+      unlink(p);
+      order[k] = p;
+      ++tag;
+      stamp[p] = tag;
+      clique.clear();
+      for (int v : var_adj[p])
+        if (state[v] == 0 && stamp[v] != tag) { stamp[v] = tag; clique.push_back(v); }
+      for (int e : elem_adj[p]) {
+        if (state[e] != 1) continue;
+        for (int v : members[e])
+          if (state[v] == 0 && stamp[v] != tag) { stamp[v] = tag; clique.push_back(v); }
+        state[e] = 2;
+        std::vector<int>().swap(members[e]);
+      }
+      state[p] = 1;
+      std::vector<int>().swap(var_adj[p]);
+      std::vector<int>().swap(elem_adj[p]);
+      members[p] = clique;
+      const int csize = (int)clique.size();
+      // |L_e \ L_p| for every live element that touches the new clique
+      for (int i : clique)
+        for (int e : elem_adj[i]) {
+          if (state[e] != 1) continue;
+          if (wstamp[e] != tag) { wstamp[e] = tag; wcount[e] = (int)members[e].size(); }
+          wcount[e]--;
+        }
+      for (int i : clique) {
+        unlink(i);
+        auto &va = var_adj[i];
+        size_t w = 0;
+        for (int v : va)
+          if (state[v] == 0 && stamp[v] != tag) va[w++] = v;
+        va.resize(w);
+        auto &ea = elem_adj[i];
+        w = 0;
+        long long d = 0;
+        for (int e : ea) {
+          if (state[e] != 1) continue;
+          if (wcount[e] == 0) { state[e] = 2; std::vector<int>().swap(members[e]); continue; }  // subset of the new clique
+          ea[w++] = e;
+          d += wcount[e];
+        }
+        ea.resize(w);
+        ea.push_back(p);
+        d += (long long)va.size() + (csize - 1);
+        long long bound = (long long)degree[i] + (csize - 1);
+        if (d > bound) d = bound;
+        if (d > N - k - 2) d = N - k - 2;
+        if (d < 0) d = 0;
+        degree[i] = (int)d;
+        link(i);
+        if (degree[i] < min_bucket) min_bucket = degree[i];
+      }
+    }
+  }
+};
+
+struct Upper {  // upper-triangular pattern, column compressed, with the origin of every entry
+  int N = 0;
+  std::vector<int64_t> p;
+  std::vector<int> i;
+  std::vector<int64_t> origin;  // >= 0: nnz index in triu(P); <= -2: -(nnz index in A) - 2; -1: structural diagonal only
+};
+
+}  // namespace
+
+void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
+                      Symbolic &S) {
+  const int n = P.cols, m = A.rows, N = n + mr;
+  S.n = n; S.mr = mr; S.N = N; S.too_large = false;
+  const int64_t nnzP = P.p[n], nnzA = A.p[n];
+
+  // ---- 1. upper-triangular pattern of K with origins --------------------------------
+  Upper K;
+  K.N = N;
+  std::vector<int64_t> cnt(N + 1, 0);
+  std::vector<char> has_diag(n, 0);
+  for (int j = 0; j < n; j++) {
+    for (int64_t k = P.p[j]; k < P.p[j + 1]; k++) if (P.i[k] == j) has_diag[j] = 1;
+    cnt[j] = (P.p[j + 1] - P.p[j]) + (has_diag[j] ? 0 : 1);
+  }
+  for (int r = 0; r < mr; r++) cnt[n + r] = 1;
+  for (int64_t k = 0; k < nnzA; k++) { int r = row_map[A.i[k]]; if (r >= 0) cnt[n + r]++; }
+  K.p.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) K.p[j + 1] = K.p[j] + cnt[j];
+  K.i.resize(K.p[N]); K.origin.resize(K.p[N]);
+  std::vector<int64_t> fill(K.p.begin(), K.p.end() - 1);
+  for (int j = 0; j < n; j++) {
+    for (int64_t k = P.p[j]; k < P.p[j + 1]; k++) { int64_t q = fill[j]++; K.i[q] = P.i[k]; K.origin[q] = k; }
+    if (!has_diag[j]) { int64_t q = fill[j]++; K.i[q] = j; K.origin[q] = -1; }
+  }
+  for (int j = 0; j < n; j++)
+    for (int64_t k = A.p[j]; k < A.p[j + 1]; k++) {
+      int r = row_map[A.i[k]];
+      if (r < 0) continue;
+      int64_t q = fill[n + r]++;
+      K.i[q] = j; K.origin[q] = -(k + 2);
+    }
+  for (int r = 0; r < mr; r++) { int64_t q = fill[n + r]++; K.i[q] = n + r; K.origin[q] = -1; }
+
+  // ---- 2. fill-reducing ordering -------------------------------------------------------
+  std::vector<int> order;
+  {
+    MinDegree md(N);
+    std::vector<int> deg(N, 0);
+    for (int j = 0; j < N; j++)
+      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) if (K.i[q] < j) { deg[K.i[q]]++; deg[j]++; }
+    for (int i = 0; i < N; i++) md.var_adj[i].reserve(deg[i]);
+    for (int j = 0; j < N; j++)
+      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+        int i = K.i[q];
+        if (i < j) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
+      }
+    md.run(order);
+  }
+  std::vector<int> pinv(N);
+  for (int k = 0; k < N; k++) pinv[order[k]] = k;
+
+  // ---- 3. elimination tree of the permuted matrix, node heights, level renumbering ----
+  // row-wise access to the permuted upper pattern: for column c (permuted), the rows r < c
+  auto build_cols = [&](const std::vector<int> &pv, std::vector<int64_t> &cp, std::vector<int> &ci) {
+    std::vector<int64_t> c2(N + 1, 0);
+    for (int j = 0; j < N; j++)
+      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+        int a = pv[K.i[q]], b = pv[j];
+        if (a != b) c2[std::max(a, b) + 1]++;
+      }
+    for (int j = 0; j < N; j++) c2[j + 1] += c2[j];
+    cp = c2;
+    ci.resize(c2[N]);
+    std::vector<int64_t> f(c2.begin(), c2.end() - 1);
+    for (int j = 0; j < N; j++)
+      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+        int a = pv[K.i[q]], b = pv[j];
+        if (a != b) ci[f[std::max(a, b)]++] = std::min(a, b);
+      }
+  };
+  auto etree_of = [&](const std::vector<int64_t> &cp, const std::vector<int> &ci, std::vector<int> &parent) {
+    parent.assign(N, -1);
+    std::vector<int> anc(N, -1);
+    for (int k = 0; k < N; k++)
+      for (int64_t q = cp[k]; q < cp[k + 1]; q++) {
+        int i = ci[q];
+        while (i != -1 && i < k) {  // path compression towards k
+          int nx = anc[i];
+          anc[i] = k;
+          if (nx == -1) { parent[i] = k; break; }
+          i = nx;
+        }
+      }
+  };
+  std::vector<int64_t> cp;
+  std::vector<int> ci, parent;
+  build_cols(pinv, cp, ci);
+  etree_of(cp, ci, parent);
+  std::vector<int> height(N, 0);
+  for (int k = 0; k < N; k++)
+    if (parent[k] >= 0) height[parent[k]] = std::max(height[parent[k]], height[k] + 1);
+  int nlevels = 0;
+  for (int k = 0; k < N; k++) nlevels = std::max(nlevels, height[k] + 1);
+  // stable counting sort of the pivots by height: children still precede parents, so the fill is unchanged
+  std::vector<int> lp(nlevels + 1, 0);
+  for (int k = 0; k < N; k++) lp[height[k] + 1]++;
+  for (int l = 0; l < nlevels; l++) lp[l + 1] += lp[l];
+  S.level_ptr = lp;
+  std::vector<int> newpos(N);
+  {
+    std::vector<int> f(lp.begin(), lp.end() - 1);
+    for (int k = 0; k < N; k++) newpos[k] = f[height[k]]++;
+  }
+  S.perm.resize(N); S.pinv.resize(N);
+  for (int k = 0; k < N; k++) S.perm[newpos[k]] = order[k];
+  for (int k = 0; k < N; k++) S.pinv[S.perm[k]] = k;
+  build_cols(S.pinv, cp, ci);
+  etree_of(cp, ci, parent);
+
+  // ---- 4. pattern of L: row patterns by climbing the tree from each entry of the row ----
+  std::vector<int64_t> colcount(N, 0);
+  {
+    std::vector<int> mark(N, -1);
+    int64_t total = 0;
+    for (int k = 0; k < N; k++) {
+      mark[k] = k;
+      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; colcount[i]++; total++; }
+      if (total > nnzL_limit) { S.too_large = true; S.nnzL = total; return; }
+    }
+    S.nnzL = total;
+  }
+  S.Lp.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) S.Lp[j + 1] = S.Lp[j] + colcount[j];
+  S.Li.resize(S.nnzL);
+  S.Rp.assign(N + 1, 0);
+  {
+    std::vector<int> mark(N, -1);
+    std::vector<int64_t> f(S.Lp.begin(), S.Lp.end() - 1);
+    for (int k = 0; k < N; k++) {  // rows in increasing order => every column's row list comes out ascending
+      mark[k] = k;
+      int64_t rc = 0;
+      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; S.Li[f[i]++] = k; rc++; }
+      S.Rp[k + 1] = S.Rp[k] + rc;
+    }
+  }
+  // CSR view (row k: columns ascending) with the position of each entry in the CSC arrays
+  S.Rj.resize(S.nnzL); S.Rmap.resize(S.nnzL);
+  {
+    std::vector<int64_t> f(S.Rp.begin(), S.Rp.end() - 1);
+    for (int j = 0; j < N; j++)
+      for (int64_t t = S.Lp[j]; t < S.Lp[j + 1]; t++) { int r = S.Li[t]; int64_t q = f[r]++; S.Rj[q] = j; S.Rmap[q] = t; }
+  }
+
+  // ---- 5. scatter maps from the caller's nnz order into Lx / D ------------------------
+  S.PtoL.assign(nnzP, 0);
+  S.AtoL.assign(nnzA, INT64_MIN);
+  for (int j = 0; j < N; j++)
+    for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+      int64_t org = K.origin[q];
+      if (org == -1) continue;
+      int a = S.pinv[K.i[q]], b = S.pinv[j];
+      int64_t target;
+      if (a == b) target = -(int64_t)a - 1;
+      else {
+        int c = std::min(a, b), r = std::max(a, b);
+        const int *beg = S.Li.data() + S.Lp[c], *end = S.Li.data() + S.Lp[c + 1];
+        const int *it = std::lower_bound(beg, end, r);
+        target = S.Lp[c] + (it - beg);
+      }
+      if (org >= 0) S.PtoL[org] = target; else S.AtoL[-(org + 2)] = target;
+    }
+}
+
+}  // namespace oq
