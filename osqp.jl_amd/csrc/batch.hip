@@ -1,14 +1,620 @@
-// batch.hip -- batched small-QP path (row K11): placeholder.
+// batch.hip -- batched small-QP path (rows K11/K12 of SURVEY.md section 8a,
+// BASELINE.json config 5: 4096 independent MPC QPs, n = 100, m = 200).
+//
+// One workgroup solves one QP from start to finish with everything in LDS:
+//   * the instance's values of A (shared sparsity pattern, CSC order) and of the
+//     full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates;
+//   * the reduced KKT matrix M = P + sigma I + A' diag(rho) A (n x n, 80 KB at
+//     n = 100; the 300 x 300 KKT matrix would not fit) and its Cholesky factor,
+//     rebuilt in place whenever adaptive rho changes rho.
+// Per iteration: b = sigma x - q + A'(rho z - y); L L' x~ = b (one wavefront,
+// vector in LDS); z~ = A x~; the fused x/z/y update; every `check_termination`
+// iterations the same residual / infeasibility tests as the large-problem path.
+// Same algorithm as oracle/osqp_oracle.c with the KKT system in reduced form.
+// There is no communication between instances: the multi-GPU path shards the
+// instance range over ranks and gathers the packed results once (batch.py).
+#include <algorithm>
+#include <cmath>
+
 #include "engine.hpp"
+#include "rng.hpp"
+
+namespace oq {
+namespace {
+
+constexpr int NT = 256;
+#define B_RHO_MIN 1e-6
+#define B_RHO_MAX 1e6
+#define B_MIN_SCALING 1e-4
+#define B_MAX_SCALING 1e4
+#define B_INF (OSQP_INFTY * B_MIN_SCALING)
+
+struct Pattern {        // shared by all instances; device pointers
+  int n, m, nnzA, nnzP, nnzF;
+  const int *Ap, *Ai;               // A, CSC
+  const int *Rp, *Rc, *Rmap;        // A, CSR; Rmap -> position in the CSC value array
+  const int *Fp, *Fc, *Fmap;        // full symmetric P, CSR; Fmap -> position in the triu(P) value array
+};
+
+__device__ __forceinline__ double nmax(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double lim(double v) { v = v < B_MIN_SCALING ? 1.0 : v; return v > B_MAX_SCALING ? B_MAX_SCALING : v; }
+
+// K simultaneous block reductions (max for op 0, sum for op 1); result broadcast to every thread
+template <int K>
+__device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double b = __shfl_xor(a, o, 64); a = op ? a + b : nmax(a, b); }
+    v[k] = a;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < K; k++) red[(threadIdx.x >> 6) * K + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = red[k], b = red[K + k], c = red[2 * K + k], d = red[3 * K + k];
+    v[k] = op ? (a + b) + (c + d) : nmax(nmax(a, b), nmax(c, d));
+  }
+}
+
+struct Lds {
+  double *M, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red;
+  int *ctype;
+  int ld;
+};
+__host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
+  return (size_t)n * (n + 1) + nnzA + nnzF + 9 * (size_t)n + 12 * (size_t)m + 64;
+}
+__host__ __device__ inline size_t lds_bytes(int n, int m, int nnzA, int nnzF) {
+  return lds_doubles(n, m, nnzA, nnzF) * 8 + (size_t)m * 4 + 16;
+}
+__device__ inline Lds carve(double *base, const Pattern &P) {
+  Lds s;
+  const int n = P.n, m = P.m;
+  s.ld = n + 1;
+  double *p = base;
+  s.M = p; p += (size_t)n * s.ld;
+  s.Av = p; p += P.nnzA; s.Pv = p; p += P.nnzF;
+  s.q = p; p += n; s.D = p; p += n; s.x = p; p += n; s.xp = p; p += n; s.xt = p; p += n; s.dx = p; p += n;
+  s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n;
+  s.l = p; p += m; s.u = p; p += m; s.E = p; p += m; s.rho = p; p += m; s.rhoi = p; p += m; s.z = p; p += m; s.y = p; p += m;
+  s.zp = p; p += m; s.zt = p; p += m; s.dy = p; p += m; s.Ax = p; p += m; s.tm = p; p += m;
+  s.red = p; p += 64;
+  s.ctype = (int *)p;
+  return s;
+}
+
+// y = A x (CSR), y = A' x (CSC), y = P x (full symmetric CSR); no barriers inside
+__device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
+  for (int i = threadIdx.x; i < P.m; i += NT) {
+    double a = 0.0;
+    for (int q = P.Rp[i]; q < P.Rp[i + 1]; q++) a += s.Av[P.Rmap[q]] * x[P.Rc[q]];
+    y[i] = a;
+  }
+}
+__device__ __forceinline__ void mul_At(const Pattern &P, const Lds &s, const double *x, double *y) {
+  for (int j = threadIdx.x; j < P.n; j += NT) {
+    double a = 0.0;
+    for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) a += s.Av[k] * x[P.Ai[k]];
+    y[j] = a;
+  }
+}
+__device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const double *x, double *y) {
+  for (int r = threadIdx.x; r < P.n; r += NT) {
+    double a = 0.0;
+    for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) a += s.Pv[q] * x[P.Fc[q]];
+    y[r] = a;
+  }
+}
+
+__device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classify) {
+  for (int i = threadIdx.x; i < P.m; i += NT) {
+    int t;
+    if (classify) {
+      if (s.l[i] < -B_INF && s.u[i] > B_INF) t = -1;
+      else if (s.u[i] - s.l[i] < 1e-4) t = 1;
+      else t = 0;
+      s.ctype[i] = t;
+    } else t = s.ctype[i];
+    double r = t == -1 ? B_RHO_MIN : (t == 1 ? 1e3 * rho : rho);
+    s.rho[i] = r; s.rhoi[i] = 1.0 / r;
+  }
+  __syncthreads();
+}
+
+// M = P + sigma I + A' diag(rho) A (lower triangle), then in-place Cholesky.  Returns false if not positive definite.
+__device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
+  const int n = P.n, ld = s.ld;
+  for (int j = 0; j < n; j++) {
+    for (int i = j + threadIdx.x; i < n; i += NT) {
+      // sparse dot of columns i and j of A weighted by rho (both row lists ascending)
+      int a = P.Ap[i], ae = P.Ap[i + 1], b = P.Ap[j], be = P.Ap[j + 1];
+      double acc = 0.0;
+      while (a < ae && b < be) {
+        int ra = P.Ai[a], rb = P.Ai[b];
+        if (ra == rb) { acc += s.rho[ra] * s.Av[a] * s.Av[b]; a++; b++; }
+        else if (ra < rb) a++; else b++;
+      }
+      s.M[i + j * ld] = acc + (i == j ? sigma : 0.0);
+    }
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n; r += NT)
+    for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) { int c = P.Fc[q]; if (c <= r) s.M[r + c * ld] += s.Pv[q]; }
+  __syncthreads();
+  bool ok = true;
+  for (int j = 0; j < n; j++) {
+    double d = s.M[j + j * ld];
+    if (!(d > 0.0)) ok = false;
+    double dj = sqrt(d);
+    __syncthreads();
+    if (threadIdx.x == 0) s.M[j + j * ld] = dj;
+    double inv = 1.0 / dj;
+    for (int i = j + 1 + threadIdx.x; i < n; i += NT) s.M[i + j * ld] *= inv;
+    __syncthreads();
+    for (int k = j + 1 + (threadIdx.x >> 4); k < n; k += NT / 16) {
+      double lkj = s.M[k + j * ld];
+      for (int i = k + (threadIdx.x & 15); i < n; i += 16) s.M[i + k * ld] -= s.M[i + j * ld] * lkj;
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+
+// wave 0 solves L L' v = b in place (b in LDS); the other waves wait at the caller's barrier
+__device__ void chol_solve_wave0(const Lds &s, int n, volatile double *b) {
+  const int lane = threadIdx.x;
+  const int ld = s.ld;
+  volatile double *M = s.M;
+  for (int j = 0; j < n; j++) {
+    if (lane == (j & 63)) b[j] = b[j] / M[j + j * ld];
+    __builtin_amdgcn_wave_barrier();
+    double wj = b[j];
+    for (int i = j + 1 + lane; i < n; i += 64) b[i] -= M[i + j * ld] * wj;
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    double acc = 0.0;
+    for (int i = j + 1 + lane; i < n; i += 64) acc += M[i + j * ld] * b[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) b[j] = (b[j] - acc) / M[j + j * ld];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+struct Out { double iter, status, pri, dua, obj, rho_updates; };
+
+__global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, int count, const double *__restrict__ Px_all,
+                                                    const double *__restrict__ Ax_all, const double *__restrict__ q_all,
+                                                    const double *__restrict__ l_all, const double *__restrict__ u_all,
+                                                    double *__restrict__ x_out, double *__restrict__ y_out,
+                                                    double *__restrict__ info_out, int info_stride) {
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  const int inst = blockIdx.x;
+  if (inst >= count) return;
+  const int n = P.n, m = P.m, tid = threadIdx.x;
+  Lds s = carve(lds_raw, P);
+  // ---- load the instance -------------------------------------------------
+  for (int k = tid; k < P.nnzA; k += NT) s.Av[k] = Ax_all[(size_t)inst * P.nnzA + k];
+  for (int k = tid; k < P.nnzF; k += NT) s.Pv[k] = Px_all[(size_t)inst * P.nnzP + P.Fmap[k]];
+  for (int j = tid; j < n; j += NT) { s.q[j] = q_all[(size_t)inst * n + j]; s.D[j] = 1.0; s.x[j] = 0.0; s.xp[j] = 0.0; s.dx[j] = 0.0; }
+  for (int i = tid; i < m; i += NT) {
+    s.l[i] = fmax(l_all[(size_t)inst * m + i], -OSQP_INFTY); s.u[i] = fmin(u_all[(size_t)inst * m + i], OSQP_INFTY);
+    s.E[i] = 1.0; s.z[i] = 0.0; s.y[i] = 0.0; s.zp[i] = 0.0; s.dy[i] = 0.0;
+  }
+  __syncthreads();
+  // ---- K0: Ruiz equilibration + cost scaling --------------------------------
+  double c = 1.0;
+  for (int it = 0; it < st.scaling; it++) {
+    for (int j = tid; j < n; j += NT) {
+      double mx = 0.0;
+      for (int q = P.Fp[j]; q < P.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
+      for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) mx = fmax(mx, fabs(s.Av[k]));
+      s.tn[j] = 1.0 / sqrt(lim(mx));
+    }
+    for (int i = tid; i < m; i += NT) {
+      double mx = 0.0;
+      for (int q = P.Rp[i]; q < P.Rp[i + 1]; q++) mx = fmax(mx, fabs(s.Av[P.Rmap[q]]));
+      s.tm[i] = 1.0 / sqrt(lim(mx));
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += NT)
+      for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) {
+        int cc = P.Fc[q];
+        int lo = cc < r ? cc : r, hi = cc < r ? r : cc;
+        s.Pv[q] = (s.Pv[q] * s.tn[lo]) * s.tn[hi];
+      }
+    for (int j = tid; j < n; j += NT) {
+      for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) s.Av[k] = (s.Av[k] * s.tm[P.Ai[k]]) * s.tn[j];
+      s.q[j] *= s.tn[j];
+      s.D[j] *= s.tn[j];
+    }
+    for (int i = tid; i < m; i += NT) s.E[i] *= s.tm[i];
+    __syncthreads();
+    double v[2] = {0.0, 0.0}, w[1] = {0.0};
+    for (int j = tid; j < n; j += NT) {
+      double mx = 0.0;
+      for (int q = P.Fp[j]; q < P.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
+      w[0] += mx;
+      v[0] = fmax(v[0], fabs(s.q[j]));
+    }
+    block_reduce<1>(w, 1, s.red);
+    block_reduce<2>(v, 0, s.red);
+    double c_temp = w[0] / (double)n;
+    c_temp = lim(fmax(c_temp, lim(v[0])));
+    c_temp = 1.0 / c_temp;
+    for (int k = tid; k < P.nnzF; k += NT) s.Pv[k] *= c_temp;
+    for (int j = tid; j < n; j += NT) s.q[j] *= c_temp;
+    c *= c_temp;
+    __syncthreads();
+  }
+  const double cinv = 1.0 / c;
+  for (int i = tid; i < m; i += NT) { s.l[i] *= s.E[i]; s.u[i] *= s.E[i]; }
+  __syncthreads();
+  // ---- K1, K2 ----------------------------------------------------------------
+  double rho = fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX);
+  set_rho(P, s, rho, true);
+  int status = OSQP_UNSOLVED;
+  if (!build_and_factor(P, s, st.sigma)) status = OSQP_NON_CVX;
+  const bool uns = st.scaling && !st.scaled_termination;
+  const int check = (int)st.check_termination;
+  const int rho_interval = st.adaptive_rho ? (st.adaptive_rho_interval ? (int)st.adaptive_rho_interval : 100) : 0;
+  const double alpha = st.alpha, sigma = st.sigma;
+  double pri_res = 0.0, dua_res = 0.0, obj = 0.0;
+  double nrm[14];
+  int iter = 0, rho_updates = 0;
+  bool checked_last = false;
+  double *x = s.x, *xp = s.xp, *z = s.z, *zp = s.zp;
+
+  // residual evaluation (K8): fills nrm[], pri_res, dua_res, obj
+  auto update_info = [&]() {
+    mul_A(P, s, x, s.Ax); mul_P(P, s, x, s.Px); mul_At(P, s, s.y, s.Aty);
+    __syncthreads();
+    double v[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) v[k] = 0.0;
+    double sm[2] = {0.0, 0.0};
+    for (int i = tid; i < m; i += NT) {
+      double ax = s.Ax[i], zi = z[i], e = 1.0 / s.E[i], r = ax - zi;
+      v[0] = nmax(v[0], fabs(r)); v[1] = nmax(v[1], fabs(e * r)); v[2] = nmax(v[2], fabs(zi)); v[3] = nmax(v[3], fabs(ax));
+      v[4] = nmax(v[4], fabs(e * zi)); v[5] = nmax(v[5], fabs(e * ax));
+    }
+    for (int j = tid; j < n; j += NT) {
+      double px = s.Px[j], qj = s.q[j], at = s.Aty[j], d = 1.0 / s.D[j], xj = x[j], r = (qj + px) + at;
+      v[6] = nmax(v[6], fabs(r)); v[7] = nmax(v[7], fabs(d * r)); v[8] = nmax(v[8], fabs(qj)); v[9] = nmax(v[9], fabs(at));
+      v[10] = nmax(v[10], fabs(px)); v[11] = nmax(v[11], fabs(d * qj)); v[12] = nmax(v[12], fabs(d * at)); v[13] = nmax(v[13], fabs(d * px));
+      sm[0] += xj * px; sm[1] += qj * xj;
+    }
+    block_reduce<14>(v, 0, s.red);
+    block_reduce<2>(sm, 1, s.red);
+#pragma unroll
+    for (int k = 0; k < 14; k++) nrm[k] = v[k];
+    pri_res = m == 0 ? 0.0 : (uns ? v[1] : v[0]);
+    dua_res = uns ? cinv * v[7] : v[6];
+    obj = cinv * (0.5 * sm[0] + sm[1]);
+  };
+  // termination tests; returns true when a status was set
+  auto check_termination = [&](bool approx) -> bool {
+    double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
+    if (!(pri_res <= OSQP_INFTY) || !(dua_res <= OSQP_INFTY)) { status = OSQP_NON_CVX; return true; }
+    if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+    bool pc = false, dc = false, pinf = false, dinf = false;
+    if (m == 0) pc = true;
+    else {
+      double eps_p = ea + er * (uns ? nmax(nrm[4], nrm[5]) : nmax(nrm[2], nrm[3]));
+      if (pri_res < eps_p) pc = true;
+      else {  // primal infeasibility on delta_y
+        double v[1] = {0.0}, sm[1] = {0.0};
+        for (int i = tid; i < m; i += NT) {
+          double d = s.dy[i];
+          if (s.u[i] > B_INF) { if (s.l[i] < -B_INF) d = 0.0; else d = fmin(d, 0.0); }
+          else if (s.l[i] < -B_INF) d = fmax(d, 0.0);
+          s.dy[i] = d;
+          v[0] = nmax(v[0], fabs(uns ? s.E[i] * d : d));
+          sm[0] += s.u[i] * fmax(d, 0.0) + s.l[i] * fmin(d, 0.0);
+        }
+        block_reduce<1>(v, 0, s.red);
+        block_reduce<1>(sm, 1, s.red);
+        if (v[0] > epi && sm[0] < -epi * v[0]) {
+          mul_At(P, s, s.dy, s.tn);
+          __syncthreads();
+          double w[1] = {0.0};
+          for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
+          block_reduce<1>(w, 0, s.red);
+          pinf = w[0] < epi * v[0];
+        }
+      }
+    }
+    double eps_d = ea + er * (uns ? cinv * nmax(nrm[11], nmax(nrm[12], nrm[13])) : nmax(nrm[8], nmax(nrm[9], nrm[10])));
+    if (dua_res < eps_d) dc = true;
+    else {  // dual infeasibility on delta_x
+      double v[1] = {0.0}, sm[1] = {0.0};
+      for (int j = tid; j < n; j += NT) { v[0] = nmax(v[0], fabs(uns ? s.D[j] * s.dx[j] : s.dx[j])); sm[0] += s.q[j] * s.dx[j]; }
+      block_reduce<1>(v, 0, s.red);
+      block_reduce<1>(sm, 1, s.red);
+      double cs = uns ? c : 1.0;
+      if (v[0] > edi && sm[0] < -cs * edi * v[0]) {
+        mul_P(P, s, s.dx, s.tn);
+        __syncthreads();
+        double w[1] = {0.0};
+        for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
+        block_reduce<1>(w, 0, s.red);
+        if (w[0] < cs * edi * v[0]) {
+          mul_A(P, s, s.dx, s.tm);
+          __syncthreads();
+          double bad[1] = {0.0};
+          for (int i = tid; i < m; i += NT) {
+            double a = uns ? s.tm[i] / s.E[i] : s.tm[i];
+            if ((s.u[i] < B_INF && a > edi * v[0]) || (s.l[i] > -B_INF && a < -edi * v[0]) || a != a) bad[0] = 1.0;
+          }
+          block_reduce<1>(bad, 0, s.red);
+          dinf = bad[0] == 0.0;
+        }
+      }
+    }
+    if (pc && dc) { status = approx ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED; return true; }
+    if (pinf) { status = approx ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE; return true; }
+    if (dinf) { status = approx ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE; return true; }
+    return false;
+  };
+
+  // ---- ADMM loop --------------------------------------------------------------
+  if (status == OSQP_UNSOLVED) {
+    const int max_iter = (int)st.max_iter;
+    for (iter = 1; iter <= max_iter; iter++) {
+      { double *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
+      // b = sigma x_prev - q + A'(rho z_prev - y)
+      for (int i = tid; i < m; i += NT) s.tm[i] = s.rho[i] * zp[i] - s.y[i];
+      __syncthreads();
+      for (int j = tid; j < n; j += NT) {
+        double a = sigma * xp[j] - s.q[j];
+        for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) a += s.Av[k] * s.tm[P.Ai[k]];
+        s.xt[j] = a;
+      }
+      __syncthreads();
+      if (tid < 64) chol_solve_wave0(s, n, s.xt);
+      __syncthreads();
+      mul_A(P, s, s.xt, s.zt);  // z~ = A x~
+      for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        double zh = alpha * s.zt[i] + (1.0 - alpha) * zp[i];
+        double zn = fmin(fmax(zh + s.rhoi[i] * s.y[i], s.l[i]), s.u[i]);
+        z[i] = zn;
+        double d = s.rho[i] * (zh - zn);
+        s.dy[i] = d; s.y[i] += d;
+      }
+      __syncthreads();
+      checked_last = check && (iter % check == 0);
+      if (checked_last) { update_info(); if (check_termination(false)) break; }
+      if (rho_interval && (iter % rho_interval == 0)) {
+        if (!checked_last) update_info();
+        double pr = m == 0 ? 0.0 : nrm[0] / (nmax(nrm[2], nrm[3]) + 1e-10);
+        double du = nrm[6] / (nmax(nmax(nrm[8], nrm[9]), nrm[10]) + 1e-10);
+        double est = fmin(fmax(rho * sqrt(pr / (du + 1e-10)), B_RHO_MIN), B_RHO_MAX);
+        if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
+          rho = est; rho_updates++;
+          set_rho(P, s, rho, false);
+          if (!build_and_factor(P, s, st.sigma)) { status = OSQP_NON_CVX; break; }
+        }
+      }
+    }
+    if (status == OSQP_UNSOLVED) {  // max_iter reached: last residual evaluation, then the 10x-relaxed tests
+      iter = max_iter;
+      if (!checked_last) { update_info(); check_termination(false); }
+      if (status == OSQP_UNSOLVED && !check_termination(true)) status = OSQP_MAX_ITER_REACHED;
+    }
+  }
+  // ---- store -----------------------------------------------------
+  const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
+  for (int j = tid; j < n; j += NT) x_out[(size_t)inst * n + j] = has_sol ? s.D[j] * x[j] : NAN;
+  for (int i = tid; i < m; i += NT) y_out[(size_t)inst * m + i] = has_sol ? cinv * s.E[i] * s.y[i] : NAN;
+  if (tid == 0) {
+    double *o = info_out + (size_t)inst * info_stride;
+    o[0] = (double)iter; o[1] = (double)status; o[2] = pri_res; o[3] = dua_res;
+    if (info_stride > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MPC instance generator (same statement as gen_mpc in oracle/gen.c); one
+// thread fills one instance.  Also run on the host for instance 0 to obtain the
+// shared sparsity pattern.
+// ---------------------------------------------------------------------------
+constexpr int NX = 6, NU = 4, TT = 10, NS = NX + NU, MPC_N = NS * TT, MPC_M = NX * TT + MPC_N + NU * TT;
+__host__ __device__ inline int mpc_nnzA() {
+  int c = 0;
+  for (int t = 0; t < TT; t++) c += NX * (2 + (t + 1 < TT ? NX : 0)) + NU * (NX + 2 + (t + 1 < TT ? 1 : 0));
+  return c;
+}
+__host__ __device__ inline void mpc_fill(long long inst, unsigned long long seed, int *Ap, int *Ai, double *Ax, double *Pd,
+                                         double *q, double *l, double *u) {
+  const int row_box = NX * TT, row_rate = NX * TT + MPC_N;
+  double Ad[NX][NX], Bd[NX][NU], x0[NX], xref[NX];
+  for (int r = 0; r < NX; r++) {
+    for (int c = 0; c < NX; c++) {
+      double base = (r == c ? 0.9 : 0.0) + ((r - c == 1 || c - r == 1) ? 0.05 : 0.0);
+      Ad[r][c] = base + 0.02 * gauss(seed, G_MPC_A, (unsigned long long)(inst * 36 + r * 6 + c));
+    }
+    for (int c = 0; c < NU; c++)
+      Bd[r][c] = ((r % 4) == c ? 0.5 : 0.0) + 0.1 * gauss(seed, G_MPC_B, (unsigned long long)(inst * 24 + r * 4 + c));
+    x0[r] = gauss(seed, G_MPC_X0, (unsigned long long)(inst * 6 + r));
+    xref[r] = 0.5 * gauss(seed, G_MPC_REF, (unsigned long long)(inst * 6 + r));
+  }
+  int pos = 0, j = 0;
+  for (int t = 0; t < TT; t++) {
+    for (int r = 0; r < NX; r++, j++) {
+      Pd[j] = 1.0 + 0.1 * (double)r;
+      q[j] = -(1.0 + 0.1 * (double)r) * xref[r];
+      if (Ap) Ap[j] = pos;
+      if (Ai) Ai[pos] = NX * t + r;
+      Ax[pos++] = 1.0;
+      if (t + 1 < TT) for (int c = 0; c < NX; c++) { if (Ai) Ai[pos] = NX * (t + 1) + c; Ax[pos++] = -Ad[c][r]; }
+      if (Ai) Ai[pos] = row_box + j;
+      Ax[pos++] = 1.0;
+    }
+    for (int c = 0; c < NU; c++, j++) {
+      Pd[j] = 0.1;
+      q[j] = 0.0;
+      if (Ap) Ap[j] = pos;
+      for (int r = 0; r < NX; r++) { if (Ai) Ai[pos] = NX * t + r; Ax[pos++] = -Bd[r][c]; }
+      if (Ai) Ai[pos] = row_box + j;
+      Ax[pos++] = 1.0;
+      if (Ai) Ai[pos] = row_rate + NU * t + c;
+      Ax[pos++] = 1.0;
+      if (t + 1 < TT) { if (Ai) Ai[pos] = row_rate + NU * (t + 1) + c; Ax[pos++] = -1.0; }
+    }
+  }
+  if (Ap) Ap[MPC_N] = pos;
+  for (int r = 0; r < MPC_M; r++) { l[r] = 0.0; u[r] = 0.0; }
+  for (int r = 0; r < NX; r++) {
+    double sum = 0.0;
+    for (int c = 0; c < NX; c++) sum += Ad[r][c] * x0[c];
+    l[r] = sum; u[r] = sum;
+  }
+  for (int jj = 0; jj < MPC_N; jj++) {
+    double b = (jj % NS) < NX ? 20.0 : 1.0;
+    l[row_box + jj] = -b; u[row_box + jj] = b;
+  }
+  for (int r = 0; r < NU * TT; r++) { l[row_rate + r] = -0.5; u[row_rate + r] = 0.5; }
+}
+__global__ __launch_bounds__(64) void k_gen_mpc(long long first, int count, unsigned long long seed, int nnzA, double *Ax_all,
+                                                double *Pd_all, double *q_all, double *l_all, double *u_all) {
+  int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= count) return;
+  mpc_fill(first + t, seed, nullptr, nullptr, Ax_all + (size_t)t * nnzA, Pd_all + (size_t)t * MPC_N, q_all + (size_t)t * MPC_N,
+           l_all + (size_t)t * MPC_M, u_all + (size_t)t * MPC_M);
+}
+
+// shared pattern on the device, built from host CSC patterns
+struct DevicePattern {
+  Pattern P;
+  DevBuf<int> Ap, Ai, Rp, Rc, Rmap, Fp, Fc, Fmap;
+  void build(int n, int m, const std::vector<int> &hPp, const std::vector<int> &hPi, const std::vector<int> &hAp,
+             const std::vector<int> &hAi, hipStream_t s) {
+    const int nnzA = hAp[n], nnzP = hPp[n];
+    std::vector<int> rp(m + 1, 0), rc(nnzA), rmap(nnzA);
+    for (int k = 0; k < nnzA; k++) rp[hAi[k] + 1]++;
+    for (int i = 0; i < m; i++) rp[i + 1] += rp[i];
+    std::vector<int> f(rp.begin(), rp.end() - 1);
+    for (int j = 0; j < n; j++)
+      for (int k = hAp[j]; k < hAp[j + 1]; k++) { int q = f[hAi[k]]++; rc[q] = j; rmap[q] = k; }
+    // full symmetric pattern, rows sorted by column
+    std::vector<std::vector<std::pair<int, int>>> rows(n);
+    for (int j = 0; j < n; j++)
+      for (int k = hPp[j]; k < hPp[j + 1]; k++) {
+        int i = hPi[k];
+        if (i > j) throw Error(1, "P is not upper triangular");
+        rows[j].push_back({i, k});
+        if (i != j) rows[i].push_back({j, k});
+      }
+    std::vector<int> fp(n + 1, 0), fc, fmap;
+    for (int r = 0; r < n; r++) {
+      std::sort(rows[r].begin(), rows[r].end());
+      for (auto &e : rows[r]) { fc.push_back(e.first); fmap.push_back(e.second); }
+      fp[r + 1] = (int)fc.size();
+    }
+    auto up = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    up(Ap, hAp); up(Ai, hAi); up(Rp, rp); up(Rc, rc); up(Rmap, rmap); up(Fp, fp); up(Fc, fc); up(Fmap, fmap);
+    HIP_CHECK(hipStreamSynchronize(s));
+    P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get()};
+  }
+};
+
+void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, const double *Px, const double *Ax, const double *q,
+                  const double *l, const double *u, double *x, double *y, double *info, int info_stride, hipStream_t s) {
+  const Pattern &P = dp.P;
+  size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF);
+  if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_batch_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  OQ_LAUNCH(k_batch_solve, dim3(count), dim3(NT), bytes, s, P, st, count, Px, Ax, q, l, u, x, y, info, info_stride);
+}
+
+}  // namespace
+}  // namespace oq
+
+using namespace oq;
+
 extern "C" {
-c_int osqp_amd_batch_solve(c_int, c_int, c_int, const c_int *, const c_int *, const c_float *, const c_int *, const c_int *,
-                           const c_float *, const c_float *, const c_float *, const c_float *, const OSQPSettings *, c_float *,
-                           c_float *, OSQPInfo *, c_int) {
-  oq::set_last_error("batched path not built yet");
-  return 6;
+
+c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_float *Px_all, const c_int *Ap,
+                           const c_int *Ai, const c_float *Ax_all, const c_float *q_all, const c_float *l_all, const c_float *u_all,
+                           const OSQPSettings *settings, c_float *x_out, c_float *y_out, OSQPInfo *info_out, c_int device) {
+  try {
+    if (count <= 0 || n <= 0 || m < 0 || !settings) return 1;
+    HIP_CHECK(hipSetDevice((int)device));
+    hipStream_t s = nullptr;
+    std::vector<int> hPp(Pp, Pp + n + 1), hAp(Ap, Ap + n + 1);
+    std::vector<int> hPi(Pi, Pi + Pp[n]), hAi(Ai, Ai + Ap[n]);
+    const int nnzA = hAp[n], nnzP = hPp[n];
+    DevicePattern dp;
+    dp.build((int)n, (int)m, hPp, hPi, hAp, hAi, s);
+    DevBuf<double> dPx((size_t)count * nnzP), dAx((size_t)count * nnzA), dq((size_t)count * n), dl((size_t)count * m), du((size_t)count * m);
+    DevBuf<double> dx((size_t)count * n), dy((size_t)count * m), dinfo((size_t)count * 6);
+    dPx.upload(Px_all, (size_t)count * nnzP, s); dAx.upload(Ax_all, (size_t)count * nnzA, s);
+    dq.upload(q_all, (size_t)count * n, s); dl.upload(l_all, (size_t)count * m, s); du.upload(u_all, (size_t)count * m, s);
+    auto t0 = std::chrono::steady_clock::now();
+    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), dx.get(), dy.get(), dinfo.get(), 6, s);
+    HIP_CHECK(hipDeviceSynchronize());
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> hinfo((size_t)count * 6);
+    dx.download(x_out, (size_t)count * n, s); dy.download(y_out, (size_t)count * m, s); dinfo.download(hinfo.data(), hinfo.size(), s);
+    HIP_CHECK(hipDeviceSynchronize());
+    for (c_int i = 0; i < count; i++) {
+      OSQPInfo &o = info_out[i];
+      memset(&o, 0, sizeof(OSQPInfo));
+      o.iter = (c_int)hinfo[i * 6 + 0];
+      update_status(&o, (c_int)hinfo[i * 6 + 1]);
+      o.pri_res = hinfo[i * 6 + 2]; o.dua_res = hinfo[i * 6 + 3]; o.obj_val = hinfo[i * 6 + 4];
+      o.rho_updates = (c_int)hinfo[i * 6 + 5];
+      o.solve_time = secs; o.run_time = secs;
+      o.rho_estimate = settings->rho;
+    }
+    return 0;
+  } catch (const Error &er) {
+    set_last_error(er.what());
+    return er.code ? er.code : 6;
+  } catch (const std::exception &ex) {
+    set_last_error(ex.what());
+    return 6;
+  }
 }
-c_int osqp_amd_batch_solve_generated(c_int, c_int, unsigned long long, const OSQPSettings *, c_float *, c_float *, c_float *, c_int) {
-  oq::set_last_error("batched path not built yet");
-  return 6;
+
+c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long long seed, const OSQPSettings *settings, c_float *x_dev,
+                                     c_float *y_dev, c_float *info_dev, c_int device) {
+  try {
+    if (count <= 0 || !settings) return 1;
+    HIP_CHECK(hipSetDevice((int)device));
+    hipStream_t s = nullptr;
+    const int nnzA = mpc_nnzA();
+    // shared pattern from instance `first` on the host
+    std::vector<int> hAp(MPC_N + 1), hAi(nnzA), hPp(MPC_N + 1), hPi(MPC_N);
+    {
+      std::vector<double> ax(nnzA), pd(MPC_N), q(MPC_N), l(MPC_M), u(MPC_M);
+      mpc_fill(first, seed, hAp.data(), hAi.data(), ax.data(), pd.data(), q.data(), l.data(), u.data());
+      for (int j = 0; j <= MPC_N; j++) hPp[j] = j;
+      for (int j = 0; j < MPC_N; j++) hPi[j] = j;
+    }
+    DevicePattern dp;
+    dp.build(MPC_N, MPC_M, hPp, hPi, hAp, hAi, s);
+    DevBuf<double> dPx((size_t)count * MPC_N), dAx((size_t)count * nnzA), dq((size_t)count * MPC_N), dl((size_t)count * MPC_M),
+        du((size_t)count * MPC_M);
+    OQ_LAUNCH(k_gen_mpc, dim3(blocks_for(count, 64)), dim3(64), 0, s, (long long)first, (int)count, seed, nnzA, dAx.get(), dPx.get(),
+              dq.get(), dl.get(), du.get());
+    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), x_dev, y_dev, info_dev, 4, s);
+    HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+  } catch (const Error &er) {
+    set_last_error(er.what());
+    return er.code ? er.code : 6;
+  } catch (const std::exception &ex) {
+    set_last_error(ex.what());
+    return 6;
+  }
 }
-}
+
+}  // extern "C"

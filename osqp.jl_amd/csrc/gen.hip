@@ -6,31 +6,9 @@
 // integer arithmetic, at most one fp64 multiply/add -- the same bits as the host
 // statement in oracle/gen.c (tests/test_gpu_parity.py compares them).
 #include "engine.hpp"
+#include "rng.hpp"
 
 namespace oq {
-
-enum { G_AROW = 1, G_AVAL = 2, G_UROW = 3, G_UVAL = 4, G_Q = 5, G_L = 6, G_U = 7, G_PDIAG = 8,
-       G_MPC_A = 9, G_MPC_B = 10, G_MPC_X0 = 11, G_MPC_REF = 12 };
-
-__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-__host__ __device__ __forceinline__ unsigned long long rnd(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
-  unsigned long long k = mix64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1));
-  return mix64(k ^ (idx * 0xD1B54A32D192ED03ULL + 0x8CB92BA72F3D8DD7ULL));
-}
-__host__ __device__ __forceinline__ double u01(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
-  return ((double)(rnd(seed, stream, idx) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-}
-#define GAUSS_K (1.7320508075688772 / 65536.0)
-__host__ __device__ __forceinline__ long long gauss_int(unsigned long long r) {
-  return (long long)((r & 0xFFFF) + ((r >> 16) & 0xFFFF) + ((r >> 32) & 0xFFFF) + ((r >> 48) & 0xFFFF)) - 131070;
-}
-__host__ __device__ __forceinline__ double gauss(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
-  return (double)gauss_int(rnd(seed, stream, idx)) * GAUSS_K;
-}
 
 // ---- random sparse QP --------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_gen_A(long long n, long long m, long long k, unsigned long long seed,
@@ -69,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_U(long long n, long long kp, uns
     }
     long long I = gauss_int(rnd(seed, G_UVAL, (unsigned long long)(j * kp + t)));
     Pi[base + t] = (int)row;
-    Px[base + t] = (double)I * GAUSS_K;
+    Px[base + t] = (double)I * OQ_GAUSS_K;
     unsigned long long a = (unsigned long long)(I < 0 ? -I : I);
     atomicAdd(&S[row], a);
     colsum += a;
@@ -83,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_U(long long n, long long kp, uns
 __global__ __launch_bounds__(kBlock) void k_gen_diag(long long n, const int64_t *__restrict__ Pp, double *__restrict__ Px,
                                                      const unsigned long long *__restrict__ S) {
   long long j = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (j < n) Px[Pp[j + 1] - 1] = 1.0 + (double)(long long)S[j] * GAUSS_K;
+  if (j < n) Px[Pp[j + 1] - 1] = 1.0 + (double)(long long)S[j] * OQ_GAUSS_K;
 }
 __global__ __launch_bounds__(kBlock) void k_gen_vecs(long long n, long long m, unsigned long long seed, double *__restrict__ q,
                                                      double *__restrict__ l, double *__restrict__ u) {

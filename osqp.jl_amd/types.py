@@ -203,6 +203,29 @@ ORACLE_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "oracle", "_build", "l
 _libs = {}
 
 
+def _preload_hip_runtime():
+    """torch ships its own libamdhip64.so.7; a process that loads the system one first
+    (through libosqp_amd.so) and torch's later ends up with two HIP runtimes and torch
+    finds no GPU.  Loading torch's copy first (same SONAME) makes both share it.  Only
+    needed when torch will be used in the process (bench.py, batch.py, the GPU tests)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=os.RTLD_GLOBAL | os.RTLD_NOW)
+            except OSError:
+                pass
+
+
 def load_library(path=None):
     """dlopen a library exporting the osqp_* ABI and declare its signatures.
 
@@ -218,6 +241,8 @@ def load_library(path=None):
     path = os.path.abspath(path)
     if path in _libs:
         return _libs[path]
+    if path == os.path.abspath(PRODUCT_LIB_PATH):
+        _preload_hip_runtime()
     lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
     for name, (res, args) in ABI_SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -1,0 +1,85 @@
+"""Batched small-QP path (BASELINE.json config 5) against the CPU oracle, instance by instance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import osqp_jl_amd as oq
+from osqp_jl_amd import batch
+from test_gpu_parity import _data_to_scipy
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, adaptive_rho_interval=50, max_iter=4000)
+
+
+def _mpc_instances(oracle_lib, first, count, seed):
+    probs = []
+    for i in range(first, first + count):
+        d = oracle_lib.oracle_generate(2, 100, i, seed)
+        probs.append(_data_to_scipy(d.contents))
+        oracle_lib.oracle_data_free(d)
+    return probs
+
+
+def _oracle_solutions(oracle_lib, probs):
+    out = []
+    for P, q, A, l, u in probs:
+        m = oq.Model(oracle_lib)
+        oq.setup(m, P=P, q=q, A=A, l=l, u=u, **OPTS)
+        out.append(oq.solve(m))
+    return out
+
+
+def test_batch_host_api_matches_oracle(product_lib, oracle_lib):
+    probs = _mpc_instances(oracle_lib, 0, 12, 5)
+    P0, _, A0, _, _ = probs[0]
+    for P, q, A, l, u in probs:  # shared pattern
+        assert np.array_equal(A.indices, A0.indices) and np.array_equal(A.indptr, A0.indptr)
+    Px = np.array([sp.triu(p[0]).tocsc().data for p in probs]); Ax = np.array([p[2].data for p in probs])
+    q = np.array([p[1] for p in probs]); l = np.array([p[3] for p in probs]); u = np.array([p[4] for p in probs])
+    x, y, info = batch.solve_batch(product_lib, P0, A0, Px, Ax, q, l, u, **OPTS)
+    ref = _oracle_solutions(oracle_lib, probs)
+    for i, r in enumerate(ref):
+        assert r.info.status == "Solved" and int(info[i, 1]) == 1
+        assert abs(r.info.iter - info[i, 0]) <= 50
+        assert np.max(np.abs(x[i] - r.x)) <= 2e-4 * max(1.0, np.max(np.abs(r.x)))
+        assert np.max(np.abs(y[i] - r.y)) <= 2e-4 * max(1.0, np.max(np.abs(r.y)))
+        assert abs(info[i, 4] - r.info.obj_val) <= 1e-4 * max(1.0, abs(r.info.obj_val))
+
+
+def test_batch_generated_matches_host_fed(product_lib, oracle_lib):
+    import torch
+
+    first, count, seed = 3, 20, 9
+    solver = batch.device_mpc_solver(product_lib, 0, **OPTS)
+    xg, yg, ig = batch.solve_mpc_sharded(solver, count, seed)  # world = 1: instances [0, count)
+    probs = _mpc_instances(oracle_lib, 0, count, seed)
+    P0, _, A0, _, _ = probs[0]
+    Px = np.array([sp.triu(p[0]).tocsc().data for p in probs]); Ax = np.array([p[2].data for p in probs])
+    q = np.array([p[1] for p in probs]); l = np.array([p[3] for p in probs]); u = np.array([p[4] for p in probs])
+    x, y, info = batch.solve_batch(product_lib, P0, A0, Px, Ax, q, l, u, **OPTS)
+    assert np.array_equal(ig.cpu().numpy()[:, :2], info[:, :2])           # same iterations, same status
+    assert np.max(np.abs(xg.cpu().numpy() - x)) <= 1e-12                   # device generator == host generator, bit for bit
+    assert np.max(np.abs(yg.cpu().numpy() - y)) <= 1e-12
+
+
+def test_batch_detects_infeasible_instance(product_lib, oracle_lib):
+    probs = _mpc_instances(oracle_lib, 0, 4, 2)
+    P0, _, A0, _, _ = probs[0]
+    Px = np.array([sp.triu(p[0]).tocsc().data for p in probs]); Ax = np.array([p[2].data for p in probs])
+    q = np.array([p[1] for p in probs]); l = np.array([p[3] for p in probs]); u = np.array([p[4] for p in probs])
+    # instance 2: contradictory box on the first state (row 60): x >= 5 and the dynamics/box force |x| <= 20, then x <= -5
+    l[2, 60] = 5.0; u[2, 60] = 20.0
+    l[2, 160] = -0.5  # untouched rate row
+    l[2, 0] = u[2, 0] = -30.0  # dynamics equality forces x_1[0] = -30: contradicts the box [5, 20]
+    x, y, info = batch.solve_batch(product_lib, P0, A0, Px, Ax, q, l, u, **OPTS)
+    assert int(info[2, 1]) in (-3, 3)
+    assert np.all(np.isnan(x[2]))
+    for i in (0, 1, 3):
+        assert int(info[i, 1]) == 1
+    m = oq.Model(oracle_lib)
+    P, qq, A, _, _ = probs[2]
+    oq.setup(m, P=P, q=qq, A=A, l=l[2], u=u[2], **OPTS)
+    assert oq.solve(m).info.status.startswith("Primal_infeasible")
