@@ -61,15 +61,19 @@ __device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
 }
 
 struct Lds {
-  double *M, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red;
+  double *M, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv;
   int *ctype;
+  unsigned short *Ap, *Ai, *Rp, *Rc, *Rmap, *Fp, *Fc;  // shared pattern, staged into LDS as 16-bit indices
   int ld;
 };
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (size_t)n * (n + 1) + nnzA + nnzF + 9 * (size_t)n + 12 * (size_t)m + 64;
+  return (size_t)n * (n + 1) + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 64;
+}
+__host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
+  return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
 }
 __host__ __device__ inline size_t lds_bytes(int n, int m, int nnzA, int nnzF) {
-  return lds_doubles(n, m, nnzA, nnzF) * 8 + (size_t)m * 4 + 16;
+  return lds_doubles(n, m, nnzA, nnzF) * 8 + (((size_t)m * 4 + 15) / 16) * 16 + lds_shorts(n, m, nnzA, nnzF) * 2 + 16;
 }
 __device__ inline Lds carve(double *base, const Pattern &P) {
   Lds s;
@@ -79,11 +83,14 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
   s.M = p; p += (size_t)n * s.ld;
   s.Av = p; p += P.nnzA; s.Pv = p; p += P.nnzF;
   s.q = p; p += n; s.D = p; p += n; s.x = p; p += n; s.xp = p; p += n; s.xt = p; p += n; s.dx = p; p += n;
-  s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n;
+  s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n; s.ldinv = p; p += n;
   s.l = p; p += m; s.u = p; p += m; s.E = p; p += m; s.rho = p; p += m; s.rhoi = p; p += m; s.z = p; p += m; s.y = p; p += m;
   s.zp = p; p += m; s.zt = p; p += m; s.dy = p; p += m; s.Ax = p; p += m; s.tm = p; p += m;
   s.red = p; p += 64;
   s.ctype = (int *)p;
+  unsigned short *h = (unsigned short *)((char *)p + (((size_t)m * 4 + 15) / 16) * 16);
+  s.Ap = h; h += n + 1; s.Fp = h; h += n + 1; s.Rp = h; h += m + 1;
+  s.Ai = h; h += P.nnzA; s.Rc = h; h += P.nnzA; s.Rmap = h; h += P.nnzA; s.Fc = h;
   return s;
 }
 
@@ -91,21 +98,21 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
 __device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
   for (int i = threadIdx.x; i < P.m; i += NT) {
     double a = 0.0;
-    for (int q = P.Rp[i]; q < P.Rp[i + 1]; q++) a += s.Av[P.Rmap[q]] * x[P.Rc[q]];
+    for (int q = s.Rp[i]; q < s.Rp[i + 1]; q++) a += s.Av[s.Rmap[q]] * x[s.Rc[q]];
     y[i] = a;
   }
 }
 __device__ __forceinline__ void mul_At(const Pattern &P, const Lds &s, const double *x, double *y) {
   for (int j = threadIdx.x; j < P.n; j += NT) {
     double a = 0.0;
-    for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) a += s.Av[k] * x[P.Ai[k]];
+    for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) a += s.Av[k] * x[s.Ai[k]];
     y[j] = a;
   }
 }
 __device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const double *x, double *y) {
   for (int r = threadIdx.x; r < P.n; r += NT) {
     double a = 0.0;
-    for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) a += s.Pv[q] * x[P.Fc[q]];
+    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) a += s.Pv[q] * x[s.Fc[q]];
     y[r] = a;
   }
 }
@@ -131,10 +138,10 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
   for (int j = 0; j < n; j++) {
     for (int i = j + threadIdx.x; i < n; i += NT) {
       // sparse dot of columns i and j of A weighted by rho (both row lists ascending)
-      int a = P.Ap[i], ae = P.Ap[i + 1], b = P.Ap[j], be = P.Ap[j + 1];
+      int a = s.Ap[i], ae = s.Ap[i + 1], b = s.Ap[j], be = s.Ap[j + 1];
       double acc = 0.0;
       while (a < ae && b < be) {
-        int ra = P.Ai[a], rb = P.Ai[b];
+        int ra = s.Ai[a], rb = s.Ai[b];
         if (ra == rb) { acc += s.rho[ra] * s.Av[a] * s.Av[b]; a++; b++; }
         else if (ra < rb) a++; else b++;
       }
@@ -143,7 +150,7 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
   }
   __syncthreads();
   for (int r = threadIdx.x; r < n; r += NT)
-    for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) { int c = P.Fc[q]; if (c <= r) s.M[r + c * ld] += s.Pv[q]; }
+    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) { int c = s.Fc[q]; if (c <= r) s.M[r + c * ld] += s.Pv[q]; }
   __syncthreads();
   bool ok = true;
   for (int j = 0; j < n; j++) {
@@ -151,8 +158,8 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
     if (!(d > 0.0)) ok = false;
     double dj = sqrt(d);
     __syncthreads();
-    if (threadIdx.x == 0) s.M[j + j * ld] = dj;
     double inv = 1.0 / dj;
+    if (threadIdx.x == 0) { s.M[j + j * ld] = dj; s.ldinv[j] = inv; }
     for (int i = j + 1 + threadIdx.x; i < n; i += NT) s.M[i + j * ld] *= inv;
     __syncthreads();
     for (int k = j + 1 + (threadIdx.x >> 4); k < n; k += NT / 16) {
@@ -161,29 +168,97 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
     }
     __syncthreads();
   }
+  // the solves read columns / rows of L without masks: keep zeros on and above the diagonal (1/L_jj is in ldinv)
+  for (int j = 0; j < n; j++)
+    for (int i = threadIdx.x; i <= j; i += NT) s.M[i + j * ld] = 0.0;
+  __syncthreads();
   return ok;
 }
 
-// wave 0 solves L L' v = b in place (b in LDS); the other waves wait at the caller's barrier
-__device__ void chol_solve_wave0(const Lds &s, int n, volatile double *b) {
+// broadcast of one lane's double through two v_readlane_b32 (the source lane is wave-uniform)
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  long long bits = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFLL), src);
+  int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Wave 0 solves L L' v = b in place; the other waves wait at the caller's barrier.
+// The vector lives in registers (row i = lane + 64 r, r < 3, so n <= 192).  After the factorisation the
+// diagonal and the upper triangle of M are zeroed (1/L_jj is kept in ldinv), so a step is branch-free:
+//   forward  step j:  w_j = b_j / L_jj (v_readlane broadcast);  b -= L[:, j] w_j   (rows <= j see zeros)
+//   backward step j:  v_j = b_j / L_jj;                         b -= L[j, :]' v_j  (rows >= j see zeros)
+// and b_j is simply never touched again; the scaling by 1/L_jj of the kept entries happens once at the end
+// of each sweep.  Steps are grouped by the register that owns row j and blocked by 4 with the next block's
+// LDS reads in flight.  Lanes beyond n carry garbage that nobody reads.
+template <int RJ, bool FWD>
+__device__ __forceinline__ void tri_phase(const double *M, const double *dinv, int ld, int n, int lane, double &b0, double &b1, double &b2) {
+  const int jb = RJ * 64, je = n < jb + 64 ? n : jb + 64;
+  if (jb >= je) return;
+  constexpr int U = 4;
+  const int r0 = lane < n ? lane : n - 1, r1 = lane + 64 < n ? lane + 64 : n - 1, r2 = lane + 128 < n ? lane + 128 : n - 1;
+  double c0[U], c1[U], c2[U], dv[U], n0[U], n1[U], n2[U], nd[U];
+  auto load = [&](int jq, double (&a0)[U], double (&a1)[U], double (&a2)[U], double (&d)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int j = FWD ? jq + u : jq - u;
+      j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+      if (FWD) {  // column j of L: rows > j
+        const double *col = M + (size_t)j * ld;
+        if (RJ == 0) a0[u] = col[r0];
+        if (RJ <= 1) a1[u] = col[r1];
+        a2[u] = col[r2];
+      } else {    // row j of L: columns < j
+        const double *row = M + j;
+        a0[u] = row[(size_t)r0 * ld];
+        if (RJ >= 1) a1[u] = row[(size_t)r1 * ld];
+        if (RJ == 2) a2[u] = row[(size_t)r2 * ld];
+      }
+      d[u] = dinv[j];
+    }
+  };
+  const int first = FWD ? jb : je - 1;
+  load(first, c0, c1, c2, dv);
+  for (int q = 0; q < je - jb; q += U) {
+    const int jq = FWD ? jb + q : je - 1 - q;
+    load(FWD ? jq + U : jq - U, n0, n1, n2, nd);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = FWD ? jq + u : jq - u;
+      if (FWD ? j < je : j >= jb) {
+        const double piv = readlane_d(RJ == 0 ? b0 : (RJ == 1 ? b1 : b2), j & 63) * dv[u];
+        if (FWD) {
+          if (RJ == 0) b0 -= c0[u] * piv;
+          if (RJ <= 1) b1 -= c1[u] * piv;
+          b2 -= c2[u] * piv;
+        } else {
+          b0 -= c0[u] * piv;
+          if (RJ >= 1) b1 -= c1[u] * piv;
+          if (RJ == 2) b2 -= c2[u] * piv;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) { c0[u] = n0[u]; c1[u] = n1[u]; c2[u] = n2[u]; dv[u] = nd[u]; }
+  }
+}
+__device__ void chol_solve_wave0(const Lds &s, int n, double *b) {
   const int lane = threadIdx.x;
   const int ld = s.ld;
-  volatile double *M = s.M;
-  for (int j = 0; j < n; j++) {
-    if (lane == (j & 63)) b[j] = b[j] / M[j + j * ld];
-    __builtin_amdgcn_wave_barrier();
-    double wj = b[j];
-    for (int i = j + 1 + lane; i < n; i += 64) b[i] -= M[i + j * ld] * wj;
-    __builtin_amdgcn_wave_barrier();
-  }
-  for (int j = n - 1; j >= 0; j--) {
-    double acc = 0.0;
-    for (int i = j + 1 + lane; i < n; i += 64) acc += M[i + j * ld] * b[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) b[j] = (b[j] - acc) / M[j + j * ld];
-    __builtin_amdgcn_wave_barrier();
-  }
+  const double *M = s.M, *dinv = s.ldinv;
+  const bool h0 = lane < n, h1 = lane + 64 < n, h2 = lane + 128 < n;
+  double b0 = h0 ? b[lane] : 0.0, b1 = h1 ? b[lane + 64] : 0.0, b2 = h2 ? b[lane + 128] : 0.0;
+  const double d0 = h0 ? dinv[lane] : 0.0, d1 = h1 ? dinv[lane + 64] : 0.0, d2 = h2 ? dinv[lane + 128] : 0.0;
+  tri_phase<0, true>(M, dinv, ld, n, lane, b0, b1, b2);
+  tri_phase<1, true>(M, dinv, ld, n, lane, b0, b1, b2);
+  tri_phase<2, true>(M, dinv, ld, n, lane, b0, b1, b2);
+  b0 *= d0; b1 *= d1; b2 *= d2;
+  tri_phase<2, false>(M, dinv, ld, n, lane, b0, b1, b2);
+  tri_phase<1, false>(M, dinv, ld, n, lane, b0, b1, b2);
+  tri_phase<0, false>(M, dinv, ld, n, lane, b0, b1, b2);
+  if (h0) b[lane] = b0 * d0;
+  if (h1) b[lane + 64] = b1 * d1;
+  if (h2) b[lane + 128] = b2 * d2;
 }
 
 struct Out { double iter, status, pri, dua, obj, rho_updates; };
@@ -198,7 +273,11 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   if (inst >= count) return;
   const int n = P.n, m = P.m, tid = threadIdx.x;
   Lds s = carve(lds_raw, P);
-  // ---- load the instance -------------------------------------------------
+  // ---- stage the shared pattern (16-bit) and load the instance -----------------
+  for (int k = tid; k <= n; k += NT) { s.Ap[k] = (unsigned short)P.Ap[k]; s.Fp[k] = (unsigned short)P.Fp[k]; }
+  for (int k = tid; k <= m; k += NT) s.Rp[k] = (unsigned short)P.Rp[k];
+  for (int k = tid; k < P.nnzA; k += NT) { s.Ai[k] = (unsigned short)P.Ai[k]; s.Rc[k] = (unsigned short)P.Rc[k]; s.Rmap[k] = (unsigned short)P.Rmap[k]; }
+  for (int k = tid; k < P.nnzF; k += NT) s.Fc[k] = (unsigned short)P.Fc[k];
   for (int k = tid; k < P.nnzA; k += NT) s.Av[k] = Ax_all[(size_t)inst * P.nnzA + k];
   for (int k = tid; k < P.nnzF; k += NT) s.Pv[k] = Px_all[(size_t)inst * P.nnzP + P.Fmap[k]];
   for (int j = tid; j < n; j += NT) { s.q[j] = q_all[(size_t)inst * n + j]; s.D[j] = 1.0; s.x[j] = 0.0; s.xp[j] = 0.0; s.dx[j] = 0.0; }
@@ -212,24 +291,24 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   for (int it = 0; it < st.scaling; it++) {
     for (int j = tid; j < n; j += NT) {
       double mx = 0.0;
-      for (int q = P.Fp[j]; q < P.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
-      for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) mx = fmax(mx, fabs(s.Av[k]));
+      for (int q = s.Fp[j]; q < s.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
+      for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) mx = fmax(mx, fabs(s.Av[k]));
       s.tn[j] = 1.0 / sqrt(lim(mx));
     }
     for (int i = tid; i < m; i += NT) {
       double mx = 0.0;
-      for (int q = P.Rp[i]; q < P.Rp[i + 1]; q++) mx = fmax(mx, fabs(s.Av[P.Rmap[q]]));
+      for (int q = s.Rp[i]; q < s.Rp[i + 1]; q++) mx = fmax(mx, fabs(s.Av[s.Rmap[q]]));
       s.tm[i] = 1.0 / sqrt(lim(mx));
     }
     __syncthreads();
     for (int r = tid; r < n; r += NT)
-      for (int q = P.Fp[r]; q < P.Fp[r + 1]; q++) {
-        int cc = P.Fc[q];
+      for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) {
+        int cc = s.Fc[q];
         int lo = cc < r ? cc : r, hi = cc < r ? r : cc;
         s.Pv[q] = (s.Pv[q] * s.tn[lo]) * s.tn[hi];
       }
     for (int j = tid; j < n; j += NT) {
-      for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) s.Av[k] = (s.Av[k] * s.tm[P.Ai[k]]) * s.tn[j];
+      for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) s.Av[k] = (s.Av[k] * s.tm[s.Ai[k]]) * s.tn[j];
       s.q[j] *= s.tn[j];
       s.D[j] *= s.tn[j];
     }
@@ -238,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
     double v[2] = {0.0, 0.0}, w[1] = {0.0};
     for (int j = tid; j < n; j += NT) {
       double mx = 0.0;
-      for (int q = P.Fp[j]; q < P.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
+      for (int q = s.Fp[j]; q < s.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
       w[0] += mx;
       v[0] = fmax(v[0], fabs(s.q[j]));
     }
@@ -372,13 +451,17 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
       __syncthreads();
       for (int j = tid; j < n; j += NT) {
         double a = sigma * xp[j] - s.q[j];
-        for (int k = P.Ap[j]; k < P.Ap[j + 1]; k++) a += s.Av[k] * s.tm[P.Ai[k]];
+        for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) a += s.Av[k] * s.tm[s.Ai[k]];
         s.xt[j] = a;
       }
       __syncthreads();
+#ifndef OQ_NO_TRISOLVE
       if (tid < 64) chol_solve_wave0(s, n, s.xt);
+#endif
       __syncthreads();
+#ifndef OQ_NO_MULA
       mul_A(P, s, s.xt, s.zt);  // z~ = A x~
+#endif
       for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
       __syncthreads();
       for (int i = tid; i < m; i += NT) {
@@ -529,6 +612,7 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
                   const double *l, const double *u, double *x, double *y, double *info, int info_stride, hipStream_t s) {
   const Pattern &P = dp.P;
   size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF);
+  if (P.n > 192 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 192 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
   HIP_CHECK(hipFuncSetAttribute((const void *)k_batch_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   OQ_LAUNCH(k_batch_solve, dim3(count), dim3(NT), bytes, s, P, st, count, Px, Ax, q, l, u, x, y, info, info_stride);

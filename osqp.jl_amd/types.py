@@ -197,7 +197,7 @@ EXT_SYMBOLS = {
 }
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-PRODUCT_LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libosqp_amd.so")
+PRODUCT_LIB_PATH = os.environ.get("OSQP_AMD_LIB") or os.path.join(_PKG_DIR, "csrc", "libosqp_amd.so")
 ORACLE_LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "oracle", "_build", "libosqp_oracle.so")
 
 _libs = {}
