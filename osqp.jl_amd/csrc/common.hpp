@@ -93,12 +93,25 @@ struct DevBuf {
 };
 
 // ---- device CSR matrix: 64-bit row pointers, 32-bit column indices, fp64 values
+// Column-panel copy of a CSR matrix for the LDS-staged SpMV (panel.hip): the columns are cut into
+// B panels of W = 2^shift columns; entries are stored panel-major, row-minor, with 16-bit local column
+// indices, so that a workgroup can keep its panel of x (W doubles) in LDS and gather from there.
+struct DevPanel {
+  bool active = false;
+  int W = 0, shift = 0, B = 0, R = 0, T = 0;  // R rows per workgroup tile, T = ceil(rows / R) tiles
+  DevBuf<uint32_t> pptr;                     // [B * rows + 1] start of (panel b, row i)
+  DevBuf<uint16_t> pcol;                     // [nnz] column index inside the panel
+  DevBuf<double> pval;                       // [nnz]
+  DevBuf<double> partial;                    // [B * rows] per-panel row sums, reduced in fixed order
+};
+
 struct DevCsr {
   int rows = 0, cols = 0;
   int64_t nnz = 0;
   DevBuf<int64_t> rowptr;
   DevBuf<int> col;
   DevBuf<double> val;
+  DevPanel panel;
   int group = 64;  // lanes per row chosen for the SpMV kernel (1..64)
   double spmv_bytes() const {  // algorithmic bytes of one y = M x
     return 12.0 * (double)nnz + 4.0 * ((double)rows + 1.0) + 8.0 * ((double)rows + (double)cols);

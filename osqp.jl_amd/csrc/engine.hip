@@ -159,6 +159,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   for (int i = 0; i < m; i++) if (h_l[i] > h_u[i]) throw Error(1, "lower bound greater than upper bound");
 
   if (st.scaling) scale_data();
+  refresh_panels();
   set_rho_vec();
   h_x.assign(n, 0.0); h_y.assign(m, 0.0); h_dx.assign(n, 0.0); h_dy.assign(m, 0.0);
   lambda0 = 0.15;
@@ -243,6 +244,15 @@ void Engine::scale_data() {
   vec_ew_recip(Einv.get(), E.get(), m, stream);
   vec_ew_prod(l.get(), l.get(), E.get(), m, stream);
   vec_ew_prod(u.get(), u.get(), E.get(), m, stream);
+}
+
+// LDS-staged panel copies of the matrices whose x vector does not fit the caches (panel.hip)
+void Engine::refresh_panels() {
+  for (DevCsr *M : {&A, &At, &Pf}) {
+    if (M->rows == 0 || M->nnz == 0) continue;
+    if (M->panel.active) panel_fill(*M, false, stream);
+    else if (panel_wanted(*M)) panel_build(*M, stream);
+  }
 }
 
 void Engine::unscale_data() {
@@ -680,6 +690,7 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
   if (doP) scatter(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
   if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
   if (st.scaling) scale_data();
+  refresh_panels();
   int e = lin->update_matrices();
   reset_info(ws->info);
   end_update();

@@ -100,6 +100,7 @@ struct Engine {
   // ---- algorithm ----
   void scale_data();
   void unscale_data();
+  void refresh_panels();
   void set_rho_vec();
   int update_rho_vec_from_bounds();
   void cold_start();

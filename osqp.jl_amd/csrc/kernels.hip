@@ -317,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int rows, const int64_t *__rest
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
           hipStream_t s) {
   if (M.rows == 0) return;
+  if (M.panel.active) { spmv_panel(M, x, y, rscale, beta, gamma, v, s); return; }
   const int G = M.group;
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
 #define OQ_SPMV(GG) \

@@ -25,6 +25,13 @@ int pick_group(int rows, int64_t nnz);
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
           const double *v, hipStream_t s);
 
+// LDS-staged column-panel variant (panel.hip); spmv() dispatches to it when M.panel.active
+bool panel_wanted(const DevCsr &M);
+void panel_build(DevCsr &M, hipStream_t s);                    // structure + values from the CSR arrays
+void panel_fill(DevCsr &M, bool with_cols, hipStream_t s);     // refresh the values after the CSR values changed
+void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
+                const double *v, hipStream_t s);
+
 // ---------------- K0: Ruiz equilibration pieces ----------------
 void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);  // out[i] = max(|row i|) (or max with old)
 // order 0: (v*r[row])*c[col]; 1: symmetric (v*r[min])*r[max]; 2: (v*c[col])*r[row]; then *scalar
