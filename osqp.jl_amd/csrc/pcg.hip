@@ -6,10 +6,16 @@
 // the random-sparsity configs, whose LDL' factor cannot fit in any memory
 // (SURVEY.md section 0.3).  CPU statement: oracle/pcg.c.
 //
-// Per CG iteration: 3 SpMV (A p, P p, A' t) + 2 fused vector kernels; the scalars
-// alpha and beta never leave the device (read from reduction slots by the next
-// kernel); the host reads back ||r||inf and p'Mp once per iteration for the
-// stopping test.
+// SpMV budget.  A textbook statement spends 5 SpMV per ADMM iteration outside the CG loop
+// (right-hand side, M x0 for the initial residual, z~ = A x~).  Here A x~ and M x~ are carried
+// along the CG recurrences (A x~ += alpha A p, M x~ += alpha M p, both products exist anyway),
+// so a solve costs 1 SpMV (right-hand side) + 3 per CG iteration; the two carried vectors are
+// recomputed from scratch every kRefresh solves and whenever rho or the matrices change, which
+// bounds the drift of the recurrences.
+//
+// Per CG iteration: A p, P p, A' t + 3 fused vector kernels; alpha and beta never leave the
+// device (read from reduction slots by the next kernel); the host reads back ||r||inf and
+// p'Mp once per iteration for the stopping test.
 #include "engine.hpp"
 
 #include <cmath>
@@ -18,15 +24,20 @@ namespace oq {
 
 namespace {
 
+constexpr int kRefresh = 25;
+
 struct Pcg : Linsys {
   Engine &e;
-  DevBuf<double> xs, r, zz, p, w, t, b1, dinv;
+  DevBuf<double> xs, r, zz, p, w, t, u, b1, dinv, Axs, Mxs;
   long long total_iters = 0;
   int max_iter = 20000;
+  bool carried_valid = false;
+  int since_refresh = 0;
   // slots: S_T0 rz (ping), S_T1 rz (pong), S_T2 pw, S_T3 ||r||inf, S_T4 ||b1||inf
   explicit Pcg(Engine &en) : e(en) {
     size_t n = e.n, m = e.m;
-    xs.alloc(n); r.alloc(n); zz.alloc(n); p.alloc(n); w.alloc(n); b1.alloc(n); dinv.alloc(n); t.alloc(m);
+    xs.alloc(n); r.alloc(n); zz.alloc(n); p.alloc(n); w.alloc(n); b1.alloc(n); dinv.alloc(n); Mxs.alloc(n);
+    t.alloc(m); u.alloc(m); Axs.alloc(m);
     xs.zero(e.stream);
     precond();
   }
@@ -35,12 +46,15 @@ struct Pcg : Linsys {
 
   void precond() { pcg_precond(e.At, e.Pf, e.rho.get(), e.st.sigma, dinv.get(), e.stream); }
 
-  // out = (P + sigma I + A' rho A) v
-  void apply_M(const double *v, double *out) {
+  // Av = A v ; out = (P + sigma I) v + A'(rho .* Av)
+  void apply_M(const double *v, double *Av, double *out) {
     hipStream_t s = e.stream;
-    if (e.m > 0) spmv(e.A, v, t.get(), e.rho.get(), 0.0, 0.0, nullptr, s);   // t = rho .* (A v)
-    spmv(e.Pf, v, out, nullptr, 0.0, e.st.sigma, v, s);                      // out = P v + sigma v
-    if (e.m > 0) spmv(e.At, t.get(), out, nullptr, 1.0, 0.0, nullptr, s);     // out += A' t
+    if (e.m > 0) {
+      spmv(e.A, v, Av, nullptr, 0.0, 0.0, nullptr, s);
+      vec_ew_prod(t.get(), e.rho.get(), Av, e.m, s);
+    }
+    spmv(e.Pf, v, out, nullptr, 0.0, e.st.sigma, v, s);
+    if (e.m > 0) spmv(e.At, t.get(), out, nullptr, 1.0, 0.0, nullptr, s);
   }
 
   int solve(double *xz, double cand) override {
@@ -56,9 +70,14 @@ struct Pcg : Linsys {
     }
     HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
     reduce_absmax(b1.get(), nullptr, n, slots + S_T4, s);
+    // carried products of the start vector
+    if (!carried_valid || ++since_refresh >= kRefresh) {
+      apply_M(xs.get(), Axs.get(), Mxs.get());
+      carried_valid = true;
+      since_refresh = 0;
+    }
     // r = b1 - M x0 ; zz = dinv r ; p = zz
-    apply_M(xs.get(), w.get());
-    pcg_init_residual(n, b1.get(), w.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0,
+    pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0,
                       slots + S_T3, s);
     e.fetch_slots();
     const double bnorm = e.h_slots[S_T4];
@@ -74,32 +93,35 @@ struct Pcg : Linsys {
     while (it < max_iter) {
       if (rn <= tol) break;
       if (rn != rn) { status = 5; break; }
-      apply_M(p.get(), w.get());
+      apply_M(p.get(), u.get(), w.get());
       reduce_dot(p.get(), w.get(), n, e.partials.get(), slots + S_T2, s);
+      // alpha = rz / pw on the device: A x~ += alpha A p ; x~ += alpha p ; M x~ += alpha w ; r -= alpha w ; zz = dinv r
+      if (m > 0) vec_axpy_dev(Axs.get(), slots + S_T0 + cur, slots + S_T2, u.get(), m, s);
+      vec_axpy_dev(Mxs.get(), slots + S_T0 + cur, slots + S_T2, w.get(), n, s);
       pcg_update_xr(n, slots + S_T0 + cur, slots + S_T2, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(),
                     e.partials.get(), slots + S_T0 + (1 - cur), slots + S_T3, s);
       pcg_update_p(n, slots + S_T0 + (1 - cur), slots + S_T0 + cur, zz.get(), p.get(), s);
       e.fetch_slots();
-      if (!(e.h_slots[S_T2] > 0.0)) { status = 5; break; }  // p'Mp <= 0: M is not positive definite
+      if (!(e.h_slots[S_T2] > 0.0)) { status = 5; carried_valid = false; break; }  // p'Mp <= 0: M is not positive definite
       rn = e.h_slots[S_T3];
       cur = 1 - cur;
       it++;
     }
     total_iters += it;
     vec_copy(xz, xs.get(), n, s);
-    if (m > 0) spmv(e.A, xs.get(), xz + n, nullptr, 0.0, 0.0, nullptr, s);
+    if (m > 0) vec_copy(xz + n, Axs.get(), m, s);  // z~ = A x~
     return status;
   }
-  int update_rho() override { precond(); return 0; }
-  int update_matrices() override { precond(); return 0; }
-  void set_guess(const double *x) override { vec_copy(xs.get(), x, e.n, e.stream); }
+  int update_rho() override { precond(); carried_valid = false; return 0; }
+  int update_matrices() override { precond(); carried_valid = false; return 0; }
+  void set_guess(const double *x) override { vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; }
   float time_solve(int reps) override {
     // one operator application (3 SpMV) as the unit of the indirect back-end
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    apply_M(p.get(), w.get());
+    apply_M(p.get(), u.get(), w.get());
     HIP_CHECK(hipEventRecord(a, e.stream));
-    for (int i = 0; i < reps; i++) apply_M(p.get(), w.get());
+    for (int i = 0; i < reps; i++) apply_M(p.get(), u.get(), w.get());
     HIP_CHECK(hipEventRecord(b, e.stream));
     HIP_CHECK(hipEventSynchronize(b));
     float ms = 0;
