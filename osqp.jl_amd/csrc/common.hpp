@@ -103,6 +103,13 @@ struct DevPanel {
   DevBuf<uint16_t> pcol;                     // [nnz] column index inside the panel
   DevBuf<double> pval;                       // [nnz]
   DevBuf<double> partial;                    // [B * rows] per-panel row sums, reduced in fixed order
+  // workgroup tiles: tile k = rows [tile_r0[k], tile_r1[k]) of panel tile_b[k], cut at ~equal nnz
+  DevBuf<int> tile_b, tile_r0, tile_r1;
+  int ntiles = 0;
+  // sub-chunks of a tile for the streaming kernel: tile k owns entries [tile_sub0[k], tile_sub0[k] + tile_nsub[k]]
+  // of sub_row / sub_k (row boundaries and their non-zero offsets, <= kPanelChunk non-zeros and < 1024 rows each)
+  DevBuf<int> tile_sub0, tile_nsub, sub_row;
+  DevBuf<uint32_t> sub_k;
 };
 
 struct DevCsr {

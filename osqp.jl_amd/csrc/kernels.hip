@@ -271,6 +271,7 @@ void convert_i64_i32(int64_t n, const int64_t *in, int *out, hipStream_t s) {
 }
 
 int pick_group(int rows, int64_t nnz) {
+  if (const char *e = getenv("OSQP_AMD_SPMV_G")) return atoi(e);
   double mean = rows > 0 ? (double)nnz / (double)rows : 0.0;
   if (mean <= 1.5) return 1;
   if (mean <= 3.0) return 2;
