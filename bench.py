@@ -109,7 +109,9 @@ def main():
     st = oq.stats(model)
     nnzA, nnzPf = st[1], st[2]
     if st[0] == 2:   # indirect back-end: CSR SpMV y = A x
-        kname, which, abytes = "k_spmv (y = A x)", 0, st[10]
+        variant = int(st[12]) if len(st) > 12 else 0
+        kname = ["k_spmv<G> (CSR, y = A x)", "k_spmv_panel (LDS-staged x panels, y = A x)", "k_spmv_sell (LDS-staged x panels, sliced-ELL tiles, y = A x)"][variant]
+        which, abytes = 0, st[10]
     else:            # direct back-end: forward+backward triangular solve
         kname, which, abytes = "sptrsv forward+backward", 3, st[11]
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))

@@ -260,6 +260,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *  6 total CG iterations so far              7 total ADMM iterations so far
  *  8 numeric factorisations so far           9 device bytes allocated
  * 10 algorithmic bytes of one SpMV with A   11 algorithmic bytes of one forward+backward trisolve
+ * 12 SpMV kernel used for A: 0 CSR (k_spmv), 1 LDS-staged panels + CSR tiles, 2 LDS-staged panels + sliced-ELL tiles
  * Returns the number of entries written. */
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 

@@ -283,7 +283,7 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
 c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   if (!w || !out) return 0;
   const Engine &e = *E(w);
-  c_float v[12] = {0};
+  c_float v[13] = {0};
   v[0] = (c_float)e.lin->kind();
   v[1] = (c_float)e.nnzA;
   v[2] = (c_float)e.Pf.nnz;
@@ -296,8 +296,9 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[9] = (c_float)g_device_bytes;
   v[10] = e.A.spmv_bytes();
   v[11] = e.lin->trisolve_bytes();
+  v[12] = e.A.panel.active ? (e.A.panel.sell ? 2.0 : 1.0) : 0.0;
   c_int k = 0;
-  for (; k < count && k < 12; k++) out[k] = v[k];
+  for (; k < count && k < 13; k++) out[k] = v[k];
   return k;
 }
 
@@ -313,7 +314,7 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
       case 0: spmv(e.A, e.x.get(), e.tm2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 1: spmv(e.At, e.y.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 2: spmv(e.Pf, e.x.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
-      case 6: if (!e.A.panel.active) throw Error(1, "no panel copy"); spmv_panel_probe(e.A, e.x.get(), s); break;
+      case 6: if (!e.A.panel.active || e.A.panel.sell) throw Error(1, "no panel-CSR copy"); spmv_panel_probe(e.A, e.x.get(), s); break;
       case 4:
         admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.x_prev.get(), e.z_prev.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
                     e.u.get(), e.tn.get(), e.tm.get(), e.tm2.get(), e.tn2.get(), e.Ax.get(), s);

@@ -110,6 +110,15 @@ struct DevPanel {
   // of sub_row / sub_k (row boundaries and their non-zero offsets, <= kPanelChunk non-zeros and < 1024 rows each)
   DevBuf<int> tile_sub0, tile_nsub, sub_row;
   DevBuf<uint32_t> sub_k;
+  // sliced-ELL copy of every tile (panel_sell.hip): slice = 64 rows of the tile sorted by length, stored
+  // column-major (element k of lane l at slice base + 64 k + l); tile k owns slices [tile_sub0[k], +tile_nsub[k]),
+  // sub_k = slice base offset, sub_row = slice length, slice_rows = the 64 row ids of the slice (-1: empty lane)
+  bool sell = false;
+  DevBuf<uint32_t> cellbase;                 // [B * rows] base offset of (panel, row) inside sval / scol
+  DevBuf<double> sval;
+  DevBuf<uint16_t> scol;
+  DevBuf<int> slice_rows;
+  size_t padded = 0;
 };
 
 struct DevCsr {

@@ -202,6 +202,7 @@ bool panel_wanted(const DevCsr &M) {
 
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s) {
   DevPanel &P = M.panel;
+  if (P.sell) { panel_sell_fill(M, with_cols, s); return; }
   OQ_LAUNCH(k_panel_scatter, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(), M.col.get(),
             M.val.get(), P.pptr.get(), P.pcol.get(), P.pval.get(), with_cols ? 1 : 0);
 }
@@ -241,15 +242,16 @@ void panel_build(DevCsr &M, hipStream_t s) {
         r = r_end;
       }
     }
-    panel_stream_prepare(M, hp, tb, t0, t1, s);  // sub-chunks for the streaming kernel (may split tiles)
+    // 1 (default): sliced-ELL tiles (panel_sell.hip); 0: panel-CSR tiles with one lane group per row segment
+    if (env_int("OSQP_AMD_PANEL_KERNEL", 1) == 1) panel_sell_prepare(M, hp, tb, t0, t1, s);
     P.ntiles = (int)tb.size();
     P.tile_b.alloc(tb.size()); P.tile_r0.alloc(tb.size()); P.tile_r1.alloc(tb.size());
     P.tile_b.upload(tb.data(), tb.size(), s); P.tile_r0.upload(t0.data(), t0.size(), s); P.tile_r1.upload(t1.data(), t1.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
   }
-  P.pcol.alloc((size_t)M.nnz);
-  P.pval.alloc((size_t)M.nnz);
+  if (!P.sell) { P.pcol.alloc((size_t)M.nnz); P.pval.alloc((size_t)M.nnz); }
   P.partial.alloc(cells);
+  P.partial.zero(s);  // cells of rows without entries in a panel are never written again
   panel_fill(M, true, s);
   const int lds = (int)(sizeof(double) << P.shift);
   HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -266,8 +268,7 @@ void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscal
 #define OQ_PANEL(GG)                                                                                                          \
   OQ_LAUNCH(k_spmv_panel<GG>, dim3(P.ntiles), dim3(kPanelThreads), lds, s, M.rows, M.cols, P.shift, P.tile_b.get(), P.tile_r0.get(), \
             P.tile_r1.get(), P.pptr.get(), P.pcol.get(), P.pval.get(), x, P.partial.get())
-  static const int variant = env_int("OSQP_AMD_PANEL_KERNEL", 1);  // 1: streaming kernel (panel_stream.hip), 0: group-per-row
-  if (variant == 1) spmv_panel_stream(M, x, s);
+  if (P.sell) spmv_panel_sell(M, x, s);
   else if (G == 4) OQ_PANEL(4); else if (G == 16) OQ_PANEL(16); else OQ_PANEL(8);
 #undef OQ_PANEL
   OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.B, P.partial.get(), y, rscale, beta, gamma, v);
