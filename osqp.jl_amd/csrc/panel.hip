@@ -193,9 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const 
 bool panel_wanted(const DevCsr &M) {
   const int shift = panel_shift();
   if (const char *e = getenv("OSQP_AMD_PANEL")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return M.cols > (1 << shift); }
-  // x must be too large for the per-XCD L2 (4 MB) and the row segments per panel long enough to pay for the partial sums
+  // Worth it when the matrix is large enough to be bandwidth-bound, spans at least two panels and its row
+  // segments per panel are long enough to pay for the partial sums.  Measured (tools/sweep_spmv.py): at
+  // n = 1e6 / 1000 per row 10.8 -> 2.4 ms per SpMV, at n = 1e5 / 100 per row 0.052 -> 0.028 ms.
   const int B = (M.cols + (1 << shift) - 1) >> shift;
-  if ((size_t)M.cols * 8 < (size_t)3 << 20) return false;
+  if (B < 2 || M.nnz < 2000000) return false;
   if (M.nnz >= 4000000000LL) return false;  // 32-bit panel offsets
   return (double)M.nnz / ((double)M.rows * B) >= 4.0;
 }

@@ -1,0 +1,118 @@
+# OSQPAMD.jl -- thin Julia layer over the extension entry points of libosqp_amd.so.
+#
+# The 30 `osqp_*` symbols that osqp/OSQP.jl binds need no new Julia code: point `OSQP.osqp` at
+# libosqp_amd.so (INTEGRATION.md, section 2) and the reference's `setup!/solve!/update!/warm_start!`
+# and its MathOptInterface wrapper run on the MI355X unchanged.  This module only adds what the
+# reference has no call for: problems generated directly in HBM, the batched small-QP path, device
+# selection, statistics.  Style follows [REF src/interface.jl]: one `ccall` per entry point, a
+# non-zero exit flag becomes `error(...)`.
+#
+# NOTE: Julia is not installed in the build image, so this file is not executed by the test suite;
+# the same entry points are exercised through the Python mirror (osqp.jl_amd/interface.py, batch.py).
+module OSQPAMD
+
+using OSQP
+using SparseArrays
+
+const lib = get(ENV, "OSQP_AMD_LIB", joinpath(@__DIR__, "..", "csrc", "libosqp_amd.so"))
+const Cc_int = OSQP.Cc_int
+
+@enum ProblemKind RANDOM_QP = 0 LASSO = 1 MPC = 2
+
+"""
+    set_device(local_rank)
+
+Select the HIP device for workspaces created afterwards (one process per GPU).
+"""
+function set_device(device::Integer)
+    flag = ccall((:osqp_amd_set_device, lib), Cc_int, (Cc_int,), device)
+    flag == 0 || error("Error selecting device $(device): $(last_error())")
+    return nothing
+end
+
+last_error() = unsafe_string(ccall((:osqp_amd_last_error, lib), Cstring, ()))
+
+"""
+    setup_generated!(model, kind, n; per_row = 0, seed = 1, settings...)
+
+Build one of the synthetic problem families of SURVEY.md 8d directly in HBM and run setup on it.
+Mirrors `OSQP.setup!` [REF src/interface.jl:35-162] after the point where the data are handed to C.
+"""
+function setup_generated!(model::OSQP.Model, kind::ProblemKind, n::Integer; per_row::Integer = 0, seed::Integer = 1, settings...)
+    settings_dict = Dict{Symbol,Any}(settings)
+    stgs = OSQP.Settings(settings_dict)
+    workspace = Ref{Ptr{OSQP.Workspace}}()
+    flag = ccall(
+        (:osqp_amd_setup_generated, lib),
+        Cc_int,
+        (Ptr{Ptr{OSQP.Workspace}}, Cc_int, Cc_int, Cc_int, Culonglong, Ptr{OSQP.Settings}),
+        workspace, Int(kind), n, per_row, seed, Ref(stgs),
+    )
+    flag == 0 || error("Error in OSQP setup: $(last_error())")
+    model.workspace = workspace[]
+    (nn, m) = OSQP.dimensions(model)
+    resize!(model.lcache, m)
+    resize!(model.ucache, m)
+    model.isempty = false
+    return model
+end
+
+"""
+    stats(model) -> Vector{Float64}
+
+Back-end in use, non-zero counts, nnz(L), CG / ADMM iteration totals, device bytes, algorithmic bytes
+of the dominant kernels (see include/osqp_amd.h, `osqp_amd_get_stats`).
+"""
+function stats(model::OSQP.Model)
+    out = zeros(Float64, 13)
+    k = ccall((:osqp_amd_get_stats, lib), Cc_int, (Ptr{OSQP.Workspace}, Ptr{Cdouble}, Cc_int), model.workspace, out, length(out))
+    return out[1:k]
+end
+
+"""
+    iterate!(model, iters)
+
+Run exactly `iters` ADMM iterations from the current iterate (benchmark hook).
+"""
+function iterate!(model::OSQP.Model, iters::Integer)
+    flag = ccall((:osqp_amd_iterate, lib), Cc_int, (Ptr{OSQP.Workspace}, Cc_int), model.workspace, iters)
+    flag == 0 || error("Error iterating: $(last_error())")
+    return nothing
+end
+
+"""
+    batch_solve(P, A, Px, Ax, q, l, u; device = 0, settings...) -> (x, y, infos)
+
+`count` independent QPs that share the sparsity pattern of `P` (upper triangle) and `A`; the value arrays
+are `count x nnz` / `count x n|m` matrices stored row-major on the C side, hence the transposes.
+One workgroup per QP with the reduced KKT system factorised in LDS (csrc/batch.hip).
+"""
+function batch_solve(P::SparseMatrixCSC, A::SparseMatrixCSC, Px::Matrix{Float64}, Ax::Matrix{Float64},
+                     q::Matrix{Float64}, l::Matrix{Float64}, u::Matrix{Float64}; device::Integer = 0, settings...)
+    Pu = istriu(P) ? P : triu(P)
+    n = size(A, 2); m = size(A, 1); count = size(q, 1)
+    stgs = OSQP.Settings(Dict{Symbol,Any}(settings))
+    Pp = convert(Vector{Cc_int}, Pu.colptr .- 1); Pi = convert(Vector{Cc_int}, Pu.rowval .- 1)
+    Ap = convert(Vector{Cc_int}, A.colptr .- 1);  Ai = convert(Vector{Cc_int}, A.rowval .- 1)
+    # row-major [count x .] on the C side = column-major [. x count] here
+    Pxt = permutedims(Px); Axt = permutedims(Ax); qt = permutedims(q)
+    lt = permutedims(max.(l, -OSQP.OSQP_INFTY)); ut = permutedims(min.(u, OSQP.OSQP_INFTY))
+    x = Matrix{Float64}(undef, n, count); y = Matrix{Float64}(undef, m, count)
+    infos = Vector{OSQP.CInfo}(undef, count)
+    flag = ccall(
+        (:osqp_amd_batch_solve, lib),
+        Cc_int,
+        (Cc_int, Cc_int, Cc_int, Ptr{Cc_int}, Ptr{Cc_int}, Ptr{Cdouble}, Ptr{Cc_int}, Ptr{Cc_int}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{OSQP.Settings}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{OSQP.CInfo}, Cc_int),
+        count, n, m, Pp, Pi, Pxt, Ap, Ai, Axt, qt, lt, ut, Ref(stgs), x, y, infos, device,
+    )
+    flag == 0 || error("Error in batched solve: $(last_error())")
+    results = map(infos) do ci
+        info = OSQP.Info()
+        OSQP.copyto!(info, ci)
+        info
+    end
+    return permutedims(x), permutedims(y), results
+end
+
+end # module
