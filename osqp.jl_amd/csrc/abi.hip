@@ -316,7 +316,7 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
       case 2: spmv(e.Pf, e.x.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 6: if (!e.A.panel.active || e.A.panel.sell) throw Error(1, "no panel-CSR copy"); spmv_panel_probe(e.A, e.x.get(), s); break;
       case 4:
-        admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.x_prev.get(), e.z_prev.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
+        admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
                     e.u.get(), e.tn.get(), e.tm.get(), e.tm2.get(), e.tn2.get(), e.Ax.get(), s);
         break;
       default: throw Error(1, "unknown kernel id");

@@ -166,6 +166,41 @@ __global__ __launch_bounds__(kBlock) void k_perm_out(int N, int n, const int *__
   if (rho_inv && o >= n) out[o] += rho_inv[o - n] * v; else out[o] = v;
 }
 
+// fused iteration ends (direct back-end): the right-hand side is written straight into the pivot order and the
+// ADMM update reads the solution through the inverse permutation, so an iteration is rhs | trisolves | update.
+__global__ __launch_bounds__(kBlock) void k_direct_rhs(int n, int m, double sigma, const int *__restrict__ pinv,
+                                                       const double *__restrict__ x, const double *__restrict__ q,
+                                                       const double *__restrict__ z, const double *__restrict__ rho_inv,
+                                                       const double *__restrict__ y, double *__restrict__ bp) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o < n) bp[pinv[o]] = sigma * x[o] - q[o];
+  else if (o < n + m) { int j = o - n; bp[pinv[o]] = z[j] - rho_inv[j] * y[j]; }
+}
+__global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double alpha, const int *__restrict__ pinv,
+                                                          const double *__restrict__ bp, const double *__restrict__ rho,
+                                                          const double *__restrict__ rho_inv, const double *__restrict__ l,
+                                                          const double *__restrict__ u, double *__restrict__ x, double *__restrict__ z,
+                                                          double *__restrict__ y, double *__restrict__ delta_x,
+                                                          double *__restrict__ delta_y) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o < n) {
+    double xp = x[o];
+    double xn = alpha * bp[pinv[o]] + (1.0 - alpha) * xp;
+    x[o] = xn;
+    delta_x[o] = xn - xp;
+  } else if (o < n + m) {
+    int j = o - n;
+    double zp = z[j], yj = y[j], ri = rho_inv[j];
+    double zt = (zp - ri * yj) + ri * bp[pinv[o]];  // z~ = rhs_z + rho^-1 nu  
+    double zh = alpha * zt + (1.0 - alpha) * zp;
+    double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
+    z[j] = zn;
+    double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    y[j] = yj + dy;
+  }
+}
+
 struct Step { int kind; int a, b, G; };  // kind 0: single level [a,b) rows; 1: chain of levels [a,b)
 
 // ------------------------------------------------------------------ factor object
@@ -295,6 +330,16 @@ struct Direct : Linsys {
   explicit Direct(Engine &en) : e(en) {}
   int kind() const override { return 0; }
   int solve(double *xz, double) override { F->solve(xz, e.rho_inv.get()); return 0; }
+  bool fused_step() override {
+    hipStream_t s = e.stream;
+    const int N = e.n + e.m;
+    OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), e.x.get(), e.q.get(),
+              e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
+    F->run_steps();
+    OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->bp.get(),
+              e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
+    return true;
+  }
   int update_rho() override { return F->refactor(e.rho_inv.get()); }
   int update_matrices() override { return F->refactor(e.rho_inv.get()); }
   double nnzL() const override { return (double)F->S.nnzL; }

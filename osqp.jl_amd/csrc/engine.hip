@@ -56,6 +56,7 @@ static double limit_scaling(double v) {
 Engine::Engine() {}
 Engine::~Engine() {
   lin.reset();
+  if (chunk_exec) (void)hipGraphExecDestroy(chunk_exec);
   if (h_slots) (void)hipHostFree(h_slots);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -307,14 +308,44 @@ int Engine::kkt_solve() {
   return lin->solve(xz.get(), cand);
 }
 
-// one iteration; x/x_prev and z/z_prev have been swapped by the caller
+// one iteration, in place on (x, z, y)
 int Engine::admm_step() {
-  admm_rhs(n, m, st.sigma, x_prev.get(), q.get(), z_prev.get(), rho_inv.get(), y.get(), xz.get(), stream);
-  int rc = kkt_solve();
-  admm_update(n, m, st.alpha, xz.get(), x_prev.get(), z_prev.get(), rho.get(), rho_inv.get(), l.get(), u.get(), x.get(),
-              z.get(), y.get(), dx.get(), dy.get(), stream);
   admm_iters_total++;
+  if (lin->fused_step()) return 0;  // back-end specific fusion of rhs / permutation / update (direct.hip)
+  admm_rhs(n, m, st.sigma, x.get(), q.get(), z.get(), rho_inv.get(), y.get(), xz.get(), stream);
+  int rc = kkt_solve();
+  admm_update(n, m, st.alpha, xz.get(), rho.get(), rho_inv.get(), l.get(), u.get(), x.get(), z.get(), y.get(), dx.get(),
+              dy.get(), stream);
   return rc;
+}
+
+// A chunk = `check_termination` iterations of the direct back-end (no host round trip inside), captured once
+// in a hipGraph and replayed: removes the per-launch host cost that dominates problems whose iteration is a
+// few short kernels.  Only when nothing has to happen between two residual evaluations.
+bool Engine::can_chunk(long long iter, long long max_iter) const {
+  static const bool enabled = !(getenv("OSQP_AMD_GRAPH") && atoi(getenv("OSQP_AMD_GRAPH")) == 0);
+  const long long k = st.check_termination;
+  if (!enabled || g_debug_sync || lin->kind() != 0 || k < 2 || st.verbose || st.time_limit != 0.0) return false;
+  if ((iter - 1) % k != 0 || iter + k - 1 > max_iter) return false;
+  if (st.adaptive_rho && (st.adaptive_rho_interval == 0 || st.adaptive_rho_interval % k != 0)) return false;
+  return true;
+}
+
+void Engine::run_chunk() {
+  const int k = (int)st.check_termination;
+  if (chunk_exec && chunk_len != k) { (void)hipGraphExecDestroy(chunk_exec); chunk_exec = nullptr; }
+  if (!chunk_exec) {
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < k; i++) admm_step();
+    HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    chunk_len = k;
+    admm_iters_total -= k;  // the capture pass did not execute anything
+  }
+  HIP_CHECK(hipGraphLaunch(chunk_exec, stream));
+  admm_iters_total += k;
 }
 
 // --------------------------------------------------------------------------
@@ -534,9 +565,10 @@ int Engine::solve() {
       can_check_termination = false;
       break;
     }
-    std::swap(x, x_prev);
-    std::swap(z, z_prev);
-    if (admm_step()) {  // negative curvature in the indirect solve
+    if (can_chunk(iter, max_iter)) {
+      run_chunk();
+      iter += st.check_termination - 1;
+    } else if (admm_step()) {  // negative curvature in the indirect solve
       update_status(info, OSQP_NON_CVX); info->obj_val = NAN; info->iter = iter;
       break;
     }
@@ -606,9 +638,8 @@ int Engine::iterate(long long iters) {
   tic();
   lin->set_guess(x.get());
   for (long long it = 1; it <= iters; it++) {
-    std::swap(x, x_prev);
-    std::swap(z, z_prev);
-    admm_step();
+    if (can_chunk(it, iters)) { run_chunk(); it += st.check_termination - 1; }
+    else admm_step();
     if (st.check_termination && (it % st.check_termination == 0)) update_info(it, false);
   }
   update_info(iters, true);

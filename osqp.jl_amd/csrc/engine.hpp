@@ -31,6 +31,8 @@ struct Linsys {
   virtual int update_rho() = 0;       // engine.rho / rho_inv changed
   virtual int update_matrices() = 0;  // engine.A / At / Pf values changed
   virtual void set_guess(const double *x) {}
+  // one whole ADMM iteration with back-end specific fusion; false = not provided (generic path runs)
+  virtual bool fused_step() { return false; }
   virtual double nnzL() const { return 0.0; }
   virtual double levels() const { return 0.0; }
   virtual double trisolve_bytes() const { return 0.0; }
@@ -78,6 +80,9 @@ struct Engine {
 
   // statistics
   long long admm_iters_total = 0;
+  // graph of `check_termination` iterations (direct back-end)
+  hipGraphExec_t chunk_exec = nullptr;
+  int chunk_len = 0;
   // timers
   std::chrono::steady_clock::time_point t0;
   bool clear_update_time = false, rho_update_from_solve = false;
@@ -107,6 +112,8 @@ struct Engine {
   int solve();
   int iterate(long long iters);
   int admm_step();
+  bool can_chunk(long long iter, long long max_iter) const;
+  void run_chunk();
   int kkt_solve();
   void update_info(long long iter, bool compute_objective);
   double obj_from_slots_fresh();

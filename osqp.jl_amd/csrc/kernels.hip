@@ -510,21 +510,22 @@ void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q,
               const double *y, double *xz, hipStream_t s) {
   OQ_LAUNCH(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz);
 }
+// in place: x and z hold the previous iterate on entry and the new one on exit (no x_prev / z_prev copies,
+// no pointer swap -- which also keeps every launch argument constant, so the iteration can be graph-captured)
 __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alpha, const double *__restrict__ xz,
-                                                        const double *__restrict__ x_prev, const double *__restrict__ z_prev,
                                                         const double *__restrict__ rho, const double *__restrict__ rho_inv,
                                                         const double *__restrict__ l, const double *__restrict__ u,
                                                         double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
                                                         double *__restrict__ delta_x, double *__restrict__ delta_y) {
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
-    double xp = x_prev[i];
+    double xp = x[i];
     double xn = alpha * xz[i] + (1.0 - alpha) * xp;
     x[i] = xn;
     delta_x[i] = xn - xp;
   } else if (i < n + m) {
     int j = i - n;
-    double zt = xz[i], zp = z_prev[j], yj = y[j];
+    double zt = xz[i], zp = z[j], yj = y[j];
     double zh = alpha * zt + (1.0 - alpha) * zp;
     double zn = zh + rho_inv[j] * yj;
     zn = fmin(fmax(zn, l[j]), u[j]);
@@ -534,11 +535,10 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
     y[j] = yj + dy;
   }
 }
-void admm_update(int n, int m, double alpha, const double *xz, const double *x_prev, const double *z_prev, const double *rho,
-                 const double *rho_inv, const double *l, const double *u, double *x, double *z, double *y, double *delta_x,
-                 double *delta_y, hipStream_t s) {
-  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, x_prev, z_prev, rho,
-                     rho_inv, l, u, x, z, y, delta_x, delta_y);
+void admm_update(int n, int m, double alpha, const double *xz, const double *rho, const double *rho_inv, const double *l,
+                 const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s) {
+  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, rho, rho_inv, l, u, x, z, y,
+            delta_x, delta_y);
 }
 
 // --------------------------------------------------------------------------

@@ -68,9 +68,9 @@ void rho_vec_update(int m, const double *l, const double *u, int *ctype, double 
 // ---------------- K5: ADMM vector updates ----------------
 void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q, const double *z_prev,
               const double *rho_inv, const double *y, double *xz, hipStream_t s);
-void admm_update(int n, int m, double alpha, const double *xz, const double *x_prev, const double *z_prev,
-                 const double *rho, const double *rho_inv, const double *l, const double *u, double *x, double *z,
-                 double *y, double *delta_x, double *delta_y, hipStream_t s);
+// in place on x, z (previous iterate in, new iterate out)
+void admm_update(int n, int m, double alpha, const double *xz, const double *rho, const double *rho_inv, const double *l,
+                 const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s);
 
 // ---------------- K8: residual norms + objective pieces ----------------
 void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px,
