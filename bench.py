@@ -116,8 +116,15 @@ def main():
         kname, which, abytes = "sptrsv forward+backward", 3, st[11]
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None  # HBM bytes per launch from PMC counters: collected in separate rocprofv3 passes, committed under profiles/
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+        if pm and st[0] == 2 and int(st[12]) == 2:
+            traffic = pm["fetch_bytes"] + pm["write_bytes"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "ms_per_launch": round(ms, 4),
                 "algorithmic_bytes_per_launch": abytes}
 
     # final gather of per-instance results over RCCL (the only collective of the path)
