@@ -58,10 +58,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # test hooks for a 1-GPU box: all ranks on device 0 over gloo (RCCL refuses two ranks on one GPU)
+    if os.environ.get("OSQP_AMD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("OSQP_AMD_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     lib = oq.load_library()  # HIP engine; hard error if missing
     assert lib.osqp_amd_set_device(local_rank) == 0
