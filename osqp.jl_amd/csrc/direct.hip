@@ -51,43 +51,48 @@ __global__ __launch_bounds__(kBlock) void k_scatter_A(int64_t nnz, const int64_t
 }
 
 // ------------------------------------------------------------------ K2: numeric LDL'
-// One wavefront per column k of the level.  On entry Lx[col k] and D[k] hold the entries of K
-// (lower part), on exit the column of L and the pivot.  For every j in the row pattern of k
-// (CSR row k, ascending j; column j is final):  c[i] -= L_ij * (L_kj d_j) for the rows i > k of
-// column j, located in column k by binary search; d_k -= L_kj^2 d_j.
-__global__ __launch_bounds__(kBlock) void k_ldl_level(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                      double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                      const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                      double *__restrict__ D, double *__restrict__ Dinv, int *__restrict__ status) {
+// Dot-product form, two launches per level (levels ascending; every column of a level only needs columns of
+// lower levels).  On entry Lx / D hold the entries of K (lower part), on exit L and the pivots.
+//   phase 1, one wavefront per column k:   d_k = K_kk - sum_j L_kj^2 d_j              (row k of L, CSR view)
+//   phase 2, one thread per entry (i, k):  L_ik = (K_ik - sum_j L_ij L_kj d_j) / d_k   (merge of rows i and k,
+//            both sorted by column; only j < k can match because row k ends at k)
+// All entries of a column -- and all columns of a level -- are independent, so a dense trailing block
+// exposes (N - k) lanes per column instead of one wavefront walking k updates one after the other.
+__global__ __launch_bounds__(kBlock) void k_ldl_diag(int c0, int c1, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                     const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
+                                                     double *__restrict__ D, double *__restrict__ Dinv, int *__restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int k = c0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
   if (k >= c1) return;
-  const int64_t cs = Lp[k], ce = Lp[k + 1];
-  double dk = D[k];
-  for (int64_t q = Rp[k]; q < Rp[k + 1]; q++) {
-    const int j = Rj[q];
-    const int64_t pos = Rmap[q];
-    const double lkj = Lx[pos];
-    const double f = lkj * D[j];
-    dk -= lkj * f;
-    const int64_t je = Lp[j + 1];
-    for (int64_t t = pos + 1 + lane; t < je; t += 64) {
-      const int i = Li[t];
-      const double v = Lx[t] * f;
-      int64_t lo = cs, hi = ce;  // first position in column k with row >= i (it is there: struct(L_j) below k is inside struct(L_k))
-      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (Li[mid] < i) lo = mid + 1; else hi = mid; }
-      Lx[lo] -= v;
-    }
-    __threadfence_block();  // the next j may touch the same entries from other lanes
-  }
-  const bool bad = (dk == 0.0) || (dk != dk);
-  const double dinv = 1.0 / dk;
-  for (int64_t t = cs + lane; t < ce; t += 64) Lx[t] *= dinv;
+  double acc = 0.0;
+  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) { const double l = Lx[Rmap[q]]; acc += l * l * D[Rj[q]]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) {
-    D[k] = dk; Dinv[k] = dinv;
+    const double dk = D[k] - acc;
+    const bool bad = (dk == 0.0) || (dk != dk);
+    D[k] = dk; Dinv[k] = 1.0 / dk;
     if (bad) atomicOr(&status[0], 1);
     else if (dk > 0.0) atomicAdd(&status[1], 1);
   }
+}
+__global__ __launch_bounds__(kBlock) void k_ldl_entries(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                        double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                        const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
+                                                        const double *__restrict__ D, const double *__restrict__ Dinv) {
+  const int64_t e = Lp[c0] + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= Lp[c1]) return;
+  int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
+  const int k = lo, i = Li[e];
+  int64_t a = Rp[i], ae = Rp[i + 1], b = Rp[k], be = Rp[k + 1];
+  double acc = 0.0;
+  while (a < ae && b < be) {
+    const int ja = Rj[a], jb = Rj[b];
+    if (ja == jb) { acc += Lx[Rmap[a]] * Lx[Rmap[b]] * D[ja]; a++; b++; }
+    else if (ja < jb) a++; else b++;
+  }
+  Lx[e] = (Lx[e] - acc) * Dinv[k];
 }
 __global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
                                                        double *__restrict__ Rx) {
@@ -121,17 +126,19 @@ __global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int6
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
 }
-// chains of narrow levels inside one workgroup (4 lanes per row, barrier between levels)
+// chains of narrow levels inside one workgroup (barrier between levels); 4 lanes per row, or a whole
+// wavefront per row when the level has at most 16 rows (the long rows of a dense trailing block)
 __global__ __launch_bounds__(kChainThreads) void k_fwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
                                                              const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
                                                              const double *__restrict__ Rx, double *__restrict__ b) {
-  const int lane = threadIdx.x & 3, grp = threadIdx.x >> 2;
   for (int l = l0; l < l1; l++) {
     const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
-    for (int row = r0 + grp; row < r1; row += kChainThreads / 4) {
+    const int G = (r1 - r0) <= kChainThreads / 64 ? 64 : 4;
+    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    for (int row = r0 + grp; row < r1; row += kChainThreads / G) {
       double acc = 0.0;
-      for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += 4) acc += Rx[q] * b[Rj[q]];
-      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+      for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (lane == 0) b[row] -= acc;
     }
     __syncthreads();
@@ -141,13 +148,14 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain(int l0, int l1, con
                                                              const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                              const double *__restrict__ Lx, const double *__restrict__ Dinv,
                                                              double *__restrict__ b) {
-  const int lane = threadIdx.x & 3, grp = threadIdx.x >> 2;
   for (int l = l1 - 1; l >= l0; l--) {
     const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
-    for (int row = r0 + grp; row < r1; row += kChainThreads / 4) {
+    const int G = (r1 - r0) <= kChainThreads / 64 ? 64 : 4;
+    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    for (int row = r0 + grp; row < r1; row += kChainThreads / G) {
       double acc = 0.0;
-      for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += 4) acc += Lx[t] * b[Li[t]];
-      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+      for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += G) acc += Lx[t] * b[Li[t]];
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
     }
     __syncthreads();
@@ -275,9 +283,13 @@ struct LdlFactor {
     if (e.nnzA > 0)
       OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
     for (int l = 0; l < nlev; l++) {
-      int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
-      OQ_LAUNCH(k_ldl_level, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(),
-                Rp.get(), Rj.get(), Rmap.get(), D.get(), Dinv.get(), status.get());
+      const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
+      OQ_LAUNCH(k_ldl_diag, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(),
+                Rmap.get(), D.get(), Dinv.get(), status.get());
+      const int64_t entries = S.Lp[c1] - S.Lp[c0];
+      if (entries > 0)
+        OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
+                  Rj.get(), Rmap.get(), D.get(), Dinv.get());
     }
     if (S.nnzL > 0) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
     int st[2] = {0, 0};
@@ -361,6 +373,15 @@ struct Direct : Linsys {
   }
 };
 
+double factor_flops_limit() {
+  if (const char *v = getenv("OSQP_AMD_FLOPS_LIMIT")) return atof(v);
+  return 5e8;
+}
+int level_limit() {
+  if (const char *v = getenv("OSQP_AMD_LEVEL_LIMIT")) return atoi(v);
+  return 3000;
+}
+
 int64_t factor_limit(const Engine &e, bool forced) {
   if (const char *v = getenv("OSQP_AMD_NNZL_LIMIT")) return atoll(v);
   (void)e;
@@ -376,6 +397,11 @@ std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
   std::unique_ptr<Direct> d(new Direct(e));
   d->F.reset(new LdlFactor(e, ident, e.m, e.st.sigma, 0.0, factor_limit(e, e.st.linsys_solver == AMD_DIRECT_SOLVER)));
   if (d->F->S.too_large) { *err = -1; return nullptr; }
+  // auto mode also gives the problem to PCG when the factorisation itself would take too long
+  // (sum of squared column counts ~ multiply-adds of one numeric factorisation; it is redone at every rho update)
+  // or when the level schedule is so deep that the triangular solves are a serial chain (dense trailing block):
+  // measured, n = m = 5000 with 10 per row: 4623 levels, 1.1 s per iteration -- PCG needs milliseconds there
+  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->nlev > level_limit())) { *err = -1; return nullptr; }
   int rc = d->F->refactor(e.rho_inv.get());
   if (rc) { *err = rc; return nullptr; }
   return std::unique_ptr<Linsys>(d.release());

@@ -229,7 +229,7 @@ void panel_build(DevCsr &M, hipStream_t s) {
     P.pptr.download(hp.data(), cells + 1, s);
     HIP_CHECK(hipStreamSynchronize(s));
     const uint32_t budget = (uint32_t)panel_tile_nnz();
-    const int max_rows = 16384;
+    const int max_rows = 3968;  // = kTileRowsMax of panel_sell.hip (row sums of a tile are staged in LDS)
     std::vector<int> tb, t0, t1;
     for (int b = 0; b < P.B; b++) {
       const uint32_t *pp = hp.data() + (size_t)b * M.rows;

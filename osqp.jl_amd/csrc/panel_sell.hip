@@ -23,6 +23,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+constexpr int kTileRowsMax = 3968;  // row sums of a tile are staged in LDS (31 KB next to the 128 KB x panel)
 
 __device__ __forceinline__ int64_t lb_col(const int *__restrict__ col, int64_t s, int64_t e, int target) {
   while (s < e) { int64_t mid = (s + e) >> 1; if (col[mid] < target) s = mid + 1; else e = mid; }
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
 }
 
 __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, const int *__restrict__ tile_b,
+                                                        const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
                                                         const int *__restrict__ tile_s0, const int *__restrict__ tile_ns,
                                                         const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
                                                         const int *__restrict__ slice_rows, const uint16_t *__restrict__ scol,
@@ -59,10 +61,13 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
   const int W = 1 << shift;
   const int c0 = b << shift;
   const int wlen = cols - c0 < W ? cols - c0 : W;
+  const int r0 = tile_r0[blockIdx.x], nrows = tile_r1[blockIdx.x] - r0;
+  double *ys = xs + W;  // row sums of the tile: written scattered here, stored to HBM as one contiguous block
   for (int i = threadIdx.x; i < wlen; i += kThreads) xs[i] = x[c0 + i];
+  for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *out = partial + (size_t)b * rows;
+  double *out = partial + (size_t)b * rows + r0;
   for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
     const size_t base = (size_t)slice_base[sl] + lane;
     const int L = slice_len[sl];
@@ -77,8 +82,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
       a0 += v0 * xs[c0_]; a0 += v1 * xs[c1_]; a0 += v2 * xs[c2_]; a0 += v3 * xs[c3_];
     }
     for (; k < L; k++) a1 += v[(size_t)k * 64] * xs[c[(size_t)k * 64]];
-    if (row >= 0) out[row] = a0 + a1;
+    if (row >= 0) ys[row - r0] = a0 + a1;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrows; i += kThreads) out[i] = ys[i];
 }
 
 }  // namespace
@@ -130,7 +137,10 @@ void panel_sell_prepare(DevCsr &M, const std::vector<uint32_t> &hp, const std::v
   P.sval.alloc(padded); P.scol.alloc(padded);
   P.sval.zero(s); P.scol.zero(s);
   HIP_CHECK(hipStreamSynchronize(s));
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) << P.shift)));
+  for (size_t t = 0; t < tb.size(); t++)
+    if (t1[t] - t0[t] > kTileRowsMax) throw Error(6, "internal: tile taller than the LDS row-sum buffer");
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((sizeof(double) << P.shift) + sizeof(double) * kTileRowsMax)));
   P.sell = true;
 }
 
@@ -142,8 +152,8 @@ void panel_sell_fill(DevCsr &M, bool with_cols, hipStream_t s) {
 
 void spmv_panel_sell(const DevCsr &M, const double *x, hipStream_t s) {
   const DevPanel &P = M.panel;
-  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), sizeof(double) << P.shift, s, M.rows, M.cols, P.shift, P.tile_b.get(),
-            P.tile_sub0.get(), P.tile_nsub.get(), P.sub_k.get(), P.sub_row.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x,
+  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), (sizeof(double) << P.shift) + sizeof(double) * kTileRowsMax, s, M.rows,
+            M.cols, P.shift, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get(), P.tile_sub0.get(), P.tile_nsub.get(), P.sub_k.get(), P.sub_row.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x,
             P.partial.get());
 }
 

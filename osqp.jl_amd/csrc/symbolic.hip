@@ -237,6 +237,8 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       if (total > nnzL_limit) { S.too_large = true; S.nnzL = total; return; }
     }
     S.nnzL = total;
+    S.flops = 0.0;
+    for (int k = 0; k < N; k++) S.flops += (double)colcount[k] * (double)colcount[k];
   }
   S.Lp.assign(N + 1, 0);
   for (int j = 0; j < N; j++) S.Lp[j + 1] = S.Lp[j] + colcount[j];

@@ -29,6 +29,7 @@ struct Symbolic {
   std::vector<int64_t> PtoL;         // one per nnz of triu(P) (caller's CSC order)
   std::vector<int64_t> AtoL;         // one per nnz of A (caller's CSC order); INT64_MIN for rows not selected
   int64_t nnzL = 0;
+  double flops = 0.0;                // sum of squared column counts of L (cost model of one numeric factorisation)
   bool too_large = false;            // predicted factor exceeds the limit: nothing else is filled in
 };
 
