@@ -209,3 +209,23 @@ def test_full_size_properties(product_lib):
     r2 = oq.solve(m)
     assert r2.info.status == "Solved" and r2.info.iter <= 25
     assert abs(r2.info.obj_val - r.info.obj_val) <= 1e-3 * abs(r.info.obj_val)
+
+
+def test_cleanup_releases_device_memory(product_lib):
+    """osqp_cleanup frees everything the workspace owns in HBM (the Julia finalizer relies on it
+    [REF src/interface.jl:24-25, 223-233]); repeated setup / cleanup does not accumulate."""
+    base = None
+    for rep in range(4):
+        m = oq.Model(product_lib)
+        oq.setup_generated(m, 0, 30000, 40, 1 + rep, verbose=False, linsys_solver="pcg")
+        used = oq.stats(m)[9]
+        assert used > 30000 * 40 * 12
+        oq.solve(m)
+        oq.clean(m)
+        m2 = oq.Model(product_lib)
+        oq.setup_generated(m2, 1, 1000, 0, 1, verbose=False)
+        after = oq.stats(m2)[9]          # bytes held now = only the small model
+        oq.clean(m2)
+        if base is None:
+            base = after
+        assert after == base
