@@ -34,6 +34,11 @@ struct Pattern {        // shared by all instances; device pointers
   const int *Ap, *Ai;               // A, CSC
   const int *Rp, *Rc, *Rmap;        // A, CSR; Rmap -> position in the CSC value array
   const int *Fp, *Fc, *Fmap;        // full symmetric P, CSR; Fmap -> position in the triu(P) value array
+  // structure of A' diag(rho) A (lower triangle), pre-computed once for the shared pattern: non-zero pair t is
+  // entry (Ti[t], Tj[t]) = sum over terms q in [Tp[t], Tp[t+1]) of rho[Tr[q]] * Av[Ta[q]] * Av[Tb[q]]
+  int npair;
+  const int *Tp;
+  const unsigned short *Ti, *Tj, *Tr, *Ta, *Tb;
 };
 
 __device__ __forceinline__ double nmax(double a, double b) { return (a > b || a != a) ? a : b; }
@@ -132,136 +137,80 @@ __device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classif
   __syncthreads();
 }
 
-// M = P + sigma I + A' diag(rho) A (lower triangle), then in-place Cholesky.  Returns false if not positive definite.
+// M = P + sigma I + A' diag(rho) A, then M <- M^-1 in place.  Returns false if M is not positive definite.
+//
+// The inverse is applied to thousands of right-hand sides (one per ADMM iteration) between two rho updates,
+// and a dense product M^-1 b keeps every row independent while a triangular solve is a chain of 2n dependent
+// steps; so the factorisation step is an explicit symmetric inversion by n Gauss-Jordan sweeps (Goodnight's
+// sweep operator): every sweep is one rank-1 update of the whole n x n array, spread over the workgroup, with
+// two barriers -- no serial column loop anywhere.  The pivots are the Schur complements of M, so the
+// positive-definiteness test of the Cholesky factorisation carries over unchanged.
 __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
   const int n = P.n, ld = s.ld;
-  for (int j = 0; j < n; j++) {
-    for (int i = j + threadIdx.x; i < n; i += NT) {
-      // sparse dot of columns i and j of A weighted by rho (both row lists ascending)
-      int a = s.Ap[i], ae = s.Ap[i + 1], b = s.Ap[j], be = s.Ap[j + 1];
-      double acc = 0.0;
-      while (a < ae && b < be) {
-        int ra = s.Ai[a], rb = s.Ai[b];
-        if (ra == rb) { acc += s.rho[ra] * s.Av[a] * s.Av[b]; a++; b++; }
-        else if (ra < rb) a++; else b++;
-      }
-      s.M[i + j * ld] = acc + (i == j ? sigma : 0.0);
-    }
+  // A' rho A from the pre-computed term lists (the intersections of the columns of A do not depend on the instance)
+  for (int e = threadIdx.x; e < n * ld; e += NT) s.M[e] = 0.0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < P.npair; t += NT) {
+    double acc = 0.0;
+    for (int q = P.Tp[t]; q < P.Tp[t + 1]; q++) acc += s.rho[P.Tr[q]] * s.Av[P.Ta[q]] * s.Av[P.Tb[q]];
+    const int i = P.Ti[t], j = P.Tj[t];
+    s.M[i + j * ld] = acc;
+    s.M[j + i * ld] = acc;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += NT) s.M[i + i * ld] += sigma;
   __syncthreads();
   for (int r = threadIdx.x; r < n; r += NT)
-    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) { int c = s.Fc[q]; if (c <= r) s.M[r + c * ld] += s.Pv[q]; }
+    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) s.M[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
   __syncthreads();
   bool ok = true;
-  for (int j = 0; j < n; j++) {
-    double d = s.M[j + j * ld];
+  // thread layout of a sweep: row i = tid % 128 (+128 on a second pass when n > 128), columns j = tid / 128, +2, ...
+  const int ti = threadIdx.x & 127, tj = threadIdx.x >> 7;
+  for (int k = 0; k < n; k++) {
+    for (int i = threadIdx.x; i < n; i += NT) s.tn[i] = s.M[i + k * ld];
+    __syncthreads();
+    const double d = s.tn[k];
     if (!(d > 0.0)) ok = false;
-    double dj = sqrt(d);
+    const double p = 1.0 / d;
+    // rank-1 update of the whole array (row and column k are overwritten right after)
+    for (int i = ti; i < n; i += 128) {
+      const double f = s.tn[i] * p;
+      double *Mi = s.M + i;
+      int j = tj;
+      for (; j + 6 < n; j += 8) {  // 4 independent read-modify-writes in flight
+        const double m0 = Mi[j * ld], m1 = Mi[(j + 2) * ld], m2 = Mi[(j + 4) * ld], m3 = Mi[(j + 6) * ld];
+        const double t0 = s.tn[j], t1 = s.tn[j + 2], t2 = s.tn[j + 4], t3 = s.tn[j + 6];
+        Mi[j * ld] = m0 - f * t0; Mi[(j + 2) * ld] = m1 - f * t1; Mi[(j + 4) * ld] = m2 - f * t2; Mi[(j + 6) * ld] = m3 - f * t3;
+      }
+      for (; j < n; j += 2) Mi[j * ld] -= f * s.tn[j];
+    }
     __syncthreads();
-    double inv = 1.0 / dj;
-    if (threadIdx.x == 0) { s.M[j + j * ld] = dj; s.ldinv[j] = inv; }
-    for (int i = j + 1 + threadIdx.x; i < n; i += NT) s.M[i + j * ld] *= inv;
-    __syncthreads();
-    for (int k = j + 1 + (threadIdx.x >> 4); k < n; k += NT / 16) {
-      double lkj = s.M[k + j * ld];
-      for (int i = k + (threadIdx.x & 15); i < n; i += 16) s.M[i + k * ld] -= s.M[i + j * ld] * lkj;
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const double v = (i == k) ? -p : s.tn[i] * p;
+      s.M[i + k * ld] = v;
+      s.M[k + i * ld] = v;
     }
     __syncthreads();
   }
-  // the solves read columns / rows of L without masks: keep zeros on and above the diagonal (1/L_jj is in ldinv)
-  for (int j = 0; j < n; j++)
-    for (int i = threadIdx.x; i <= j; i += NT) s.M[i + j * ld] = 0.0;
+  for (int i = ti; i < n; i += 128) {
+    double *Mi = s.M + i;
+    for (int j = tj; j < n; j += 2) Mi[j * ld] = -Mi[j * ld];
+  }
   __syncthreads();
   return ok;
 }
 
-// broadcast of one lane's double through two v_readlane_b32 (the source lane is wave-uniform)
-__device__ __forceinline__ double readlane_d(double v, int src) {
-  long long bits = __double_as_longlong(v);
-  int lo = __builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFLL), src);
-  int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Wave 0 solves L L' v = b in place; the other waves wait at the caller's barrier.
-// The vector lives in registers (row i = lane + 64 r, r < 3, so n <= 192).  After the factorisation the
-// diagonal and the upper triangle of M are zeroed (1/L_jj is kept in ldinv), so a step is branch-free:
-//   forward  step j:  w_j = b_j / L_jj (v_readlane broadcast);  b -= L[:, j] w_j   (rows <= j see zeros)
-//   backward step j:  v_j = b_j / L_jj;                         b -= L[j, :]' v_j  (rows >= j see zeros)
-// and b_j is simply never touched again; the scaling by 1/L_jj of the kept entries happens once at the end
-// of each sweep.  Steps are grouped by the register that owns row j and blocked by 4 with the next block's
-// LDS reads in flight.  Lanes beyond n carry garbage that nobody reads.
-template <int RJ, bool FWD>
-__device__ __forceinline__ void tri_phase(const double *M, const double *dinv, int ld, int n, int lane, double &b0, double &b1, double &b2) {
-  const int jb = RJ * 64, je = n < jb + 64 ? n : jb + 64;
-  if (jb >= je) return;
-  constexpr int U = 4;
-  const int r0 = lane < n ? lane : n - 1, r1 = lane + 64 < n ? lane + 64 : n - 1, r2 = lane + 128 < n ? lane + 128 : n - 1;
-  double c0[U], c1[U], c2[U], dv[U], n0[U], n1[U], n2[U], nd[U];
-  auto load = [&](int jq, double (&a0)[U], double (&a1)[U], double (&a2)[U], double (&d)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      int j = FWD ? jq + u : jq - u;
-      j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
-      if (FWD) {  // column j of L: rows > j
-        const double *col = M + (size_t)j * ld;
-        if (RJ == 0) a0[u] = col[r0];
-        if (RJ <= 1) a1[u] = col[r1];
-        a2[u] = col[r2];
-      } else {    // row j of L: columns < j
-        const double *row = M + j;
-        a0[u] = row[(size_t)r0 * ld];
-        if (RJ >= 1) a1[u] = row[(size_t)r1 * ld];
-        if (RJ == 2) a2[u] = row[(size_t)r2 * ld];
-      }
-      d[u] = dinv[j];
-    }
-  };
-  const int first = FWD ? jb : je - 1;
-  load(first, c0, c1, c2, dv);
-  for (int q = 0; q < je - jb; q += U) {
-    const int jq = FWD ? jb + q : je - 1 - q;
-    load(FWD ? jq + U : jq - U, n0, n1, n2, nd);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int j = FWD ? jq + u : jq - u;
-      if (FWD ? j < je : j >= jb) {
-        const double piv = readlane_d(RJ == 0 ? b0 : (RJ == 1 ? b1 : b2), j & 63) * dv[u];
-        if (FWD) {
-          if (RJ == 0) b0 -= c0[u] * piv;
-          if (RJ <= 1) b1 -= c1[u] * piv;
-          b2 -= c2[u] * piv;
-        } else {
-          b0 -= c0[u] * piv;
-          if (RJ >= 1) b1 -= c1[u] * piv;
-          if (RJ == 2) b2 -= c2[u] * piv;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) { c0[u] = n0[u]; c1[u] = n1[u]; c2[u] = n2[u]; dv[u] = nd[u]; }
-  }
-}
-__device__ void chol_solve_wave0(const Lds &s, int n, double *b) {
-  const int lane = threadIdx.x;
-  const int ld = s.ld;
-  const double *M = s.M, *dinv = s.ldinv;
-  const bool h0 = lane < n, h1 = lane + 64 < n, h2 = lane + 128 < n;
-  double b0 = h0 ? b[lane] : 0.0, b1 = h1 ? b[lane + 64] : 0.0, b2 = h2 ? b[lane + 128] : 0.0;
-  const double d0 = h0 ? dinv[lane] : 0.0, d1 = h1 ? dinv[lane + 64] : 0.0, d2 = h2 ? dinv[lane + 128] : 0.0;
-  tri_phase<0, true>(M, dinv, ld, n, lane, b0, b1, b2);
-  tri_phase<1, true>(M, dinv, ld, n, lane, b0, b1, b2);
-  tri_phase<2, true>(M, dinv, ld, n, lane, b0, b1, b2);
-  b0 *= d0; b1 *= d1; b2 *= d2;
-  tri_phase<2, false>(M, dinv, ld, n, lane, b0, b1, b2);
-  tri_phase<1, false>(M, dinv, ld, n, lane, b0, b1, b2);
-  tri_phase<0, false>(M, dinv, ld, n, lane, b0, b1, b2);
-  if (h0) b[lane] = b0 * d0;
-  if (h1) b[lane + 64] = b1 * d1;
-  if (h2) b[lane + 128] = b2 * d2;
-}
-
 struct Out { double iter, status, pri, dua, obj, rho_updates; };
+
+#ifdef OQ_BATCH_PROFILE
+#define PROF_DECL long long pt0 = clock64(), pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(k) { long long pt1 = clock64(); pacc[k] += pt1 - pt0; pt0 = pt1; }
+#define PROF_PRINT if (inst == 0 && tid == 0) printf("cycles: load %lld scale %lld factor %lld rhs %lld solve %lld mulA+upd %lld check %lld rho %lld iters %d\n", pacc[0], pacc[1], pacc[2], pacc[3], pacc[4], pacc[5], pacc[6], pacc[7], iter);
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_PRINT
+#endif
 
 __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, int count, const double *__restrict__ Px_all,
                                                     const double *__restrict__ Ax_all, const double *__restrict__ q_all,
@@ -273,6 +222,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   if (inst >= count) return;
   const int n = P.n, m = P.m, tid = threadIdx.x;
   Lds s = carve(lds_raw, P);
+  PROF_DECL
   // ---- stage the shared pattern (16-bit) and load the instance -----------------
   for (int k = tid; k <= n; k += NT) { s.Ap[k] = (unsigned short)P.Ap[k]; s.Fp[k] = (unsigned short)P.Fp[k]; }
   for (int k = tid; k <= m; k += NT) s.Rp[k] = (unsigned short)P.Rp[k];
@@ -286,6 +236,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
     s.E[i] = 1.0; s.z[i] = 0.0; s.y[i] = 0.0; s.zp[i] = 0.0; s.dy[i] = 0.0;
   }
   __syncthreads();
+  PROF(0)
   // ---- K0: Ruiz equilibration + cost scaling --------------------------------
   double c = 1.0;
   for (int it = 0; it < st.scaling; it++) {
@@ -334,11 +285,13 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   const double cinv = 1.0 / c;
   for (int i = tid; i < m; i += NT) { s.l[i] *= s.E[i]; s.u[i] *= s.E[i]; }
   __syncthreads();
+  PROF(1)
   // ---- K1, K2 ----------------------------------------------------------------
   double rho = fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX);
   set_rho(P, s, rho, true);
   int status = OSQP_UNSOLVED;
   if (!build_and_factor(P, s, st.sigma)) status = OSQP_NON_CVX;
+  PROF(2)
   const bool uns = st.scaling && !st.scaled_termination;
   const int check = (int)st.check_termination;
   const int rho_interval = st.adaptive_rho ? (st.adaptive_rho_interval ? (int)st.adaptive_rho_interval : 100) : 0;
@@ -455,10 +408,25 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
         s.xt[j] = a;
       }
       __syncthreads();
-#ifndef OQ_NO_TRISOLVE
-      if (tid < 64) chol_solve_wave0(s, n, s.xt);
-#endif
+      PROF(3)
+      // x~ = M^-1 b: four lanes per row (quarters of the row added through shuffles)
+      for (int row = tid >> 2; row < n; row += NT / 4) {
+        const int part = tid & 3;
+        const int q4 = (n + 3) >> 2;
+        const int j0 = part * q4, j1 = (j0 + q4 < n) ? j0 + q4 : n;
+        double a0 = 0.0, a1 = 0.0;
+        int j = j0;
+        for (; j + 1 < j1; j += 2) { a0 += s.M[row + j * s.ld] * s.xt[j]; a1 += s.M[row + (j + 1) * s.ld] * s.xt[j + 1]; }
+        if (j < j1) a0 += s.M[row + j * s.ld] * s.xt[j];
+        double acc = a0 + a1;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0) s.tn[row] = acc;
+      }
       __syncthreads();
+      for (int i = tid; i < n; i += NT) s.xt[i] = s.tn[i];
+      __syncthreads();
+      PROF(4)
 #ifndef OQ_NO_MULA
       mul_A(P, s, s.xt, s.zt);  // z~ = A x~
 #endif
@@ -472,8 +440,10 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
         s.dy[i] = d; s.y[i] += d;
       }
       __syncthreads();
+      PROF(5)
       checked_last = check && (iter % check == 0);
       if (checked_last) { update_info(); if (check_termination(false)) break; }
+      PROF(6)
       if (rho_interval && (iter % rho_interval == 0)) {
         if (!checked_last) update_info();
         double pr = m == 0 ? 0.0 : nrm[0] / (nmax(nrm[2], nrm[3]) + 1e-10);
@@ -485,6 +455,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
           if (!build_and_factor(P, s, st.sigma)) { status = OSQP_NON_CVX; break; }
         }
       }
+      PROF(7)
     }
     if (status == OSQP_UNSOLVED) {  // max_iter reached: last residual evaluation, then the 10x-relaxed tests
       iter = max_iter;
@@ -492,6 +463,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
       if (status == OSQP_UNSOLVED && !check_termination(true)) status = OSQP_MAX_ITER_REACHED;
     }
   }
+  PROF_PRINT
   // ---- store -----------------------------------------------------
   const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
   for (int j = tid; j < n; j += NT) x_out[(size_t)inst * n + j] = has_sol ? s.D[j] * x[j] : NAN;
@@ -576,7 +548,8 @@ __global__ __launch_bounds__(64) void k_gen_mpc(long long first, int count, unsi
 // shared pattern on the device, built from host CSC patterns
 struct DevicePattern {
   Pattern P;
-  DevBuf<int> Ap, Ai, Rp, Rc, Rmap, Fp, Fc, Fmap;
+  DevBuf<int> Ap, Ai, Rp, Rc, Rmap, Fp, Fc, Fmap, Tp;
+  DevBuf<unsigned short> Ti, Tj, Tr, Ta, Tb;
   void build(int n, int m, const std::vector<int> &hPp, const std::vector<int> &hPi, const std::vector<int> &hAp,
              const std::vector<int> &hAi, hipStream_t s) {
     const int nnzA = hAp[n], nnzP = hPp[n];
@@ -604,7 +577,24 @@ struct DevicePattern {
     auto up = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
     up(Ap, hAp); up(Ai, hAi); up(Rp, rp); up(Rc, rc); up(Rmap, rmap); up(Fp, fp); up(Fc, fc); up(Fmap, fmap);
     HIP_CHECK(hipStreamSynchronize(s));
-    P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get()};
+    // term lists of A' rho A: rows of A give the products, grouped by (i >= j) pair in ascending row order
+    // (the order of the sparse dot product of columns i and j, so the sums are the ones the merge would form)
+    std::vector<int> tp(1, 0);
+    std::vector<unsigned short> ti, tj, tr, ta, tb;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j <= i; j++) {
+        int a = hAp[i], ae = hAp[i + 1], b = hAp[j], be = hAp[j + 1], cnt = 0;
+        while (a < ae && b < be) {
+          if (hAi[a] == hAi[b]) { tr.push_back((unsigned short)hAi[a]); ta.push_back((unsigned short)a); tb.push_back((unsigned short)b); cnt++; a++; b++; }
+          else if (hAi[a] < hAi[b]) a++; else b++;
+        }
+        if (cnt) { ti.push_back((unsigned short)i); tj.push_back((unsigned short)j); tp.push_back((int)tr.size()); }
+      }
+    auto up16 = [&](DevBuf<unsigned short> &d, const std::vector<unsigned short> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    up(Tp, tp); up16(Ti, ti); up16(Tj, tj); up16(Tr, tr); up16(Ta, ta); up16(Tb, tb);
+    HIP_CHECK(hipStreamSynchronize(s));
+    P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get(),
+                (int)ti.size(), Tp.get(), Ti.get(), Tj.get(), Tr.get(), Ta.get(), Tb.get()};
   }
 };
 
