@@ -5,10 +5,10 @@
 //   * the instance's values of A (shared sparsity pattern, CSC order) and of the
 //     full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates;
 //   * the reduced KKT matrix M = P + sigma I + A' diag(rho) A (n x n, 80 KB at
-//     n = 100; the 300 x 300 KKT matrix would not fit) and its Cholesky factor,
-//     rebuilt in place whenever adaptive rho changes rho.
-// Per iteration: b = sigma x - q + A'(rho z - y); L L' x~ = b (one wavefront,
-// vector in LDS); z~ = A x~; the fused x/z/y update; every `check_termination`
+//     n = 100; the 300 x 300 KKT matrix would not fit), inverted in place by
+//     Gauss-Jordan sweeps and rebuilt whenever adaptive rho changes rho.
+// Per iteration: b = sigma x - q + A'(rho z - y); x~ = M^-1 b (dense product,
+// four lanes per row); z~ = A x~; the fused x/z/y update; every `check_termination`
 // iterations the same residual / infeasibility tests as the large-problem path.
 // Same algorithm as oracle/osqp_oracle.c with the KKT system in reduced form.
 // There is no communication between instances: the multi-GPU path shards the
@@ -200,7 +200,6 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
   return ok;
 }
 
-struct Out { double iter, status, pri, dua, obj, rho_updates; };
 
 #ifdef OQ_BATCH_PROFILE
 #define PROF_DECL long long pt0 = clock64(), pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -427,9 +426,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
       for (int i = tid; i < n; i += NT) s.xt[i] = s.tn[i];
       __syncthreads();
       PROF(4)
-#ifndef OQ_NO_MULA
       mul_A(P, s, s.xt, s.zt);  // z~ = A x~
-#endif
       for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
       __syncthreads();
       for (int i = tid; i < m; i += NT) {

@@ -147,7 +147,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   auto alloc0 = [&](DevBuf<double> &b, size_t cnt) { b.alloc(cnt); b.zero(stream); };
   alloc0(D, n); alloc0(Dinv, n); alloc0(E, m); alloc0(Einv, m); alloc0(rho, m); alloc0(rho_inv, m);
   ctype.alloc(m); ctype.zero(stream);
-  alloc0(x, n); alloc0(z, m); alloc0(y, m); alloc0(x_prev, n); alloc0(z_prev, m); alloc0(xz, (size_t)n + m);
+  alloc0(x, n); alloc0(z, m); alloc0(y, m); alloc0(xz, (size_t)n + m);
   alloc0(dx, n); alloc0(dy, m); alloc0(Ax, m); alloc0(Px_, n); alloc0(Aty, n);
   alloc0(tn, n); alloc0(tm, m); alloc0(tn2, n); alloc0(tm2, m);
   vec_set(D.get(), 1.0, n, stream); vec_set(Dinv.get(), 1.0, n, stream);

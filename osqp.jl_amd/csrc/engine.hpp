@@ -6,7 +6,7 @@
 //   Pf  CSR n x n   (full symmetric P expanded from the caller's upper triangle)
 //   k2pos maps from the caller's nnz order (CSC of A, CSC of triu P) into A / Pf,
 //   so that osqp_update_P / osqp_update_A are O(k) scatters.
-// Iterates x, z, y, x_prev, z_prev, xz_tilde, delta_x, delta_y, Ax, Px, Aty stay
+// Iterates x, z, y (updated in place), xz_tilde, delta_x, delta_y, Ax, Px, Aty stay
 // in HBM for the whole solve; every check_termination iterations 16 scalars
 // come back to the host.
 #pragma once
@@ -63,7 +63,7 @@ struct Engine {
 
   DevBuf<double> q, l, u, D, Dinv, E, Einv, rho, rho_inv;
   DevBuf<int> ctype, flag;
-  DevBuf<double> x, z, y, x_prev, z_prev, xz, dx, dy, Ax, Px_, Aty, tn, tm, tn2, tm2;
+  DevBuf<double> x, z, y, xz, dx, dy, Ax, Px_, Aty, tn, tm, tn2, tm2;
   DevBuf<double> slots, partials;
   double *h_slots = nullptr;  // pinned
   double res[16] = {0};       // norms of the last residual evaluation (Slot order)

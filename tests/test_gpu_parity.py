@@ -154,6 +154,16 @@ def test_panel_spmv_matches_scipy(product_lib, oracle_lib, monkeypatch):
         assert product_lib.osqp_amd_apply(m.workspace, op, oq.interface._fptr(vec), oq.interface._fptr(out)) == 0
         ref = mat @ vec
         assert np.max(np.abs(out - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+    # value updates reach the panel copies: scale every entry of A and of triu(P) through osqp_update_P_A
+    A2 = A.copy(); A2.data = A2.data * 1.5
+    Pu = sp.triu(P, format="csc"); Pu2 = Pu.copy(); Pu2.data = Pu2.data * 0.5
+    oq.update(m, Px=Pu2.data, Ax=A2.data)
+    P2full = Pu2 + sp.triu(Pu2, 1).T
+    for op, mat, vec in ((0, A2, xv), (1, A2.T, yv), (2, P2full, xv)):
+        out = np.zeros(n)
+        assert product_lib.osqp_amd_apply(m.workspace, op, oq.interface._fptr(vec), oq.interface._fptr(out)) == 0
+        ref = mat @ vec
+        assert np.max(np.abs(out - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
     # and a whole solve through the panel kernels equals the CSR-kernel solve to rounding
     opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, linsys_solver="pcg")
     mp_ = oq.Model(product_lib); oq.setup_generated(mp_, 0, n, k, 21, **opts); rp = oq.solve(mp_)
