@@ -261,14 +261,44 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *  8 numeric factorisations so far           9 device bytes allocated
  * 10 algorithmic bytes of one SpMV with A   11 algorithmic bytes of one forward+backward trisolve
  * 12 SpMV kernel used for A: 0 CSR (k_spmv), 1 LDS-staged panels + CSR tiles, 2 LDS-staged panels + sliced-ELL tiles
+ * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
+ * 16, 17 rows of the local blocks (n, m)
  * Returns the number of entries written. */
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 
 /* Time `reps` launches of one hot-path kernel with HIP events on the engine's
  * own stream; returns the mean milliseconds per launch, <0 on error.
  * which: 0 SpMV A*x, 1 SpMV A'*y, 2 SpMV P*x, 3 forward+backward trisolve,
- *        4 fused ADMM vector update, 5 one full ADMM iteration. */
+ *        4 fused ADMM vector update, 6 panel-CSR probe, 7 one all-gather of an n-vector (sharded workspaces). */
 c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
+
+/* ---- Row-sharded workspaces: ONE large QP over several GPUs, indirect back-end ----
+ *
+ * Rank r of R keeps rows [r*ceil(n/R), ...) of A', of the full symmetric P and of every n-vector, and rows
+ * [r*ceil(m/R), ...) of A and of every m-vector.  Per product with A, P or A' the input vector is all-gathered
+ * (n or m doubles); norms and dot products are all-gathered as scalars and combined in rank order, so all
+ * ranks take identical decisions.  Every rank calls the same entry points in the same order with the same
+ * arguments (full-length vectors; each rank reads its slice) and receives the full solution.  Not available on a
+ * sharded workspace: the direct back-end, polish (skipped), osqp_update_P / _A / _P_A, osqp_amd_apply.
+ *
+ * The communicator is one in-place all-gather of doubles; it must outlive the workspaces that use it.
+ *   host:  `fn(ctx, host_buf, count)` is called with world*count doubles, chunk `rank` filled in, and fills in the
+ *          other chunks (MPI_Allgather, gloo, ...); returns 0.
+ *   rccl:  ncclAllGather on the engine's stream.  `unique_id` = the 128 bytes osqp_amd_comm_unique_id wrote on
+ *          one rank, distributed by the caller; `librccl_path` (may be NULL) names the librccl to use when the
+ *          process does not already hold one. */
+typedef struct osqp_amd_comm osqp_amd_comm;
+typedef int (*osqp_amd_allgather_fn)(void *ctx, double *host_buf, long long count);
+c_int osqp_amd_comm_create_host(osqp_amd_comm **out, c_int rank, c_int world, osqp_amd_allgather_fn fn, void *ctx);
+c_int osqp_amd_comm_unique_id(void *out128, const char *librccl_path);
+c_int osqp_amd_comm_create_rccl(osqp_amd_comm **out, c_int rank, c_int world, const void *unique_id,
+                                const char *librccl_path);
+c_int osqp_amd_comm_destroy(osqp_amd_comm *comm);
+/* as osqp_setup [REF src/interface.jl:147-162] / osqp_amd_setup_generated, keeping this rank's row block */
+c_int osqp_amd_setup_sharded(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings,
+                             osqp_amd_comm *comm);
+c_int osqp_amd_setup_generated_sharded(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row,
+                                       unsigned long long seed, const OSQPSettings *settings, osqp_amd_comm *comm);
 
 /* Run exactly `iters` ADMM iterations from the current iterate (no
  * termination test inside, residuals refreshed at the end); used by bench.py

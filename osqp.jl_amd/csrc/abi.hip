@@ -75,7 +75,7 @@ OSQPWorkspace *new_workspace() {
 void finish_setup(OSQPWorkspace *w) {
   Impl *im = (Impl *)w->impl;
   Engine &e = im->eng;
-  im->data.n = e.n; im->data.m = e.m;
+  im->data.n = e.ng; im->data.m = e.mg;
   im->settings = e.st;
   im->solution.x = e.h_x.data(); im->solution.y = e.h_y.data();
   w->delta_x = e.h_dx.data(); w->delta_y = e.h_dy.data();
@@ -85,8 +85,9 @@ void finish_setup(OSQPWorkspace *w) {
   w->first_run = 1;
   w->summary_printed = 0;
   if (e.st.verbose)
-    printf("[osqp-amd] n = %d, m = %d, nnz(triu P) = %lld, nnz(A) = %lld, linsys = %s, device %d\n", e.n, e.m,
-           (long long)e.nnzPtriu, (long long)e.nnzA, e.lin->kind() == 0 ? "direct LDL' (HIP)" : "PCG (HIP)", e.device);
+    printf("[osqp-amd] n = %d, m = %d, nnz(triu P) = %lld, nnz(A) = %lld, linsys = %s, device %d, rank %d of %d\n", e.ng, e.mg,
+           (long long)e.nnzPtriu, (long long)e.nnzA, e.lin->kind() == 0 ? "direct LDL' (HIP)" : "PCG (HIP)", e.device, e.rank(),
+           e.comm ? e.comm->world : 1);
 }
 
 void destroy(OSQPWorkspace *w) {
@@ -132,7 +133,7 @@ void osqp_set_default_settings(OSQPSettings *s) {
 
 const char *osqp_version(void) { return "0.6.2"; }
 
-c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings) {
+static c_int setup_from_host(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, Comm *comm) {
   if (!workp) return 1;
   *workp = nullptr;
   if (validate_data(data)) { set_last_error("invalid problem data"); return 1; }
@@ -142,6 +143,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
     require_device();
     w = new_workspace();
     Engine &e = *E(w);
+    e.comm = comm;
     e.tic();
     e.setup_host(data, *settings);
     finish_setup(w);
@@ -153,8 +155,8 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
   return 0;
 }
 
-c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row, unsigned long long seed,
-                               const OSQPSettings *settings) {
+static c_int setup_from_generator(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row, unsigned long long seed,
+                                  const OSQPSettings *settings, Comm *comm) {
   if (!workp) return 1;
   *workp = nullptr;
   if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
@@ -164,6 +166,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
     require_device();
     w = new_workspace();
     Engine &e = *E(w);
+    e.comm = comm;
     DevBuf<int64_t> Pp, Ap;
     DevBuf<int> Pi, Ai;
     DevBuf<double> Px, Ax, q, l, u;
@@ -179,6 +182,49 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
   if (rc != 0) { destroy(w); return rc; }
   *workp = w;
   return 0;
+}
+
+c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings) {
+  return setup_from_host(workp, data, settings, nullptr);
+}
+
+c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row, unsigned long long seed,
+                               const OSQPSettings *settings) {
+  return setup_from_generator(workp, kind, n, per_row, seed, settings, nullptr);
+}
+
+// ---- row-sharded workspaces (row N4): every rank passes the same problem and keeps its own row block ----
+c_int osqp_amd_comm_create_host(osqp_amd_comm **out, c_int rank, c_int world, osqp_amd_allgather_fn fn, void *ctx) {
+  if (!out) return 1;
+  *out = nullptr;
+  return guarded([&]() { *out = (osqp_amd_comm *)make_host_comm((int)rank, (int)world, (host_allgather_fn)fn, ctx); return 0; });
+}
+c_int osqp_amd_comm_unique_id(void *out128, const char *librccl_path) {
+  if (!out128) return 1;
+  return guarded([&]() { require_device(); rccl_unique_id(out128, librccl_path); return 0; });
+}
+c_int osqp_amd_comm_create_rccl(osqp_amd_comm **out, c_int rank, c_int world, const void *unique_id, const char *librccl_path) {
+  if (!out) return 1;
+  *out = nullptr;
+  return guarded([&]() {
+    require_device();
+    *out = (osqp_amd_comm *)make_rccl_comm((int)rank, (int)world, unique_id, librccl_path);
+    return 0;
+  });
+}
+c_int osqp_amd_comm_destroy(osqp_amd_comm *c) {
+  if (!c) return 0;
+  try { delete (Comm *)c; } catch (...) { return 1; }
+  return 0;
+}
+c_int osqp_amd_setup_sharded(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, osqp_amd_comm *comm) {
+  if (!comm) { set_last_error("no communicator"); return 1; }
+  return setup_from_host(workp, data, settings, (Comm *)comm);
+}
+c_int osqp_amd_setup_generated_sharded(OSQPWorkspace **workp, c_int kind, c_int n, c_int per_row, unsigned long long seed,
+                                       const OSQPSettings *settings, osqp_amd_comm *comm) {
+  if (!comm) { set_last_error("no communicator"); return 1; }
+  return setup_from_generator(workp, kind, n, per_row, seed, settings, (Comm *)comm);
 }
 
 c_int osqp_solve(OSQPWorkspace *w) {
@@ -283,7 +329,7 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
 c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   if (!w || !out) return 0;
   const Engine &e = *E(w);
-  c_float v[13] = {0};
+  c_float v[18] = {0};
   v[0] = (c_float)e.lin->kind();
   v[1] = (c_float)e.nnzA;
   v[2] = (c_float)e.Pf.nnz;
@@ -297,8 +343,13 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[10] = e.A.spmv_bytes();
   v[11] = e.lin->trisolve_bytes();
   v[12] = e.A.panel.active ? (e.A.panel.sell ? 2.0 : 1.0) : 0.0;
+  v[13] = e.comm ? (c_float)e.comm->world : 1.0;
+  v[14] = e.comm ? e.comm->exchanges : 0.0;
+  v[15] = e.comm ? e.comm->bytes : 0.0;
+  v[16] = (c_float)e.n;  // local block sizes
+  v[17] = (c_float)e.m;
   c_int k = 0;
-  for (; k < count && k < 13; k++) out[k] = v[k];
+  for (; k < count && k < 18; k++) out[k] = v[k];
   return k;
 }
 
@@ -309,11 +360,14 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
     Engine &e = *E(w);
     hipStream_t s = e.stream;
     if (which == 3) { result = e.lin->time_solve((int)reps); return 0; }
+    // sharded: the local block's product on whatever the gather buffers hold (exchange timed separately, id 7)
+    const double *xin = e.comm ? e.gn.get() : e.x.get(), *yin = e.comm ? e.gm.get() : e.y.get();
     auto run = [&]() {
       switch (which) {
-      case 0: spmv(e.A, e.x.get(), e.tm2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
-      case 1: spmv(e.At, e.y.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
-      case 2: spmv(e.Pf, e.x.get(), e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 0: spmv(e.A, xin, e.tm2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 1: spmv(e.At, yin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 2: spmv(e.Pf, xin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
+      case 7: if (!e.comm) throw Error(1, "not a sharded workspace"); e.full_n(e.tn.get()); break;
       case 6: if (!e.A.panel.active || e.A.panel.sell) throw Error(1, "no panel-CSR copy"); spmv_panel_probe(e.A, e.x.get(), s); break;
       case 4:
         admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
@@ -347,6 +401,7 @@ c_int osqp_amd_apply(OSQPWorkspace *w, c_int op, const c_float *in, c_float *out
   if (!w) return 7;
   return guarded([&]() {
     Engine &e = *E(w);
+    if (e.comm) throw Error(6, "osqp_amd_apply is not available on a row-sharded workspace");
     hipStream_t s = e.stream;
     int nin = op == 0 || op == 2 ? e.n : (op == 1 ? e.m : e.n + e.m);
     int nout = op == 0 ? e.m : (op == 3 ? e.n + e.m : e.n);

@@ -492,7 +492,7 @@ int polish_run(Engine &e) {
   if (m > 0) spmv(e.At, py.get(), e.Aty.get(), nullptr, 0.0, 0.0, nullptr, s);
   residual_norms(n, m, px.get(), pz.get(), e.Ax.get(), e.Px_.get(), e.Aty.get(), e.q.get(), e.Dinv.get(), e.Einv.get(),
                  e.slots.get(), e.partials.get(), s);
-  e.fetch_slots(16);
+  e.fetch_slots(0, 16, (1u << S_XPX) | (1u << S_QX));
   const double *r = e.h_slots;
   const bool uns = e.st.scaling && !e.st.scaled_termination;
   double pol_pri = m == 0 ? 0.0 : (uns ? r[S_PRI_UNS] : r[S_PRI]);

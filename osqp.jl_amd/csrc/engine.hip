@@ -61,9 +61,74 @@ Engine::~Engine() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-void Engine::fetch_slots(int count) {
-  HIP_CHECK(hipMemcpyAsync(h_slots, slots.get(), sizeof(double) * count, hipMemcpyDeviceToHost, stream));
+void Engine::fetch_slots(int first, int count, unsigned sum_mask) {
+  combine_slots(first, count, sum_mask);
+  read_slots(first, count);
+}
+
+void Engine::read_slots(int first, int count) {
+  HIP_CHECK(hipMemcpyAsync(h_slots + first, slots.get() + first, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
   sync();
+}
+
+// --------------------------------------------------------------------------
+// row-sharded mode (row N4; comm.hpp)
+// --------------------------------------------------------------------------
+// the maximum of a host value over the ranks (decisions taken from a clock must be the same everywhere)
+double Engine::agree_max(double v) {
+  if (!comm) return v;
+  HIP_CHECK(hipMemcpyAsync(slots.get() + S_T5, &v, sizeof(double), hipMemcpyHostToDevice, stream));
+  fetch_slots(S_T5, 1);
+  return h_slots[S_T5];
+}
+
+void Engine::combine_slots(int first, int count, unsigned sum_mask) {
+  if (!comm) return;
+  HIP_CHECK(hipMemcpyAsync(gslots.get() + (size_t)comm->rank * count, slots.get() + first, sizeof(double) * count,
+                           hipMemcpyDeviceToDevice, stream));
+  comm->all_gather(gslots.get(), (size_t)count, stream);
+  combine_rank_slots(gslots.get(), comm->world, count, sum_mask, slots.get() + first, stream);
+}
+
+const double *Engine::full_n(const double *v) {
+  if (!comm) return v;
+  vec_copy(gn.get() + (size_t)comm->rank * chunk_n, v, n, stream);
+  comm->all_gather(gn.get(), (size_t)chunk_n, stream);
+  return gn.get();
+}
+
+const double *Engine::full_m(const double *v) {
+  if (!comm) return v;
+  vec_copy(gm.get() + (size_t)comm->rank * chunk_m, v, m, stream);
+  comm->all_gather(gm.get(), (size_t)chunk_m, stream);
+  return gm.get();
+}
+
+// Keep block `rank` of the rows of A, A', P and the matching slices of q, l, u; drop everything else.
+void Engine::shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_) {
+  const int R = comm->world, r = comm->rank;
+  chunk_n = (ng + R - 1) / R;
+  chunk_m = mg > 0 ? (mg + R - 1) / R : 0;
+  n0 = std::min(r * chunk_n, ng);
+  m0 = std::min(r * chunk_m, mg);
+  const int n1 = std::min(n0 + chunk_n, ng), m1 = std::min(m0 + chunk_m, mg);
+  if (n1 <= n0 || (mg > 0 && m1 <= m0)) throw Error(1, "sharded setup: fewer rows than ranks (every rank needs a non-empty block)");
+  csr_slice_rows(At, n0, n1, stream);
+  csr_slice_rows(Pf, n0, n1, stream);
+  if (mg > 0) csr_slice_rows(A, m0, m1, stream);
+  n = n1 - n0; m = m1 - m0;
+  auto slice = [&](DevBuf<double> &b, int first, int count) {
+    DevBuf<double> out((size_t)count);
+    if (count) HIP_CHECK(hipMemcpyAsync(out.get(), b.get() + first, sizeof(double) * count, hipMemcpyDeviceToDevice, stream));
+    sync();
+    b = std::move(out);
+  };
+  slice(q_, n0, n); slice(l_, m0, m); slice(u_, m0, m);
+  // value updates by nnz index and the direct back-end's symbolic phase are not available on a row block
+  A_k2pos.release(); P_k2lo.release(); P_k2up.release(); Pp_keep.release(); Pi_keep.release();
+  gn.alloc((size_t)chunk_n * R); gn.zero(stream);
+  gm.alloc((size_t)std::max(chunk_m, 1) * R); gm.zero(stream);
+  gslots.alloc((size_t)S_COUNT * R); gslots.zero(stream);
 }
 
 // --------------------------------------------------------------------------
@@ -90,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int *p, int v) {
 void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
                           DevBuf<int> &Ai, DevBuf<double> &Ax_in, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
                           const OSQPSettings &s) {
-  n = n_; m = m_; st = s;
+  n = n_; m = m_; ng = n_; mg = m_; st = s;
   HIP_CHECK(hipGetDevice(&device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipHostMalloc((void **)&h_slots, sizeof(double) * S_COUNT));
@@ -143,6 +208,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
   Px.release();
 
+  if (comm) shard_rows(q_, l_, u_);  // from here on n, m are the local sizes
   q = std::move(q_); l = std::move(l_); u = std::move(u_);
   auto alloc0 = [&](DevBuf<double> &b, size_t cnt) { b.alloc(cnt); b.zero(stream); };
   alloc0(D, n); alloc0(Dinv, n); alloc0(E, m); alloc0(Einv, m); alloc0(rho, m); alloc0(rho_inv, m);
@@ -162,7 +228,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   if (st.scaling) scale_data();
   refresh_panels();
   set_rho_vec();
-  h_x.assign(n, 0.0); h_y.assign(m, 0.0); h_dx.assign(n, 0.0); h_dy.assign(m, 0.0);
+  h_x.assign(ng, 0.0); h_y.assign(mg, 0.0); h_dx.assign(ng, 0.0); h_dy.assign(mg, 0.0);
   lambda0 = 0.15;
   if (const char *e = getenv("OSQP_AMD_PCG_LAMBDA")) lambda0 = atof(e);
   lambda = lambda0;
@@ -218,10 +284,11 @@ void Engine::scale_data() {
     if (m > 0) csr_row_absmax(A, Et, false, stream);   // ||A[i,:]||inf
     vec_limit_rsqrt(Dt, n, stream);
     vec_limit_rsqrt(Et, m, stream);
-    csr_scale_rows_cols(Pf, Dt, Dt, 1, 1.0, stream);
+    const double *Dg = full_n(Dt);  // column scalings are indexed by global ids
+    csr_scale_rows_cols(Pf, Dt, Dg, 1, 1.0, stream, n0);
     if (m > 0) {
-      csr_scale_rows_cols(A, Et, Dt, 0, 1.0, stream);
-      csr_scale_rows_cols(At, Dt, Et, 2, 1.0, stream);
+      csr_scale_rows_cols(A, Et, Dg, 0, 1.0, stream);
+      csr_scale_rows_cols(At, Dt, full_m(Et), 2, 1.0, stream);
     }
     vec_ew_prod(q.get(), q.get(), Dt, n, stream);
     vec_ew_prod(D.get(), D.get(), Dt, n, stream);
@@ -231,8 +298,8 @@ void Engine::scale_data() {
     HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double) * 2, stream));
     reduce_sum(Dt, n, partials.get(), slots.get() + S_T0, stream);
     reduce_absmax(q.get(), nullptr, n, slots.get() + S_T1, stream);
-    fetch_slots();
-    double c_temp = h_slots[S_T0] / (double)n;
+    fetch_slots(S_T0, 2, 1u);
+    double c_temp = h_slots[S_T0] / (double)ng;
     double qn = limit_scaling(h_slots[S_T1]);
     c_temp = limit_scaling(std::max(c_temp, qn));
     c_temp = 1.0 / c_temp;
@@ -283,6 +350,7 @@ int Engine::update_rho_vec_from_bounds() {
   int changed = 0;
   flag.download(&changed, 1, stream);
   sync();
+  if (comm) changed = agree_max(changed ? 1.0 : 0.0) > 0.0;
   if (changed && lin) return lin->update_rho();
   return 0;
 }
@@ -351,14 +419,20 @@ void Engine::run_chunk() {
 // --------------------------------------------------------------------------
 // K8: residuals, objective
 // --------------------------------------------------------------------------
-void Engine::update_info(long long iter, bool compute_objective) {
-  OSQPInfo *info = ws->info;
-  spmv(A, x.get(), Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
-  spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
-  if (m > 0) spmv(At, y.get(), Aty.get(), nullptr, 0.0, 0.0, nullptr, stream);
+// Ax, Px, A'y at the current iterate and the 16 norms / sums of Slot order into h_slots
+void Engine::residual_evaluation() {
+  const double *xg = full_n(x.get());
+  spmv(A, xg, Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  spmv(Pf, xg, Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  if (m > 0) spmv(At, full_m(y.get()), Aty.get(), nullptr, 0.0, 0.0, nullptr, stream);
   residual_norms(n, m, x.get(), z.get(), Ax.get(), Px_.get(), Aty.get(), q.get(), Dinv.get(), Einv.get(), slots.get(),
                  partials.get(), stream);
-  fetch_slots(16);
+  fetch_slots(0, 16, (1u << S_XPX) | (1u << S_QX));
+}
+
+void Engine::update_info(long long iter, bool compute_objective) {
+  OSQPInfo *info = ws->info;
+  residual_evaluation();
   memcpy(res, h_slots, sizeof(double) * 16);
   const bool uns = st.scaling && !st.scaled_termination;
   info->iter = iter;
@@ -387,14 +461,14 @@ double Engine::obj_from_slots() const {
 bool Engine::is_primal_infeasible(double eps) {
   const bool uns = st.scaling && !st.scaled_termination;
   prim_infeas_prep(m, dy.get(), l.get(), u.get(), uns ? E.get() : nullptr, slots.get(), partials.get(), stream);
-  fetch_slots();
+  fetch_slots(S_T0, 2, 2u);
   double norm_dy = h_slots[S_T0], ineq_lhs = h_slots[S_T1];
   if (norm_dy > eps) {
     if (ineq_lhs < -eps * norm_dy) {
-      spmv(At, dy.get(), tn.get(), nullptr, 0.0, 0.0, nullptr, stream);
+      spmv(At, full_m(dy.get()), tn.get(), nullptr, 0.0, 0.0, nullptr, stream);
       HIP_CHECK(hipMemsetAsync(slots.get() + S_T3, 0, sizeof(double), stream));
       reduce_absmax(tn.get(), uns ? Dinv.get() : nullptr, n, slots.get() + S_T3, stream);
-      fetch_slots();
+      fetch_slots(S_T3, 1);
       return h_slots[S_T3] < eps * norm_dy;
     }
   }
@@ -406,19 +480,20 @@ bool Engine::is_dual_infeasible(double eps) {
   HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double) * 6, stream));
   reduce_absmax(dx.get(), uns ? D.get() : nullptr, n, slots.get() + S_T0, stream);
   reduce_dot(q.get(), dx.get(), n, partials.get(), slots.get() + S_T1, stream);
-  fetch_slots();
+  fetch_slots(S_T0, 2, 2u);
   double norm_dx = h_slots[S_T0], qdx = h_slots[S_T1];
   double cost_scaling = uns ? c : 1.0;
   if (norm_dx > eps) {
     if (qdx < -cost_scaling * eps * norm_dx) {
-      spmv(Pf, dx.get(), tn2.get(), nullptr, 0.0, 0.0, nullptr, stream);
+      const double *dxg = full_n(dx.get());
+      spmv(Pf, dxg, tn2.get(), nullptr, 0.0, 0.0, nullptr, stream);
       HIP_CHECK(hipMemsetAsync(slots.get() + S_T3, 0, sizeof(double), stream));
       reduce_absmax(tn2.get(), uns ? Dinv.get() : nullptr, n, slots.get() + S_T3, stream);
-      fetch_slots();
+      fetch_slots(S_T3, 1);
       if (h_slots[S_T3] < cost_scaling * eps * norm_dx) {
-        spmv(A, dx.get(), tm.get(), nullptr, 0.0, 0.0, nullptr, stream);
+        spmv(A, dxg, tm.get(), nullptr, 0.0, 0.0, nullptr, stream);
         dual_infeas_rows(m, tm.get(), uns ? Einv.get() : nullptr, l.get(), u.get(), eps * norm_dx, slots.get(), stream);
-        fetch_slots();
+        fetch_slots(S_T2, 1);  // a count of violating rows: the maximum over ranks is zero iff every count is
         return h_slots[S_T2] == 0.0;
       }
     }
@@ -495,6 +570,13 @@ static bool has_solution(const OSQPInfo *info) {
          info->status_val != OSQP_NON_CVX;
 }
 
+// full-length host copies of an n-vector and / or an m-vector (sharded: gathered first, every rank gets all of it)
+void Engine::download_full(const double *vn, const double *vm, double *hn, double *hm) {
+  if (vn) HIP_CHECK(hipMemcpyAsync(hn, full_n(vn), sizeof(double) * ng, hipMemcpyDeviceToHost, stream));
+  if (vm && mg > 0) HIP_CHECK(hipMemcpyAsync(hm, full_m(vm), sizeof(double) * mg, hipMemcpyDeviceToHost, stream));
+  sync();
+}
+
 // A.5: host mirrors refreshed here (the Julia side reads solution->x/y, delta_x, delta_y as host pointers)
 void Engine::store_solution() {
   OSQPInfo *info = ws->info;
@@ -503,27 +585,26 @@ void Engine::store_solution() {
       vec_ew_prod(tn.get(), x.get(), D.get(), n, stream);
       vec_ew_prod(tm.get(), y.get(), E.get(), m, stream);
       vec_scale(tm.get(), cinv, m, stream);
-      tn.download(h_x.data(), n, stream); tm.download(h_y.data(), m, stream);
+      download_full(tn.get(), tm.get(), h_x.data(), h_y.data());
     } else {
-      x.download(h_x.data(), n, stream); y.download(h_y.data(), m, stream);
+      download_full(x.get(), y.get(), h_x.data(), h_y.data());
     }
-    sync();
   } else {
     std::fill(h_x.begin(), h_x.end(), NAN);
     std::fill(h_y.begin(), h_y.end(), NAN);
     if (info->status_val == OSQP_PRIMAL_INFEASIBLE || info->status_val == OSQP_PRIMAL_INFEASIBLE_INACCURATE) {
       HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double), stream));
       reduce_absmax(dy.get(), nullptr, m, slots.get() + S_T0, stream);
-      fetch_slots();
+      fetch_slots(S_T0, 1);
       vec_scale(dy.get(), 1.0 / h_slots[S_T0], m, stream);
-      dy.download(h_dy.data(), m, stream);
+      download_full(nullptr, dy.get(), nullptr, h_dy.data());
     }
     if (info->status_val == OSQP_DUAL_INFEASIBLE || info->status_val == OSQP_DUAL_INFEASIBLE_INACCURATE) {
       HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double), stream));
       reduce_absmax(dx.get(), nullptr, n, slots.get() + S_T0, stream);
-      fetch_slots();
+      fetch_slots(S_T0, 1);
       vec_scale(dx.get(), 1.0 / h_slots[S_T0], n, stream);
-      dx.download(h_dx.data(), n, stream);
+      download_full(dx.get(), nullptr, h_dx.data(), nullptr);
     }
     cold_start();
     sync();
@@ -542,17 +623,12 @@ int Engine::solve() {
   if (clear_update_time) info->update_time = 0.0;
   rho_update_from_solve = true;
   tic();
-  if (st.verbose) printf("iter   objective    pri res    dua res    rho\n");
+  if (st.verbose && rank() == 0) printf("iter   objective    pri res    dua res    rho\n");
   if (!st.warm_start) cold_start();
   lin->set_guess(x.get());
   have_res = false; have_ref = false; lambda = lambda0; have_seed = false;
   if (lin->kind() == 2) {  // seed the PCG tolerance rule with the residuals of the start point (as oracle/osqp_oracle.c)
-    spmv(A, x.get(), Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
-    spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
-    if (m > 0) spmv(At, y.get(), Aty.get(), nullptr, 0.0, 0.0, nullptr, stream);
-    residual_norms(n, m, x.get(), z.get(), Ax.get(), Px_.get(), Aty.get(), q.get(), Dinv.get(), Einv.get(), slots.get(),
-                   partials.get(), stream);
-    fetch_slots(16);
+    residual_evaluation();
     g_seed = std::max(m == 0 ? 0.0 : h_slots[S_PRI], h_slots[S_DUA]);
     have_seed = true;
   }
@@ -560,7 +636,9 @@ int Engine::solve() {
   for (iter = 1; iter <= max_iter; iter++) {
     if (ws->first_run) temp_run_time = info->setup_time + toc();
     else temp_run_time = info->update_time + toc();
-    if (st.time_limit && temp_run_time >= st.time_limit) {
+    bool out_of_time = st.time_limit && temp_run_time >= st.time_limit;
+    if (comm && st.time_limit) out_of_time = agree_max(out_of_time ? 1.0 : 0.0) > 0.0;  // clocks differ between ranks
+    if (out_of_time) {
       update_status(info, OSQP_TIME_LIMIT_REACHED);
       can_check_termination = false;
       break;
@@ -576,12 +654,14 @@ int Engine::solve() {
     can_print = st.verbose && ((iter % 200 == 0) || iter == 1);
     if (can_check_termination || can_print) {
       update_info(iter, compute_cost_function);
-      if (can_print) printf("%4lld  %11.4e  %9.2e  %9.2e  %9.2e\n", iter, info->obj_val, info->pri_res, info->dua_res, st.rho);
+      if (can_print && rank() == 0) printf("%4lld  %11.4e  %9.2e  %9.2e  %9.2e\n", iter, info->obj_val, info->pri_res, info->dua_res, st.rho);
       if (can_check_termination && check_termination(false)) break;
     }
     if (st.adaptive_rho && !st.adaptive_rho_interval) {
       sync();  // the automatic interval is defined on elapsed solve time (nondeterministic, as in the reference)
-      if (toc() > st.adaptive_rho_fraction * info->setup_time) {
+      bool reached = toc() > st.adaptive_rho_fraction * info->setup_time;
+      if (comm) reached = agree_max(reached ? 1.0 : 0.0) > 0.0;  // one decision for all ranks
+      if (reached) {
         long long base = st.check_termination ? st.check_termination : 25;
         long long rounded = base * (long long)std::floor((double)iter / (double)base + 0.5);
         if (rounded < base) rounded = base;
@@ -609,13 +689,13 @@ int Engine::solve() {
   info->rho_estimate = compute_rho_estimate();
   sync();
   info->solve_time = toc();
-  if (st.polish && info->status_val == OSQP_SOLVED) polish();
+  if (st.polish && info->status_val == OSQP_SOLVED && !comm) polish();  // polish needs the direct back-end: not on a row block
   if (ws->first_run) info->run_time = info->setup_time + info->solve_time + info->polish_time;
   else info->run_time = info->update_time + info->solve_time + info->polish_time;
   ws->first_run = 0;
   clear_update_time = true;
   rho_update_from_solve = false;
-  if (st.verbose)
+  if (st.verbose && rank() == 0)
     printf("status: %s, iterations: %lld, objective: %.6e, run time: %.3es\n", info->status, (long long)info->iter,
            info->obj_val, info->run_time);
   store_solution();
@@ -625,10 +705,10 @@ int Engine::solve() {
 
 // objective at the current x (Px recomputed: the last residual evaluation may be older than x)
 double Engine::obj_from_slots_fresh() {
-  spmv(Pf, x.get(), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
+  spmv(Pf, full_n(x.get()), Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
   reduce_dot(x.get(), Px_.get(), n, partials.get(), slots.get() + S_T4, stream);
   reduce_dot(q.get(), x.get(), n, partials.get(), slots.get() + S_T5, stream);
-  fetch_slots();
+  fetch_slots(S_T4, 2, 3u);
   double obj = 0.5 * h_slots[S_T4] + h_slots[S_T5];
   if (st.scaling) obj *= cinv;
   return obj;
@@ -666,7 +746,7 @@ void Engine::end_update() { sync(); ws->info->update_time += toc(); }
 
 int Engine::update_lin_cost(const double *q_new) {
   begin_update();
-  q.upload(q_new, n, stream);
+  q.upload(q_new + n0, n, stream);
   sync();
   if (st.scaling) vec_scale_by_vec_scalar(q.get(), D.get(), c, n, stream);
   reset_info(ws->info);
@@ -677,9 +757,12 @@ int Engine::update_lin_cost(const double *q_new) {
 int Engine::update_bounds(const double *l_new, const double *u_new) {
   begin_update();
   std::vector<double> nl(h_l), nu(h_u);
-  if (l_new) nl.assign(l_new, l_new + m);
-  if (u_new) nu.assign(u_new, u_new + m);
-  for (int i = 0; i < m; i++) if (nl[i] > nu[i]) return 1;
+  if (l_new) nl.assign(l_new + m0, l_new + m0 + m);
+  if (u_new) nu.assign(u_new + m0, u_new + m0 + m);
+  bool bad = false;
+  for (int i = 0; i < m; i++) if (nl[i] > nu[i]) bad = true;
+  if (comm) bad = agree_max(bad ? 1.0 : 0.0) > 0.0;
+  if (bad) return 1;
   h_l.swap(nl); h_u.swap(nu);
   if (l_new) { l.upload(h_l.data(), m, stream); sync(); if (st.scaling) vec_ew_prod(l.get(), l.get(), E.get(), m, stream); }
   if (u_new) { u.upload(h_u.data(), m, stream); sync(); if (st.scaling) vec_ew_prod(u.get(), u.get(), E.get(), m, stream); }
@@ -702,6 +785,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_vals(int64_t k, const long l
 
 int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const double *Ax_new, const c_int *Aidx, c_int An,
                       bool doP, bool doA) {
+  if (comm) throw Error(6, "osqp_update_P / osqp_update_A are not available on a row-sharded workspace");
   begin_update();
   if (doP) { if (Pidx) { if (Pn > nnzPtriu) return 1; } else if (Pn != nnzPtriu && Pn != 0) return 1; }
   if (doA) { if (Aidx) { if (An > nnzA) return 2; } else if (An != nnzA && An != 0) return 2; }
@@ -732,14 +816,14 @@ int Engine::warm_start(const double *xw, const double *yw) {
   st.warm_start = 1;
   ws->settings->warm_start = 1;
   if (xw) {
-    x.upload(xw, n, stream); sync();
+    x.upload(xw + n0, n, stream); sync();
     if (st.scaling) vec_ew_prod(x.get(), x.get(), Dinv.get(), n, stream);
-    if (m > 0) spmv(A, x.get(), z.get(), nullptr, 0.0, 0.0, nullptr, stream);
+    if (m > 0) spmv(A, full_n(x.get()), z.get(), nullptr, 0.0, 0.0, nullptr, stream);
   } else {
     x.zero(stream); z.zero(stream);
   }
   if (yw) {
-    y.upload(yw, m, stream); sync();
+    y.upload(yw + m0, m, stream); sync();
     if (st.scaling) vec_scale_by_vec_scalar(y.get(), Einv.get(), c, m, stream);
   } else {
     y.zero(stream);
@@ -754,6 +838,11 @@ int Engine::warm_start(const double *xw, const double *yw) {
 // --------------------------------------------------------------------------
 void Engine::select_linsys() {
   int want = st.linsys_solver;
+  if (comm) {  // a row block: only the indirect back-end shards (triangular solves are a dependency chain)
+    if (want == AMD_DIRECT_SOLVER) throw Error(2, "the direct back-end is not available on a row-sharded workspace");
+    lin = make_pcg(*this);
+    return;
+  }
   if (want == AMD_PCG_SOLVER) { lin = make_pcg(*this); return; }
   // QDLDL / MKL Pardiso / AMD_DIRECT: direct LDL'.  For QDLDL ("auto") fall back to PCG when the
   // KKT matrix is too large for a host symbolic analysis or its factor cannot fit.

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <memory>
 
+#include "comm.hpp"
 #include "kernels.hpp"
 
 namespace oq {
@@ -49,6 +50,15 @@ struct HostCsc {  // host copy of a sparsity pattern (for the symbolic phase of 
 
 struct Engine {
   int n = 0, m = 0;
+  // Row-sharded mode (row N4, comm.hpp): `comm` is set before setup and this engine holds block `rank` of the
+  // row partition.  n, m are then the LOCAL sizes (all per-element kernels run on the local slices), ng, mg the
+  // global ones; A is m x ng, At n x mg, Pf n x ng with global column ids; the input of a sparse product is
+  // all-gathered into gn / gm first (full_n / full_m) and every scalar the host or a later kernel reads is
+  // combined over the ranks in rank order (combine_slots).  Without a communicator ng = n, mg = m and all of
+  // that is a no-op.
+  Comm *comm = nullptr;  // not owned
+  int ng = 0, mg = 0, n0 = 0, m0 = 0, chunk_n = 0, chunk_m = 0;
+  DevBuf<double> gn, gm, gslots;
   OSQPSettings st;
   hipStream_t stream = nullptr;
   int device = 0;
@@ -115,6 +125,7 @@ struct Engine {
   bool can_chunk(long long iter, long long max_iter) const;
   void run_chunk();
   int kkt_solve();
+  void residual_evaluation();
   void update_info(long long iter, bool compute_objective);
   double obj_from_slots_fresh();
   void polish();
@@ -127,6 +138,7 @@ struct Engine {
   int adapt_rho();
   int update_rho(double rho_new);
   void store_solution();
+  void download_full(const double *vn, const double *vm, double *hn, double *hm);
   double obj_from_slots() const;
 
   // ---- updates ----
@@ -139,7 +151,16 @@ struct Engine {
   void tic() { t0 = std::chrono::steady_clock::now(); }
   double toc() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
-  void fetch_slots(int count = S_COUNT);
+  // slots [first, first + count) to h_slots; sharded: combined over the ranks first (bit k of sum_mask: slot
+  // first + k is a sum, otherwise a max).  A slot must not be combined twice.
+  void fetch_slots(int first, int count, unsigned sum_mask = 0);
+  void combine_slots(int first, int count, unsigned sum_mask);
+  void read_slots(int first, int count);  // plain copy to h_slots + stream sync
+  double agree_max(double v);
+  const double *full_n(const double *v);  // v (n local entries) as a full-length vector
+  const double *full_m(const double *v);
+  void shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_);
+  int rank() const { return comm ? comm->rank : 0; }
   void select_linsys();
 };
 

@@ -362,11 +362,13 @@ void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s
 
 // val[k] = ((val[k] * a) * b) * scalar.  order 0: a = r[row], b = c[col];  order 2: a = c[col], b = r[row]
 // (so that A and its transposed copy A' round identically);  order 1: a = r[min(row,col)], b = r[max(row,col)]
-// (the order in which the CPU statement multiplies an upper-triangular entry, so P stays bit-symmetric)
+// (the order in which the CPU statement multiplies an upper-triangular entry, so P stays bit-symmetric;
+// both read from c, which is indexed by global row and column ids)
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int64_t *__restrict__ rp, const int *__restrict__ ci,
                                                             double *__restrict__ va, const double *__restrict__ r,
-                                                            const double *__restrict__ c, int symmetric_order, double scalar) {
+                                                            const double *__restrict__ c, int symmetric_order, double scalar,
+                                                            int row0) {
   const int lane = threadIdx.x & (G - 1);
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
   if (row >= rows) return;
@@ -376,7 +378,11 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int6
     if (r) {
       const int col = ci[k];
       double a, b;
-      if (symmetric_order == 1) { int lo = col < (int)row ? col : (int)row, hi = col < (int)row ? (int)row : col; a = r[lo]; b = r[hi]; }
+      if (symmetric_order == 1) {  // c is indexed by global row / column (row0 = first row of a row block)
+        const int gi = (int)row + row0;
+        int lo = col < gi ? col : gi, hi = col < gi ? gi : col;
+        a = c[lo]; b = c[hi];
+      }
       else if (symmetric_order == 2) { a = c[col]; b = r[row]; }
       else { a = r[row]; b = c[col]; }
       x = (x * a) * b;
@@ -385,13 +391,14 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int6
     va[k] = x;
   }
 }
-void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmetric_order, double scalar, hipStream_t s) {
+void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmetric_order, double scalar, hipStream_t s,
+                         int row0) {
   if (M.rows == 0 || M.nnz == 0) return;
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
-  if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
-  else if (G == 8) OQ_LAUNCH(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
-  else OQ_LAUNCH(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar);
+  if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
+  else if (G == 8) OQ_LAUNCH(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
+  else OQ_LAUNCH(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
 }
 
 #define MIN_SCALING 1e-4
@@ -641,23 +648,24 @@ void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double
 __global__ __launch_bounds__(kBlock) void k_pcg_precond(int n, const int64_t *__restrict__ atp, const int *__restrict__ ati,
                                                         const double *__restrict__ atx, const int64_t *__restrict__ pp,
                                                         const int *__restrict__ pi, const double *__restrict__ px,
-                                                        const double *__restrict__ rho, double sigma, double *__restrict__ dinv) {
+                                                        const double *__restrict__ rho, double sigma, double *__restrict__ dinv,
+                                                        int row0) {
   constexpr int G = 8;
   const int lane = threadIdx.x & (G - 1);
   const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
   if (j >= n) return;
   double acc = 0.0;
   if (atp) for (int64_t k = atp[j] + lane; k < atp[j + 1]; k += G) { double a = atx[k]; acc += rho[ati[k]] * a * a; }
-  for (int64_t k = pp[j] + lane; k < pp[j + 1]; k += G) if (pi[k] == (int)j) acc += px[k];
+  for (int64_t k = pp[j] + lane; k < pp[j + 1]; k += G) if (pi[k] == (int)j + row0) acc += px[k];
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) dinv[j] = 1.0 / (sigma + acc);
 }
-void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s) {
+void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s, int row0) {
   int n = Pf.rows;
   OQ_LAUNCH(k_pcg_precond, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n,
                      At.cols > 0 && At.rows > 0 ? At.rowptr.get() : (const int64_t *)nullptr, At.col.get(), At.val.get(),
-                     Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, sigma, dinv);
+                     Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, sigma, dinv, row0);
 }
 
 __global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ w,
@@ -724,6 +732,52 @@ __global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, con
 void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s) {
   if (n <= 0) return;
   OQ_LAUNCH(k_axpy_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, y, slot_num, slot_den, x, n);
+}
+
+// ---------------- row blocks of a CSR matrix and rank-ordered scalar combination (sharded path, row N4) ----------------
+__global__ __launch_bounds__(kBlock) void k_rebase_rowptr(int count, const int64_t *__restrict__ in, int64_t base,
+                                                          int64_t *__restrict__ out) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < count) out[i] = in[i] - base;
+}
+void csr_slice_rows(DevCsr &M, int r0, int r1, hipStream_t s) {
+  if (r0 < 0 || r1 > M.rows || r1 < r0) throw Error(6, "csr_slice_rows: bad range");
+  int64_t be[2];
+  HIP_CHECK(hipMemcpyAsync(&be[0], M.rowptr.get() + r0, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(&be[1], M.rowptr.get() + r1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  DevCsr out;
+  out.rows = r1 - r0; out.cols = M.cols; out.nnz = be[1] - be[0];
+  out.rowptr.alloc((size_t)out.rows + 1);
+  OQ_LAUNCH(k_rebase_rowptr, dim3(blocks_for(out.rows + 1)), dim3(kBlock), 0, s, out.rows + 1, M.rowptr.get() + r0, be[0],
+            out.rowptr.get());
+  out.col.alloc((size_t)out.nnz); out.val.alloc((size_t)out.nnz);
+  if (out.nnz > 0) {
+    HIP_CHECK(hipMemcpyAsync(out.col.get(), M.col.get() + be[0], sizeof(int) * (size_t)out.nnz, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(out.val.get(), M.val.get() + be[0], sizeof(double) * (size_t)out.nnz, hipMemcpyDeviceToDevice, s));
+  }
+  out.group = pick_group(out.rows, out.nnz);
+  HIP_CHECK(hipStreamSynchronize(s));
+  M = std::move(out);
+}
+
+// One wavefront; every rank runs the same loop over the same gathered copies in rank order, so all ranks end up
+// with bit-identical scalars (the host control flow of the ranks must never diverge).
+__global__ void k_combine_rank_slots(const double *__restrict__ gathered, int world, int count, unsigned sum_mask,
+                                     double *__restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= count) return;
+  const bool is_sum = (sum_mask >> k) & 1u;
+  double acc = gathered[k];
+  for (int r = 1; r < world; r++) {
+    const double v = gathered[(size_t)r * count + k];
+    acc = is_sum ? acc + v : nanmax(acc, v);
+  }
+  out[k] = acc;
+}
+void combine_rank_slots(const double *gathered, int world, int count, unsigned sum_mask, double *out, hipStream_t s) {
+  if (count > 32) throw Error(6, "combine_rank_slots: at most 32 slots");
+  OQ_LAUNCH(k_combine_rank_slots, dim3(1), dim3(64), 0, s, gathered, world, count, sum_mask, out);
 }
 
 }  // namespace oq

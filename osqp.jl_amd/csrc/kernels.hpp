@@ -41,7 +41,8 @@ void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscal
 // ---------------- K0: Ruiz equilibration pieces ----------------
 void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);  // out[i] = max(|row i|) (or max with old)
 // order 0: (v*r[row])*c[col]; 1: symmetric (v*r[min])*r[max]; 2: (v*c[col])*r[row]; then *scalar
-void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s);
+// row0: global id of the first row when M is a row block (order 1 indexes c by global row and column)
+void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0 = 0);
 void vec_limit_rsqrt(double *d, int n, hipStream_t s);  // d <- 1/sqrt(limit(d))
 void vec_limit(double *d, int n, hipStream_t s);
 void vec_ew_prod(double *out, const double *a, const double *b, int n, hipStream_t s);       // out = a.*b
@@ -88,7 +89,9 @@ void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double
 
 // ---------------- K9: PCG pieces ----------------
 // dinv[j] = 1 / (sigma + Pdiag[j] + sum_i rho[i] A[i,j]^2) with At = CSR of A'
-void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s);
+// (row blocks: rho is indexed by global constraint id, row0 = global id of the first row of the blocks)
+void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s,
+                 int row0 = 0);
 // r = b - w; zz = dinv.*r; p = zz; partials -> slot rz = r'zz ; slot rn = ||r||inf
 void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
                        double *partials, double *slot_rz, double *slot_rn, hipStream_t s);
@@ -98,6 +101,10 @@ void pcg_update_xr(int n, const double *slot_rz, const double *slot_pw, double *
                    double *slot_rn, hipStream_t s);
 // beta = rz_new / rz ; p = zz + beta p
 void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s);
+// row block [r0, r1) of M (pattern and values; panels are not carried over)
+void csr_slice_rows(DevCsr &M, int r0, int r1, hipStream_t s);
+// out[first + k] = sum (bit k of sum_mask set) or max over the `world` rank copies gathered[r * count + k]
+void combine_rank_slots(const double *gathered, int world, int count, unsigned sum_mask, double *out, hipStream_t s);
 // y += (slot_num/slot_den) * x   (device-side scalar)
 void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s);
 

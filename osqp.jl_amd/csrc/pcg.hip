@@ -33,7 +33,7 @@ struct Pcg : Linsys {
   int max_iter = 20000;
   bool carried_valid = false;
   int since_refresh = 0;
-  // slots: S_T0 rz (ping), S_T1 rz (pong), S_T2 pw, S_T3 ||r||inf, S_T4 ||b1||inf
+  // slots: (S_T0 r'z, S_T1 ||r||inf) and (S_T2, S_T3) alternate between iterations, S_T4 p'Mp, S_T5 ||b1||inf
   explicit Pcg(Engine &en) : e(en) {
     size_t n = e.n, m = e.m;
     xs.alloc(n); r.alloc(n); zz.alloc(n); p.alloc(n); w.alloc(n); b1.alloc(n); dinv.alloc(n); Mxs.alloc(n);
@@ -44,17 +44,18 @@ struct Pcg : Linsys {
   int kind() const override { return 2; }
   double cg_iters() const override { return (double)total_iters; }
 
-  void precond() { pcg_precond(e.At, e.Pf, e.rho.get(), e.st.sigma, dinv.get(), e.stream); }
+  void precond() { pcg_precond(e.At, e.Pf, e.full_m(e.rho.get()), e.st.sigma, dinv.get(), e.stream, e.n0); }
 
   // Av = A v ; out = (P + sigma I) v + A'(rho .* Av)
   void apply_M(const double *v, double *Av, double *out) {
     hipStream_t s = e.stream;
+    const double *vg = e.full_n(v);  // sharded: the one n-vector exchange of the product ...
     if (e.m > 0) {
-      spmv(e.A, v, Av, nullptr, 0.0, 0.0, nullptr, s);
+      spmv(e.A, vg, Av, nullptr, 0.0, 0.0, nullptr, s);
       vec_ew_prod(t.get(), e.rho.get(), Av, e.m, s);
     }
-    spmv(e.Pf, v, out, nullptr, 0.0, e.st.sigma, v, s);
-    if (e.m > 0) spmv(e.At, t.get(), out, nullptr, 1.0, 0.0, nullptr, s);
+    spmv(e.Pf, vg, out, nullptr, 0.0, e.st.sigma, v, s);
+    if (e.m > 0) spmv(e.At, e.full_m(t.get()), out, nullptr, 1.0, 0.0, nullptr, s);  // ... and the one m-vector exchange
   }
 
   int solve(double *xz, double cand) override {
@@ -64,12 +65,12 @@ struct Pcg : Linsys {
     // b1 = r_x + A'(rho .* r_z)
     if (m > 0) {
       vec_ew_prod(t.get(), e.rho.get(), xz + n, m, s);
-      spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s);
+      spmv(e.At, e.full_m(t.get()), b1.get(), nullptr, 0.0, 1.0, xz, s);
     } else {
       vec_copy(b1.get(), xz, n, s);
     }
     HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
-    reduce_absmax(b1.get(), nullptr, n, slots + S_T4, s);
+    reduce_absmax(b1.get(), nullptr, n, slots + S_T5, s);
     // carried products of the start vector
     if (!carried_valid || ++since_refresh >= kRefresh) {
       apply_M(xs.get(), Axs.get(), Mxs.get());
@@ -78,32 +79,35 @@ struct Pcg : Linsys {
     }
     // r = b1 - M x0 ; zz = dinv r ; p = zz
     pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0,
-                      slots + S_T3, s);
-    e.fetch_slots();
-    const double bnorm = e.h_slots[S_T4];
+                      slots + S_T1, s);
+    e.fetch_slots(S_T0, 6, 1u);  // r'z is a sum, the norms are maxima, the rest is zero
+    const double bnorm = e.h_slots[S_T5];
     // tolerance rule (same statement as oracle/osqp_oracle.c pcg_tolerance)
     const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
     double tol = hi;
     if (cand >= 0.0) tol = cand;
     if (!(tol < hi)) tol = hi;
     if (tol < lo) tol = lo;
-    double rn = e.h_slots[S_T3];
-    int it = 0, cur = 0;  // cur: which of S_T0/S_T1 holds the current r'z
+    double rn = e.h_slots[S_T1];
+    int it = 0, cur = 0;  // cur: which pair holds the current r'z
     int status = 0;
     while (it < max_iter) {
       if (rn <= tol) break;
       if (rn != rn) { status = 5; break; }
       apply_M(p.get(), u.get(), w.get());
-      reduce_dot(p.get(), w.get(), n, e.partials.get(), slots + S_T2, s);
+      double *rz = slots + S_T0 + 2 * cur, *rz_new = slots + S_T0 + 2 * (1 - cur), *pw = slots + S_T4;
+      reduce_dot(p.get(), w.get(), n, e.partials.get(), pw, s);
+      e.combine_slots(S_T4, 1, 1u);
       // alpha = rz / pw on the device: A x~ += alpha A p ; x~ += alpha p ; M x~ += alpha w ; r -= alpha w ; zz = dinv r
-      if (m > 0) vec_axpy_dev(Axs.get(), slots + S_T0 + cur, slots + S_T2, u.get(), m, s);
-      vec_axpy_dev(Mxs.get(), slots + S_T0 + cur, slots + S_T2, w.get(), n, s);
-      pcg_update_xr(n, slots + S_T0 + cur, slots + S_T2, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(),
-                    e.partials.get(), slots + S_T0 + (1 - cur), slots + S_T3, s);
-      pcg_update_p(n, slots + S_T0 + (1 - cur), slots + S_T0 + cur, zz.get(), p.get(), s);
-      e.fetch_slots();
-      if (!(e.h_slots[S_T2] > 0.0)) { status = 5; carried_valid = false; break; }  // p'Mp <= 0: M is not positive definite
-      rn = e.h_slots[S_T3];
+      if (m > 0) vec_axpy_dev(Axs.get(), rz, pw, u.get(), m, s);
+      vec_axpy_dev(Mxs.get(), rz, pw, w.get(), n, s);
+      pcg_update_xr(n, rz, pw, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(), e.partials.get(), rz_new,
+                    rz_new + 1, s);
+      e.combine_slots(S_T0 + 2 * (1 - cur), 2, 1u);  // the new r'z (sum) and ||r||inf (max) in one exchange
+      pcg_update_p(n, rz_new, rz, zz.get(), p.get(), s);
+      e.read_slots(S_T0, 5);  // already combined
+      if (!(e.h_slots[S_T4] > 0.0)) { status = 5; carried_valid = false; break; }  // p'Mp <= 0: M is not positive definite
+      rn = e.h_slots[S_T1 + 2 * (1 - cur)];
       cur = 1 - cur;
       it++;
     }

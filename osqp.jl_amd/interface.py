@@ -182,8 +182,9 @@ def make_settings(lib, settings):
     return s
 
 
-def setup(model, P=None, q=None, A=None, l=None, u=None, **settings):
-    """[REF src/interface.jl:35-162]"""
+def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, **settings):
+    """[REF src/interface.jl:35-162].  Extension: `comm` (sharded.HostComm / sharded.RcclComm) makes this rank keep
+    its row block of one QP shared by all ranks of the communicator (osqp_amd_setup_sharded)."""
     if P is None:
         if q is not None:
             n = len(q)
@@ -227,7 +228,11 @@ def setup(model, P=None, q=None, A=None, l=None, u=None, **settings):
     stgs = make_settings(model.lib, settings)
     data = T.Data(n, m, C.pointer(managedP.ccsc), C.pointer(managedA.ccsc), _fptr(q), _fptr(l), _fptr(u))
     workspace = T.Workspace_p()
-    exitflag = model.lib.osqp_setup(C.byref(workspace), C.byref(data), C.byref(stgs))
+    if comm is None:
+        exitflag = model.lib.osqp_setup(C.byref(workspace), C.byref(data), C.byref(stgs))
+    else:
+        exitflag = model.lib.osqp_amd_setup_sharded(C.byref(workspace), C.byref(data), C.byref(stgs), comm.handle)
+        model.comm = comm  # the communicator must outlive the workspace
     model.workspace = workspace
     if exitflag != 0:
         model.workspace = T.Workspace_p()
@@ -236,12 +241,17 @@ def setup(model, P=None, q=None, A=None, l=None, u=None, **settings):
     return model
 
 
-def setup_generated(model, kind, n, per_row=0, seed=1, **settings):
+def setup_generated(model, kind, n, per_row=0, seed=1, comm=None, **settings):
     """Extension: build one of the synthetic families directly where the library
     wants it (HBM for the product) and run setup on it (osqp_amd_setup_generated)."""
     stgs = make_settings(model.lib, settings)
     workspace = T.Workspace_p()
-    exitflag = model.lib.osqp_amd_setup_generated(C.byref(workspace), kind, n, per_row, seed, C.byref(stgs))
+    if comm is None:
+        exitflag = model.lib.osqp_amd_setup_generated(C.byref(workspace), kind, n, per_row, seed, C.byref(stgs))
+    else:
+        exitflag = model.lib.osqp_amd_setup_generated_sharded(C.byref(workspace), kind, n, per_row, seed, C.byref(stgs),
+                                                              comm.handle)
+        model.comm = comm
     if exitflag != 0:
         raise OSQPError("Error in OSQP setup")
     model.workspace = workspace
@@ -477,7 +487,7 @@ def warm_start(model, x=None, y=None):
         warm_start_y(model, y)
 
 
-def stats(model, count=13):
+def stats(model, count=18):
     """Extension: osqp_amd_get_stats as a list of floats."""
     out = np.zeros(count)
     k = model.lib.osqp_amd_get_stats(model.workspace, _fptr(out), count)

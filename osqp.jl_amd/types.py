@@ -174,6 +174,9 @@ ABI_SYMBOLS = {
 }
 
 # extension entry points (include/osqp_amd.h part 2); optional in the oracle
+# int fn(void *ctx, double *host_buf, long long count)  (include/osqp_amd.h: osqp_amd_allgather_fn)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong)
+
 EXT_SYMBOLS = {
     "osqp_amd_setup_generated": (c_int, [C.POINTER(Workspace_p), c_int, c_int, c_int, C.c_ulonglong, C.POINTER(Settings)]),
     "osqp_amd_get_stats": (c_int, [Workspace_p, c_float_p, c_int]),
@@ -189,6 +192,13 @@ EXT_SYMBOLS = {
         c_int,
         [c_int, c_int, C.c_ulonglong, C.POINTER(Settings), C.c_void_p, C.c_void_p, C.c_void_p, c_int],
     ),
+    "osqp_amd_comm_create_host": (c_int, [C.POINTER(C.c_void_p), c_int, c_int, ALLGATHER_FN, C.c_void_p]),
+    "osqp_amd_comm_unique_id": (c_int, [C.c_void_p, C.c_char_p]),
+    "osqp_amd_comm_create_rccl": (c_int, [C.POINTER(C.c_void_p), c_int, c_int, C.c_void_p, C.c_char_p]),
+    "osqp_amd_comm_destroy": (c_int, [C.c_void_p]),
+    "osqp_amd_setup_sharded": (c_int, [C.POINTER(Workspace_p), C.POINTER(Data), C.POINTER(Settings), C.c_void_p]),
+    "osqp_amd_setup_generated_sharded": (
+        c_int, [C.POINTER(Workspace_p), c_int, c_int, c_int, C.c_ulonglong, C.POINTER(Settings), C.c_void_p]),
     "osqp_amd_last_error": (C.c_char_p, []),
     "osqp_amd_set_device": (c_int, [c_int]),
     # oracle-only helpers

@@ -1,0 +1,110 @@
+"""Row-sharded solve of one QP against the single-device solve of the same problem.
+
+Several ranks share the one GPU of the test box through the host-staged transport (gloo); the RCCL transport is
+exercised with a one-rank communicator (RCCL refuses two ranks on one device).  Everything but the wire is the
+code the multi-GPU run uses."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(tmp_path, world, transport, case, settings=None, extra=()):
+    out = str(tmp_path / "out.json")
+    port = str(_free_port())
+    procs = []
+    for r in range(world):
+        cmd = [sys.executable, os.path.join(HERE, "_sharded_worker.py"), str(r), str(world), port, out, transport, case,
+               json.dumps(settings or {})] + list(extra)
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-4000:])
+    return [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+
+
+SETTINGS = dict(eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, verbose=False, linsys_solver="pcg")
+
+
+def single(product_lib, kind, n, per_row, seed, second=False):
+    import osqp_jl_amd as oq
+    m = oq.Model(product_lib)
+    oq.setup_generated(m, kind, n, per_row, seed, **SETTINGS)
+    r = oq.solve(m)
+    rec = dict(status=r.info.status, iter=r.info.iter, obj=r.info.obj_val, x=r.x.copy(), y=r.y.copy())
+    if second:
+        nn, mm = oq.dimensions(m)
+        oq.update_q(m, np.random.default_rng(5).standard_normal(nn))
+        oq.warm_start(m, x=r.x.copy(), y=r.y.copy())
+        r2 = oq.solve(m)
+        rec["second"] = dict(status=r2.info.status, iter=r2.info.iter, obj=r2.info.obj_val, x=r2.x.copy())
+    oq.clean(m)
+    return rec
+
+
+@pytest.mark.parametrize("world,kind,n,per_row", [(2, 0, 3000, 12), (3, 0, 2501, 9), (2, 1, 900, 0), (4, 0, 40000, 256)])
+def test_sharded_matches_single(product_lib, tmp_path, world, kind, n, per_row):
+    ref = single(product_lib, kind, n, per_row, 7, second=True)
+    recs = run_ranks(tmp_path, world, "host", "gen:%d:%d:%d:7" % (kind, n, per_row), SETTINGS, extra=["--second"])
+    for rec in recs:
+        assert rec["status"] == ref["status"] == "Solved"
+        # same algorithm, same decisions; only the summation order of dot products differs (rank-ordered partial sums)
+        assert abs(rec["iter"] - ref["iter"]) <= 25
+        assert abs(rec["obj"] - ref["obj"]) <= 1e-5 * max(1.0, abs(ref["obj"]))
+        assert np.max(np.abs(np.array(rec["x"]) - ref["x"])) <= 1e-4 * max(1.0, np.max(np.abs(ref["x"])))
+        assert np.max(np.abs(np.array(rec["y"]) - ref["y"])) <= 1e-4 * max(1.0, np.max(np.abs(ref["y"])))
+        assert rec["second"]["status"] == ref["second"]["status"]
+        assert abs(rec["second"]["obj"] - ref["second"]["obj"]) <= 1e-5 * max(1.0, abs(ref["second"]["obj"]))
+        assert rec["stats"][13] == world and rec["stats"][14] > 0
+    # every rank holds the same full solution, bit for bit
+    for rec in recs[1:]:
+        assert rec["x"] == recs[0]["x"] and rec["y"] == recs[0]["y"] and rec["iter"] == recs[0]["iter"]
+
+
+SHARDABLE_CASES = [
+    "case_basic_qp", "case_update_q", "case_update_l", "case_update_u", "case_update_max_iter",
+    "case_update_check_termination", "case_update_rho", "case_time_limit", "case_non_convex_big_sigma",
+    "case_dual_infeasible_lp", "case_dual_infeasible_qp", "case_primal_dual_infeasible_warm",
+    "case_primal_dual_infeasible_cold", "case_primal_infeasible_random", "case_unconstrained", "case_feasibility",
+    "case_warm_start", "case_moi_lp", "case_equality_lsq", "case_bounds_validation",
+]
+
+
+def test_reference_known_answers_sharded(tmp_path):
+    """The reference's known-answer cases with every setup cut over two ranks."""
+    recs = run_ranks(tmp_path, 2, "host", "cases:" + ",".join(SHARDABLE_CASES))
+    for rec in recs:
+        bad = {k: v for k, v in rec.items() if v != "ok"}
+        assert not bad, "\n".join("%s:\n%s" % kv for kv in bad.items())
+
+
+def test_rccl_transport_one_rank(product_lib, tmp_path):
+    """ncclCommInitRank / ncclAllGather resolved from the process's librccl, on the engine's stream."""
+    ref = single(product_lib, 0, 3000, 12, 7)
+    rec = run_ranks(tmp_path, 1, "rccl", "gen:0:3000:12:7", SETTINGS)[0]
+    assert rec["status"] == "Solved" and rec["iter"] == ref["iter"]
+    assert np.max(np.abs(np.array(rec["x"]) - ref["x"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x"])))
+    assert rec["stats"][14] > 0
