@@ -10,6 +10,14 @@ timed region.  Each rank (one process per GPU) owns an independent QP instance
 (seed = 1 + rank): the path shards over instances with no data-path collective;
 the only exchange is the final RCCL gather of per-instance results (weak scaling).
 
+With more than one rank and an indirect-back-end workload the line also carries
+`sharded`: the SAME QP as the 1-GPU run (seed 1) cut into row blocks over the
+ranks (all-gather of the product inputs over RCCL), timed
+the same way -- strong scaling of one solve.  `--mode sharded` makes that the
+headline `value` instead of the replicas.  The sharded leg runs after the
+replica leg and under a watchdog, so a transport problem cannot take the
+replica numbers with it.
+
 The JSON line carries `roofline` for the dominant kernel (CSR SpMV y = A x,
 measured live with HIP events on the engine's stream) and `cpu_baseline` (the
 CPU oracle timed on rank 0's host core on a bounded sample).
@@ -45,6 +53,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("OSQP_AMD_BENCH_WORKLOAD", "rand-1e6"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default=os.environ.get("OSQP_AMD_BENCH_MODE", "replicas"),
+                    help="which multi-GPU leg is the headline value (both are measured when N > 1)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the row-sharded leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -140,12 +151,9 @@ def main():
     else:
         summaries = [summary.cpu().tolist()]
 
-    cpu_baseline = None
-    if rank == 0 and not args.no_cpu:
-        cpu_baseline = cpu_leg(oq, args)
-
+    its_per_s = args.steps * world / elapsed
+    out = None
     if rank == 0:
-        its_per_s = args.steps * world / elapsed
         out = {
             "metric": "ADMM iterations/sec", "value": round(its_per_s, 3), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,11 +168,108 @@ def main():
             "pri_res": res.info.pri_res, "dua_res": res.info.dua_res, "rho_updates": int(res.info.rho_updates),
             "setup_s": round(setup_s, 3), "device_gb": round(st[9] / 1e9, 2),
             "per_rank": summaries,
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": None,
         }
-        print(json.dumps(out))
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+    want_sharded = world > 1 and st[0] == 2 and not args.no_sharded
+    watchdog = None
+    if want_sharded:
+        # from here on a hang (a transport that never completes) must not lose the numbers above
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["sharded"] = {"error": "watchdog: the row-sharded leg did not finish in time"}
+            emit()
+            os._exit(0)
+
+        watchdog = threading.Timer((0 if args.no_cpu else args.cpu_seconds + 90.0) + 300.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    if rank == 0 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_leg(oq, args)
+
+    if want_sharded:
+        oq.clean(model)  # the replica's 80 GB go before the sharded copy is built
+        try:
+            sh = sharded_leg(args, oq, lib, torch, dist, rank, world, kind, n, per_row, its_per_s / world)
+        except Exception as exc:  # reported, not hidden: the replica leg stays the value
+            sh = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        watchdog.cancel()
+        if rank == 0:
+            out["sharded"] = sh
+            if args.mode == "sharded" and "error" not in sh:
+                out.update({"value": sh["value"], "ms_per_step": sh["ms_per_step"], "scaling": "strong",
+                            "time_to_eps_s": sh["time_to_eps_s"], "iters_to_eps": sh["iters_to_eps"], "status": sh["status"]})
+                out["config"]["sharding"] = sh["sharding"]
+                out["config"]["instances"] = 1
+    emit()
     if world > 1:
         dist.destroy_process_group()
+
+
+def sharded_leg(args, oq, lib, torch, dist, rank, world, kind, n, per_row, one_gpu_its):
+    """One QP (seed 1, the 1-GPU run's instance) cut into row blocks over the ranks; same timing protocol."""
+    from osqp_jl_amd import sharded
+
+    host = os.environ.get("OSQP_AMD_BENCH_BACKEND", "nccl") == "gloo"
+    comm = sharded.HostComm(lib=lib) if host else sharded.RcclComm(lib=lib)
+    model = oq.Model(lib)
+    t0 = time.time()
+    oq.setup_generated(model, kind, n, per_row, 1, comm=comm, linsys_solver="pcg", **SETTINGS)
+    setup_s = time.time() - t0
+    ws = model.workspace
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        assert lib.osqp_amd_iterate(ws, args.warmup) == 0
+    st0 = oq.stats(model)
+    barrier()
+    t0 = time.perf_counter()
+    assert lib.osqp_amd_iterate(ws, args.steps) == 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st1 = oq.stats(model)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    oq.update_settings(model, warm_start=0)
+    barrier()
+    t0 = time.perf_counter()
+    res = oq.solve(model)
+    torch.cuda.synchronize()
+    solve_s = time.perf_counter() - t0
+    ms_spmv = float(lib.osqp_amd_time_kernel(ws, 0, 20))
+    ms_xchg = float(lib.osqp_amd_time_kernel(ws, 7, 20))
+    st = oq.stats(model)
+    value = args.steps / elapsed
+    rec = {
+        "value": round(value, 3), "unit": "iterations/s", "scaling": "strong", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "speedup_vs_one_gpu_replica": round(value / one_gpu_its, 3) if one_gpu_its > 0 else None,
+        "time_to_eps_s": round(solve_s, 4), "iters_to_eps": int(res.info.iter), "status": res.info.status,
+        "pri_res": res.info.pri_res, "dua_res": res.info.dua_res,
+        "cg_iters_per_admm_iter": round((st1[6] - st0[6]) / max(args.steps, 1), 3),
+        "exchanges_per_admm_iter": round((st1[14] - st0[14]) / max(args.steps, 1), 2),
+        "exchange_bytes_per_admm_iter": round((st1[15] - st0[15]) / max(args.steps, 1), 1),
+        "setup_s": round(setup_s, 3), "device_gb_per_rank": round(st[9] / 1e9, 2), "transport": "host/gloo" if host else "rccl",
+        "local_rows": [int(st[16]), int(st[17])],
+        "spmv_local_ms": round(ms_spmv, 4),
+        "spmv_local_GBs": round(st[10] / (ms_spmv * 1e-3) / 1e9, 1) if ms_spmv > 0 else None,
+        "allgather_n_ms": round(ms_xchg, 4),
+        "sharding": f"one QP, rows of A, A' and P cut into {world} blocks; all-gather of each product's input vector",
+    }
+    oq.clean(model)
+    comm.close()
+    return rec
 
 
 def bench_batch(args, oq, lib, torch, dist, rank, local_rank, world):

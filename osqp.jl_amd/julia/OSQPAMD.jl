@@ -115,4 +115,102 @@ function batch_solve(P::SparseMatrixCSC, A::SparseMatrixCSC, Px::Matrix{Float64}
     return permutedims(x), permutedims(y), results
 end
 
+# ---------------------------------------------------------------------------------------------
+# Row-sharded solve of one large QP over several GPUs (include/osqp_amd.h, "Row-sharded workspaces")
+# ---------------------------------------------------------------------------------------------
+
+"""
+Opaque handle of the library's communicator (one in-place all-gather of doubles).  Must outlive the models
+set up with it.
+"""
+mutable struct Comm
+    handle::Ptr{Cvoid}
+    rank::Int
+    world::Int
+    keep::Any   # the @cfunction / closure of the host transport, kept alive
+end
+
+function close!(comm::Comm)
+    comm.handle == C_NULL || ccall((:osqp_amd_comm_destroy, lib), Cc_int, (Ptr{Cvoid},), comm.handle)
+    comm.handle = C_NULL
+    return nothing
+end
+
+"""
+    unique_id() -> Vector{UInt8}
+
+The 128 bytes of an ncclUniqueId; call on one rank and distribute (e.g. `MPI.Bcast!`).
+"""
+function unique_id(; librccl::Union{Nothing,String} = nothing)
+    id = Vector{UInt8}(undef, 128)
+    flag = ccall((:osqp_amd_comm_unique_id, lib), Cc_int, (Ptr{UInt8}, Cstring), id, librccl === nothing ? C_NULL : librccl)
+    flag == 0 || error("Error creating the RCCL id: $(last_error())")
+    return id
+end
+
+"""
+    rccl_comm(rank, world, id) -> Comm
+
+ncclAllGather on the engine's stream (RCCL over xGMI); `id` from `unique_id()` of rank 0.
+"""
+function rccl_comm(rank::Integer, world::Integer, id::Vector{UInt8}; librccl::Union{Nothing,String} = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    flag = ccall((:osqp_amd_comm_create_rccl, lib), Cc_int, (Ptr{Ptr{Cvoid}}, Cc_int, Cc_int, Ptr{UInt8}, Cstring),
+                 h, rank, world, id, librccl === nothing ? C_NULL : librccl)
+    flag == 0 || error("Error creating the RCCL communicator: $(last_error())")
+    return Comm(h[], rank, world, nothing)
+end
+
+"""
+    host_comm(rank, world, allgather!) -> Comm
+
+Host-staged transport: `allgather!(buf::Vector{Float64}, count)` receives world*count doubles with chunk `rank`
+filled in and fills in the others (e.g. `MPI.Allgather!(MPI.IN_PLACE, UBuffer(buf, count), comm)`).
+"""
+function host_comm(rank::Integer, world::Integer, allgather!)
+    function trampoline(ctx::Ptr{Cvoid}, buf::Ptr{Cdouble}, count::Clonglong)::Cint
+        try
+            allgather!(unsafe_wrap(Array, buf, world * count), Int(count))
+            return 0
+        catch
+            return 1
+        end
+    end
+    cb = @cfunction($trampoline, Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Clonglong))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    flag = ccall((:osqp_amd_comm_create_host, lib), Cc_int, (Ptr{Ptr{Cvoid}}, Cc_int, Cc_int, Ptr{Cvoid}, Ptr{Cvoid}),
+                 h, rank, world, cb, C_NULL)
+    flag == 0 || error("Error creating the host communicator: $(last_error())")
+    return Comm(h[], rank, world, cb)
+end
+
+"""
+    setup_sharded!(model, comm; P, q, A, l, u, settings...)
+
+As `OSQP.setup!` [REF src/interface.jl:35-162] with the same (full) problem on every rank; the library keeps
+this rank's row block.  `OSQP.solve!`, `update_q!`, `update_bounds!`, `warm_start!` then work unchanged (every
+rank calls them in the same order and receives the full solution).
+"""
+function setup_sharded!(model::OSQP.Model, comm::Comm; P::SparseMatrixCSC, q::Vector{Float64}, A::SparseMatrixCSC,
+                        l::Vector{Float64}, u::Vector{Float64}, settings...)
+    n = size(P, 1); m = size(A, 1)
+    Pu = istriu(P) ? P : triu(P)
+    u = min.(u, OSQP.OSQP_INFTY); l = max.(l, -OSQP.OSQP_INFTY)
+    managedP = OSQP.ManagedCcsc(Pu); managedA = OSQP.ManagedCcsc(A)
+    stgs = OSQP.Settings(Dict{Symbol,Any}(settings))
+    workspace = Ref{Ptr{OSQP.Workspace}}()
+    GC.@preserve managedP managedA q l u begin
+        data = OSQP.Data(n, m, Base.unsafe_convert(Ptr{OSQP.Ccsc}, Ref(OSQP.Ccsc(managedP))),
+                         Base.unsafe_convert(Ptr{OSQP.Ccsc}, Ref(OSQP.Ccsc(managedA))), pointer(q), pointer(l), pointer(u))
+        flag = ccall((:osqp_amd_setup_sharded, lib), Cc_int,
+                     (Ptr{Ptr{OSQP.Workspace}}, Ptr{OSQP.Data}, Ptr{OSQP.Settings}, Ptr{Cvoid}),
+                     workspace, Ref(data), Ref(stgs), comm.handle)
+    end
+    flag == 0 || error("Error in OSQP setup: $(last_error())")
+    model.workspace = workspace[]
+    resize!(model.lcache, m); resize!(model.ucache, m)
+    model.isempty = false
+    return model
+end
+
 end # module
