@@ -160,15 +160,34 @@ __global__ __launch_bounds__(kBlock) void k_sort_rows_small(int rows, const int6
     col[s + j + 1] = c; src[s + j + 1] = q;
   }
 }
+// A row longer than the LDS tile (a dense constraint row such as sum(x) = 1): the normalised bitonic network
+// (every compare-exchange ascending; the first step of a merge mirrors inside its block, i ^ (k - 1)) on the
+// (col, src) pairs where they lie in global memory.  Partners past the end are skipped -- they stand for +inf
+// padding, which an all-ascending network never moves -- so any length works.  One workgroup per row.
+__device__ void sort_row_global(int *col, int *src, int64_t len) {
+  int64_t N = 1;
+  while (N < len) N <<= 1;
+  for (int64_t k = 2; k <= N; k <<= 1)
+    for (int64_t j = k >> 1; j > 0; j >>= 1) {
+      for (int64_t i = threadIdx.x; i < len; i += kBlock) {
+        const int64_t p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+        if (p > i && p < len) {
+          const int ca = col[i], cb = col[p], sa = src[i], sb = src[p];
+          if (ca > cb || (ca == cb && sa > sb)) { col[i] = cb; col[p] = ca; src[i] = sb; src[p] = sa; }
+        }
+      }
+      __syncthreads();
+    }
+}
 // rows of kSmallRow < length <= kLdsRow: one workgroup per row, bitonic sort of 64-bit keys in LDS
 __global__ __launch_bounds__(kBlock) void k_sort_rows_lds(int rows, const int64_t *__restrict__ rp, int *__restrict__ col,
-                                                          int *__restrict__ src, int *__restrict__ n_long) {
+                                                          int *__restrict__ src) {
   __shared__ unsigned long long key[kLdsRow];
   int r = blockIdx.x;
   int64_t s = rp[r];
   int64_t len64 = rp[r + 1] - s;
   if (len64 <= kSmallRow) return;
-  if (len64 > kLdsRow) { if (threadIdx.x == 0) atomicAdd(n_long, 1); return; }
+  if (len64 > kLdsRow) { sort_row_global(col + s, src + s, len64); return; }
   int len = (int)len64, N = 1;
   while (N < len) N <<= 1;
   for (int i = threadIdx.x; i < N; i += kBlock)
@@ -209,31 +228,7 @@ void csr_from_coo(int rows, int cols, int64_t E, const int *erow, const int *eco
     HIP_CHECK(hipMemcpyAsync(counts.get(), out.rowptr.get(), sizeof(int64_t) * (size_t)rows, hipMemcpyDeviceToDevice, s));
     OQ_LAUNCH(k_scatter_coo, dim3(blocks_for(E)), dim3(kBlock), 0, s, E, erow, ecol, counts.get(), out.col.get(), src.get());
     OQ_LAUNCH(k_sort_rows_small, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get());
-    DevBuf<int> n_long(1);
-    n_long.zero(s);
-    OQ_LAUNCH(k_sort_rows_lds, dim3(rows), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get(), n_long.get());
-    int h_long = 0;
-    n_long.download(&h_long, 1, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (h_long > 0) {  // rare: rows longer than the LDS tile are ordered on the host
-      std::vector<int64_t> rp((size_t)rows + 1);
-      out.rowptr.download(rp.data(), rp.size(), s);
-      HIP_CHECK(hipStreamSynchronize(s));
-      std::vector<unsigned long long> keys;
-      std::vector<int> hc, hs;
-      for (int r = 0; r < rows; r++) {
-        int64_t len = rp[r + 1] - rp[r];
-        if (len <= kLdsRow) continue;
-        hc.resize(len); hs.resize(len); keys.resize(len);
-        HIP_CHECK(hipMemcpy(hc.data(), out.col.get() + rp[r], sizeof(int) * len, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(hs.data(), src.get() + rp[r], sizeof(int) * len, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < len; i++) keys[i] = ((unsigned long long)(unsigned)hc[i] << 32) | (unsigned)hs[i];
-        std::sort(keys.begin(), keys.end());
-        for (int64_t i = 0; i < len; i++) { hc[i] = (int)(keys[i] >> 32); hs[i] = (int)(keys[i] & 0xFFFFFFFFu); }
-        HIP_CHECK(hipMemcpy(out.col.get() + rp[r], hc.data(), sizeof(int) * len, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(src.get() + rp[r], hs.data(), sizeof(int) * len, hipMemcpyHostToDevice));
-      }
-    }
+    OQ_LAUNCH(k_sort_rows_lds, dim3(rows), dim3(kBlock), 0, s, rows, out.rowptr.get(), out.col.get(), src.get());
   }
   out.group = pick_group(rows, nnz);
 }
