@@ -260,7 +260,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *  6 total CG iterations so far              7 total ADMM iterations so far
  *  8 numeric factorisations so far           9 device bytes allocated
  * 10 algorithmic bytes of one SpMV with A   11 algorithmic bytes of one forward+backward trisolve
- * 12 SpMV kernel used for A: 0 CSR (k_spmv), 1 LDS-staged panels + CSR tiles, 2 LDS-staged panels + sliced-ELL tiles
+ * 12 SpMV kernel used for A: 0 CSR (k_spmv), 2 LDS-staged column panels with sliced-ELL tiles (k_spmv_sell)
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
  * 16, 17 rows of the local blocks (n, m)
  * Returns the number of entries written. */
@@ -269,7 +269,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 /* Time `reps` launches of one hot-path kernel with HIP events on the engine's
  * own stream; returns the mean milliseconds per launch, <0 on error.
  * which: 0 SpMV A*x, 1 SpMV A'*y, 2 SpMV P*x, 3 forward+backward trisolve,
- *        4 fused ADMM vector update, 6 panel-CSR probe, 7 one all-gather of an n-vector (sharded workspaces). */
+ *        4 fused ADMM vector update, 7 one all-gather of an n-vector (sharded workspaces). */
 c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
 
 /* ---- Row-sharded workspaces: ONE large QP over several GPUs, indirect back-end ----

@@ -342,7 +342,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[9] = (c_float)g_device_bytes;
   v[10] = e.A.spmv_bytes();
   v[11] = e.lin->trisolve_bytes();
-  v[12] = e.A.panel.active ? (e.A.panel.sell ? 2.0 : 1.0) : 0.0;
+  v[12] = e.A.panel.active ? 2.0 : 0.0;
   v[13] = e.comm ? (c_float)e.comm->world : 1.0;
   v[14] = e.comm ? e.comm->exchanges : 0.0;
   v[15] = e.comm ? e.comm->bytes : 0.0;
@@ -368,7 +368,6 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
       case 1: spmv(e.At, yin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 2: spmv(e.Pf, xin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 7: if (!e.comm) throw Error(1, "not a sharded workspace"); e.full_n(e.tn.get()); break;
-      case 6: if (!e.A.panel.active || e.A.panel.sell) throw Error(1, "no panel-CSR copy"); spmv_panel_probe(e.A, e.x.get(), s); break;
       case 4:
         admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
                     e.u.get(), e.tn.get(), e.tm.get(), e.tm2.get(), e.tn2.get(), e.Ax.get(), s);

@@ -93,32 +93,24 @@ struct DevBuf {
 };
 
 // ---- device CSR matrix: 64-bit row pointers, 32-bit column indices, fp64 values
-// Column-panel copy of a CSR matrix for the LDS-staged SpMV (panel.hip): the columns are cut into
-// B panels of W = 2^shift columns; entries are stored panel-major, row-minor, with 16-bit local column
-// indices, so that a workgroup can keep its panel of x (W doubles) in LDS and gather from there.
+// Column-panel copy of a CSR matrix for the LDS-staged SpMV (panel.hip): the columns are cut into B panels of
+// W = 2^shift columns so that a workgroup can keep its panel of x (W doubles) in LDS and gather from there.
+// Workgroup tile t = rows [tile_r0[t], tile_r1[t]) of panel tile_b[t], cut at ~equal non-zero counts; inside a
+// tile the entries are stored as sliced ELL: slice = 64 rows of the tile ordered by length, column-major
+// (element k of lane l at slice_base + 64 k + l), 16-bit column ids local to the panel.
 struct DevPanel {
   bool active = false;
-  int W = 0, shift = 0, B = 0, R = 0, T = 0;  // R rows per workgroup tile, T = ceil(rows / R) tiles
-  DevBuf<uint32_t> pptr;                     // [B * rows + 1] start of (panel b, row i)
-  DevBuf<uint16_t> pcol;                     // [nnz] column index inside the panel
-  DevBuf<double> pval;                       // [nnz]
-  DevBuf<double> partial;                    // [B * rows] per-panel row sums, reduced in fixed order
-  // workgroup tiles: tile k = rows [tile_r0[k], tile_r1[k]) of panel tile_b[k], cut at ~equal nnz
+  int W = 0, shift = 0, B = 0, ntiles = 0;
   DevBuf<int> tile_b, tile_r0, tile_r1;
-  int ntiles = 0;
-  // sub-chunks of a tile for the streaming kernel: tile k owns entries [tile_sub0[k], tile_sub0[k] + tile_nsub[k]]
-  // of sub_row / sub_k (row boundaries and their non-zero offsets, <= kPanelChunk non-zeros and < 1024 rows each)
-  DevBuf<int> tile_sub0, tile_nsub, sub_row;
-  DevBuf<uint32_t> sub_k;
-  // sliced-ELL copy of every tile (panel_sell.hip): slice = 64 rows of the tile sorted by length, stored
-  // column-major (element k of lane l at slice base + 64 k + l); tile k owns slices [tile_sub0[k], +tile_nsub[k]),
-  // sub_k = slice base offset, sub_row = slice length, slice_rows = the 64 row ids of the slice (-1: empty lane)
-  bool sell = false;
-  DevBuf<uint32_t> cellbase;                 // [B * rows] base offset of (panel, row) inside sval / scol
+  DevBuf<int> tile_s0, tile_ns;              // tile t owns slices [tile_s0[t], tile_s0[t] + tile_ns[t])
+  DevBuf<uint32_t> slice_base;               // offset of the slice inside sval / scol
+  DevBuf<int> slice_len;                     // padded row length of the slice
+  DevBuf<int> slice_rows;                    // [64 per slice] row id of every lane (-1: empty lane)
+  DevBuf<uint32_t> cellbase;                 // [B * rows] slot of the first entry of (panel, row): value refresh
   DevBuf<double> sval;
   DevBuf<uint16_t> scol;
-  DevBuf<int> slice_rows;
-  size_t padded = 0;
+  DevBuf<double> partial;                    // [B * rows] per-panel row sums, reduced in fixed order
+  size_t padded = 0;                         // stored entries including padding
 };
 
 struct DevCsr {

@@ -29,12 +29,6 @@ void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, dou
 bool panel_wanted(const DevCsr &M);
 void panel_build(DevCsr &M, hipStream_t s);                    // structure + values from the CSR arrays
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s);     // refresh the values after the CSR values changed
-void spmv_panel_probe(const DevCsr &M, const double *x, hipStream_t s);  // measurement only
-// sliced-ELL tiles (panel_sell.hip): built from the host copy of the panel offsets and the tile list
-void panel_sell_prepare(DevCsr &M, const std::vector<uint32_t> &hp, const std::vector<int> &tb, const std::vector<int> &t0,
-                        const std::vector<int> &t1, hipStream_t s);
-void panel_sell_fill(DevCsr &M, bool with_cols, hipStream_t s);
-void spmv_panel_sell(const DevCsr &M, const double *x, hipStream_t s);  // fills M.panel.partial
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
                 const double *v, hipStream_t s);
 

@@ -6,13 +6,30 @@
 // fetch and the kernel runs at ~1.1 TB/s of algorithmic bandwidth (profiles/r01_a_*).
 // Here the columns are cut into panels of W = 2^shift columns (default 16384 = 128 KB of x); a
 // 1024-thread workgroup stages its panel of x in LDS once, then streams a tile of rows of that
-// panel (values fp64 + 16-bit local column indices, G lanes per row segment) and gathers from
-// LDS.  Tiles are cut at equal non-zero counts (not equal row counts) so that dense corners
-// do not leave a tail.  Per-panel row sums go to a [B x rows] buffer that a second kernel adds
-// up in panel order (fixed order => reproducible) together with the SpMV epilogue.
+// panel and gathers from LDS.  Tiles are cut at equal non-zero counts (not equal row counts) so
+// that dense corners do not leave a tail.  Per-panel row sums go to a [B x rows] buffer that a
+// second kernel adds up in panel order (fixed order => reproducible) together with the SpMV
+// epilogue.
+//
+// Inside a tile the entries are laid out as sliced ELL:
+//   * the rows of the tile are ordered by their length inside the panel, longest first;
+//   * 64 consecutive rows of that order form a slice, stored column-major and padded to the
+//     longest row of the slice (sorted => a few per cent of padding): element k of lane l sits at
+//     slice_base + 64 k + l, so one load instruction of a wavefront moves 512 contiguous bytes of
+//     values or 128 contiguous bytes of 16-bit column indices;
+//   * lane = row: no shuffles, no reduction; the lane adds its row in ascending column order.
+//     Rows with no entry in the panel are not stored at all (their cell of the partial-sum
+//     buffer is zeroed once at build time).
+// The 16 wavefronts of a workgroup share the LDS copy of the x panel and take slices round-robin;
+// the tile's row sums are staged in LDS and stored as one contiguous block.
+// (A group-per-row CSR walk over the same panels moves fewer bytes but reached only 3.3 TB/s
+// of real traffic with its 8- and 2-byte loads on ~16-entry segments; profiles/r01_e_panel_sweep.md.)
+//
+// The whole layout is planned on the device (tile cuts, per-tile ordering, slice offsets): the
+// host only reads back three totals.
 //
 // Algorithmic bytes keep the CSR accounting of SURVEY.md 8d (12 nnz + ...); the panel copy
-// actually moves 10 B per non-zero + 4 B per (row, panel) + 16 B per (row, panel) of partials.
+// actually moves 10 B per stored entry + 16 B per (row, panel) of partial sums.
 #include <algorithm>
 
 #include "kernels.hpp"
@@ -21,12 +38,15 @@ namespace oq {
 
 namespace {
 
-constexpr int kPanelThreads = 1024;
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kTileRowsMax = 3968;  // row sums of a tile are staged in LDS (31 KB next to the 128 KB x panel)
+constexpr int kSortN = 4096;        // power of two >= kTileRowsMax: per-tile ordering of the rows in LDS
+
 // tunables (defaults from the sweep in profiles/r01_e_panel_sweep.md; overridable for experiments)
 int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-int panel_shift() { return env_int("OSQP_AMD_PANEL_SHIFT", 14); }        // W = 16384 columns = 128 KB of fp64 in LDS
+int panel_shift() { return env_int("OSQP_AMD_PANEL_SHIFT", 14); }           // W = 16384 columns = 128 KB of fp64 in LDS
 int panel_tile_nnz() { return env_int("OSQP_AMD_PANEL_TILE_NNZ", 65536); }  // non-zeros per workgroup tile
-int panel_group() { return env_int("OSQP_AMD_PANEL_G", 8); }             // lanes per row segment
 
 // first position in [s, e) with col >= target (cols ascending inside a row)
 __device__ __forceinline__ int64_t lower_bound_col(const int *__restrict__ col, int64_t s, int64_t e, int target) {
@@ -34,6 +54,9 @@ __device__ __forceinline__ int64_t lower_bound_col(const int *__restrict__ col, 
   return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// planning
+// ---------------------------------------------------------------------------------------------
 // cnt[b * rows + i] = entries of row i inside panel b   (one wavefront per row, lane = panel)
 __global__ __launch_bounds__(kBlock) void k_panel_count(int rows, int B, int shift, const int64_t *__restrict__ rp,
                                                         const int *__restrict__ col, int64_t *__restrict__ cnt) {
@@ -47,14 +70,129 @@ __global__ __launch_bounds__(kBlock) void k_panel_count(int rows, int B, int shi
     cnt[(size_t)b * rows + row] = hi - lo;
   }
 }
-__global__ __launch_bounds__(kBlock) void k_to_u32(int64_t n, const int64_t *__restrict__ in, uint32_t *__restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) out[i] = (uint32_t)in[i];
+
+// Tile cuts.  Every (panel, row) cell costs max(entries, cmin) with cmin = ceil(budget / kTileRowsMax); coff is the
+// exclusive scan of the costs (panel-major).  Inside panel b the cells whose cost offset falls into the same
+// window of `budget` share a tile: ~budget non-zeros where the rows are long enough, never more than
+// kTileRowsMax rows where they are short.  start[c] = 1 when cell c = (b, r) opens a tile.
+__global__ __launch_bounds__(kBlock) void k_tile_cost(int64_t cells, int64_t cmin, int64_t *__restrict__ cnt) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c < cells && cnt[c] < cmin) cnt[c] = cmin;
 }
-// copy every entry to its (panel, row) slot; with_cols = 0 refreshes the values only
-__global__ __launch_bounds__(kBlock) void k_panel_scatter(int rows, int shift, const int64_t *__restrict__ rp, const int *__restrict__ col,
-                                                          const double *__restrict__ val, const uint32_t *__restrict__ pptr,
-                                                          uint16_t *__restrict__ pcol, double *__restrict__ pval, int with_cols) {
+__global__ __launch_bounds__(kBlock) void k_tile_starts(int rows, int64_t cells, const int64_t *__restrict__ coff, int64_t budget,
+                                                        int64_t *__restrict__ start) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cells) return;
+  const int64_t b = c / rows;
+  const int r = (int)(c - b * rows);
+  const int64_t *po = coff + b * rows;
+  const int64_t base = po[0];
+  start[c] = (r == 0 || (po[r - 1] - base) / budget != (po[r] - base) / budget) ? 1 : 0;
+}
+// tile id of an opening cell = exclusive scan of start; fill (panel, first row) of every tile
+__global__ __launch_bounds__(kBlock) void k_tile_fill(int rows, int64_t cells, const int64_t *__restrict__ start,
+                                                      const int64_t *__restrict__ tid, int *__restrict__ tile_b, int *__restrict__ tile_r0) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cells || !start[c]) return;
+  const int64_t b = c / rows;
+  tile_b[tid[c]] = (int)b;
+  tile_r0[tid[c]] = (int)(c - b * rows);
+}
+__global__ __launch_bounds__(kBlock) void k_tile_ends(int rows, int ntiles, const int *__restrict__ tile_b, const int *__restrict__ tile_r0,
+                                                      int *__restrict__ tile_r1) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= ntiles) return;
+  tile_r1[t] = (t + 1 < ntiles && tile_b[t + 1] == tile_b[t]) ? tile_r0[t + 1] : rows;
+}
+
+// The rows of a tile ordered by length inside the panel, longest first, ties by row id: bitonic sort of
+// (maxlen - length) << 12 | local row in LDS (one 1024-thread workgroup; lengths <= W <= 2^15, rows < 2^12).
+// On return key[i] & 4095 is the i-th local row and *nz_rows the number of rows with at least one entry.
+__device__ void order_tile_rows(uint32_t *key, const int64_t *__restrict__ po, int r0, int nrows, int *nz_rows) {
+  if (threadIdx.x == 0) *nz_rows = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < kSortN; i += kThreads) {
+    uint32_t k = 0xFFFFFFFFu;
+    if (i < nrows) {
+      const uint32_t len = (uint32_t)(po[r0 + i + 1] - po[r0 + i]);
+      k = ((0x7FFFFu - len) << 12) | (uint32_t)i;
+      mine += len > 0;
+    }
+    key[i] = k;
+  }
+  if (mine) atomicAdd(nz_rows, mine);
+  __syncthreads();
+  for (int k = 2; k <= kSortN; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < kSortN; i += kThreads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint32_t a = key[i], b = key[p];
+          if ((a > b) == ((i & k) == 0)) { key[i] = b; key[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+}
+__device__ __forceinline__ uint32_t key_len(uint32_t key) { return 0x7FFFFu - (key >> 12); }
+
+// pass 1: number of slices and padded size of every tile
+__global__ __launch_bounds__(kThreads) void k_tile_measure(int rows, const int *__restrict__ tile_b, const int *__restrict__ tile_r0,
+                                                           const int *__restrict__ tile_r1, const int64_t *__restrict__ off,
+                                                           int64_t *__restrict__ nslices, int64_t *__restrict__ padded) {
+  __shared__ uint32_t key[kSortN];
+  __shared__ int nz;
+  __shared__ unsigned long long total;
+  const int t = blockIdx.x;
+  const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
+  if (threadIdx.x == 0) total = 0ULL;
+  order_tile_rows(key, off + (size_t)tile_b[t] * rows, r0, nrows, &nz);
+  const int ns = (nz + 63) >> 6;
+  unsigned long long mine = 0;
+  for (int sl = threadIdx.x; sl < ns; sl += kThreads) mine += 64ULL * key_len(key[sl * 64]);
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) { nslices[t] = ns; padded[t] = (int64_t)total; }
+}
+// pass 2: slice tables and the (panel, row) -> slot map
+__global__ __launch_bounds__(kThreads) void k_tile_layout(int rows, const int *__restrict__ tile_b, const int *__restrict__ tile_r0,
+                                                          const int *__restrict__ tile_r1, const int64_t *__restrict__ off,
+                                                          const int64_t *__restrict__ slice0, const int64_t *__restrict__ padded0,
+                                                          int *__restrict__ tile_s0, int *__restrict__ tile_ns,
+                                                          uint32_t *__restrict__ slice_base, int *__restrict__ slice_len,
+                                                          int *__restrict__ slice_rows, uint32_t *__restrict__ cellbase) {
+  __shared__ uint32_t key[kSortN];
+  __shared__ uint32_t sbase[kSortN / 64 + 1];
+  __shared__ int nz;
+  const int t = blockIdx.x, b = tile_b[t];
+  const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
+  order_tile_rows(key, off + (size_t)b * rows, r0, nrows, &nz);
+  const int ns = (nz + 63) >> 6;
+  if (threadIdx.x == 0) {  // at most 62 slices: a serial prefix sum is fine
+    uint32_t acc = (uint32_t)padded0[t];
+    for (int sl = 0; sl < ns; sl++) { sbase[sl] = acc; acc += 64u * key_len(key[sl * 64]); }
+    tile_s0[t] = (int)slice0[t];
+    tile_ns[t] = ns;
+  }
+  __syncthreads();
+  const int64_t s0 = slice0[t];
+  for (int i = threadIdx.x; i < ns * 64; i += kThreads) {
+    const int sl = i >> 6, lane = i & 63;
+    int row = -1;
+    if (i < nz) {
+      row = r0 + (int)(key[i] & 4095u);
+      cellbase[(size_t)b * rows + row] = sbase[sl] + (uint32_t)lane;
+    }
+    slice_rows[(size_t)(s0 + sl) * 64 + lane] = row;
+    if (lane == 0) { slice_base[s0 + sl] = sbase[sl]; slice_len[s0 + sl] = (int)key_len(key[sl * 64]); }
+  }
+}
+
+// copy every entry of the CSR matrix to its sliced-ELL slot; with_cols = 0 refreshes the values only
+__global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, const int64_t *__restrict__ rp, const int *__restrict__ col,
+                                                         const double *__restrict__ val, const uint32_t *__restrict__ cellbase,
+                                                         uint16_t *__restrict__ scol, double *__restrict__ sval, int with_cols) {
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (row >= rows) return;
@@ -64,114 +202,52 @@ __global__ __launch_bounds__(kBlock) void k_panel_scatter(int rows, int shift, c
     const int c = col[k];
     const int b = c >> shift;
     const int64_t seg = lower_bound_col(col, s, k + 1, b << shift);  // first entry of this row in panel b
-    const size_t dst = (size_t)pptr[(size_t)b * rows + row] + (size_t)(k - seg);
-    pval[dst] = val[k];
-    if (with_cols) pcol[dst] = (uint16_t)(c & mask);
+    const size_t dst = (size_t)cellbase[(size_t)b * rows + row] + (size_t)(k - seg) * 64;
+    sval[dst] = val[k];
+    if (with_cols) scol[dst] = (uint16_t)(c & mask);
   }
 }
 
-// One workgroup = one tile (rows [r0, r1) of panel b): stage x[b*W .. b*W+W) in LDS, stream the tile,
-// gather from LDS.  Each G-lane group walks 4 rows at a time and 2 chunks of G entries per row per pass
-// (8 independent value/index loads in flight per lane); the row bounds of the next batch are fetched
-// while the current one is processed.
-template <int G>
-__global__ __launch_bounds__(kPanelThreads) void k_spmv_panel(int rows, int cols, int shift, const int *__restrict__ tile_b,
-                                                              const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
-                                                              const uint32_t *__restrict__ pptr, const uint16_t *__restrict__ pcol,
-                                                              const double *__restrict__ pval, const double *__restrict__ x,
-                                                              double *__restrict__ partial) {
+// ---------------------------------------------------------------------------------------------
+// the product
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, const int *__restrict__ tile_b,
+                                                        const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                                        const int *__restrict__ tile_s0, const int *__restrict__ tile_ns,
+                                                        const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
+                                                        const int *__restrict__ slice_rows, const uint16_t *__restrict__ scol,
+                                                        const double *__restrict__ sval, const double *__restrict__ x,
+                                                        double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int b = tile_b[blockIdx.x], r0 = tile_r0[blockIdx.x], r1 = tile_r1[blockIdx.x];
+  const int b = tile_b[blockIdx.x], s0 = tile_s0[blockIdx.x], ns = tile_ns[blockIdx.x];
   const int W = 1 << shift;
   const int c0 = b << shift;
   const int wlen = cols - c0 < W ? cols - c0 : W;
-  for (int i = threadIdx.x; i < wlen; i += kPanelThreads) xs[i] = x[c0 + i];
+  const int r0 = tile_r0[blockIdx.x], nrows = tile_r1[blockIdx.x] - r0;
+  double *ys = xs + W;  // row sums of the tile: written scattered here, stored to HBM as one contiguous block
+  for (int i = threadIdx.x; i < wlen; i += kThreads) xs[i] = x[c0 + i];
+  for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
   __syncthreads();
-  constexpr int NG = kPanelThreads / G;
-  const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-  const uint32_t *pp = pptr + (size_t)b * rows;
-  double *out = partial + (size_t)b * rows;
-  uint32_t s[4], e[4];
-  int row = r0 + grp;
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int r = row + u * NG;
-    const bool ok = r < r1;
-    s[u] = ok ? pp[r] : 0u;
-    e[u] = ok ? pp[r + 1] : 0u;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *out = partial + (size_t)b * rows + r0;
+  for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
+    const size_t base = (size_t)slice_base[sl] + lane;
+    const int L = slice_len[sl];
+    const int row = slice_rows[(size_t)sl * 64 + lane];
+    const double *v = sval + base;
+    const uint16_t *c = scol + base;
+    double a0 = 0.0, a1 = 0.0;
+    int k = 0;
+    for (; k + 4 <= L; k += 4) {
+      const double v0 = v[(size_t)k * 64], v1 = v[(size_t)(k + 1) * 64], v2 = v[(size_t)(k + 2) * 64], v3 = v[(size_t)(k + 3) * 64];
+      const uint16_t c0_ = c[(size_t)k * 64], c1_ = c[(size_t)(k + 1) * 64], c2_ = c[(size_t)(k + 2) * 64], c3_ = c[(size_t)(k + 3) * 64];
+      a0 += v0 * xs[c0_]; a0 += v1 * xs[c1_]; a0 += v2 * xs[c2_]; a0 += v3 * xs[c3_];
+    }
+    for (; k < L; k++) a1 += v[(size_t)k * 64] * xs[c[(size_t)k * 64]];
+    if (row >= 0) ys[row - r0] = a0 + a1;
   }
-  while (row < r1) {
-    const int nrow = row + 4 * NG;
-    uint32_t ns[4], ne[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int r = nrow + u * NG;
-      const bool ok = r < r1;
-      ns[u] = ok ? pp[r] : 0u;
-      ne[u] = ok ? pp[r + 1] : 0u;
-    }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    while (true) {
-      bool any = false;
-#pragma unroll
-      for (int u = 0; u < 4; u++) any |= s[u] < e[u];
-      if (!any) break;
-      uint16_t ca[4], cb[4];
-      double va[4], vb[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t k0 = s[u] + lane, k1 = k0 + G;
-        const bool ok0 = k0 < e[u], ok1 = k1 < e[u];
-        ca[u] = ok0 ? pcol[k0] : (uint16_t)0;
-        va[u] = ok0 ? pval[k0] : 0.0;
-        cb[u] = ok1 ? pcol[k1] : (uint16_t)0;
-        vb[u] = ok1 ? pval[k1] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        acc[u] += va[u] * xs[ca[u]];
-        acc[u] += vb[u] * xs[cb[u]];
-        s[u] = s[u] + 2 * G < e[u] ? s[u] + 2 * G : e[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      double a = acc[u];
-#pragma unroll
-      for (int o = G >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-      const int r = row + u * NG;
-      if (lane == 0 && r < r1) out[r] = a;
-      s[u] = ns[u]; e[u] = ne[u];
-    }
-    row = nrow;
-  }
-}
-
-
-// Bandwidth probe (measurement only, osqp_amd_time_kernel which = 6): same tiles, same LDS staging of x, but the
-// tile's non-zero range is streamed lane-contiguously (16 B of values + 4 B of indices per lane per load) with no
-// row structure -- the ceiling a CSR-stream variant of the kernel could reach.
-__global__ __launch_bounds__(kPanelThreads) void k_panel_stream_probe(int rows, int cols, int shift, const int *__restrict__ tile_b,
-                                                                      const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
-                                                                      const uint32_t *__restrict__ pptr, const uint16_t *__restrict__ pcol,
-                                                                      const double *__restrict__ pval, const double *__restrict__ x,
-                                                                      double *__restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int b = tile_b[blockIdx.x], r0 = tile_r0[blockIdx.x], r1 = tile_r1[blockIdx.x];
-  const int W = 1 << shift;
-  const int c0 = b << shift;
-  const int wlen = cols - c0 < W ? cols - c0 : W;
-  for (int i = threadIdx.x; i < wlen; i += kPanelThreads) xs[i] = x[c0 + i];
   __syncthreads();
-  const uint32_t *pp = pptr + (size_t)b * rows;
-  const uint32_t k0 = pp[r0] & ~1u, k1 = pp[r1];
-  double acc = 0.0;
-  for (uint32_t k = k0 + 2 * threadIdx.x; k + 1 < k1; k += 2 * kPanelThreads) {
-    const double2 v = *reinterpret_cast<const double2 *>(pval + k);
-    const ushort2 c = *reinterpret_cast<const ushort2 *>(pcol + k);
-    acc += v.x * xs[c.x] + v.y * xs[c.y];
-  }
-  if (r0 + (int)threadIdx.x < r1) partial[(size_t)b * rows + r0 + threadIdx.x] = acc;
+  for (int i = threadIdx.x; i < nrows; i += kThreads) out[i] = ys[i];
 }
 
 // y[i] = (rscale ? rscale[i] : 1) * sum_b partial[b][i] + beta * y[i] + gamma * v[i]   (panel order is fixed)
@@ -188,6 +264,15 @@ __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const 
   y[i] = acc;
 }
 
+size_t spmv_lds_bytes(int shift) { return (sizeof(double) << shift) + sizeof(double) * kTileRowsMax; }
+
+int64_t read_i64(const int64_t *dev, hipStream_t s) {
+  int64_t v = 0;
+  HIP_CHECK(hipMemcpyAsync(&v, dev, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  return v;
+}
+
 }  // namespace
 
 bool panel_wanted(const DevCsr &M) {
@@ -195,94 +280,78 @@ bool panel_wanted(const DevCsr &M) {
   if (const char *e = getenv("OSQP_AMD_PANEL")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return M.cols > (1 << shift); }
   // Worth it when the matrix is large enough to be bandwidth-bound, spans at least two panels and its row
   // segments per panel are long enough to pay for the partial sums.  Measured (tools/sweep_spmv.py): at
-  // n = 1e6 / 1000 per row 10.8 -> 2.4 ms per SpMV, at n = 1e5 / 100 per row 0.052 -> 0.028 ms.
+  // n = 1e6 / 1000 per row 10.8 -> 2.1 ms per SpMV, at n = 1e5 / 100 per row 0.052 -> 0.027 ms.
   const int B = (M.cols + (1 << shift) - 1) >> shift;
   if (B < 2 || M.nnz < 2000000) return false;
-  if (M.nnz >= 4000000000LL) return false;  // 32-bit panel offsets
+  if (M.nnz >= 4000000000LL) return false;  // 32-bit slot offsets
   return (double)M.nnz / ((double)M.rows * B) >= 4.0;
 }
 
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s) {
   DevPanel &P = M.panel;
-  if (P.sell) { panel_sell_fill(M, with_cols, s); return; }
-  OQ_LAUNCH(k_panel_scatter, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(), M.col.get(),
-            M.val.get(), P.pptr.get(), P.pcol.get(), P.pval.get(), with_cols ? 1 : 0);
+  OQ_LAUNCH(k_sell_scatter, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(), M.col.get(),
+            M.val.get(), P.cellbase.get(), P.scol.get(), P.sval.get(), with_cols ? 1 : 0);
 }
 
 void panel_build(DevCsr &M, hipStream_t s) {
   DevPanel &P = M.panel;
   P.shift = panel_shift(); P.W = 1 << P.shift;
+  if (P.shift > 15) throw Error(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
   P.B = (M.cols + P.W - 1) >> P.shift;
-  const size_t cells = (size_t)P.B * M.rows;
-  {
-    DevBuf<int64_t> cnt(cells + 1), ptr(cells + 1);
-    OQ_LAUNCH(k_panel_count, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.B, P.shift, M.rowptr.get(),
-              M.col.get(), cnt.get());
-    exclusive_scan(cnt.get(), ptr.get(), (int64_t)cells, s);
-    P.pptr.alloc(cells + 1);
-    OQ_LAUNCH(k_to_u32, dim3(blocks_for((int64_t)cells + 1)), dim3(kBlock), 0, s, (int64_t)cells + 1, ptr.get(), P.pptr.get());
-    HIP_CHECK(hipStreamSynchronize(s));
-  }
-  // tiles of ~equal non-zero count inside each panel (host: one pass over the offsets)
-  {
-    std::vector<uint32_t> hp(cells + 1);
-    P.pptr.download(hp.data(), cells + 1, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-    const uint32_t budget = (uint32_t)panel_tile_nnz();
-    const int max_rows = 3968;  // = kTileRowsMax of panel_sell.hip (row sums of a tile are staged in LDS)
-    std::vector<int> tb, t0, t1;
-    for (int b = 0; b < P.B; b++) {
-      const uint32_t *pp = hp.data() + (size_t)b * M.rows;
-      int r = 0;
-      while (r < M.rows) {
-        const uint32_t *lim = std::upper_bound(pp + r, pp + M.rows + 1, pp[r] + budget);
-        int r_end = (int)(lim - pp) - 1;           // last row boundary with offset <= start + budget
-        if (r_end <= r) r_end = r + 1;             // a single row longer than the budget
-        if (r_end > M.rows) r_end = M.rows;
-        if (r_end - r > max_rows) r_end = r + max_rows;
-        tb.push_back(b); t0.push_back(r); t1.push_back(r_end);
-        r = r_end;
-      }
-    }
-    // 1 (default): sliced-ELL tiles (panel_sell.hip); 0: panel-CSR tiles with one lane group per row segment
-    if (env_int("OSQP_AMD_PANEL_KERNEL", 1) == 1) panel_sell_prepare(M, hp, tb, t0, t1, s);
-    P.ntiles = (int)tb.size();
-    P.tile_b.alloc(tb.size()); P.tile_r0.alloc(tb.size()); P.tile_r1.alloc(tb.size());
-    P.tile_b.upload(tb.data(), tb.size(), s); P.tile_r0.upload(t0.data(), t0.size(), s); P.tile_r1.upload(t1.data(), t1.size(), s);
-    HIP_CHECK(hipStreamSynchronize(s));
-  }
-  if (!P.sell) { P.pcol.alloc((size_t)M.nnz); P.pval.alloc((size_t)M.nnz); }
-  P.partial.alloc(cells);
+  const int64_t cells = (int64_t)P.B * M.rows;
+  // per-(panel, row) counts and their offsets
+  DevBuf<int64_t> cnt((size_t)cells + 1), off((size_t)cells + 1);
+  OQ_LAUNCH(k_panel_count, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.B, P.shift, M.rowptr.get(),
+            M.col.get(), cnt.get());
+  exclusive_scan(cnt.get(), off.get(), cells, s);
+  // tiles of ~equal non-zero count inside each panel (cnt is reused: costs, then tile-start flags)
+  DevBuf<int64_t> tid((size_t)cells + 1);
+  const int64_t budget = std::max(panel_tile_nnz(), kTileRowsMax);
+  const int64_t cmin = (budget + kTileRowsMax - 1) / kTileRowsMax;
+  OQ_LAUNCH(k_tile_cost, dim3(blocks_for(cells)), dim3(kBlock), 0, s, cells, cmin, cnt.get());
+  exclusive_scan(cnt.get(), tid.get(), cells, s);
+  OQ_LAUNCH(k_tile_starts, dim3(blocks_for(cells)), dim3(kBlock), 0, s, M.rows, cells, tid.get(), budget, cnt.get());
+  exclusive_scan(cnt.get(), tid.get(), cells, s);
+  const int64_t ntiles = read_i64(tid.get() + cells, s);
+  if (ntiles <= 0 || ntiles >= 2147483647LL) throw Error(6, "panel layout: bad tile count");
+  P.ntiles = (int)ntiles;
+  P.tile_b.alloc((size_t)ntiles); P.tile_r0.alloc((size_t)ntiles); P.tile_r1.alloc((size_t)ntiles);
+  OQ_LAUNCH(k_tile_fill, dim3(blocks_for(cells)), dim3(kBlock), 0, s, M.rows, cells, cnt.get(), tid.get(), P.tile_b.get(), P.tile_r0.get());
+  OQ_LAUNCH(k_tile_ends, dim3(blocks_for(ntiles)), dim3(kBlock), 0, s, M.rows, P.ntiles, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get());
+  HIP_CHECK(hipStreamSynchronize(s));
+  cnt.release(); tid.release();
+  // slices: measure every tile, scan, lay out
+  DevBuf<int64_t> nsl((size_t)ntiles + 1), pad((size_t)ntiles + 1), slice0((size_t)ntiles + 1), padded0((size_t)ntiles + 1);
+  OQ_LAUNCH(k_tile_measure, dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get(), off.get(),
+            nsl.get(), pad.get());
+  exclusive_scan(nsl.get(), slice0.get(), ntiles, s);
+  exclusive_scan(pad.get(), padded0.get(), ntiles, s);
+  const int64_t nslices = read_i64(slice0.get() + ntiles, s), padded = read_i64(padded0.get() + ntiles, s);
+  if (padded >= 4294967295LL) throw Error(6, "sliced-ELL copy exceeds 2^32 entries");
+  P.padded = (size_t)padded;
+  P.tile_s0.alloc((size_t)ntiles); P.tile_ns.alloc((size_t)ntiles);
+  P.slice_base.alloc((size_t)nslices); P.slice_len.alloc((size_t)nslices); P.slice_rows.alloc((size_t)nslices * 64);
+  P.cellbase.alloc((size_t)cells); P.cellbase.zero(s);
+  OQ_LAUNCH(k_tile_layout, dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get(), off.get(),
+            slice0.get(), padded0.get(), P.tile_s0.get(), P.tile_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(),
+            P.cellbase.get());
+  P.sval.alloc((size_t)padded); P.scol.alloc((size_t)padded);
+  P.sval.zero(s); P.scol.zero(s);  // padding slots: value 0 times x[panel column 0]
+  P.partial.alloc((size_t)cells);
   P.partial.zero(s);  // cells of rows without entries in a panel are never written again
   panel_fill(M, true, s);
-  const int lds = (int)(sizeof(double) << P.shift);
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_panel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_panel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spmv_lds_bytes(P.shift)));
   P.active = true;
 }
 
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
                 hipStream_t s) {
   const DevPanel &P = M.panel;
-  static const int G = panel_group();
-  const size_t lds = sizeof(double) << P.shift;
-#define OQ_PANEL(GG)                                                                                                          \
-  OQ_LAUNCH(k_spmv_panel<GG>, dim3(P.ntiles), dim3(kPanelThreads), lds, s, M.rows, M.cols, P.shift, P.tile_b.get(), P.tile_r0.get(), \
-            P.tile_r1.get(), P.pptr.get(), P.pcol.get(), P.pval.get(), x, P.partial.get())
-  if (P.sell) spmv_panel_sell(M, x, s);
-  else if (G == 4) OQ_PANEL(4); else if (G == 16) OQ_PANEL(16); else OQ_PANEL(8);
-#undef OQ_PANEL
+  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.tile_b.get(),
+            P.tile_r0.get(), P.tile_r1.get(), P.tile_s0.get(), P.tile_ns.get(), P.slice_base.get(), P.slice_len.get(),
+            P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get());
   OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.B, P.partial.get(), y, rscale, beta, gamma, v);
-}
-
-void spmv_panel_probe(const DevCsr &M, const double *x, hipStream_t s) {
-  const DevPanel &P = M.panel;
-  const size_t lds = sizeof(double) << P.shift;
-  static bool once = false;
-  if (!once) { HIP_CHECK(hipFuncSetAttribute((const void *)k_panel_stream_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-  OQ_LAUNCH(k_panel_stream_probe, dim3(P.ntiles), dim3(kPanelThreads), lds, s, M.rows, M.cols, P.shift, P.tile_b.get(), P.tile_r0.get(),
-            P.tile_r1.get(), P.pptr.get(), P.pcol.get(), P.pval.get(), x, P.partial.get());
 }
 
 }  // namespace oq

@@ -117,7 +117,7 @@ struct Upper {  // upper-triangular pattern, column compressed, with the origin 
 
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
                       Symbolic &S) {
-  const int n = P.cols, m = A.rows, N = n + mr;
+  const int n = P.cols, N = n + mr;
   S.n = n; S.mr = mr; S.N = N; S.too_large = false;
   const int64_t nnzP = P.p[n], nnzA = A.p[n];
 

@@ -16,9 +16,5 @@ out = {"cfg": sys.argv[2:]}
 for which, name in ((0, "A"), (1, "At"), (2, "P")):
     ms = float(lib.osqp_amd_time_kernel(m.workspace, which, 10))
     out[name + "_ms"] = round(ms, 4)
-try:
-    out["probe_ms"] = round(float(lib.osqp_amd_time_kernel(m.workspace, 6, 10)), 4)
-except Exception:
-    pass
 out["A_GBs"] = round(st[10] / out["A_ms"] / 1e6, 1)
 print(json.dumps(out))
