@@ -1,0 +1,46 @@
+"""Standard QP classes (tests/qp_zoo.py): the CPU oracle against an independent evaluation of the stopping criteria
+(CPU), and the HIP engine against the oracle and the same evaluation (GPU)."""
+import numpy as np
+import pytest
+
+import osqp_jl_amd as oq
+import qp_zoo
+
+EPS = 1e-5
+OPTS = dict(verbose=False, eps_abs=EPS, eps_rel=EPS, max_iter=20000, adaptive_rho_interval=25, polish=False)
+
+
+def _solve(lib, prob, linsys):
+    m = oq.Model(lib)
+    oq.setup(m, linsys_solver=linsys, **prob, **OPTS)
+    r = oq.solve(m)
+    oq.clean(m)
+    return r
+
+
+def _check(prob, r):
+    assert r.info.status == "Solved"
+    pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, r.x, r.y, EPS)
+    assert pri <= 1.5 * eps_pri and dua <= 1.5 * eps_dua, (pri, eps_pri, dua, eps_dua)
+
+
+@pytest.mark.parametrize("name", sorted(qp_zoo.ZOO))
+def test_oracle_on_zoo(oracle_lib, name):
+    prob = qp_zoo.ZOO[name]()
+    r = _solve(oracle_lib, prob, "qdldl")
+    _check(prob, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("linsys", ["qdldl", "pcg"])
+@pytest.mark.parametrize("name", sorted(qp_zoo.ZOO))
+def test_engine_on_zoo(product_lib, oracle_lib, name, linsys):
+    prob = qp_zoo.ZOO[name]()
+    ro = _solve(oracle_lib, prob, "qdldl")
+    rp = _solve(product_lib, prob, linsys)
+    _check(prob, rp)
+    assert ro.info.status == "Solved"
+    assert abs(ro.info.obj_val - rp.info.obj_val) <= 2e-4 * max(1.0, abs(ro.info.obj_val))
+    if linsys == "qdldl":  # exact KKT solves on both sides: same trajectory
+        assert ro.info.iter == rp.info.iter
+        assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
