@@ -52,6 +52,21 @@ static void min_degree_order(c_int N, const c_int *Kp, const c_int *Ki, c_int *p
   c_int *cnt = (c_int *)calloc((size_t)N + 1, sizeof(c_int));
   for (j = 0; j < N; j++)
     for (p = Kp[j]; p < Kp[j + 1]; p++) { i = Ki[p]; if (i < j) { cnt[i]++; cnt[j]++; } }
+  /* nodes of very high degree (dense constraint rows) stay out of the quotient graph and are eliminated last:
+     pruning their adjacency at every step would make the ordering quadratic */
+  char *dense = (char *)calloc((size_t)N, 1);
+  c_int *extra = (c_int *)calloc((size_t)N, sizeof(c_int)); /* dense neighbours: a constant part of the degree */
+  c_int ndense = 0;
+  {
+    double limit = 10.0 * sqrt((double)N);
+    if (limit < 16.0) limit = 16.0;
+    for (i = 0; i < N; i++) if ((double)cnt[i] > limit) { dense[i] = 1; ndense++; }
+    if (ndense) {
+      memset(cnt, 0, sizeof(c_int) * ((size_t)N + 1));
+      for (j = 0; j < N; j++)
+        for (p = Kp[j]; p < Kp[j + 1]; p++) { i = Ki[p]; if (i < j && !dense[i] && !dense[j]) { cnt[i]++; cnt[j]++; } }
+    }
+  }
   c_int *ap = (c_int *)malloc(sizeof(c_int) * ((size_t)N + 1));
   ap[0] = 0;
   for (i = 0; i < N; i++) ap[i + 1] = ap[i] + cnt[i];
@@ -61,7 +76,9 @@ static void min_degree_order(c_int N, const c_int *Kp, const c_int *Ki, c_int *p
   for (j = 0; j < N; j++)
     for (p = Kp[j]; p < Kp[j + 1]; p++) {
       i = Ki[p];
-      if (i < j) { adj[ap[i] + nv[i]++] = j; adj[ap[j] + nv[j]++] = i; }
+      if (i >= j) continue;
+      if (!dense[i] && !dense[j]) { adj[ap[i] + nv[i]++] = j; adj[ap[j] + nv[j]++] = i; }
+      else { if (!dense[i]) extra[i]++; if (!dense[j]) extra[j]++; }
     }
   c_int **Le = (c_int **)calloc((size_t)N, sizeof(c_int *));
   c_int *Lsz = (c_int *)calloc((size_t)N, sizeof(c_int));
@@ -75,7 +92,7 @@ static void min_degree_order(c_int N, const c_int *Kp, const c_int *Ki, c_int *p
   c_int *w = (c_int *)calloc((size_t)N, sizeof(c_int));
   c_int *Lp = (c_int *)malloc(sizeof(c_int) * (size_t)(N > 0 ? N : 1));
   for (i = 0; i <= N; i++) head[i] = -1;
-  for (i = 0; i < N; i++) { next[i] = prev[i] = -1; deg[i] = nv[i]; }
+  for (i = 0; i < N; i++) { next[i] = prev[i] = -1; deg[i] = nv[i] + extra[i]; if (deg[i] > N - 1) deg[i] = N - 1; }
   for (i = N - 1; i >= 0; i--) degree_list_insert(i, head, next, prev, deg);
   c_int mindeg = 0, tag = 0;
   for (k = 0; k < N; k++) {
@@ -135,16 +152,25 @@ static void min_degree_order(c_int N, const c_int *Kp, const c_int *Ki, c_int *p
       }
       adj[base + nvn + nen++] = p;
       nv[i] = nvn; ne[i] = nen;
-      d += nvn + (len - 1);
+      d += nvn + (len - 1) + extra[i];
       c_int bound = deg[i] + (len - 1);
       if (d > bound) d = bound;
-      if (d > N - k - 2) d = N - k - 2;
+      if (d > N - 1) d = N - 1;
       if (d < 0) d = 0;
       deg[i] = d;
       degree_list_insert(i, head, next, prev, deg);
       if (d < mindeg) mindeg = d;
     }
   }
+  if (ndense) { /* isolated in the pruned graph, so their position is free: move them to the end (stable) */
+    c_int *tmp = (c_int *)malloc(sizeof(c_int) * (size_t)N);
+    c_int a = 0;
+    for (k = 0; k < N; k++) if (!dense[perm[k]]) tmp[a++] = perm[k];
+    for (k = 0; k < N; k++) if (dense[perm[k]]) tmp[a++] = perm[k];
+    memcpy(perm, tmp, sizeof(c_int) * (size_t)N);
+    free(tmp);
+  }
+  free(dense); free(extra);
   for (i = 0; i < N; i++) if (Le[i]) free(Le[i]);
   free(cnt); free(ap); free(adj); free(nv); free(ne); free(Le); free(Lsz); free(status);
   free(deg); free(head); free(next); free(prev); free(mark); free(wmark); free(w); free(Lp);

@@ -94,6 +94,42 @@ __global__ __launch_bounds__(kBlock) void k_ldl_entries(int c0, int c1, const in
   }
   Lx[e] = (Lx[e] - acc) * Dinv[k];
 }
+// Phase 2 for levels whose rows are long (the dense trailing block behind a few dense constraint rows): the
+// thread-per-entry merge walks 10^4 entries serially.  Instead row k is scattered once into a dense work row
+// w_k[j] = L_kj d_j (k_ldl_wrow, one wavefront per column of the level; fill = 0 clears it again afterwards),
+// and one wavefront per entry (i, k) takes the sparse-times-dense product of row i with w_k: coalesced reads of
+// row i, gathers from a work row that stays in L2.  Only columns below the level contribute (two columns of one
+// level are independent in the elimination tree), which also keeps the waves of a level off each other's output.
+__global__ __launch_bounds__(kBlock) void k_ldl_wrow(int c0, int c1, int N, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                     const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
+                                                     const double *__restrict__ D, double *__restrict__ W, int fill) {
+  const int lane = threadIdx.x & 63;
+  const int k = c0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (k >= c1) return;
+  double *w = W + (size_t)(k - c0) * N;
+  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) { const int j = Rj[q]; w[j] = fill ? Lx[Rmap[q]] * D[j] : 0.0; }
+}
+__global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                          double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                          const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
+                                                          const double *__restrict__ W, const double *__restrict__ Dinv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (e >= Lp[c1]) return;
+  int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
+  const int k = lo, i = Li[e];
+  const double *w = W + (size_t)(k - c0) * N;
+  double acc = 0.0;
+  for (int64_t q = Rp[i] + lane; q < Rp[i + 1]; q += 64) {
+    const int j = Rj[q];
+    if (j >= c0) break;  // columns ascending: nothing below the level is left (for any lane at or after this one)
+    acc += Lx[Rmap[q]] * w[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
+}
 __global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
                                                        double *__restrict__ Rx) {
   int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -126,18 +162,46 @@ __global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int6
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
 }
-// chains of narrow levels inside one workgroup (barrier between levels); 4 lanes per row, or a whole
-// wavefront per row when the level has at most 16 rows (the long rows of a dense trailing block)
+// Chains of narrow levels inside one workgroup (barrier between levels); 4 lanes per row, or a whole
+// wavefront per row when the level has at most 16 rows.  A row of a chain splits at Rsplit[row] into the
+// entries whose columns lie before the chain (all of them solved when the chain starts: k_fwd_far takes
+// them for every row of the chain at once, T threads per row) and the entries inside the chain (the only part
+// that is sequential).  With a dense trailing block -- a few dense constraint rows -- the first part is the
+// long one: 10^4 entries per row against 10^2 inside the chain.
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_t *__restrict__ Rp, const int64_t *__restrict__ Rsplit,
+                                                    const int *__restrict__ Rj, const double *__restrict__ Rx, double *__restrict__ b) {
+  __shared__ double part[kBlock / 64];
+  const int lane = threadIdx.x & (T - 1);
+  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
+  double acc = 0.0;
+  if (row < r1)
+    for (int64_t q = Rp[row] + lane; q < Rsplit[row]; q += T) acc += Rx[q] * b[Rj[q]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (T == 64) {
+    if (lane == 0 && row < r1) b[row] -= acc;
+  } else {  // T == kBlock: one row per workgroup
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && row < r1) {
+      double t = 0.0;
+      for (int w = 0; w < kBlock / 64; w++) t += part[w];
+      b[row] -= t;
+    }
+  }
+}
 __global__ __launch_bounds__(kChainThreads) void k_fwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
-                                                             const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                             const double *__restrict__ Rx, double *__restrict__ b) {
+                                                             const int64_t *__restrict__ Rsplit, const int64_t *__restrict__ Rp,
+                                                             const int *__restrict__ Rj, const double *__restrict__ Rx,
+                                                             double *__restrict__ b) {
   for (int l = l0; l < l1; l++) {
     const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
     const int G = (r1 - r0) <= kChainThreads / 64 ? 64 : 4;
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     for (int row = r0 + grp; row < r1; row += kChainThreads / G) {
       double acc = 0.0;
-      for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
+      for (int64_t q = Rsplit[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
       for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (lane == 0) b[row] -= acc;
     }
@@ -209,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double a
   }
 }
 
-struct Step { int kind; int a, b, G; };  // kind 0: single level [a,b) rows; 1: chain of levels [a,b)
+struct Step { int kind; int a, b, G; };  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
+                                         // G threads per row for the part of its rows that lies before the chain
 
 // ------------------------------------------------------------------ factor object
 struct LdlFactor {
@@ -217,9 +282,10 @@ struct LdlFactor {
   Symbolic S;
   int N = 0, n = 0, mr = 0, nlev = 0;
   double sigma = 0, cconst = 0;
-  DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL;
+  DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit;
   DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
-  DevBuf<double> Lx, Rx, D, Dinv, bp;
+  DevBuf<double> Lx, Rx, D, Dinv, bp, W;
+  std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
   std::vector<Step> fwd, bwd;
   long long factorizations = 0;
 
@@ -235,6 +301,20 @@ struct LdlFactor {
     up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
     up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
     Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
+    {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
+      long_rows.assign(nlev, 0);
+      size_t wmax = 0;
+      for (int l = 0; l < nlev; l++) {
+        const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1], width = c1 - c0;
+        if (width == 0 || S.Lp[c1] == S.Lp[c0]) continue;
+        const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)width;
+        if (mean >= 128.0 && (size_t)width * (size_t)N * sizeof(double) <= ((size_t)256 << 20)) {
+          long_rows[l] = 1;
+          wmax = std::max(wmax, (size_t)width * (size_t)N);
+        }
+      }
+      if (wmax) { W.alloc(wmax); W.zero(s); }
+    }
     e.sync();
     build_schedule();
     // the big index arrays are only needed on the device from here on
@@ -247,6 +327,7 @@ struct LdlFactor {
   void build_schedule() {
     const auto &lp = S.level_ptr;
     // forward: level 0 rows have no predecessors (nothing to do); backward: every level (D^-1 applies everywhere)
+    std::vector<int64_t> split(S.Rp.begin(), S.Rp.end() - 1);
     auto make = [&](bool forward) {
       std::vector<Step> steps;
       int l = forward ? 1 : 0;
@@ -255,7 +336,18 @@ struct LdlFactor {
         if (width <= kChainRows) {
           int l2 = l;
           while (l2 < nlev && lp[l2 + 1] - lp[l2] <= kChainRows) l2++;
-          steps.push_back({1, l, l2, 4});
+          int T = 64;
+          if (forward) {  // split the rows of the chain at its first pivot
+            const int c0 = lp[l], c1 = lp[l2];
+            int64_t far = 0;
+            for (int r = c0; r < c1; r++) {
+              const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
+              split[r] = S.Rp[r] + (std::lower_bound(beg, end, c0) - beg);
+              far += split[r] - S.Rp[r];
+            }
+            if (far / std::max(1, c1 - c0) > 1024) T = kBlock;
+          }
+          steps.push_back({1, l, l2, T});
           l = l2;
         } else {
           const std::vector<int64_t> &ptr = forward ? S.Rp : S.Lp;
@@ -269,6 +361,9 @@ struct LdlFactor {
     fwd = make(true);
     bwd = make(false);
     std::reverse(bwd.begin(), bwd.end());
+    Rsplit.alloc(split.size());
+    Rsplit.upload(split.data(), split.size(), e.stream);
+    e.sync();
   }
 
   // returns 0 ok, 4 zero pivot, 5 wrong inertia
@@ -287,7 +382,13 @@ struct LdlFactor {
       OQ_LAUNCH(k_ldl_diag, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(),
                 Rmap.get(), D.get(), Dinv.get(), status.get());
       const int64_t entries = S.Lp[c1] - S.Lp[c0];
-      if (entries > 0)
+      if (entries > 0 && long_rows[l]) {
+        const dim3 gw(blocks_for((int64_t)(c1 - c0) * 64));
+        OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 1);
+        OQ_LAUNCH(k_ldl_entries_w, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, N, Lp.get(), Li.get(), Lx.get(),
+                  Rp.get(), Rj.get(), Rmap.get(), W.get(), Dinv.get());
+        OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 0);
+      } else if (entries > 0)
         OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
                   Rj.get(), Rmap.get(), D.get(), Dinv.get());
     }
@@ -304,7 +405,13 @@ struct LdlFactor {
   void run_steps() {
     hipStream_t s = e.stream;
     for (const Step &t : fwd) {
-      if (t.kind == 1) { OQ_LAUNCH(k_fwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rp.get(), Rj.get(), Rx.get(), bp.get()); continue; }
+      if (t.kind == 1) {
+        const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
+        if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
+        else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
+        OQ_LAUNCH(k_fwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+        continue;
+      }
       dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
       switch (t.G) {
       case 1: OQ_LAUNCH(k_fwd_level<1>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <numeric>
 
 #include "engine.hpp"
@@ -23,10 +24,11 @@ struct MinDegree {
   std::vector<std::vector<int>> var_adj, elem_adj, members;
   std::vector<char> state;  // 0 variable, 1 element, 2 dead
   std::vector<int> degree, bucket_head, next, prev, stamp, wstamp, wcount;
+  std::vector<int> extra;  // neighbours kept out of the graph (dense nodes, eliminated last): a constant part of every degree
   int min_bucket = 0;
 
   explicit MinDegree(int n) : N(n), var_adj(n), elem_adj(n), members(n), state(n, 0), degree(n, 0), bucket_head(n + 1, -1),
-                              next(n, -1), prev(n, -1), stamp(n, 0), wstamp(n, 0), wcount(n, 0) {}
+                              next(n, -1), prev(n, -1), stamp(n, 0), wstamp(n, 0), wcount(n, 0), extra(n, 0) {}
 
   void unlink(int i) {
     if (prev[i] >= 0) next[prev[i]] = next[i]; else bucket_head[degree[i]] = next[i];
@@ -42,7 +44,7 @@ struct MinDegree {
 
   void run(std::vector<int> &order) {
     order.resize(N);
-    for (int i = 0; i < N; i++) degree[i] = (int)var_adj[i].size();
+    for (int i = 0; i < N; i++) degree[i] = std::min(N - 1, (int)var_adj[i].size() + extra[i]);
     for (int i = N - 1; i >= 0; i--) link(i);
     std::vector<int> clique;
     int tag = 0;
@@ -93,10 +95,10 @@ struct MinDegree {
         }
         ea.resize(w);
         ea.push_back(p);
-        d += (long long)va.size() + (csize - 1);
+        d += (long long)va.size() + (csize - 1) + extra[i];
         long long bound = (long long)degree[i] + (csize - 1);
         if (d > bound) d = bound;
-        if (d > N - k - 2) d = N - k - 2;
+        if (d > N - 1) d = N - 1;
         if (d < 0) d = 0;
         degree[i] = (int)d;
         link(i);
@@ -150,19 +152,35 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   for (int r = 0; r < mr; r++) { int64_t q = fill[n + r]++; K.i[q] = n + r; K.origin[q] = -1; }
 
   // ---- 2. fill-reducing ordering -------------------------------------------------------
+  // Nodes of very high degree (a dense constraint row such as a budget 1'x = 1, a dense column of P) are kept out
+  // of the quotient graph and eliminated last: pruning their adjacency at every step would make the ordering
+  // quadratic, and wherever they are eliminated they fill their whole row anyway.
   std::vector<int> order;
   {
     MinDegree md(N);
     std::vector<int> deg(N, 0);
     for (int j = 0; j < N; j++)
       for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) if (K.i[q] < j) { deg[K.i[q]]++; deg[j]++; }
+    const double dense_limit = std::max(16.0, 10.0 * std::sqrt((double)N));
+    std::vector<char> dense(N, 0);
+    int ndense = 0;
+    for (int i = 0; i < N; i++) if ((double)deg[i] > dense_limit) { dense[i] = 1; ndense++; }
+    if (ndense) {
+      std::fill(deg.begin(), deg.end(), 0);
+      for (int j = 0; j < N; j++)
+        for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) { int i = K.i[q]; if (i < j && !dense[i] && !dense[j]) { deg[i]++; deg[j]++; } }
+    }
     for (int i = 0; i < N; i++) md.var_adj[i].reserve(deg[i]);
     for (int j = 0; j < N; j++)
       for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
         int i = K.i[q];
-        if (i < j) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
+        if (i >= j) continue;
+        if (!dense[i] && !dense[j]) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
+        else { if (!dense[i]) md.extra[i]++; if (!dense[j]) md.extra[j]++; }
       }
     md.run(order);
+    if (ndense)  // isolated in the pruned graph, so their position is free: move them to the end
+      std::stable_partition(order.begin(), order.end(), [&](int v) { return !dense[v]; });
   }
   std::vector<int> pinv(N);
   for (int k = 0; k < N; k++) pinv[order[k]] = k;
