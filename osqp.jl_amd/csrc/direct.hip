@@ -235,19 +235,26 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain(int l0, int l1, con
 constexpr int kChainLdsRows = 8192, kChainLdsLevels = 8192;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Two rows ahead: the bounds of the row after next (so that fetching the entries of the next row never waits for
-// its own bounds), one row ahead: bounds, first 128 entries and 1/d of the next row.
+// its own bounds), one row ahead: bounds, first 64 U entries and 1/d of the next row (U = 2, 4 or 8 by the
+// longest row inside the chain: a dense trailing block has rows as long as the block).
+template <int U>
 struct RowPrefetch {
   int64_t q0, q1;    // entries of the next row inside the chain
   int64_t nq0, nq1;  // the same for the row after it
-  double v0, v1, dinv;
-  int c0_, c1_;
+  double v[U], dinv;
+  int c[U];
 };
-__device__ __forceinline__ void prefetch_entries(RowPrefetch &p, const int *__restrict__ idx, const double *__restrict__ val, int lane) {
+template <int U>
+__device__ __forceinline__ void prefetch_entries(RowPrefetch<U> &p, const int *__restrict__ idx, const double *__restrict__ val, int lane) {
   p.q0 = p.nq0; p.q1 = p.nq1;
-  const int64_t a = p.q0 + lane, b = p.q0 + 64 + lane;
-  p.v0 = a < p.q1 ? val[a] : 0.0; p.c0_ = a < p.q1 ? idx[a] : -1;
-  p.v1 = b < p.q1 ? val[b] : 0.0; p.c1_ = b < p.q1 ? idx[b] : -1;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t a = p.q0 + 64 * u + lane;
+    p.v[u] = a < p.q1 ? val[a] : 0.0;
+    p.c[u] = a < p.q1 ? idx[a] : -1;
+  }
 }
+template <int U>
 __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
                                                                  const int64_t *__restrict__ Rsplit, const int64_t *__restrict__ Rp,
                                                                  const int *__restrict__ Rj, const double *__restrict__ Rx,
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1,
   for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int next = c0 + wave;
-  RowPrefetch pf;
+  RowPrefetch<U> pf;
   pf.nq0 = pf.nq1 = 0;
   if (next < c1) { pf.nq0 = Rsplit[next]; pf.nq1 = Rp[next + 1]; prefetch_entries(pf, Rj, Rx, lane); }
   if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1,
     const int r1 = lp[l + 1];
     while (next < r1) {
       double acc = 0.0;
-      if (pf.c0_ >= 0) acc += pf.v0 * bl[pf.c0_ - c0];
-      if (pf.c1_ >= 0) acc += pf.v1 * bl[pf.c1_ - c0];
-      for (int64_t q = pf.q0 + 128 + lane; q < pf.q1; q += 64) acc += Rx[q] * bl[Rj[q] - c0];
+#pragma unroll
+      for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
+      for (int64_t q = pf.q0 + 64 * U + lane; q < pf.q1; q += 64) acc += Rx[q] * bl[Rj[q] - c0];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (lane == 0) bl[next - c0] -= acc;
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1,
 }
 // backward: the column of L below pivot k is row k of L'; its rows inside the chain are read from LDS, rows
 // above the chain (solved earlier in the backward pass) from global memory.  Pivots and levels descend.
+template <int U>
 __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
                                                                  const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                                  const double *__restrict__ Lx, const double *__restrict__ Dinv,
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1,
   for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int next = c1 - 1 - wave;
-  RowPrefetch pf;
+  RowPrefetch<U> pf;
   pf.nq0 = pf.nq1 = 0; pf.dinv = 0.0;
   if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lp[next + 1]; pf.dinv = Dinv[next]; prefetch_entries(pf, Li, Lx, lane); }
   if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
@@ -306,9 +314,9 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1,
     const int r0 = lp[l];
     while (next >= r0) {
       double acc = 0.0;
-      if (pf.c0_ >= 0) acc += pf.v0 * (pf.c0_ < c1 ? bl[pf.c0_ - c0] : b[pf.c0_]);
-      if (pf.c1_ >= 0) acc += pf.v1 * (pf.c1_ < c1 ? bl[pf.c1_ - c0] : b[pf.c1_]);
-      for (int64_t t = pf.q0 + 128 + lane; t < pf.q1; t += 64) { const int i = Li[t]; acc += Lx[t] * (i < c1 ? bl[i - c0] : b[i]); }
+#pragma unroll
+      for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * (pf.c[u] < c1 ? bl[pf.c[u] - c0] : b[pf.c[u]]);
+      for (int64_t t = pf.q0 + 64 * U + lane; t < pf.q1; t += 64) { const int i = Li[t]; acc += Lx[t] * (i < c1 ? bl[i - c0] : b[i]); }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (lane == 0) bl[next - c0] = bl[next - c0] * pf.dinv - acc;
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double a
   }
 }
 
-struct Step { int kind; int a, b, G; };  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
+struct Step { int kind; int a, b, G; int U = 2; };  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
 
 // ------------------------------------------------------------------ factor object
@@ -442,7 +450,14 @@ struct LdlFactor {
             }
             if (far / std::max(1, c1 - c0) > 1024) T = kBlock;
           }
-          steps.push_back({1, l, l2, T});
+          Step st{1, l, l2, T};
+          {  // longest row inside the chain decides how many entries a lane keeps prefetched
+            const int c0 = lp[l], c1 = lp[l2];
+            int64_t longest = 0;
+            for (int r = c0; r < c1; r++) longest = std::max(longest, forward ? S.Rp[r + 1] - split[r] : S.Lp[r + 1] - S.Lp[r]);
+            st.U = longest > 320 ? 8 : (longest > 224 ? 4 : 2);  // measured: 200-row blocks are fastest with 2, 500-row with 8
+          }
+          steps.push_back(st);
           l = l2;
         } else {
           const std::vector<int64_t> &ptr = forward ? S.Rp : S.Lp;
@@ -505,7 +520,9 @@ struct LdlFactor {
         if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
         else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
         if (c1 - c0 <= kChainLdsRows && t.b - t.a <= kChainLdsLevels)
-          OQ_LAUNCH(k_fwd_chain_lds, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+          if (t.U == 8) OQ_LAUNCH(k_fwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+          else if (t.U == 4) OQ_LAUNCH(k_fwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+          else OQ_LAUNCH(k_fwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
         else
           OQ_LAUNCH(k_fwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
         continue;
@@ -521,7 +538,9 @@ struct LdlFactor {
     for (const Step &t : bwd) {
       if (t.kind == 1) {
         if (S.level_ptr[t.b] - S.level_ptr[t.a] <= kChainLdsRows && t.b - t.a <= kChainLdsLevels)
-          OQ_LAUNCH(k_bwd_chain_lds, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+          if (t.U == 8) OQ_LAUNCH(k_bwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+          else if (t.U == 4) OQ_LAUNCH(k_bwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+          else OQ_LAUNCH(k_bwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
         else
           OQ_LAUNCH(k_bwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
         continue;
