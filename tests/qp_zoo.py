@@ -95,7 +95,28 @@ def equality_qp(n=800, seed=5):
     return dict(P=P, q=q, A=A, l=b, u=b.copy())
 
 
-ZOO = {"portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
+def control(nx=8, nu=4, T=30, seed=6):
+    """Linear MPC: min sum x_t'Q x_t + u_t'R u_t  s.t.  x_{t+1} = A x_t + B u_t, x_0 given, box bounds
+    (variables [x_0 .. x_T; u_0 .. u_{T-1}]; banded KKT system, elimination tree = a long chain)"""
+    rng = np.random.default_rng(seed)
+    Ad = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx))
+    Ad *= 0.95 / max(1.0, np.max(np.abs(np.linalg.eigvals(Ad))))
+    Bd = rng.standard_normal((nx, nu))
+    Q = sp.diags(rng.random(nx) * 10.0)
+    R = 0.1 * sp.eye(nu)
+    x0 = rng.standard_normal(nx)
+    P = sp.block_diag([sp.kron(sp.eye(T + 1), Q), sp.kron(sp.eye(T), R)], format="csc")
+    q = np.zeros((T + 1) * nx + T * nu)
+    Ax = sp.kron(sp.eye(T + 1), -sp.eye(nx)) + sp.kron(sp.eye(T + 1, k=-1), sp.csc_matrix(Ad))
+    Bu = sp.kron(sp.vstack([sp.csc_matrix((1, T)), sp.eye(T)]), sp.csc_matrix(Bd))
+    Aeq = sp.hstack([Ax, Bu])
+    leq = np.concatenate([-x0, np.zeros(T * nx)])
+    A = sp.vstack([Aeq, sp.eye((T + 1) * nx + T * nu)], format="csc")
+    lo = np.concatenate([-5.0 * np.ones((T + 1) * nx), -0.5 * np.ones(T * nu)])
+    return dict(P=P, q=q, A=A, l=np.concatenate([leq, lo]), u=np.concatenate([leq, -lo]))
+
+
+ZOO = {"control": control, "portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
 
 
 def kkt_check(prob, x, y, eps):

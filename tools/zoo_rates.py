@@ -9,7 +9,7 @@ import qp_zoo
 
 SIZES = {
     "portfolio": dict(n=20000, k=200), "svm": dict(n=200, m=20000), "huber": dict(n=200, m=20000),
-    "lasso_data": dict(n=500, m=10000), "equality_qp": dict(n=6000),
+    "lasso_data": dict(n=500, m=10000), "equality_qp": dict(n=6000), "control": dict(nx=12, nu=6, T=800),
 }
 OPTS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, max_iter=4000, adaptive_rho_interval=50, check_termination=25, polish=False)
 prod, ora = oq.load_library(), oq.load_library(oq.ORACLE_LIB_PATH)
