@@ -656,7 +656,7 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
   OSQPWorkspace *w = (OSQPWorkspace *)calloc(1, sizeof(OSQPWorkspace));
   *workp = w;
   w->impl = calloc(1, sizeof(priv_t));
-  PRIV(w)->pcg_lambda0 = 0.15;
+  PRIV(w)->pcg_lambda0 = 0.015;
   if (getenv("OSQP_ORACLE_PCG_LAMBDA")) PRIV(w)->pcg_lambda0 = atof(getenv("OSQP_ORACLE_PCG_LAMBDA"));
   PRIV(w)->pcg_lambda = PRIV(w)->pcg_lambda0;
   tic(w);

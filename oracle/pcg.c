@@ -6,8 +6,11 @@
  * configs cannot fit in any memory -- SURVEY.md section 0.3).  Eliminating nu
  * from   [P + sigma I, A'; A, -diag(rho)^-1] [x~; nu] = [r_x; r_z]   gives
  *     (P + sigma I + A' diag(rho) A) x~ = r_x + A' (rho .* r_z),   z~ = A x~,
- * solved by Jacobi-preconditioned conjugate gradients, warm-started from the
- * previous x~.  This is the CPU statement the HIP PCG path is checked against.
+ * solved by Jacobi-preconditioned conjugate gradients.  Start vector: from the last
+ * two solutions x1 (newest), x0 the point x1 + theta (x1 - x0) closest to the new
+ * solution in the energy norm, theta = e'r / e'Me, e = x1 - x0, r = b - M x1 (clamped
+ * to [-1, 4]; plain warm start x1 on the first solve after M changed or x~ was reset).
+ * This is the CPU statement the HIP PCG path is checked against.
  */
 #include "oracle.h"
 #include <stdlib.h>
@@ -21,6 +24,8 @@ struct pcg_solver {
   c_float *rho;           /* copy of rho_vec */
   c_float *dinv;          /* inverse Jacobi diagonal */
   c_float *x, *r, *z, *p, *w, *t, *b1;
+  c_float *x0, *w0;       /* previous solution and M times it */
+  int have_prev;
   c_int total_iters, max_iter;
 };
 
@@ -48,6 +53,8 @@ pcg_solver *pcg_init(const csc *P, const csc *A, c_float sigma, const c_float *r
   s->p = (c_float *)calloc(nn, sizeof(c_float));
   s->w = (c_float *)calloc(nn, sizeof(c_float));
   s->b1 = (c_float *)calloc(nn, sizeof(c_float));
+  s->x0 = (c_float *)calloc(nn, sizeof(c_float));
+  s->w0 = (c_float *)calloc(nn, sizeof(c_float));
   s->t = (c_float *)calloc(mm, sizeof(c_float));
   s->max_iter = 20000;
   build_precond(s);
@@ -71,8 +78,31 @@ c_int pcg_solve(pcg_solver *s, c_float *b, c_float tol_abs) {
   for (j = 0; j < m; j++) s->t[j] = s->rho[j] * b[n + j];
   for (j = 0; j < n; j++) s->b1[j] = b[j];
   mat_tpose_vec(s->A, s->t, s->b1, 1, 0);
-  /* r = b1 - M x0 */
+  /* start vector and w = M x */
   apply_M(s, s->x, s->w);
+  if (s->have_prev) {
+    c_float num = 0.0, den = 0.0, theta;
+    for (j = 0; j < n; j++) {
+      c_float e = s->x[j] - s->x0[j];
+      num += e * (s->b1[j] - s->w[j]);
+      den += e * (s->w[j] - s->w0[j]);
+    }
+    theta = den > 0.0 ? num / den : 0.0;
+    if (theta != theta) theta = 0.0;
+    if (theta < -1.0) theta = -1.0;
+    if (theta > 4.0) theta = 4.0;
+    for (j = 0; j < n; j++) {
+      c_float xc = s->x[j], wc = s->w[j];
+      s->x[j] = xc + theta * (xc - s->x0[j]);
+      s->w[j] = wc + theta * (wc - s->w0[j]);
+      s->x0[j] = xc; s->w0[j] = wc;
+    }
+  } else {
+    memcpy(s->x0, s->x, sizeof(c_float) * (size_t)n);
+    memcpy(s->w0, s->w, sizeof(c_float) * (size_t)n);
+    s->have_prev = 1;
+  }
+  /* r = b1 - M x_start */
   c_float rz = 0.0;
   for (j = 0; j < n; j++) {
     s->r[j] = s->b1[j] - s->w[j];
@@ -107,11 +137,13 @@ c_int pcg_solve(pcg_solver *s, c_float *b, c_float tol_abs) {
 
 void pcg_update_matrices(pcg_solver *s, const csc *P, const csc *A) {
   s->P = P; s->A = A;
+  s->have_prev = 0;
   build_precond(s);
 }
 
 void pcg_update_rho(pcg_solver *s, const c_float *rho_vec) {
   memcpy(s->rho, rho_vec, sizeof(c_float) * (size_t)s->m);
+  s->have_prev = 0;
   build_precond(s);
 }
 
@@ -121,10 +153,11 @@ c_int pcg_total_iters(const pcg_solver *s) { return s->total_iters; }
  * at the start of every osqp_solve so that a solve depends on (x, z, y) only) */
 void pcg_set_guess(pcg_solver *s, const c_float *x) {
   memcpy(s->x, x, sizeof(c_float) * (size_t)s->n);
+  s->have_prev = 0;
 }
 
 void pcg_free(pcg_solver *s) {
   if (!s) return;
-  free(s->rho); free(s->dinv); free(s->x); free(s->r); free(s->z); free(s->p); free(s->w); free(s->t); free(s->b1);
+  free(s->rho); free(s->dinv); free(s->x); free(s->r); free(s->z); free(s->p); free(s->w); free(s->t); free(s->b1); free(s->x0); free(s->w0);
   free(s);
 }

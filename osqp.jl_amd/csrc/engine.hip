@@ -229,7 +229,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   refresh_panels();
   set_rho_vec();
   h_x.assign(ng, 0.0); h_y.assign(mg, 0.0); h_dx.assign(ng, 0.0); h_dy.assign(mg, 0.0);
-  lambda0 = 0.15;
+  lambda0 = 0.015;
   if (const char *e = getenv("OSQP_AMD_PCG_LAMBDA")) lambda0 = atof(e);
   lambda = lambda0;
   select_linsys();

@@ -83,7 +83,7 @@ struct Engine {
   std::unique_ptr<Linsys> lin;
 
   // PCG tolerance rule state
-  double sc_pri = 0, sc_dua = 0, lambda0 = 0.15, lambda = 0.15, g_ref = 0;
+  double sc_pri = 0, sc_dua = 0, lambda0 = 0.015, lambda = 0.015, g_ref = 0;
   long long it_ref = 0;
   bool have_res = false, have_ref = false, have_seed = false;
   double g_seed = 0;

@@ -718,6 +718,40 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_p(int n, const double *__
 void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s) {
   OQ_LAUNCH(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p);
 }
+// Start vector of a CG solve from the last two solutions x1 (newest), x0: the point x1 + theta (x1 - x0) that is
+// closest to the new solution in the energy norm, theta = e'r / e'Me with e = x1 - x0, r = b - M x1 (M x1, M x0
+// are known).  num = e'r, den = e'(M x1 - M x0) -> slots; k_extrapolate_dev applies theta = num / den (0 when the
+// two solutions coincide, clamped to [-1, 4]) to a vector and rotates the pair.
+__global__ __launch_bounds__(kBlock) void k_extrap_dots(int n, const double *__restrict__ x1, const double *__restrict__ x0,
+                                                        const double *__restrict__ Mx1, const double *__restrict__ Mx0,
+                                                        const double *__restrict__ b, double *__restrict__ partials) {
+  double num = 0.0, den = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double e = x1[i] - x0[i], m1 = Mx1[i];
+    num += e * (b[i] - m1);
+    den += e * (m1 - Mx0[i]);
+  }
+  num = block_sum(num);
+  den = block_sum(den);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = num; partials[kReduceBlocks + blockIdx.x] = den; }
+}
+void pcg_extrap_dots(int n, const double *x1, const double *x0, const double *Mx1, const double *Mx0, const double *b,
+                     double *partials, double *slot_num, double *slot_den, hipStream_t s) {
+  OQ_LAUNCH(k_extrap_dots, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, x1, x0, Mx1, Mx0, b, partials);
+  OQ_LAUNCH(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slot_num, slot_den);
+}
+__global__ __launch_bounds__(kBlock) void k_extrapolate_dev(double *__restrict__ v1, double *__restrict__ v0,
+                                                            const double *__restrict__ num, const double *__restrict__ den, int n) {
+  const double d = *den;
+  double theta = d > 0.0 ? *num / d : 0.0;
+  theta = theta != theta ? 0.0 : fmin(fmax(theta, -1.0), 4.0);
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) { const double cur = v1[i], old = v0[i]; v0[i] = cur; v1[i] = cur + theta * (cur - old); }
+}
+void vec_extrapolate_dev(double *v1, double *v0, const double *slot_num, const double *slot_den, int n, hipStream_t s) {
+  if (n <= 0) return;
+  OQ_LAUNCH(k_extrapolate_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, v1, v0, slot_num, slot_den, n);
+}
 __global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, const double *__restrict__ num, const double *__restrict__ den,
                                                      const double *__restrict__ x, int n) {
   const double a = *num / *den;

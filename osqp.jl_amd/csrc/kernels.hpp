@@ -99,6 +99,11 @@ void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const
 void csr_slice_rows(DevCsr &M, int r0, int r1, hipStream_t s);
 // out[first + k] = sum (bit k of sum_mask set) or max over the `world` rank copies gathered[r * count + k]
 void combine_rank_slots(const double *gathered, int world, int count, unsigned sum_mask, double *out, hipStream_t s);
+// energy-optimal extrapolation of the CG start vector from the last two solutions (kernels.hip: k_extrap_dots)
+void pcg_extrap_dots(int n, const double *x1, const double *x0, const double *Mx1, const double *Mx0, const double *b,
+                     double *partials, double *slot_num, double *slot_den, hipStream_t s);
+// v1 <- v1 + theta (v1 - v0), v0 <- old v1, theta = clamp(slot_num / slot_den) on the device
+void vec_extrapolate_dev(double *v1, double *v0, const double *slot_num, const double *slot_den, int n, hipStream_t s);
 // y += (slot_num/slot_den) * x   (device-side scalar)
 void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s);
 

@@ -28,7 +28,8 @@ constexpr int kRefresh = 25;
 
 struct Pcg : Linsys {
   Engine &e;
-  DevBuf<double> xs, r, zz, p, w, t, u, b1, dinv, Axs, Mxs;
+  DevBuf<double> xs, r, zz, p, w, t, u, b1, dinv, Axs, Mxs, xs0, Axs0, Mxs0;
+  bool extrapolate = true, have_prev = false;
   long long total_iters = 0;
   int max_iter = 20000;
   bool carried_valid = false;
@@ -39,6 +40,8 @@ struct Pcg : Linsys {
     xs.alloc(n); r.alloc(n); zz.alloc(n); p.alloc(n); w.alloc(n); b1.alloc(n); dinv.alloc(n); Mxs.alloc(n);
     t.alloc(m); u.alloc(m); Axs.alloc(m);
     xs.zero(e.stream);
+    if (const char *ev = getenv("OSQP_AMD_PCG_EXTRAP")) extrapolate = atoi(ev) != 0;
+    if (extrapolate) { xs0.alloc(n); Axs0.alloc(m); Mxs0.alloc(n); }
     precond();
   }
   int kind() const override { return 2; }
@@ -76,6 +79,22 @@ struct Pcg : Linsys {
       apply_M(xs.get(), Axs.get(), Mxs.get());
       carried_valid = true;
       since_refresh = 0;
+    }
+    // Start vector: the energy-optimal point on the line through the last two solutions (k_extrap_dots); the
+    // carried products move along with it.  Off for the first solve after M changed or x~ was reset.
+    if (extrapolate) {
+      if (have_prev) {
+        pcg_extrap_dots(n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), e.partials.get(), slots + S_T2, slots + S_T3, s);
+        e.combine_slots(S_T2, 2, 3u);
+        vec_extrapolate_dev(xs.get(), xs0.get(), slots + S_T2, slots + S_T3, n, s);
+        vec_extrapolate_dev(Mxs.get(), Mxs0.get(), slots + S_T2, slots + S_T3, n, s);
+        if (m > 0) vec_extrapolate_dev(Axs.get(), Axs0.get(), slots + S_T2, slots + S_T3, m, s);
+        HIP_CHECK(hipMemsetAsync(slots + S_T2, 0, sizeof(double) * 2, s));
+      } else {
+        vec_copy(xs0.get(), xs.get(), n, s); vec_copy(Mxs0.get(), Mxs.get(), n, s);
+        if (m > 0) vec_copy(Axs0.get(), Axs.get(), m, s);
+        have_prev = true;
+      }
     }
     // r = b1 - M x0 ; zz = dinv r ; p = zz
     pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0,
@@ -116,9 +135,9 @@ struct Pcg : Linsys {
     if (m > 0) vec_copy(xz + n, Axs.get(), m, s);  // z~ = A x~
     return status;
   }
-  int update_rho() override { precond(); carried_valid = false; return 0; }
-  int update_matrices() override { precond(); carried_valid = false; return 0; }
-  void set_guess(const double *x) override { vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; }
+  int update_rho() override { precond(); carried_valid = false; have_prev = false; return 0; }
+  int update_matrices() override { precond(); carried_valid = false; have_prev = false; return 0; }
+  void set_guess(const double *x) override { vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; have_prev = false; }
   float time_solve(int reps) override {
     // one operator application (3 SpMV) as the unit of the indirect back-end
     hipEvent_t a, b;
