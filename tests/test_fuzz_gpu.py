@@ -1,0 +1,120 @@
+"""Seeded random small QPs (ragged structure, empty rows and columns, infinite / equal / one-sided bounds, zero P,
+infeasible and unbounded instances): with the direct back-end on both sides the HIP engine must follow the CPU
+oracle's trajectory -- same status, same iteration count, same iterates to rounding."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import osqp_jl_amd as oq
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(rng):
+    n = int(rng.integers(1, 25))
+    m = int(rng.integers(0, 35))
+    dens = rng.choice([0.05, 0.2, 0.6])
+    if rng.random() < 0.2:
+        P = sp.csc_matrix((n, n))
+    else:
+        M = sp.random(n, n, density=dens, random_state=rng, data_rvs=rng.standard_normal)
+        P = (M @ M.T + (0.0 if rng.random() < 0.3 else 0.1) * sp.eye(n)).tocsc()
+    q = rng.standard_normal(n) * rng.choice([0.0, 1.0, 10.0])
+    A = sp.random(m, n, density=dens, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    center = rng.standard_normal(m)
+    width = rng.random(m) * rng.choice([0.0, 1.0, 5.0], size=m)
+    l, u = center - width, center + width
+    kind = rng.integers(0, 5, size=m)
+    l = np.where(kind == 0, -np.inf, l)
+    u = np.where(kind == 1, np.inf, u)
+    both = kind == 2
+    l = np.where(both, -np.inf, l); u = np.where(both, np.inf, u)
+    return dict(P=sp.triu(P, format="csc"), q=q, A=A, l=l, u=u)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_small_problems_follow_the_oracle(product_lib, oracle_lib, block):
+    rng = np.random.default_rng(1000 + block)
+    seen = set()
+    for k in range(25):
+        prob = random_problem(rng)
+        opts = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, max_iter=2000, adaptive_rho_interval=25,
+                    scaling=int(rng.choice([0, 1, 10])), alpha=float(rng.choice([1.0, 1.6])))
+        res = []
+        for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+            m = oq.Model(lib)
+            oq.setup(m, linsys_solver=ls, **prob, **opts)
+            res.append(oq.solve(m))
+            oq.clean(m)
+        ro, rp = res
+        tag = "block %d problem %d (n=%d, m=%d)" % (block, k, prob["P"].shape[0], prob["A"].shape[0])
+        assert ro.info.status == rp.info.status, tag
+        assert ro.info.iter == rp.info.iter, tag
+        seen.add(ro.info.status)
+        if ro.info.status in ("Solved", "Max_iter_reached"):
+            scale = max(1.0, float(np.max(np.abs(ro.x))))
+            assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * scale, tag
+            if len(ro.y):
+                assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, float(np.max(np.abs(ro.y)))), tag
+        elif ro.info.status == "Primal_infeasible":
+            assert np.max(np.abs(ro.prim_inf_cert - rp.prim_inf_cert)) <= 1e-6, tag
+        elif ro.info.status == "Dual_infeasible":
+            assert np.max(np.abs(ro.dual_inf_cert - rp.dual_inf_cert)) <= 1e-6, tag
+    assert "Solved" in seen
+
+
+def feasible_problem(rng):
+    n = int(rng.integers(2, 30))
+    m = int(rng.integers(1, 40))
+    M = sp.random(n, n, density=0.3, random_state=rng, data_rvs=rng.standard_normal)
+    P = sp.triu((M @ M.T + 0.1 * sp.eye(n)).tocsc(), format="csc")
+    A = sp.random(m, n, density=0.3, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    x0 = rng.standard_normal(n)
+    w = rng.random(m) * rng.choice([0.0, 1.0], size=m)
+    return dict(P=P, q=rng.standard_normal(n), A=A, l=A @ x0 - w, u=A @ x0 + w), x0
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_update_sequences_follow_the_oracle(product_lib, oracle_lib, block):
+    """setup -> solve -> update_q -> solve -> update_bounds -> solve -> update_P_A (all values, then an index subset)
+    -> solve -> update_rho -> solve -> warm start -> solve, the same calls on both libraries."""
+    rng = np.random.default_rng(2000 + block)
+    for k in range(12):
+        prob, x0 = feasible_problem(rng)
+        n, m = prob["P"].shape[0], prob["A"].shape[0]
+        opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+        models = []
+        for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+            mdl = oq.Model(lib)
+            oq.setup(mdl, linsys_solver=ls, **prob, **opts)
+            models.append(mdl)
+        q2 = rng.standard_normal(n)
+        shift = 0.1 * rng.standard_normal(m)
+        Px2 = prob["P"].data * (0.5 + rng.random())  # a positive multiple keeps P positive semidefinite
+        Ax2 = prob["A"].data * (1.0 + 0.2 * rng.standard_normal(prob["A"].nnz))
+        nsub = max(1, prob["A"].nnz // 3)
+        sub = np.sort(rng.choice(prob["A"].nnz, size=min(nsub, prob["A"].nnz), replace=False)) if prob["A"].nnz else np.zeros(0, int)
+        Asub = rng.standard_normal(len(sub))
+        steps = [
+            lambda mm: None,
+            lambda mm: oq.update(mm, q=q2),
+            lambda mm: oq.update(mm, l=prob["l"] + shift - 0.05, u=prob["u"] + shift + 0.05),
+            lambda mm: oq.update(mm, Px=Px2, Ax=Ax2),
+            (lambda mm: oq.update(mm, Ax=Asub, Ax_idx=sub)) if len(sub) else (lambda mm: None),
+            lambda mm: oq.update_settings(mm, rho=0.7),
+            lambda mm: oq.warm_start(mm, x=x0, y=np.zeros(m)),
+        ]
+        for si, step in enumerate(steps):
+            out = []
+            for mdl in models:
+                step(mdl)
+                out.append(oq.solve(mdl))
+            ro, rp = out
+            tag = "block %d problem %d step %d (n=%d, m=%d)" % (block, k, si, n, m)
+            assert ro.info.status == rp.info.status, tag
+            assert ro.info.iter == rp.info.iter, tag
+            if ro.info.status == "Solved":
+                assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, float(np.max(np.abs(ro.x)))), tag
+                assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, float(np.max(np.abs(ro.y)))), tag
+        for mdl in models:
+            oq.clean(mdl)
