@@ -118,3 +118,17 @@ def test_random_update_sequences_follow_the_oracle(product_lib, oracle_lib, bloc
                 assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, float(np.max(np.abs(ro.y)))), tag
         for mdl in models:
             oq.clean(mdl)
+
+
+def test_update_to_indefinite_P_is_refused_by_both(product_lib, oracle_lib):
+    """A value update that makes P indefinite breaks the inertia of the KKT factor: the direct back-end of both
+    libraries must report it through the exit flag (the Julia side raises on a non-zero flag)."""
+    P = sp.csc_matrix(np.diag([1.0, 1.0]))
+    A = sp.csc_matrix(np.eye(2))
+    for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+        m = oq.Model(lib)
+        oq.setup(m, P=P, q=np.ones(2), A=A, l=-np.ones(2), u=np.ones(2), verbose=False, linsys_solver=ls)
+        assert oq.solve(m).info.status == "Solved"
+        with pytest.raises(oq.OSQPError):
+            oq.update(m, Px=np.array([1.0, -5.0]))
+        oq.clean(m)
