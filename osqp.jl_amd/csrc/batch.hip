@@ -22,7 +22,11 @@
 namespace oq {
 namespace {
 
-constexpr int NT = 256;
+#ifndef OQ_BATCH_NT
+#define OQ_BATCH_NT 512
+#endif
+constexpr int NT = OQ_BATCH_NT;  // threads per workgroup = per QP
+constexpr int NW = NT / 64;
 #define B_RHO_MIN 1e-6
 #define B_RHO_MAX 1e6
 #define B_MIN_SCALING 1e-4
@@ -60,8 +64,10 @@ __device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    double a = red[k], b = red[K + k], c = red[2 * K + k], d = red[3 * K + k];
-    v[k] = op ? (a + b) + (c + d) : nmax(nmax(a, b), nmax(c, d));
+    double a = red[k];
+#pragma unroll
+    for (int w = 1; w < NW; w++) a = op ? a + red[w * K + k] : nmax(a, red[w * K + k]);
+    v[k] = a;
   }
 }
 
@@ -72,7 +78,7 @@ struct Lds {
   int ld;
 };
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (size_t)n * (n + 1) + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 64;
+  return (size_t)n * (n + 1) + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW;
 }
 __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
   return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
@@ -91,7 +97,7 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
   s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n; s.ldinv = p; p += n;
   s.l = p; p += m; s.u = p; p += m; s.E = p; p += m; s.rho = p; p += m; s.rhoi = p; p += m; s.z = p; p += m; s.y = p; p += m;
   s.zp = p; p += m; s.zt = p; p += m; s.dy = p; p += m; s.Ax = p; p += m; s.tm = p; p += m;
-  s.red = p; p += 64;
+  s.red = p; p += 16 * NW;  // NW * K doubles of block_reduce, K <= 14
   s.ctype = (int *)p;
   unsigned short *h = (unsigned short *)((char *)p + (((size_t)m * 4 + 15) / 16) * 16);
   s.Ap = h; h += n + 1; s.Fp = h; h += n + 1; s.Rp = h; h += m + 1;
@@ -99,27 +105,31 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
   return s;
 }
 
-// y = A x (CSR), y = A' x (CSC), y = P x (full symmetric CSR); no barriers inside
-__device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
-  for (int i = threadIdx.x; i < P.m; i += NT) {
+// y = A x (CSR), y = A' x (CSC), y = P x (full symmetric CSR); no barriers inside.  L lanes share a row (the index ->
+// value -> operand chain of LDS reads is latency-bound: 8 entries walked by one lane cost 8 round trips, by 4 lanes 2)
+// and add up with xor shuffles, so every thread of the workgroup reaches the shuffles whether it has a row or not.
+template <int L, typename F, typename G>
+__device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restrict__ ptr, double *__restrict__ y, F term, G init) {
+  const int lane = threadIdx.x & (L - 1);
+  for (int base = 0; base < rows; base += NT / L) {
+    const int r = base + threadIdx.x / L;
     double a = 0.0;
-    for (int q = s.Rp[i]; q < s.Rp[i + 1]; q++) a += s.Av[s.Rmap[q]] * x[s.Rc[q]];
-    y[i] = a;
+    if (r < rows)
+      for (int q = ptr[r] + lane; q < ptr[r + 1]; q += L) a += term(q);
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0 && r < rows) y[r] = init(r) + a;
   }
+}
+__device__ __forceinline__ double zero_init(int) { return 0.0; }
+__device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
+  rows_dot<2>(P.m, s.Rp, y, [&](int q) { return s.Av[s.Rmap[q]] * x[s.Rc[q]]; }, zero_init);
 }
 __device__ __forceinline__ void mul_At(const Pattern &P, const Lds &s, const double *x, double *y) {
-  for (int j = threadIdx.x; j < P.n; j += NT) {
-    double a = 0.0;
-    for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) a += s.Av[k] * x[s.Ai[k]];
-    y[j] = a;
-  }
+  rows_dot<4>(P.n, s.Ap, y, [&](int k) { return s.Av[k] * x[s.Ai[k]]; }, zero_init);
 }
 __device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const double *x, double *y) {
-  for (int r = threadIdx.x; r < P.n; r += NT) {
-    double a = 0.0;
-    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) a += s.Pv[q] * x[s.Fc[q]];
-    y[r] = a;
-  }
+  rows_dot<4>(P.n, s.Fp, y, [&](int q) { return s.Pv[q] * x[s.Fc[q]]; }, zero_init);
 }
 
 __device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classify) {
@@ -164,37 +174,122 @@ __device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
     for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) s.M[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
   __syncthreads();
   bool ok = true;
-  // thread layout of a sweep: row i = tid % 128 (+128 on a second pass when n > 128), columns j = tid / 128, +2, ...
-  const int ti = threadIdx.x & 127, tj = threadIdx.x >> 7;
-  for (int k = 0; k < n; k++) {
-    for (int i = threadIdx.x; i < n; i += NT) s.tn[i] = s.M[i + k * ld];
+  // Only the lower triangle (i >= j) is swept; the rest of the array is filled in by symmetry at the end.  Thread
+  // layout: rows r and n-1-r form a pair with n+1 lower-triangle elements together, so every pair is the same
+  // amount of work: pair = tid % PAIRS_PAD, position inside the pair p = tid / PAIRS_PAD, + PS, ...
+  //   p <= r: element (r, p)          p > r: element (n-1-r, n-p)    (column independent of r: no bank conflicts)
+  const int npairs = (n + 1) >> 1;  // for odd n the middle row pairs with itself and is taken once (p <= r only)
+  constexpr int PP = 64;            // pairs handled side by side (lanes of a wavefront = consecutive pairs)
+  constexpr int PS = NT / PP;       // positions handled side by side
+  const int tr = threadIdx.x % PP, tp = threadIdx.x / PP;
+  // Two pivots per pass (a block sweep on {k, k+1}: the same result as two single sweeps, with half the passes over
+  // the array and half the barriers):  M_ij -= [c0_i c1_i] B^-1 [c0_j; c1_j],  columns k, k+1 <- [c0 c1] B^-1,
+  // pivot block <- -B^-1, with B = [a b; b c] the 2 x 2 pivot block and c0, c1 the two columns.
+  double *c0 = s.tn, *c1 = s.Px;  // scratch: Px is only live inside a residual evaluation
+  int k = 0;
+  for (; k + 1 < n; k += 2) {
+    for (int i = threadIdx.x; i < n; i += NT) {
+      c0[i] = i >= k ? s.M[i + k * ld] : s.M[k + i * ld];
+      c1[i] = i >= k + 1 ? s.M[i + (k + 1) * ld] : s.M[k + 1 + i * ld];
+    }
+    __syncthreads();
+    const double pa = c0[k], pb = c0[k + 1], pc = c1[k + 1];
+    const double det = pa * pc - pb * pb;
+    if (!(pa > 0.0) || !(det > 0.0)) ok = false;  // both pivots (a and c - b^2 / a) positive
+    const double idet = 1.0 / det;
+    for (int r = tr; r < npairs; r += PP) {
+      const int r2 = n - 1 - r;
+      const double g0a = (c0[r] * pc - c1[r] * pb) * idet, g1a = (c1[r] * pa - c0[r] * pb) * idet;
+      const double g0b = (c0[r2] * pc - c1[r2] * pb) * idet, g1b = (c1[r2] * pa - c0[r2] * pb) * idet;
+      const int last = (r2 == r) ? r : n;
+      int q = tp;
+      for (; q + 3 * PS <= last; q += 4 * PS) {  // 4 independent read-modify-writes in flight
+        int idx[4];
+        double mv[4], fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int qq = q + u * PS;
+          const bool first = qq <= r;
+          const int i = first ? r : r2, j = first ? qq : n - qq;
+          idx[u] = i + j * ld;
+          mv[u] = s.M[idx[u]];
+          fv[u] = (first ? g0a : g0b) * c0[j] + (first ? g1a : g1b) * c1[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) s.M[idx[u]] = mv[u] - fv[u];
+      }
+      for (; q <= last; q += PS) {
+        const bool first = q <= r;
+        const int i = first ? r : r2, j = first ? q : n - q;
+        s.M[i + j * ld] -= (first ? g0a : g0b) * c0[j] + (first ? g1a : g1b) * c1[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) {
+      if (i == k) {
+        s.M[k + k * ld] = -pc * idet;
+        s.M[k + 1 + k * ld] = pb * idet;
+        s.M[k + 1 + (k + 1) * ld] = -pa * idet;
+      } else if (i != k + 1) {
+        const double v0 = (c0[i] * pc - c1[i] * pb) * idet, v1 = (c1[i] * pa - c0[i] * pb) * idet;
+        if (i > k) { s.M[i + k * ld] = v0; s.M[i + (k + 1) * ld] = v1; }
+        else { s.M[k + i * ld] = v0; s.M[k + 1 + i * ld] = v1; }
+      }
+    }
+    __syncthreads();
+  }
+  for (; k < n; k++) {  // odd n: the last pivot alone
+    // column k of the symmetric matrix: below the diagonal from column k, above it from row k
+    for (int i = threadIdx.x; i < n; i += NT) s.tn[i] = i >= k ? s.M[i + k * ld] : s.M[k + i * ld];
     __syncthreads();
     const double d = s.tn[k];
     if (!(d > 0.0)) ok = false;
     const double p = 1.0 / d;
-    // rank-1 update of the whole array (row and column k are overwritten right after)
-    for (int i = ti; i < n; i += 128) {
-      const double f = s.tn[i] * p;
-      double *Mi = s.M + i;
-      int j = tj;
-      for (; j + 6 < n; j += 8) {  // 4 independent read-modify-writes in flight
-        const double m0 = Mi[j * ld], m1 = Mi[(j + 2) * ld], m2 = Mi[(j + 4) * ld], m3 = Mi[(j + 6) * ld];
-        const double t0 = s.tn[j], t1 = s.tn[j + 2], t2 = s.tn[j + 4], t3 = s.tn[j + 6];
-        Mi[j * ld] = m0 - f * t0; Mi[(j + 2) * ld] = m1 - f * t1; Mi[(j + 4) * ld] = m2 - f * t2; Mi[(j + 6) * ld] = m3 - f * t3;
+    // rank-1 update of the lower triangle (row and column k are overwritten right after)
+    for (int r = tr; r < npairs; r += PP) {
+      const int r2 = n - 1 - r;
+      const double f1 = s.tn[r] * p, f2 = s.tn[r2] * p;
+      const int last = (r2 == r) ? r : n;  // positions 0..last
+      int q = tp;
+      for (; q + 3 * PS <= last; q += 4 * PS) {  // 4 independent read-modify-writes in flight
+        int idx[4];
+        double mv[4], fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int qq = q + u * PS;
+          const bool first = qq <= r;
+          const int i = first ? r : r2, j = first ? qq : n - qq;
+          idx[u] = i + j * ld;
+          mv[u] = s.M[idx[u]];
+          fv[u] = (first ? f1 : f2) * s.tn[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) s.M[idx[u]] = mv[u] - fv[u];
       }
-      for (; j < n; j += 2) Mi[j * ld] -= f * s.tn[j];
+      for (; q <= last; q += PS) {
+        const bool first = q <= r;
+        const int i = first ? r : r2, j = first ? q : n - q;
+        s.M[i + j * ld] -= (first ? f1 : f2) * s.tn[j];
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += NT) {
       const double v = (i == k) ? -p : s.tn[i] * p;
-      s.M[i + k * ld] = v;
-      s.M[k + i * ld] = v;
+      if (i >= k) s.M[i + k * ld] = v; else s.M[k + i * ld] = v;
     }
     __syncthreads();
   }
-  for (int i = ti; i < n; i += 128) {
-    double *Mi = s.M + i;
-    for (int j = tj; j < n; j += 2) Mi[j * ld] = -Mi[j * ld];
+  // negate and mirror: M^-1 as a full array for the row-wise products of the iterations
+  for (int r = tr; r < npairs; r += PP) {
+    const int r2 = n - 1 - r;
+    const int last = (r2 == r) ? r : n;
+    for (int q = tp; q <= last; q += PS) {
+      const bool first = q <= r;
+      const int i = first ? r : r2, j = first ? q : n - q;
+      const double v = -s.M[i + j * ld];
+      s.M[i + j * ld] = v;
+      s.M[j + i * ld] = v;
+    }
   }
   __syncthreads();
   return ok;
@@ -401,11 +496,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
       // b = sigma x_prev - q + A'(rho z_prev - y)
       for (int i = tid; i < m; i += NT) s.tm[i] = s.rho[i] * zp[i] - s.y[i];
       __syncthreads();
-      for (int j = tid; j < n; j += NT) {
-        double a = sigma * xp[j] - s.q[j];
-        for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) a += s.Av[k] * s.tm[s.Ai[k]];
-        s.xt[j] = a;
-      }
+      rows_dot<4>(n, s.Ap, s.xt, [&](int k) { return s.Av[k] * s.tm[s.Ai[k]]; }, [&](int j) { return sigma * xp[j] - s.q[j]; });
       __syncthreads();
       PROF(3)
       // x~ = M^-1 b: four lanes per row (quarters of the row added through shuffles)
