@@ -78,7 +78,7 @@ struct Lds {
   int ld;
 };
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (size_t)n * (n + 1) + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW;
+  return (size_t)n * (n + 1) + (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW;
 }
 __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
   return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
@@ -91,7 +91,7 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
   const int n = P.n, m = P.m;
   s.ld = n + 1;
   double *p = base;
-  s.M = p; p += (size_t)n * s.ld;
+  s.M = p; p += (size_t)n * s.ld + (NT / 128) * (size_t)n;  // the array + the partial sums of the dense product
   s.Av = p; p += P.nnzA; s.Pv = p; p += P.nnzF;
   s.q = p; p += n; s.D = p; p += n; s.x = p; p += n; s.xp = p; p += n; s.xt = p; p += n; s.dx = p; p += n;
   s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n; s.ldinv = p; p += n;
@@ -108,8 +108,9 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
 // y = A x (CSR), y = A' x (CSC), y = P x (full symmetric CSR); no barriers inside.  L lanes share a row (the index ->
 // value -> operand chain of LDS reads is latency-bound: 8 entries walked by one lane cost 8 round trips, by 4 lanes 2)
 // and add up with xor shuffles, so every thread of the workgroup reaches the shuffles whether it has a row or not.
+// finish(r, sum) runs on one lane per row.
 template <int L, typename F, typename G>
-__device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restrict__ ptr, double *__restrict__ y, F term, G init) {
+__device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restrict__ ptr, F term, G finish) {
   const int lane = threadIdx.x & (L - 1);
   for (int base = 0; base < rows; base += NT / L) {
     const int r = base + threadIdx.x / L;
@@ -118,18 +119,17 @@ __device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restr
       for (int q = ptr[r] + lane; q < ptr[r + 1]; q += L) a += term(q);
 #pragma unroll
     for (int o = L >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0 && r < rows) y[r] = init(r) + a;
+    if (lane == 0 && r < rows) finish(r, a);
   }
 }
-__device__ __forceinline__ double zero_init(int) { return 0.0; }
 __device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
-  rows_dot<2>(P.m, s.Rp, y, [&](int q) { return s.Av[s.Rmap[q]] * x[s.Rc[q]]; }, zero_init);
+  rows_dot<2>(P.m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * x[s.Rc[q]]; }, [&](int r, double a) { y[r] = a; });
 }
 __device__ __forceinline__ void mul_At(const Pattern &P, const Lds &s, const double *x, double *y) {
-  rows_dot<4>(P.n, s.Ap, y, [&](int k) { return s.Av[k] * x[s.Ai[k]]; }, zero_init);
+  rows_dot<4>(P.n, s.Ap, [&](int k) { return s.Av[k] * x[s.Ai[k]]; }, [&](int r, double a) { y[r] = a; });
 }
 __device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const double *x, double *y) {
-  rows_dot<4>(P.n, s.Fp, y, [&](int q) { return s.Pv[q] * x[s.Fc[q]]; }, zero_init);
+  rows_dot<4>(P.n, s.Fp, [&](int q) { return s.Pv[q] * x[s.Fc[q]]; }, [&](int r, double a) { y[r] = a; });
 }
 
 __device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classify) {
@@ -491,42 +491,51 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   // ---- ADMM loop --------------------------------------------------------------
   if (status == OSQP_UNSOLVED) {
     const int max_iter = (int)st.max_iter;
+    for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];
+    __syncthreads();
     for (iter = 1; iter <= max_iter; iter++) {
       { double *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
-      // b = sigma x_prev - q + A'(rho z_prev - y)
-      for (int i = tid; i < m; i += NT) s.tm[i] = s.rho[i] * zp[i] - s.y[i];
-      __syncthreads();
-      rows_dot<4>(n, s.Ap, s.xt, [&](int k) { return s.Av[k] * s.tm[s.Ai[k]]; }, [&](int j) { return sigma * xp[j] - s.q[j]; });
+      // b = sigma x_prev - q + A'(rho z_prev - y); s.zt = rho z_prev - y was left behind by the previous z / y update
+      rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * s.zt[s.Ai[k]]; },
+                  [&](int j, double a) { s.xt[j] = sigma * xp[j] - s.q[j] + a; });
       __syncthreads();
       PROF(3)
-      // x~ = M^-1 b: four lanes per row (quarters of the row added through shuffles)
-      for (int row = tid >> 2; row < n; row += NT / 4) {
-        const int part = tid & 3;
-        const int q4 = (n + 3) >> 2;
-        const int j0 = part * q4, j1 = (j0 + q4 < n) ? j0 + q4 : n;
-        double a0 = 0.0, a1 = 0.0;
-        int j = j0;
-        for (; j + 1 < j1; j += 2) { a0 += s.M[row + j * s.ld] * s.xt[j]; a1 += s.M[row + (j + 1) * s.ld] * s.xt[j + 1]; }
-        if (j < j1) a0 += s.M[row + j * s.ld] * s.xt[j];
-        double acc = a0 + a1;
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (part == 0) s.tn[row] = acc;
+      // x~ = M^-1 b: lane = row (consecutive lanes read consecutive LDS words: no bank conflicts, b[j] is a broadcast),
+      // the columns cut into NT / 128 parts whose partial sums meet in LDS
+      {
+        constexpr int PARTS = NT / 128;
+        const int part = tid >> 7;
+        const int qn = (n + PARTS - 1) / PARTS;
+        const int j0 = part * qn, j1 = (j0 + qn < n) ? j0 + qn : n;
+        double *partial = s.M + (size_t)n * s.ld;  // PARTS * n doubles behind the array (see lds_doubles)
+        for (int row = tid & 127; row < n; row += 128) {
+          double a0 = 0.0, a1 = 0.0;
+          int j = j0;
+          for (; j + 1 < j1; j += 2) { a0 += s.M[row + j * s.ld] * s.xt[j]; a1 += s.M[row + (j + 1) * s.ld] * s.xt[j + 1]; }
+          if (j < j1) a0 += s.M[row + j * s.ld] * s.xt[j];
+          partial[part * n + row] = a0 + a1;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+          double a = partial[i];
+#pragma unroll
+          for (int q = 1; q < PARTS; q++) a += partial[q * n + i];
+          s.xt[i] = a;
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      for (int i = tid; i < n; i += NT) s.xt[i] = s.tn[i];
-      __syncthreads();
       PROF(4)
-      mul_A(P, s, s.xt, s.zt);  // z~ = A x~
-      for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
-      __syncthreads();
-      for (int i = tid; i < m; i += NT) {
-        double zh = alpha * s.zt[i] + (1.0 - alpha) * zp[i];
-        double zn = fmin(fmax(zh + s.rhoi[i] * s.y[i], s.l[i]), s.u[i]);
+      // z~ = A x~ row by row, each row finished on the spot: z, y, delta_y and s.zt = rho z - y for the next right-hand side
+      rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * s.xt[s.Rc[q]]; }, [&](int i, double zt) {
+        const double zh = alpha * zt + (1.0 - alpha) * zp[i];
+        const double yo = s.y[i];
+        const double zn = fmin(fmax(zh + s.rhoi[i] * yo, s.l[i]), s.u[i]);
         z[i] = zn;
-        double d = s.rho[i] * (zh - zn);
-        s.dy[i] = d; s.y[i] += d;
-      }
+        const double d = s.rho[i] * (zh - zn);
+        s.dy[i] = d; s.y[i] = yo + d;
+        s.zt[i] = s.rho[i] * zn - (yo + d);
+      });
+      for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
       __syncthreads();
       PROF(5)
       checked_last = check && (iter % check == 0);
@@ -540,6 +549,7 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
         if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
           rho = est; rho_updates++;
           set_rho(P, s, rho, false);
+          for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];  // the carried vector follows rho
           if (!build_and_factor(P, s, st.sigma)) { status = OSQP_NON_CVX; break; }
         }
       }
