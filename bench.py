@@ -329,7 +329,7 @@ def bench_batch(args, oq, lib, torch, dist, rank, local_rank, world):
             "roofline": {"bound": "hbm", "kernel": "k_batch_solve (LDS-resident; HBM traffic is load + store of each instance only)",
                          "achieved": round(per_inst_bytes * total * args.steps / elapsed / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(per_inst_bytes * total * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": None, "note": "latency/LDS-bound by design: ~115 KB of LDS per instance, 1 workgroup per CU"},
+                         "traffic": None, "note": "latency/LDS-bound by design: ~126 KB of LDS per instance, one 512-thread workgroup per CU"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -8,7 +8,7 @@
 //     n = 100; the 300 x 300 KKT matrix would not fit), inverted in place by
 //     Gauss-Jordan sweeps and rebuilt whenever adaptive rho changes rho.
 // Per iteration: b = sigma x - q + A'(rho z - y); x~ = M^-1 b (dense product,
-// four lanes per row); z~ = A x~; the fused x/z/y update; every `check_termination`
+// lane = row); z~ = A x~ consumed row by row by the x/z/y update; every `check_termination`
 // iterations the same residual / infeasibility tests as the large-problem path.
 // Same algorithm as oracle/osqp_oracle.c with the KKT system in reduced form.
 // There is no communication between instances: the multi-GPU path shards the
