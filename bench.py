@@ -188,11 +188,11 @@ def main():
             emit()
             os._exit(0)
 
-        watchdog = threading.Timer((0 if args.no_cpu else args.cpu_seconds + 90.0) + 300.0, give_up)
+        watchdog = threading.Timer(300.0, give_up)
         watchdog.daemon = True
         watchdog.start()
 
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:  # the CPU leg belongs to the 1-GPU line only
         out["cpu_baseline"] = cpu_leg(oq, args)
 
     if want_sharded:
@@ -302,7 +302,7 @@ def bench_batch(args, oq, lib, torch, dist, rank, local_rank, world):
     info = info.cpu().numpy()
     iters = float(info[:, 0].sum())
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:
         ora = oq.load_library(oq.ORACLE_LIB_PATH)
         t0 = time.perf_counter()
         k, its = 0, 0
