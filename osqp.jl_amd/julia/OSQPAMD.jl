@@ -197,14 +197,15 @@ function setup_sharded!(model::OSQP.Model, comm::Comm; P::SparseMatrixCSC, q::Ve
     Pu = istriu(P) ? P : triu(P)
     u = min.(u, OSQP.OSQP_INFTY); l = max.(l, -OSQP.OSQP_INFTY)
     managedP = OSQP.ManagedCcsc(Pu); managedA = OSQP.ManagedCcsc(A)
+    Pdata = Ref(OSQP.Ccsc(managedP)); Adata = Ref(OSQP.Ccsc(managedA))
     stgs = OSQP.Settings(Dict{Symbol,Any}(settings))
     workspace = Ref{Ptr{OSQP.Workspace}}()
-    GC.@preserve managedP managedA q l u begin
-        data = OSQP.Data(n, m, Base.unsafe_convert(Ptr{OSQP.Ccsc}, Ref(OSQP.Ccsc(managedP))),
-                         Base.unsafe_convert(Ptr{OSQP.Ccsc}, Ref(OSQP.Ccsc(managedA))), pointer(q), pointer(l), pointer(u))
-        flag = ccall((:osqp_amd_setup_sharded, lib), Cc_int,
-                     (Ptr{Ptr{OSQP.Workspace}}, Ptr{OSQP.Data}, Ptr{OSQP.Settings}, Ptr{Cvoid}),
-                     workspace, Ref(data), Ref(stgs), comm.handle)
+    flag = GC.@preserve managedP Pdata managedA Adata q l u begin   # as [REF src/interface.jl:132-155]
+        data = OSQP.Data(n, m, Base.unsafe_convert(Ptr{OSQP.Ccsc}, Pdata), Base.unsafe_convert(Ptr{OSQP.Ccsc}, Adata),
+                         pointer(q), pointer(l), pointer(u))
+        ccall((:osqp_amd_setup_sharded, lib), Cc_int,
+              (Ptr{Ptr{OSQP.Workspace}}, Ptr{OSQP.Data}, Ptr{OSQP.Settings}, Ptr{Cvoid}),
+              workspace, Ref(data), Ref(stgs), comm.handle)
     end
     flag == 0 || error("Error in OSQP setup: $(last_error())")
     model.workspace = workspace[]
