@@ -392,10 +392,11 @@ struct LdlFactor {
   std::vector<Step> fwd, bwd;
   long long factorizations = 0;
 
-  LdlFactor(Engine &en, const std::vector<int> &row_map, int mr_, double sigma_, double cconst_, int64_t limit)
+  LdlFactor(Engine &en, const std::vector<int> &row_map, int mr_, double sigma_, double cconst_, int64_t limit,
+            double flops_limit = 0.0)
       : e(en), sigma(sigma_), cconst(cconst_) {
     e.fetch_host_pattern();
-    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, S);
+    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, S);
     if (S.too_large) return;
     hipStream_t s = e.stream;
     N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
@@ -625,7 +626,8 @@ std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
   std::vector<int> ident(e.m);
   for (int i = 0; i < e.m; i++) ident[i] = i;
   std::unique_ptr<Direct> d(new Direct(e));
-  d->F.reset(new LdlFactor(e, ident, e.m, e.st.sigma, 0.0, factor_limit(e, e.st.linsys_solver == AMD_DIRECT_SOLVER)));
+  const bool forced = e.st.linsys_solver == AMD_DIRECT_SOLVER;
+  d->F.reset(new LdlFactor(e, ident, e.m, e.st.sigma, 0.0, factor_limit(e, forced), forced ? 0.0 : factor_flops_limit()));
   if (d->F->S.too_large) { *err = -1; return nullptr; }
   // auto mode also gives the problem to PCG when the factorisation itself would take too long
   // (sum of squared column counts ~ multiply-adds of one numeric factorisation; it is redone at every rho update)

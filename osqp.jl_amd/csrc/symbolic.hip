@@ -25,6 +25,10 @@ struct MinDegree {
   std::vector<char> state;  // 0 variable, 1 element, 2 dead
   std::vector<int> degree, bucket_head, next, prev, stamp, wstamp, wcount;
   std::vector<int> extra;  // neighbours kept out of the graph (dense nodes, eliminated last): a constant part of every degree
+  // budget: the clique sizes are the column counts of L for this ordering, so the run can stop as soon as the
+  // factor is known to be too large (the caller then goes to the indirect back-end without waiting for the rest)
+  double nnz_limit = 0.0, flops_limit = 0.0, nnz = 0.0, flops = 0.0;
+  bool aborted = false;
   int min_bucket = 0;
 
   explicit MinDegree(int n) : N(n), var_adj(n), elem_adj(n), members(n), state(n, 0), degree(n, 0), bucket_head(n + 1, -1),
@@ -70,6 +74,9 @@ struct MinDegree {
       std::vector<int>().swap(elem_adj[p]);
       members[p] = clique;
       const int csize = (int)clique.size();
+      const double colcount = (double)csize + (double)extra[p];  // dense neighbours sit below every column they touch
+      nnz += colcount; flops += colcount * colcount;
+      if ((nnz_limit > 0.0 && nnz > nnz_limit) || (flops_limit > 0.0 && flops > flops_limit)) { aborted = true; return; }
       // |L_e \ L_p| for every live element that touches the new clique
       for (int i : clique)
         for (int e : elem_adj[i]) {
@@ -118,7 +125,7 @@ struct Upper {  // upper-triangular pattern, column compressed, with the origin 
 }  // namespace
 
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
-                      Symbolic &S) {
+                      double flops_limit, Symbolic &S) {
   const int n = P.cols, N = n + mr;
   S.n = n; S.mr = mr; S.N = N; S.too_large = false;
   const int64_t nnzP = P.p[n], nnzA = A.p[n];
@@ -178,7 +185,9 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
         if (!dense[i] && !dense[j]) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
         else { if (!dense[i]) md.extra[i]++; if (!dense[j]) md.extra[j]++; }
       }
+    md.nnz_limit = (double)nnzL_limit; md.flops_limit = flops_limit;
     md.run(order);
+    if (md.aborted) { S.too_large = true; S.nnzL = (int64_t)md.nnz; S.flops = md.flops; return; }
     if (ndense)  // isolated in the pruned graph, so their position is free: move them to the end
       std::stable_partition(order.begin(), order.end(), [&](int v) { return !dense[v]; });
   }

@@ -35,8 +35,10 @@ struct Symbolic {
 
 // row_map[i] = index of constraint row i inside the reduced block (0..mr-1) or -1 when the row is left out
 // (identity for the ADMM KKT system; the active-set selection for polish).
-// nnzL_limit: stop and set too_large when the factor would have more entries than this.
+// nnzL_limit / flops_limit (0 = none): stop and set too_large as soon as the factor is known to have more entries
+// than the first or a sum of squared column counts above the second (checked while the ordering runs, so that a
+// hopeless problem is handed to the indirect back-end without paying for the whole analysis).
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
-                      Symbolic &out);
+                      double flops_limit, Symbolic &out);
 
 }  // namespace oq
