@@ -130,6 +130,93 @@ __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N,
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
 }
+// ------------------------------------------------------------------ dense top block
+// The top of the elimination tree of a problem with a few dense rows / columns (a budget constraint, a factor
+// model, a data matrix) is a dense block: every pivot its own level, rows as long as the block.  Its triangular
+// solves are a chain of k dependent steps forward and k backward whatever the kernel.  So the last kD pivots are
+// not factorised at all: their Schur complement S0 = K22 - L21 D1 L21' is assembled as a dense kD x kD array,
+// inverted once per factorisation by kD Gauss-Jordan sweeps (one launch each, ping-pong buffers, the pivots
+// are the same Schur complements LDL' would meet, so the inertia count is unchanged), and a solve replaces both
+// chains by one dense product x2 = S0^-1 (b2 - L21 y1).
+// wave per entry (i, k) of columns [b0, b1) of L's pattern inside the block; the work rows w_k hold L_kj d_j (k_ldl_wrow)
+__global__ __launch_bounds__(kBlock) void k_dense_entries(int b0, int b1, int cD, int kD, int N, const int64_t *__restrict__ Lp,
+                                                          const int *__restrict__ Li, const double *__restrict__ Lx,
+                                                          const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                          const int64_t *__restrict__ Rmap, const double *__restrict__ W,
+                                                          double *__restrict__ S0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = Lp[b0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (e >= Lp[b1]) return;
+  int lo = b0, hi = b1;
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
+  const int k = lo, i = Li[e];
+  const double *w = W + (size_t)(k - b0) * N;
+  double acc = 0.0;
+  for (int64_t q = Rp[i] + lane; q < Rp[i + 1]; q += 64) {
+    const int j = Rj[q];
+    if (j >= cD) break;
+    acc += Lx[Rmap[q]] * w[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    const double v = Lx[e] - acc;
+    S0[(size_t)(i - cD) + (size_t)(k - cD) * kD] = v;
+    S0[(size_t)(k - cD) + (size_t)(i - cD) * kD] = v;
+  }
+}
+// wave per column k of [b0, b1): diagonal of the Schur complement
+__global__ __launch_bounds__(kBlock) void k_dense_diag(int b0, int b1, int cD, int kD, int N, const double *__restrict__ Lx,
+                                                       const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                       const int64_t *__restrict__ Rmap, const double *__restrict__ D,
+                                                       const double *__restrict__ W, double *__restrict__ S0) {
+  const int lane = threadIdx.x & 63;
+  const int k = b0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (k >= b1) return;
+  const double *w = W + (size_t)(k - b0) * N;
+  double acc = 0.0;
+  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) {
+    const int j = Rj[q];
+    if (j >= cD) break;
+    acc += Lx[Rmap[q]] * w[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) S0[(size_t)(k - cD) * (kD + 1)] = D[k] - acc;
+}
+// one Gauss-Jordan sweep on pivot p, out of place (no ordering between the threads of a launch is needed)
+__global__ __launch_bounds__(kBlock) void k_dense_sweep(int kD, int p, const double *__restrict__ Sold, double *__restrict__ Snew,
+                                                        int *__restrict__ status) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (int64_t)kD * kD) return;
+  const int i = (int)(idx % kD), j = (int)(idx / kD);
+  const double piv = Sold[(size_t)p * (kD + 1)];
+  const double ip = 1.0 / piv;
+  const double aip = Sold[(size_t)i + (size_t)p * kD], apj = Sold[(size_t)p + (size_t)j * kD];
+  double v;
+  if (i == p && j == p) v = -ip;
+  else if (i == p) v = apj * ip;
+  else if (j == p) v = aip * ip;
+  else v = Sold[idx] - aip * apj * ip;
+  Snew[idx] = v;
+  if (idx == 0) {
+    if (piv == 0.0 || piv != piv) atomicOr(&status[0], 1);
+    else if (piv > 0.0) atomicAdd(&status[1], 1);
+  }
+}
+// x2 = -(S v) with S = -S0^-1 as the sweeps leave it (symmetric: row a is read as column a, contiguous); wave per row
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, const double *__restrict__ S, const double *__restrict__ v,
+                                                        double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int a = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (a >= kD) return;
+  const double *col = S + (size_t)a * kD;
+  double acc = 0.0;
+  for (int b = lane; b < kD; b += 64) acc += col[b] * v[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[a] = -acc;
+}
 __global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
                                                        double *__restrict__ Rx) {
   int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -387,7 +474,9 @@ struct LdlFactor {
   double sigma = 0, cconst = 0;
   DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit;
   DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
-  DevBuf<double> Lx, Rx, D, Dinv, bp, W;
+  DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2;
+  int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
+  double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
   std::vector<Step> fwd, bwd;
   long long factorizations = 0;
@@ -405,10 +494,11 @@ struct LdlFactor {
     up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
     up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
     Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
+    choose_dense_block();
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
-      for (int l = 0; l < nlev; l++) {
+      for (int l = 0; l < lD; l++) {
         const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1], width = c1 - c0;
         if (width == 0 || S.Lp[c1] == S.Lp[c0]) continue;
         const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)width;
@@ -417,7 +507,9 @@ struct LdlFactor {
           wmax = std::max(wmax, (size_t)width * (size_t)N);
         }
       }
+      if (kD) wmax = std::max(wmax, (size_t)dense_batch() * (size_t)N);
       if (wmax) { W.alloc(wmax); W.zero(s); }
+      if (kD) { S0a.alloc((size_t)kD * kD); S0b.alloc((size_t)kD * kD); x2.alloc(kD); }
     }
     e.sync();
     build_schedule();
@@ -428,6 +520,29 @@ struct LdlFactor {
 
   static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
 
+  // The dense top block: the longest suffix of the top chain (levels of at most kChainRows pivots) with at most
+  // kDenseMax pivots, taken when at least an eighth of its lower triangle is in the pattern of L.
+  static constexpr int kDenseMax = 2048, kDenseMin = 32;
+  void choose_dense_block() {
+    const auto &lp = S.level_ptr;
+    lD = nlev; cD = N; kD = 0;
+    static const bool enabled = !(getenv("OSQP_AMD_DENSE_TOP") && atoi(getenv("OSQP_AMD_DENSE_TOP")) == 0);
+    if (!enabled || nlev < 2) return;
+    int l = nlev;
+    while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && N - lp[l - 1] <= kDenseMax) l--;
+    const int c = lp[l], k = N - c;
+    if (k < kDenseMin) return;
+    int64_t inside = 0;
+    for (int r = c; r < N; r++) {
+      const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
+      inside += end - std::lower_bound(beg, end, c);
+    }
+    if (inside * 8 < (int64_t)k * k) return;
+    lD = l; cD = c; kD = k;
+  }
+  // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
+  int dense_batch() const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)kD, ((size_t)256 << 20) / ((size_t)N * sizeof(double)))); }
+
   void build_schedule() {
     const auto &lp = S.level_ptr;
     // forward: level 0 rows have no predecessors (nothing to do); backward: every level (D^-1 applies everywhere)
@@ -435,11 +550,11 @@ struct LdlFactor {
     auto make = [&](bool forward) {
       std::vector<Step> steps;
       int l = forward ? 1 : 0;
-      while (l < nlev) {
+      while (l < lD) {
         int width = lp[l + 1] - lp[l];
         if (width <= kChainRows) {
           int l2 = l;
-          while (l2 < nlev && lp[l2 + 1] - lp[l2] <= kChainRows) l2++;
+          while (l2 < lD && lp[l2 + 1] - lp[l2] <= kChainRows) l2++;
           int T = 64;
           if (forward) {  // split the rows of the chain at its first pivot
             const int c0 = lp[l], c1 = lp[l2];
@@ -472,6 +587,10 @@ struct LdlFactor {
     fwd = make(true);
     bwd = make(false);
     std::reverse(bwd.begin(), bwd.end());
+    for (int r = cD; r < N; r++) {  // rows of the dense block split at its first pivot
+      const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
+      split[r] = S.Rp[r] + (std::lower_bound(beg, end, cD) - beg);
+    }
     Rsplit.alloc(split.size());
     Rsplit.upload(split.data(), split.size(), e.stream);
     e.sync();
@@ -488,7 +607,7 @@ struct LdlFactor {
                 e.Pf.val.get(), Lx.get(), D.get());
     if (e.nnzA > 0)
       OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
-    for (int l = 0; l < nlev; l++) {
+    for (int l = 0; l < lD; l++) {
       const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
       OQ_LAUNCH(k_ldl_diag, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(),
                 Rmap.get(), D.get(), Dinv.get(), status.get());
@@ -503,6 +622,7 @@ struct LdlFactor {
         OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
                   Rj.get(), Rmap.get(), D.get(), Dinv.get());
     }
+    if (kD) factor_dense_block();
     if (S.nnzL > 0) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
     int st[2] = {0, 0};
     status.download(st, 2, s);
@@ -511,6 +631,30 @@ struct LdlFactor {
     if (st[0]) return 4;
     if (st[1] != n) return 5;
     return 0;
+  }
+
+  void factor_dense_block() {
+    hipStream_t s = e.stream;
+    S0a.zero(s);
+    const int bw = dense_batch();
+    for (int b0 = cD; b0 < N; b0 += bw) {
+      const int b1 = std::min(N, b0 + bw);
+      const dim3 gw(blocks_for((int64_t)(b1 - b0) * 64));
+      OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, b0, b1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 1);
+      const int64_t entries = S.Lp[b1] - S.Lp[b0];
+      if (entries > 0)
+        OQ_LAUNCH(k_dense_entries, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, b0, b1, cD, kD, N, Lp.get(), Li.get(), Lx.get(),
+                  Rp.get(), Rj.get(), Rmap.get(), W.get(), S0a.get());
+      OQ_LAUNCH(k_dense_diag, gw, dim3(kBlock), 0, s, b0, b1, cD, kD, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), S0a.get());
+      OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, b0, b1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 0);
+    }
+    double *cur = S0a.get(), *nxt = S0b.get();
+    const dim3 gs(blocks_for((int64_t)kD * kD));
+    for (int p = 0; p < kD; p++) {
+      OQ_LAUNCH(k_dense_sweep, gs, dim3(kBlock), 0, s, kD, p, cur, nxt, status.get());
+      std::swap(cur, nxt);
+    }
+    Sinv = cur;
   }
 
   void run_steps() {
@@ -535,6 +679,11 @@ struct LdlFactor {
       case 16: OQ_LAUNCH(k_fwd_level<16>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
       default: OQ_LAUNCH(k_fwd_level<64>, grid, block, 0, s, t.a, t.b, Rp.get(), Rj.get(), Rx.get(), bp.get()); break;
       }
+    }
+    if (kD) {  // x2 = S0^-1 (b2 - L21 y1)
+      OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
+      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, Sinv, bp.get() + cD, x2.get());
+      HIP_CHECK(hipMemcpyAsync(bp.get() + cD, x2.get(), sizeof(double) * kD, hipMemcpyDeviceToDevice, s));
     }
     for (const Step &t : bwd) {
       if (t.kind == 1) {
