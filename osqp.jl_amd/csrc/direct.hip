@@ -780,9 +780,9 @@ std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
   if (d->F->S.too_large) { *err = -1; return nullptr; }
   // auto mode also gives the problem to PCG when the factorisation itself would take too long
   // (sum of squared column counts ~ multiply-adds of one numeric factorisation; it is redone at every rho update)
-  // or when the level schedule is so deep that the triangular solves are a serial chain (dense trailing block):
-  // measured, n = m = 5000 with 10 per row: 4623 levels, 1.1 s per iteration -- PCG needs milliseconds there
-  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->nlev > level_limit())) { *err = -1; return nullptr; }
+  // or when the level schedule below the dense top block is so deep that the triangular solves are a serial chain
+  // (measured, n = m = 5000 with 10 per row: 4623 levels, 60 ms per iteration -- PCG needs a fraction of a millisecond there)
+  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->lD > level_limit())) { *err = -1; return nullptr; }
   int rc = d->F->refactor(e.rho_inv.get());
   if (rc) { *err = rc; return nullptr; }
   return std::unique_ptr<Linsys>(d.release());
