@@ -44,3 +44,24 @@ def test_engine_on_zoo(product_lib, oracle_lib, name, linsys):
     if linsys == "qdldl":  # exact KKT solves on both sides: same trajectory
         assert ro.info.iter == rp.info.iter
         assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+
+
+@pytest.mark.gpu
+def test_dense_top_block_at_high_accuracy(product_lib, oracle_lib):
+    """The dense top block of the direct back-end (Schur complement inverted explicitly, csrc/direct.hip) must not
+    cost accuracy: eps = 1e-10 with polish, same iteration count and solution as the oracle's LDL'."""
+    prob = qp_zoo.portfolio(n=2000, k=80)
+    out = []
+    for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver=ls, verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iter=20000, adaptive_rho_interval=25,
+                 polish=True, **prob)
+        out.append(oq.solve(m))
+        if lib is product_lib:
+            assert oq.stats(m)[5] > 80  # one level per pivot of the block: the dense path is what ran
+        oq.clean(m)
+    ro, rp = out
+    assert ro.info.status == rp.info.status == "Solved"
+    assert ro.info.iter == rp.info.iter
+    assert ro.info.status_polish == rp.info.status_polish == 1
+    assert np.max(np.abs(ro.x - rp.x)) <= 1e-10 and abs(ro.info.obj_val - rp.info.obj_val) <= 1e-10
