@@ -485,8 +485,16 @@ struct LdlFactor {
             double flops_limit = 0.0)
       : e(en), sigma(sigma_), cconst(cconst_) {
     e.fetch_host_pattern();
-    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, S);
+    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
     if (S.too_large) return;
+    // A deep level schedule under min-degree (banded / multi-stage structure: the elimination tree is a chain) gets a
+    // second analysis with nested dissection; the cheaper triangular solve by the model below wins.
+    static const bool try_nd = !(getenv("OSQP_AMD_ND") && atoi(getenv("OSQP_AMD_ND")) == 0);
+    if (try_nd && (int)S.level_ptr.size() - 1 > 400) {
+      Symbolic S2;
+      symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
+      if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
+    }
     hipStream_t s = e.stream;
     N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
@@ -520,8 +528,25 @@ struct LdlFactor {
 
   static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
 
+  // Rough time of one forward + backward solve: a launch per wide level, a chain step per narrow level below the
+  // dense top block, the bytes of L at 2 TB/s, the dense block's product.  Only used to compare two orderings.
+  static double solve_cost_us(const Symbolic &Y) {
+    const auto &lp = Y.level_ptr;
+    const int nl = (int)lp.size() - 1, NN = Y.N;
+    int l = nl;
+    while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && NN - lp[l - 1] <= kDenseMax) l--;
+    const int k = NN - lp[l];
+    const int top = k >= kDenseMin ? l : nl;
+    double us = 0.0;
+    for (int q = 0; q < top; q++) us += (lp[q + 1] - lp[q] > kChainRows) ? 6.0 : 1.4;
+    us += (double)Y.nnzL * 24.0 / 2.0e6;
+    if (top < nl) us += (double)k * (double)k * 8.0 / 4.0e6 + 10.0;
+    return us;
+  }
+
   // The dense top block: the longest suffix of the top chain (levels of at most kChainRows pivots) with at most
-  // kDenseMax pivots, taken when at least an eighth of its lower triangle is in the pattern of L.
+  // kDenseMax pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when one dense
+  // product costs less than its levels.
   static constexpr int kDenseMax = 2048, kDenseMin = 32;
   void choose_dense_block() {
     const auto &lp = S.level_ptr;
@@ -537,7 +562,10 @@ struct LdlFactor {
       const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
       inside += end - std::lower_bound(beg, end, c);
     }
-    if (inside * 8 < (int64_t)k * k) return;
+    // worth it when the block is dense (then the chain rows are long) or when the dense product is cheaper than
+    // walking the block's levels one by one (a block-sparse top of a nested-dissection tree)
+    const double dense_us = (double)k * (double)k * 8.0 / 4.0e6 + 10.0, chain_us = 1.4 * (double)(nlev - l);
+    if (inside * 8 < (int64_t)k * k && dense_us > chain_us) return;
     lD = l; cD = c; kD = k;
   }
   // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
@@ -554,7 +582,8 @@ struct LdlFactor {
         int width = lp[l + 1] - lp[l];
         if (width <= kChainRows) {
           int l2 = l;
-          while (l2 < lD && lp[l2 + 1] - lp[l2] <= kChainRows) l2++;
+          while (l2 < lD && lp[l2 + 1] - lp[l2] <= kChainRows && lp[l2 + 1] - lp[l] <= kChainLdsRows) l2++;  // pieces that fit LDS
+          if (l2 == l) l2 = l + 1;
           int T = 64;
           if (forward) {  // split the rows of the chain at its first pivot
             const int c0 = lp[l], c1 = lp[l2];

@@ -115,6 +115,123 @@ struct MinDegree {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Nested dissection by level structures (George & Liu's automatic nested dissection): a connected piece is cut at a
+// small middle level of the breadth-first level structure rooted at a pseudo-peripheral node; the two sides are
+// ordered first (recursively), the separator last.  On banded / chain-like graphs (multi-stage control problems) the
+// min-degree elimination tree is one long chain -- thousands of sequential levels -- while this ordering gives a
+// balanced tree of height O(separator size x log stages) at 2-3x the fill; the separators at the top of the tree
+// form the dense block that the direct back-end inverts explicitly.
+// ---------------------------------------------------------------------------
+struct NestedDissection {
+  int N;
+  const std::vector<int64_t> &xadj;
+  const std::vector<int> &adj;
+  std::vector<int> tag, dist, order;
+  int next_tag = 0;
+  int leaf_size;
+
+  NestedDissection(int n, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf)
+      : N(n), xadj(xa), adj(ad), tag(n, -1), dist(n, -1), leaf_size(leaf) {}
+
+  // breadth-first levels of the piece marked `t` from root r; returns the level sets
+  void bfs(int r, int t, std::vector<std::vector<int>> &levels) {
+    levels.clear();
+    std::vector<int> cur{r};
+    dist[r] = ++stamp;
+    while (!cur.empty()) {
+      levels.push_back(cur);
+      std::vector<int> nxt;
+      for (int v : cur)
+        for (int64_t q = xadj[v]; q < xadj[v + 1]; q++) {
+          int w = adj[q];
+          if (tag[w] == t && dist[w] != stamp) { dist[w] = stamp; nxt.push_back(w); }
+        }
+      cur.swap(nxt);
+    }
+  }
+  int stamp = 0;
+
+  void leaf(const std::vector<int> &V) {  // min-degree on the induced subgraph
+    const int k = (int)V.size();
+    if (k <= 2) { for (int v : V) order.push_back(v); return; }
+    std::vector<int> local(k);
+    const int t = ++next_tag;
+    for (int i = 0; i < k; i++) { tag[V[i]] = t; dist[V[i]] = i; }
+    MinDegree md(k);
+    for (int i = 0; i < k; i++)
+      for (int64_t q = xadj[V[i]]; q < xadj[V[i] + 1]; q++) {
+        int w = adj[q];
+        if (tag[w] == t) md.var_adj[i].push_back(dist[w]);
+        else md.extra[i]++;  // neighbours outside the leaf (separators above it) are eliminated later
+      }
+    md.run(local);
+    for (int i = 0; i < k; i++) order.push_back(V[local[i]]);
+    for (int v : V) dist[v] = -1;
+  }
+
+  void dissect(std::vector<int> V) {
+    if ((int)V.size() <= leaf_size) { leaf(V); return; }
+    // connected components, one after the other (a loop: a graph can fall into thousands of pieces)
+    const int t = ++next_tag;
+    for (int v : V) tag[v] = t;
+    std::vector<std::vector<int>> levels;
+    size_t first_unseen = 0;
+    std::vector<std::vector<int>> comps;
+    const int base = stamp;
+    for (size_t i = 0; i < V.size(); i++) {
+      if (dist[V[i]] > base) continue;  // reached by one of this call's searches
+      bfs(V[i], t, levels);
+      std::vector<int> comp;
+      for (auto &L : levels) comp.insert(comp.end(), L.begin(), L.end());
+      comps.push_back(std::move(comp));
+    }
+    (void)first_unseen;
+    if (comps.size() > 1) {
+      for (auto &c : comps) dissect(std::move(c));
+      return;
+    }
+    // a single connected piece: levels from V[0] are in `levels`
+    connected(std::move(comps[0]), t, levels);
+  }
+
+  void connected(std::vector<int> V, int t, std::vector<std::vector<int>> &levels) {
+    // pseudo-peripheral root: restart from a smallest-degree node of the last level while the depth grows
+    for (int pass = 0; pass < 4; pass++) {
+      const auto &last = levels.back();
+      int r = last[0];
+      for (int v : last) if (xadj[v + 1] - xadj[v] < xadj[r + 1] - xadj[r]) r = v;
+      std::vector<std::vector<int>> l2;
+      bfs(r, t, l2);
+      const bool deeper = l2.size() > levels.size();
+      levels.swap(l2);
+      if (!deeper) break;
+    }
+    const int nl = (int)levels.size();
+    if (nl < 3) { leaf(V); return; }
+    // separator: the smallest level whose sides both hold at least 30 % of the piece; otherwise the level at the median
+    const double total = (double)V.size();
+    int best = -1;
+    size_t before = levels[0].size();
+    int median = 1;
+    double gap = 1e300;
+    for (int l = 1; l + 1 < nl; l++) {
+      const double a = (double)before, b = total - a - (double)levels[l].size();
+      if (a >= 0.3 * total && b >= 0.3 * total && (best < 0 || levels[l].size() < levels[best].size())) best = l;
+      if (std::fabs(a - b) < gap) { gap = std::fabs(a - b); median = l; }
+      before += levels[l].size();
+    }
+    if (best < 0) best = median;
+    std::vector<int> A, B, Sep = levels[best];
+    for (int l = 0; l < best; l++) A.insert(A.end(), levels[l].begin(), levels[l].end());
+    for (int l = best + 1; l < nl; l++) B.insert(B.end(), levels[l].begin(), levels[l].end());
+    std::vector<std::vector<int>>().swap(levels);
+    dissect(std::move(A));
+    dissect(std::move(B));
+    for (int v : Sep) order.push_back(v);
+  }
+};
+
 struct Upper {  // upper-triangular pattern, column compressed, with the origin of every entry
   int N = 0;
   std::vector<int64_t> p;
@@ -125,7 +242,7 @@ struct Upper {  // upper-triangular pattern, column compressed, with the origin 
 }  // namespace
 
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
-                      double flops_limit, Symbolic &S) {
+                      double flops_limit, int ordering, Symbolic &S) {
   const int n = P.cols, N = n + mr;
   S.n = n; S.mr = mr; S.N = N; S.too_large = false;
   const int64_t nnzP = P.p[n], nnzA = A.p[n];
@@ -185,9 +302,23 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
         if (!dense[i] && !dense[j]) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
         else { if (!dense[i]) md.extra[i]++; if (!dense[j]) md.extra[j]++; }
       }
-    md.nnz_limit = (double)nnzL_limit; md.flops_limit = flops_limit;
-    md.run(order);
-    if (md.aborted) { S.too_large = true; S.nnzL = (int64_t)md.nnz; S.flops = md.flops; return; }
+    if (ordering == 1) {  // nested dissection of the graph without its dense nodes
+      std::vector<int64_t> xadj(N + 1, 0);
+      for (int i = 0; i < N; i++) xadj[i + 1] = xadj[i] + (int64_t)md.var_adj[i].size();
+      std::vector<int> adj((size_t)xadj[N]);
+      for (int i = 0; i < N; i++) std::copy(md.var_adj[i].begin(), md.var_adj[i].end(), adj.begin() + xadj[i]);
+      NestedDissection nd(N, xadj, adj, 64);
+      std::vector<int> all;
+      all.reserve(N);
+      for (int i = 0; i < N; i++) if (!dense[i]) all.push_back(i);
+      if (!all.empty()) nd.dissect(std::move(all));
+      order = nd.order;
+      for (int i = 0; i < N; i++) if (dense[i]) order.push_back(i);
+    } else {
+      md.nnz_limit = (double)nnzL_limit; md.flops_limit = flops_limit;
+      md.run(order);
+      if (md.aborted) { S.too_large = true; S.nnzL = (int64_t)md.nnz; S.flops = md.flops; return; }
+    }
     if (ndense)  // isolated in the pruned graph, so their position is free: move them to the end
       std::stable_partition(order.begin(), order.end(), [&](int v) { return !dense[v]; });
   }
