@@ -65,3 +65,24 @@ def test_dense_top_block_at_high_accuracy(product_lib, oracle_lib):
     assert ro.info.iter == rp.info.iter
     assert ro.info.status_polish == rp.info.status_polish == 1
     assert np.max(np.abs(ro.x - rp.x)) <= 1e-10 and abs(ro.info.obj_val - rp.info.obj_val) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
+    """A banded multi-stage problem: the engine's second ordering (nested dissection, csrc/symbolic.hip) replaces the
+    min-degree chain of thousands of levels; the trajectory must still be the oracle's (exact solves on both sides)."""
+    prob = qp_zoo.control(nx=8, nu=4, T=400)
+    out = []
+    for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver=ls, verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25, **prob)
+        out.append(oq.solve(m))
+        if lib is product_lib:
+            levels = oq.stats(m)[5]
+            assert 50 < levels < 1000  # min-degree leaves > 4000 levels here
+        oq.clean(m)
+    ro, rp = out
+    assert ro.info.status == rp.info.status == "Solved"
+    assert ro.info.iter == rp.info.iter
+    assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+    assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, np.max(np.abs(ro.y)))
