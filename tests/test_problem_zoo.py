@@ -86,3 +86,23 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
     assert ro.info.iter == rp.info.iter
     assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
     assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, np.max(np.abs(ro.y)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["portfolio", "svm", "huber", "lasso_data", "equality_qp", "control"])
+def test_polish_on_zoo(product_lib, oracle_lib, name):
+    """Polish on the standard classes: same outcome and objective as the oracle's polish."""
+    prob = qp_zoo.ZOO[name]()
+    out = []
+    for lib in (oracle_lib, product_lib):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver="qdldl", **prob, **dict(OPTS, polish=True))
+        out.append(oq.solve(m))
+        oq.clean(m)
+    ro, rp = out
+    assert ro.info.status == rp.info.status == "Solved"
+    assert ro.info.status_polish == rp.info.status_polish
+    assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-6 * max(1.0, abs(ro.info.obj_val))
+    if ro.info.status_polish == 1:
+        pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, rp.x, rp.y, 1e-7)
+        assert pri <= 1e-6 and dua <= 1e-5, (pri, dua)
