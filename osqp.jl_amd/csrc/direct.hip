@@ -278,43 +278,9 @@ __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_
     }
   }
 }
-__global__ __launch_bounds__(kChainThreads) void k_fwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
-                                                             const int64_t *__restrict__ Rsplit, const int64_t *__restrict__ Rp,
-                                                             const int *__restrict__ Rj, const double *__restrict__ Rx,
-                                                             double *__restrict__ b) {
-  for (int l = l0; l < l1; l++) {
-    const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
-    const int G = (r1 - r0) <= kChainThreads / 64 ? 64 : 4;
-    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    for (int row = r0 + grp; row < r1; row += kChainThreads / G) {
-      double acc = 0.0;
-      for (int64_t q = Rsplit[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
-      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (lane == 0) b[row] -= acc;
-    }
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(kChainThreads) void k_bwd_chain(int l0, int l1, const int *__restrict__ level_ptr,
-                                                             const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                             const double *__restrict__ Lx, const double *__restrict__ Dinv,
-                                                             double *__restrict__ b) {
-  for (int l = l1 - 1; l >= l0; l--) {
-    const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
-    const int G = (r1 - r0) <= kChainThreads / 64 ? 64 : 4;
-    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    for (int row = r0 + grp; row < r1; row += kChainThreads / G) {
-      double acc = 0.0;
-      for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += G) acc += Lx[t] * b[Li[t]];
-      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
-    }
-    __syncthreads();
-  }
-}
-// LDS-resident chains.  When the pivots [c0, c1) of a chain and its level table fit in LDS, the segment of the
-// solution lives there for the whole chain and the workgroup never touches global memory on the critical
-// path: row r belongs to wavefront (r - c0) mod 16 for good, so a wavefront knows its next row ahead of time and
+// LDS-resident chains.  A chain is cut so that its pivots [c0, c1) and its level table fit in LDS (build_schedule):
+// the segment of the solution lives there for the whole chain and the workgroup never touches global memory on the
+// critical path: row r belongs to wavefront (r - c0) mod 16 for good, so a wavefront knows its next row ahead of time and
 // fetches its bounds and first 128 entries right after finishing the current one, levels before they are
 // needed; the barrier between levels only waits for LDS traffic (s_waitcnt lgkmcnt(0); s_barrier -- the plain
 // __syncthreads would also drain those prefetches).  Per level that leaves an LDS gather, a wavefront reduction
@@ -693,12 +659,9 @@ struct LdlFactor {
         const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
         if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
         else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
-        if (c1 - c0 <= kChainLdsRows && t.b - t.a <= kChainLdsLevels)
-          if (t.U == 8) OQ_LAUNCH(k_fwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+        if (t.U == 8) OQ_LAUNCH(k_fwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
           else if (t.U == 4) OQ_LAUNCH(k_fwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
           else OQ_LAUNCH(k_fwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
-        else
-          OQ_LAUNCH(k_fwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
         continue;
       }
       dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
@@ -716,12 +679,9 @@ struct LdlFactor {
     }
     for (const Step &t : bwd) {
       if (t.kind == 1) {
-        if (S.level_ptr[t.b] - S.level_ptr[t.a] <= kChainLdsRows && t.b - t.a <= kChainLdsLevels)
-          if (t.U == 8) OQ_LAUNCH(k_bwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+        if (t.U == 8) OQ_LAUNCH(k_bwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
           else if (t.U == 4) OQ_LAUNCH(k_bwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
           else OQ_LAUNCH(k_bwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
-        else
-          OQ_LAUNCH(k_bwd_chain, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
         continue;
       }
       dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
