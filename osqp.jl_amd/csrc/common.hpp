@@ -94,22 +94,23 @@ struct DevBuf {
 
 // ---- device CSR matrix: 64-bit row pointers, 32-bit column indices, fp64 values
 // Column-panel copy of a CSR matrix for the LDS-staged SpMV (panel.hip): the columns are cut into B panels of
-// W = 2^shift columns so that a workgroup can keep its panel of x (W doubles) in LDS and gather from there.
-// Workgroup tile t = rows [tile_r0[t], tile_r1[t]) of panel tile_b[t], cut at ~equal non-zero counts; inside a
-// tile the entries are stored as sliced ELL: slice = 64 rows of the tile ordered by length, column-major
-// (element k of lane l at slice_base + 64 k + l), 16-bit column ids local to the panel.
+// W = 2^shift columns so that a workgroup can keep a panel of x (W doubles) in LDS and gather from there; Gp consecutive
+// panels form a group (NG groups).  Workgroup tile t = rows [tile_r0[t], tile_r1[t]) of group tile_g[t], cut at ~equal
+// non-zero counts; unit t * Gp + j = the tile inside the j-th panel of its group, stored as sliced ELL: slice = 64 rows
+// of the unit ordered by length, column-major (element k of lane l at slice_base + 64 k + l), 16-bit column ids local
+// to the panel.
 struct DevPanel {
   bool active = false;
-  int W = 0, shift = 0, B = 0, ntiles = 0;
-  DevBuf<int> tile_b, tile_r0, tile_r1;
-  DevBuf<int> tile_s0, tile_ns;              // tile t owns slices [tile_s0[t], tile_s0[t] + tile_ns[t])
+  int W = 0, shift = 0, B = 0, Gp = 1, NG = 0, ntiles = 0;
+  DevBuf<int> tile_g, tile_r0, tile_r1;
+  DevBuf<int> unit_s0, unit_ns;              // unit u owns slices [unit_s0[u], unit_s0[u] + unit_ns[u])
   DevBuf<uint32_t> slice_base;               // offset of the slice inside sval / scol
   DevBuf<int> slice_len;                     // padded row length of the slice
   DevBuf<int> slice_rows;                    // [64 per slice] row id of every lane (-1: empty lane)
   DevBuf<uint32_t> cellbase;                 // [B * rows] slot of the first entry of (panel, row): value refresh
   DevBuf<double> sval;
   DevBuf<uint16_t> scol;
-  DevBuf<double> partial;                    // [B * rows] per-panel row sums, reduced in fixed order
+  DevBuf<double> partial;                    // [NG * rows] per-group row sums, reduced in fixed order
   size_t padded = 0;                         // stored entries including padding
 };
 

@@ -5,11 +5,14 @@
 // random 8-byte access per non-zero; at n = 1e6 every gather is an L2 / Infinity-Fabric line
 // fetch and the kernel runs at ~1.1 TB/s of algorithmic bandwidth (profiles/r01_a_*).
 // Here the columns are cut into panels of W = 2^shift columns (default 16384 = 128 KB of x); a
-// 1024-thread workgroup stages its panel of x in LDS once, then streams a tile of rows of that
-// panel and gathers from LDS.  Tiles are cut at equal non-zero counts (not equal row counts) so
-// that dense corners do not leave a tail.  Per-panel row sums go to a [B x rows] buffer that a
-// second kernel adds up in panel order (fixed order => reproducible) together with the SpMV
-// epilogue.
+// 1024-thread workgroup stages a panel of x in LDS, then streams the rows of its tile inside that
+// panel and gathers from LDS.  Consecutive panels form groups of Gp (1 for mid-size matrices, 4 when
+// there are enough non-zeros to keep > 1000 workgroups busy); the rows of every group are cut into
+// tiles at equal non-zero counts (not equal row counts: dense corners leave no tail, and the cut
+// is two-dimensional -- a matrix whose density varies along its columns stays balanced).  A
+// workgroup walks the Gp panels of its tile one after the other with the row sums staying in LDS,
+// and writes them once per group to an [NG x rows] buffer that a second kernel adds up in group
+// order (fixed order => reproducible) together with the SpMV epilogue.
 //
 // Inside a tile the entries are laid out as sliced ELL:
 //   * the rows of the tile are ordered by their length inside the panel, longest first;
@@ -71,8 +74,33 @@ __global__ __launch_bounds__(kBlock) void k_panel_count(int rows, int B, int shi
   }
 }
 
-// Tile cuts.  Every (panel, row) cell costs max(entries, cmin) with cmin = ceil(budget / kTileRowsMax); coff is the
-// exclusive scan of the costs (panel-major).  Inside panel b the cells whose cost offset falls into the same
+// gcnt[g * rows + i] = entries of row i inside the panels of group g
+__global__ __launch_bounds__(kBlock) void k_group_count(int rows, int B, int Gp, int64_t gcells, const int64_t *__restrict__ cnt,
+                                                        int64_t *__restrict__ gcnt) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= gcells) return;
+  const int64_t g = c / rows;
+  const int r = (int)(c - g * rows);
+  int64_t a = 0;
+  for (int b = (int)g * Gp; b < B && b < ((int)g + 1) * Gp; b++) a += cnt[(size_t)b * rows + r];
+  gcnt[c] = a;
+}
+// unit u = t * Gp + j is tile t inside the j-th panel of its group (an empty row range when the group has fewer panels)
+__global__ __launch_bounds__(kBlock) void k_expand_units(int ntiles, int B, int Gp, const int *__restrict__ tile_g,
+                                                         const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                                         int *__restrict__ ub, int *__restrict__ u0, int *__restrict__ u1) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= (int64_t)ntiles * Gp) return;
+  const int t = (int)(u / Gp), j = (int)(u - (int64_t)t * Gp);
+  const int b = tile_g[t] * Gp + j;
+  const bool real = b < B;
+  ub[u] = real ? b : 0;
+  u0[u] = tile_r0[t];
+  u1[u] = real ? tile_r1[t] : tile_r0[t];
+}
+
+// Tile cuts.  Every (group, row) cell costs max(entries, cmin) with cmin = ceil(budget / kTileRowsMax); coff is the
+// exclusive scan of the costs (group-major).  Inside group g the cells whose cost offset falls into the same
 // window of `budget` share a tile: ~budget non-zeros where the rows are long enough, never more than
 // kTileRowsMax rows where they are short.  start[c] = 1 when cell c = (b, r) opens a tile.
 __global__ __launch_bounds__(kBlock) void k_tile_cost(int64_t cells, int64_t cmin, int64_t *__restrict__ cnt) {
@@ -211,46 +239,67 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
 // ---------------------------------------------------------------------------------------------
 // the product
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, const int *__restrict__ tile_b,
+__global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
                                                         const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
-                                                        const int *__restrict__ tile_s0, const int *__restrict__ tile_ns,
+                                                        const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
                                                         const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
                                                         const int *__restrict__ slice_rows, const uint16_t *__restrict__ scol,
                                                         const double *__restrict__ sval, const double *__restrict__ x,
                                                         double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int b = tile_b[blockIdx.x], s0 = tile_s0[blockIdx.x], ns = tile_ns[blockIdx.x];
+  const int t = blockIdx.x, g = tile_g[t];
   const int W = 1 << shift;
-  const int c0 = b << shift;
-  const int wlen = cols - c0 < W ? cols - c0 : W;
-  const int r0 = tile_r0[blockIdx.x], nrows = tile_r1[blockIdx.x] - r0;
-  double *ys = xs + W;  // row sums of the tile: written scattered here, stored to HBM as one contiguous block
-  for (int i = threadIdx.x; i < wlen; i += kThreads) xs[i] = x[c0 + i];
+  const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
+  double *ys = xs + W;  // row sums of the tile: accumulated here over the panels of the group, stored as one contiguous block
   for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
-  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *out = partial + (size_t)b * rows + r0;
-  for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
-    const size_t base = (size_t)slice_base[sl] + lane;
-    const int L = slice_len[sl];
-    const int row = slice_rows[(size_t)sl * 64 + lane];
-    const double *v = sval + base;
-    const uint16_t *c = scol + base;
-    double a0 = 0.0, a1 = 0.0;
-    int k = 0;
-    for (; k + 4 <= L; k += 4) {
-      const double v0 = v[(size_t)k * 64], v1 = v[(size_t)(k + 1) * 64], v2 = v[(size_t)(k + 2) * 64], v3 = v[(size_t)(k + 3) * 64];
-      const uint16_t c0_ = c[(size_t)k * 64], c1_ = c[(size_t)(k + 1) * 64], c2_ = c[(size_t)(k + 2) * 64], c3_ = c[(size_t)(k + 3) * 64];
-      a0 += v0 * xs[c0_]; a0 += v1 * xs[c1_]; a0 += v2 * xs[c2_]; a0 += v3 * xs[c3_];
+  bool first = true;
+  for (int j = 0; j < Gp; j++) {
+    const int b = g * Gp + j;
+    if (b >= B) break;
+    const int s0 = unit_s0[(size_t)t * Gp + j], ns = unit_ns[(size_t)t * Gp + j];
+    if (ns == 0) continue;           // the same decision in every thread
+    if (!first) __syncthreads();     // the previous panel is no longer read
+    first = false;
+    const int c0 = b << shift;
+    const int wlen = cols - c0 < W ? cols - c0 : W;
+    for (int i = threadIdx.x; i < wlen; i += kThreads) xs[i] = x[c0 + i];
+    __syncthreads();
+    for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
+      const size_t base = (size_t)slice_base[sl] + lane;
+      const int L = slice_len[sl];
+      const int row = slice_rows[(size_t)sl * 64 + lane];
+      const double *v = sval + base;
+      const uint16_t *c = scol + base;
+      double a0 = 0.0, a1 = 0.0;
+      int k = 0;
+      for (; k + 8 <= L; k += 8) {  // 16 loads in flight per lane before the first one is consumed
+        double cv[8];
+        uint16_t cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) a0 += cv[u] * xs[cc[u]];
+      }
+      if (k + 4 <= L) {
+        double cv[4];
+        uint16_t cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) a0 += cv[u] * xs[cc[u]];
+        k += 4;
+      }
+      for (; k < L; k++) a1 += v[(size_t)k * 64] * xs[c[(size_t)k * 64]];
+      if (row >= 0) ys[row - r0] += a0 + a1;  // a row appears once per panel; panels are separated by barriers
     }
-    for (; k < L; k++) a1 += v[(size_t)k * 64] * xs[c[(size_t)k * 64]];
-    if (row >= 0) ys[row - r0] = a0 + a1;
   }
   __syncthreads();
+  double *out = partial + (size_t)g * rows + r0;
   for (int i = threadIdx.x; i < nrows; i += kThreads) out[i] = ys[i];
 }
 
-// y[i] = (rscale ? rscale[i] : 1) * sum_b partial[b][i] + beta * y[i] + gamma * v[i]   (panel order is fixed)
+// y[i] = (rscale ? rscale[i] : 1) * sum_g partial[g][i] + beta * y[i] + gamma * v[i]   (group order is fixed)
 __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
                                                          const double *__restrict__ rscale, double beta, double gamma,
                                                          const double *__restrict__ v) {
@@ -304,41 +353,55 @@ void panel_build(DevCsr &M, hipStream_t s) {
   OQ_LAUNCH(k_panel_count, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.B, P.shift, M.rowptr.get(),
             M.col.get(), cnt.get());
   exclusive_scan(cnt.get(), off.get(), cells, s);
-  // tiles of ~equal non-zero count inside each panel (cnt is reused: costs, then tile-start flags)
-  DevBuf<int64_t> tid((size_t)cells + 1);
-  const int64_t budget = std::max(panel_tile_nnz(), kTileRowsMax);
+  // groups of consecutive panels: 4 when that still leaves > 1000 workgroups (measured at nnz = 1e9: 4 and 8 are equal,
+  // 16 is slower), otherwise every panel on its own
+  P.Gp = 1;
+  {
+    const int want = env_int("OSQP_AMD_PANEL_GROUP", 0);
+    if (want > 0) P.Gp = std::min(want, P.B);
+    else if ((double)M.nnz / (4.0 * (double)panel_tile_nnz()) >= 1024.0) P.Gp = std::min(4, P.B);
+  }
+  P.NG = (P.B + P.Gp - 1) / P.Gp;
+  const int64_t gcells = (int64_t)P.NG * M.rows;
+  // tiles of ~equal non-zero count inside each group (gcnt is reused: counts, costs, then tile-start flags)
+  DevBuf<int64_t> gcnt((size_t)gcells + 1), tid((size_t)gcells + 1);
+  OQ_LAUNCH(k_group_count, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, P.B, P.Gp, gcells, cnt.get(), gcnt.get());
+  cnt.release();
+  const int64_t budget = std::max<int64_t>((int64_t)panel_tile_nnz() * P.Gp, kTileRowsMax);
   const int64_t cmin = (budget + kTileRowsMax - 1) / kTileRowsMax;
-  OQ_LAUNCH(k_tile_cost, dim3(blocks_for(cells)), dim3(kBlock), 0, s, cells, cmin, cnt.get());
-  exclusive_scan(cnt.get(), tid.get(), cells, s);
-  OQ_LAUNCH(k_tile_starts, dim3(blocks_for(cells)), dim3(kBlock), 0, s, M.rows, cells, tid.get(), budget, cnt.get());
-  exclusive_scan(cnt.get(), tid.get(), cells, s);
-  const int64_t ntiles = read_i64(tid.get() + cells, s);
-  if (ntiles <= 0 || ntiles >= 2147483647LL) throw Error(6, "panel layout: bad tile count");
+  OQ_LAUNCH(k_tile_cost, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, gcells, cmin, gcnt.get());
+  exclusive_scan(gcnt.get(), tid.get(), gcells, s);
+  OQ_LAUNCH(k_tile_starts, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, gcells, tid.get(), budget, gcnt.get());
+  exclusive_scan(gcnt.get(), tid.get(), gcells, s);
+  const int64_t ntiles = read_i64(tid.get() + gcells, s);
+  if (ntiles <= 0 || ntiles * P.Gp >= 2147483647LL) throw Error(6, "panel layout: bad tile count");
   P.ntiles = (int)ntiles;
-  P.tile_b.alloc((size_t)ntiles); P.tile_r0.alloc((size_t)ntiles); P.tile_r1.alloc((size_t)ntiles);
-  OQ_LAUNCH(k_tile_fill, dim3(blocks_for(cells)), dim3(kBlock), 0, s, M.rows, cells, cnt.get(), tid.get(), P.tile_b.get(), P.tile_r0.get());
-  OQ_LAUNCH(k_tile_ends, dim3(blocks_for(ntiles)), dim3(kBlock), 0, s, M.rows, P.ntiles, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get());
+  P.tile_g.alloc((size_t)ntiles); P.tile_r0.alloc((size_t)ntiles); P.tile_r1.alloc((size_t)ntiles);
+  OQ_LAUNCH(k_tile_fill, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, gcells, gcnt.get(), tid.get(), P.tile_g.get(), P.tile_r0.get());
+  OQ_LAUNCH(k_tile_ends, dim3(blocks_for(ntiles)), dim3(kBlock), 0, s, M.rows, P.ntiles, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get());
+  const int64_t nunits = ntiles * P.Gp;
+  DevBuf<int> ub((size_t)nunits), u0((size_t)nunits), u1((size_t)nunits);
+  OQ_LAUNCH(k_expand_units, dim3(blocks_for(nunits)), dim3(kBlock), 0, s, P.ntiles, P.B, P.Gp, P.tile_g.get(), P.tile_r0.get(),
+            P.tile_r1.get(), ub.get(), u0.get(), u1.get());
   HIP_CHECK(hipStreamSynchronize(s));
-  cnt.release(); tid.release();
+  gcnt.release(); tid.release();
   // slices: measure every tile, scan, lay out
-  DevBuf<int64_t> nsl((size_t)ntiles + 1), pad((size_t)ntiles + 1), slice0((size_t)ntiles + 1), padded0((size_t)ntiles + 1);
-  OQ_LAUNCH(k_tile_measure, dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get(), off.get(),
-            nsl.get(), pad.get());
-  exclusive_scan(nsl.get(), slice0.get(), ntiles, s);
-  exclusive_scan(pad.get(), padded0.get(), ntiles, s);
-  const int64_t nslices = read_i64(slice0.get() + ntiles, s), padded = read_i64(padded0.get() + ntiles, s);
+  DevBuf<int64_t> nsl((size_t)nunits + 1), pad((size_t)nunits + 1), slice0((size_t)nunits + 1), padded0((size_t)nunits + 1);
+  OQ_LAUNCH(k_tile_measure, dim3((unsigned)nunits), dim3(kThreads), 0, s, M.rows, ub.get(), u0.get(), u1.get(), off.get(), nsl.get(), pad.get());
+  exclusive_scan(nsl.get(), slice0.get(), nunits, s);
+  exclusive_scan(pad.get(), padded0.get(), nunits, s);
+  const int64_t nslices = read_i64(slice0.get() + nunits, s), padded = read_i64(padded0.get() + nunits, s);
   if (padded >= 4294967295LL) throw Error(6, "sliced-ELL copy exceeds 2^32 entries");
   P.padded = (size_t)padded;
-  P.tile_s0.alloc((size_t)ntiles); P.tile_ns.alloc((size_t)ntiles);
+  P.unit_s0.alloc((size_t)nunits); P.unit_ns.alloc((size_t)nunits);
   P.slice_base.alloc((size_t)nslices); P.slice_len.alloc((size_t)nslices); P.slice_rows.alloc((size_t)nslices * 64);
   P.cellbase.alloc((size_t)cells); P.cellbase.zero(s);
-  OQ_LAUNCH(k_tile_layout, dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.tile_b.get(), P.tile_r0.get(), P.tile_r1.get(), off.get(),
-            slice0.get(), padded0.get(), P.tile_s0.get(), P.tile_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(),
-            P.cellbase.get());
+  OQ_LAUNCH(k_tile_layout, dim3((unsigned)nunits), dim3(kThreads), 0, s, M.rows, ub.get(), u0.get(), u1.get(), off.get(), slice0.get(),
+            padded0.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), P.cellbase.get());
   P.sval.alloc((size_t)padded); P.scol.alloc((size_t)padded);
   P.sval.zero(s); P.scol.zero(s);  // padding slots: value 0 times x[panel column 0]
-  P.partial.alloc((size_t)cells);
-  P.partial.zero(s);  // cells of rows without entries in a panel are never written again
+  P.partial.alloc((size_t)gcells);
+  P.partial.zero(s);  // every (group, row) cell is rewritten by each product: the zeroes only matter before the first one
   panel_fill(M, true, s);
   HIP_CHECK(hipStreamSynchronize(s));
   HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spmv_lds_bytes(P.shift)));
@@ -348,10 +411,10 @@ void panel_build(DevCsr &M, hipStream_t s) {
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
                 hipStream_t s) {
   const DevPanel &P = M.panel;
-  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.tile_b.get(),
-            P.tile_r0.get(), P.tile_r1.get(), P.tile_s0.get(), P.tile_ns.get(), P.slice_base.get(), P.slice_len.get(),
+  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B, P.Gp, P.tile_g.get(),
+            P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),
             P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get());
-  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.B, P.partial.get(), y, rscale, beta, gamma, v);
+  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v);
 }
 
 }  // namespace oq
