@@ -132,3 +132,32 @@ def test_update_to_indefinite_P_is_refused_by_both(product_lib, oracle_lib):
         with pytest.raises(oq.OSQPError):
             oq.update(m, Px=np.array([1.0, -5.0]))
         oq.clean(m)
+
+
+def test_two_workspaces_interleaved(product_lib):
+    """Distinct workspaces are independent [REF SURVEY 8b threading]: two models set up together and driven in
+    alternation (solve, update, warm start) give what each gives alone."""
+    rng = np.random.default_rng(77)
+    probs = [feasible_problem(rng)[0] for _ in range(2)]
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25)
+
+    def alone(prob, q2, ls):
+        m = oq.Model(product_lib); oq.setup(m, linsys_solver=ls, **prob, **opts)
+        a = oq.solve(m); oq.update(m, q=q2); b = oq.solve(m); oq.clean(m)
+        return a, b
+
+    q2s = [rng.standard_normal(p["P"].shape[0]) for p in probs]
+    for ls in ("qdldl", "pcg"):
+        ref = [alone(p, q2, ls) for p, q2 in zip(probs, q2s)]
+        ms = []
+        for p in probs:
+            m = oq.Model(product_lib); oq.setup(m, linsys_solver=ls, **p, **opts); ms.append(m)
+        first = [oq.solve(ms[0]), oq.solve(ms[1])]
+        oq.update(ms[1], q=q2s[1]); oq.update(ms[0], q=q2s[0])
+        second = [None, None]
+        second[1] = oq.solve(ms[1]); second[0] = oq.solve(ms[0])
+        for i in range(2):
+            assert first[i].info.iter == ref[i][0].info.iter and np.array_equal(first[i].x, ref[i][0].x)
+            assert second[i].info.iter == ref[i][1].info.iter and np.array_equal(second[i].x, ref[i][1].x)
+        for m in ms:
+            oq.clean(m)
