@@ -257,7 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int6
 // long one: 10^4 entries per row against 10^2 inside the chain.
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_t *__restrict__ Rp, const int64_t *__restrict__ Rsplit,
-                                                    const int *__restrict__ Rj, const double *__restrict__ Rx, double *__restrict__ b) {
+                                                    const int *__restrict__ Rj, const double *__restrict__ Rx, double *__restrict__ b,
+                                                    double *__restrict__ out) {  // out != nullptr: out[row - r0] instead of b[row]
   __shared__ double part[kBlock / 64];
   const int lane = threadIdx.x & (T - 1);
   const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
@@ -267,14 +268,14 @@ __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (T == 64) {
-    if (lane == 0 && row < r1) b[row] -= acc;
+    if (lane == 0 && row < r1) { if (out) out[row - r0] = b[row] - acc; else b[row] -= acc; }
   } else {  // T == kBlock: one row per workgroup
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0 && row < r1) {
       double t = 0.0;
       for (int w = 0; w < kBlock / 64; w++) t += part[w];
-      b[row] -= t;
+      if (out) out[row - r0] = b[row] - t; else b[row] -= t;
     }
   }
 }
@@ -657,8 +658,8 @@ struct LdlFactor {
     for (const Step &t : fwd) {
       if (t.kind == 1) {
         const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
-        if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
-        else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
+        if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), (double *)nullptr);
+        else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), (double *)nullptr);
         if (t.U == 8) OQ_LAUNCH(k_fwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
           else if (t.U == 4) OQ_LAUNCH(k_fwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
           else OQ_LAUNCH(k_fwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
@@ -673,9 +674,9 @@ struct LdlFactor {
       }
     }
     if (kD) {  // x2 = S0^-1 (b2 - L21 y1)
-      OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get());
-      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, Sinv, bp.get() + cD, x2.get());
-      HIP_CHECK(hipMemcpyAsync(bp.get() + cD, x2.get(), sizeof(double) * kD, hipMemcpyDeviceToDevice, s));
+      // the reduced right-hand side goes to x2, the product straight back into the block's slots of the solution
+      OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), x2.get());
+      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, Sinv, x2.get(), bp.get() + cD);
     }
     for (const Step &t : bwd) {
       if (t.kind == 1) {
