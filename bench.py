@@ -15,8 +15,9 @@ With more than one rank and an indirect-back-end workload the line also carries
 ranks (all-gather of the product inputs over RCCL), timed
 the same way -- strong scaling of one solve.  `--mode sharded` makes that the
 headline `value` instead of the replicas.  The sharded leg runs after the
-replica leg and under a watchdog, so a transport problem cannot take the
-replica numbers with it.
+replica leg in child processes of its own (one per rank, their own process
+group on MASTER_PORT + 1, a time limit), so that neither an exception nor a
+hang nor a crash in the transport can take the replica numbers with it.
 
 The JSON line carries `roofline` for the dominant kernel (CSR SpMV y = A x,
 measured live with HIP events on the engine's stream) and `cpu_baseline` (the
@@ -56,6 +57,7 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "sharded"], default=os.environ.get("OSQP_AMD_BENCH_MODE", "replicas"),
                     help="which multi-GPU leg is the headline value (both are measured when N > 1)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the row-sharded leg")
+    ap.add_argument("--sharded-child", type=float, default=None, help=argparse.SUPPRESS)  # internal: run only the sharded leg
     args = ap.parse_args()
 
     import numpy as np
@@ -79,6 +81,15 @@ def main():
 
     lib = oq.load_library()  # HIP engine; hard error if missing
     assert lib.osqp_amd_set_device(local_rank) == 0
+
+    if args.sharded_child is not None:  # child of a multi-rank run: the row-sharded leg alone, its record on rank 0's stdout
+        kind, n, per_row, _ = WORKLOADS[args.workload]
+        rec = sharded_leg(args, oq, lib, torch, dist, rank, world, kind, n, per_row, args.sharded_child)
+        if rank == 0:
+            print("SHARDED_RECORD " + json.dumps(rec))
+            sys.stdout.flush()
+        dist.destroy_process_group()
+        return
 
     if args.workload == "mpc-batch":
         return bench_batch(args, oq, lib, torch, dist, rank, local_rank, world)
@@ -176,32 +187,12 @@ def main():
             print(json.dumps(out))
             sys.stdout.flush()
 
-    want_sharded = world > 1 and st[0] == 2 and not args.no_sharded
-    watchdog = None
-    if want_sharded:
-        # from here on a hang (a transport that never completes) must not lose the numbers above
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["sharded"] = {"error": "watchdog: the row-sharded leg did not finish in time"}
-            emit()
-            os._exit(0)
-
-        watchdog = threading.Timer(300.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-
     if rank == 0 and not args.no_cpu and world == 1:  # the CPU leg belongs to the 1-GPU line only
         out["cpu_baseline"] = cpu_leg(oq, args)
 
-    if want_sharded:
+    if world > 1 and st[0] == 2 and not args.no_sharded:
         oq.clean(model)  # the replica's 80 GB go before the sharded copy is built
-        try:
-            sh = sharded_leg(args, oq, lib, torch, dist, rank, world, kind, n, per_row, its_per_s / world)
-        except Exception as exc:  # reported, not hidden: the replica leg stays the value
-            sh = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        watchdog.cancel()
+        sh = run_sharded_child(args, rank, its_per_s / world)
         if rank == 0:
             out["sharded"] = sh
             if args.mode == "sharded" and "error" not in sh:
@@ -212,6 +203,30 @@ def main():
     emit()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_sharded_child(args, rank, one_gpu_its, limit_s=240.0):
+    """Every rank starts one child (same script, --sharded-child) that joins a process group of the children on
+    MASTER_PORT + 1; the record comes back on rank 0's child's stdout.  Whatever happens to the children -- exception,
+    hang, crash -- this process keeps its own numbers."""
+    import subprocess
+
+    # the launcher's agent hosts the rendezvous store of THIS group only: the children host their own on the next port
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", repr(float(one_gpu_its)), "--workload", args.workload,
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--gpus", str(args.gpus), "--no-cpu"]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the row-sharded leg did not finish within %.0f s" % limit_s}
+    if rank != 0:
+        return {}
+    for line in p.stdout.decode(errors="replace").splitlines():
+        if line.startswith("SHARDED_RECORD "):
+            return json.loads(line[len("SHARDED_RECORD "):])
+    tail = (p.stderr.decode(errors="replace").strip().splitlines() or ["no output"])[-1]
+    return {"error": "child exit code %d: %s" % (p.returncode, tail[:300])}
 
 
 def sharded_leg(args, oq, lib, torch, dist, rank, world, kind, n, per_row, one_gpu_its):
