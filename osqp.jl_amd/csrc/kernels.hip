@@ -720,8 +720,8 @@ void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const
 }
 // Start vector of a CG solve from the last two solutions x1 (newest), x0: the point x1 + theta (x1 - x0) that is
 // closest to the new solution in the energy norm, theta = e'r / e'Me with e = x1 - x0, r = b - M x1 (M x1, M x0
-// are known).  num = e'r, den = e'(M x1 - M x0) -> slots; k_extrapolate_dev applies theta = num / den (0 when the
-// two solutions coincide, clamped to [-1, 4]) to a vector and rotates the pair.
+// are known).  num = e'r, den = e'(M x1 - M x0) -> slots; k_extrapolate3_dev applies theta = num / den (0 when the
+// two solutions coincide, clamped to [-1, 4]) to x, M x and A x and rotates the pairs.
 __global__ __launch_bounds__(kBlock) void k_extrap_dots(int n, const double *__restrict__ x1, const double *__restrict__ x0,
                                                         const double *__restrict__ Mx1, const double *__restrict__ Mx0,
                                                         const double *__restrict__ b, double *__restrict__ partials) {
@@ -740,27 +740,40 @@ void pcg_extrap_dots(int n, const double *x1, const double *x0, const double *Mx
   OQ_LAUNCH(k_extrap_dots, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, x1, x0, Mx1, Mx0, b, partials);
   OQ_LAUNCH(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slot_num, slot_den);
 }
-__global__ __launch_bounds__(kBlock) void k_extrapolate_dev(double *__restrict__ v1, double *__restrict__ v0,
-                                                            const double *__restrict__ num, const double *__restrict__ den, int n) {
+// the three vector pairs of a CG start (x, M x over n; A x over m) in one launch
+__global__ __launch_bounds__(kBlock) void k_extrapolate3_dev(double *__restrict__ a1, double *__restrict__ a0, double *__restrict__ b1,
+                                                             double *__restrict__ b0, int n, double *__restrict__ c1,
+                                                             double *__restrict__ c0, int m, const double *__restrict__ num,
+                                                             const double *__restrict__ den) {
   const double d = *den;
   double theta = d > 0.0 ? *num / d : 0.0;
   theta = theta != theta ? 0.0 : fmin(fmax(theta, -1.0), 4.0);
   int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) { const double cur = v1[i], old = v0[i]; v0[i] = cur; v1[i] = cur + theta * (cur - old); }
+  if (i < n) {
+    double cur = a1[i], old = a0[i]; a0[i] = cur; a1[i] = cur + theta * (cur - old);
+    cur = b1[i]; old = b0[i]; b0[i] = cur; b1[i] = cur + theta * (cur - old);
+  } else if (i < n + m) {
+    const int j = i - n;
+    const double cur = c1[j], old = c0[j]; c0[j] = cur; c1[j] = cur + theta * (cur - old);
+  }
 }
-void vec_extrapolate_dev(double *v1, double *v0, const double *slot_num, const double *slot_den, int n, hipStream_t s) {
-  if (n <= 0) return;
-  OQ_LAUNCH(k_extrapolate_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, v1, v0, slot_num, slot_den, n);
+void pcg_extrapolate3(double *x1, double *x0, double *Mx1, double *Mx0, int n, double *Ax1, double *Ax0, int m,
+                      const double *slot_num, const double *slot_den, hipStream_t s) {
+  OQ_LAUNCH(k_extrapolate3_dev, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, x1, x0, Mx1, Mx0, n, Ax1, Ax0, m, slot_num, slot_den);
 }
-__global__ __launch_bounds__(kBlock) void k_axpy_dev(double *__restrict__ y, const double *__restrict__ num, const double *__restrict__ den,
-                                                     const double *__restrict__ x, int n) {
+// y1 += (num/den) x1 over n1 and y2 += (num/den) x2 over n2 in one launch
+__global__ __launch_bounds__(kBlock) void k_axpy2_dev(double *__restrict__ y1, const double *__restrict__ x1, int n1, double *__restrict__ y2,
+                                                      const double *__restrict__ x2, int n2, const double *__restrict__ num,
+                                                      const double *__restrict__ den) {
   const double a = *num / *den;
   int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) y[i] += a * x[i];
+  if (i < n1) y1[i] += a * x1[i];
+  else if (i < n1 + n2) y2[i - n1] += a * x2[i - n1];
 }
-void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s) {
-  if (n <= 0) return;
-  OQ_LAUNCH(k_axpy_dev, dim3(blocks_for(n)), dim3(kBlock), 0, s, y, slot_num, slot_den, x, n);
+void vec_axpy2_dev(double *y1, const double *x1, int n1, double *y2, const double *x2, int n2, const double *slot_num,
+                   const double *slot_den, hipStream_t s) {
+  if (n1 + n2 <= 0) return;
+  OQ_LAUNCH(k_axpy2_dev, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, y1, x1, n1, y2, x2, n2, slot_num, slot_den);
 }
 
 // ---------------- row blocks of a CSR matrix and rank-ordered scalar combination (sharded path, row N4) ----------------

@@ -102,9 +102,10 @@ void combine_rank_slots(const double *gathered, int world, int count, unsigned s
 // energy-optimal extrapolation of the CG start vector from the last two solutions (kernels.hip: k_extrap_dots)
 void pcg_extrap_dots(int n, const double *x1, const double *x0, const double *Mx1, const double *Mx0, const double *b,
                      double *partials, double *slot_num, double *slot_den, hipStream_t s);
-// v1 <- v1 + theta (v1 - v0), v0 <- old v1, theta = clamp(slot_num / slot_den) on the device
-void vec_extrapolate_dev(double *v1, double *v0, const double *slot_num, const double *slot_den, int n, hipStream_t s);
-// y += (slot_num/slot_den) * x   (device-side scalar)
-void vec_axpy_dev(double *y, const double *slot_num, const double *slot_den, const double *x, int n, hipStream_t s);
+// v1 <- v1 + theta (v1 - v0), v0 <- old v1 for the pairs (x, M x, A x), theta = clamp(slot_num / slot_den) on the device
+void pcg_extrapolate3(double *x1, double *x0, double *Mx1, double *Mx0, int n, double *Ax1, double *Ax0, int m,
+                      const double *slot_num, const double *slot_den, hipStream_t s);  // the three pairs of a CG start at once
+void vec_axpy2_dev(double *y1, const double *x1, int n1, double *y2, const double *x2, int n2, const double *slot_num,
+                   const double *slot_den, hipStream_t s);  // two device-scalar axpys in one launch
 
 }  // namespace oq

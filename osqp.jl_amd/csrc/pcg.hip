@@ -86,9 +86,7 @@ struct Pcg : Linsys {
       if (have_prev) {
         pcg_extrap_dots(n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), e.partials.get(), slots + S_T2, slots + S_T3, s);
         e.combine_slots(S_T2, 2, 3u);
-        vec_extrapolate_dev(xs.get(), xs0.get(), slots + S_T2, slots + S_T3, n, s);
-        vec_extrapolate_dev(Mxs.get(), Mxs0.get(), slots + S_T2, slots + S_T3, n, s);
-        if (m > 0) vec_extrapolate_dev(Axs.get(), Axs0.get(), slots + S_T2, slots + S_T3, m, s);
+        pcg_extrapolate3(xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), n, Axs.get(), Axs0.get(), m, slots + S_T2, slots + S_T3, s);
         HIP_CHECK(hipMemsetAsync(slots + S_T2, 0, sizeof(double) * 2, s));
       } else {
         vec_copy(xs0.get(), xs.get(), n, s); vec_copy(Mxs0.get(), Mxs.get(), n, s);
@@ -118,8 +116,7 @@ struct Pcg : Linsys {
       reduce_dot(p.get(), w.get(), n, e.partials.get(), pw, s);
       e.combine_slots(S_T4, 1, 1u);
       // alpha = rz / pw on the device: A x~ += alpha A p ; x~ += alpha p ; M x~ += alpha w ; r -= alpha w ; zz = dinv r
-      if (m > 0) vec_axpy_dev(Axs.get(), rz, pw, u.get(), m, s);
-      vec_axpy_dev(Mxs.get(), rz, pw, w.get(), n, s);
+      vec_axpy2_dev(Mxs.get(), w.get(), n, Axs.get(), u.get(), m, rz, pw, s);
       pcg_update_xr(n, rz, pw, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(), e.partials.get(), rz_new,
                     rz_new + 1, s);
       e.combine_slots(S_T0 + 2 * (1 - cur), 2, 1u);  // the new r'z (sum) and ||r||inf (max) in one exchange
