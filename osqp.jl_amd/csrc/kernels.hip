@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__rest
 }
 void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
                        double *partials, double *slot_rz, double *slot_rn, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
+  // *slot_rn must be zero on entry (the caller clears its slot block once per solve)
   OQ_LAUNCH(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn);
   OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz);
 }
@@ -760,6 +760,16 @@ __global__ __launch_bounds__(kBlock) void k_extrapolate3_dev(double *__restrict_
 void pcg_extrapolate3(double *x1, double *x0, double *Mx1, double *Mx0, int n, double *Ax1, double *Ax0, int m,
                       const double *slot_num, const double *slot_den, hipStream_t s) {
   OQ_LAUNCH(k_extrapolate3_dev, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, x1, x0, Mx1, Mx0, n, Ax1, Ax0, m, slot_num, slot_den);
+}
+__global__ __launch_bounds__(kBlock) void k_copy2(double *__restrict__ d1, const double *__restrict__ s1, int n1, double *__restrict__ d2,
+                                                  const double *__restrict__ s2, int n2) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n1) d1[i] = s1[i];
+  else if (i < n1 + n2) d2[i - n1] = s2[i - n1];
+}
+void vec_copy2(double *d1, const double *s1, int n1, double *d2, const double *s2, int n2, hipStream_t s) {
+  if (n1 + n2 <= 0) return;
+  OQ_LAUNCH(k_copy2, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, d1, s1, n1, d2, s2, n2);
 }
 // y1 += (num/den) x1 over n1 and y2 += (num/den) x2 over n2 in one launch
 __global__ __launch_bounds__(kBlock) void k_axpy2_dev(double *__restrict__ y1, const double *__restrict__ x1, int n1, double *__restrict__ y2,

@@ -44,6 +44,7 @@ void vec_ew_recip(double *out, const double *a, int n, hipStream_t s);          
 void vec_scale(double *x, double a, int n, hipStream_t s);                                   // x *= a
 void vec_set(double *x, double a, int n, hipStream_t s);
 void vec_copy(double *dst, const double *src, int n, hipStream_t s);
+void vec_copy2(double *d1, const double *s1, int n1, double *d2, const double *s2, int n2, hipStream_t s);  // two copies, one launch
 void vec_scale_by_vec_scalar(double *x, const double *d, double a, int n, hipStream_t s);    // x = (x.*d)*a
 void vec_axpy(double *y, double a, const double *x, int n, hipStream_t s);                   // y += a x
 void vec_clamp(double *x, double lo, double hi, int n, hipStream_t s);
@@ -86,7 +87,7 @@ void dual_infeas_rows(int m, const double *Adx, const double *Einv, const double
 // (row blocks: rho is indexed by global constraint id, row0 = global id of the first row of the blocks)
 void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s,
                  int row0 = 0);
-// r = b - w; zz = dinv.*r; p = zz; partials -> slot rz = r'zz ; slot rn = ||r||inf
+// r = b - w; zz = dinv.*r; p = zz; partials -> slot rz = r'zz ; slot rn = max(slot rn, ||r||inf) (zero it before)
 void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
                        double *partials, double *slot_rz, double *slot_rn, hipStream_t s);
 // alpha = rz / pw (read from slots); x += alpha p; Ax += alpha t...; r -= alpha w; zz = dinv r; -> rz_new, ||r||inf

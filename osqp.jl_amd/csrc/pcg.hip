@@ -87,7 +87,6 @@ struct Pcg : Linsys {
         pcg_extrap_dots(n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), e.partials.get(), slots + S_T2, slots + S_T3, s);
         e.combine_slots(S_T2, 2, 3u);
         pcg_extrapolate3(xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), n, Axs.get(), Axs0.get(), m, slots + S_T2, slots + S_T3, s);
-        HIP_CHECK(hipMemsetAsync(slots + S_T2, 0, sizeof(double) * 2, s));
       } else {
         vec_copy(xs0.get(), xs.get(), n, s); vec_copy(Mxs0.get(), Mxs.get(), n, s);
         if (m > 0) vec_copy(Axs0.get(), Axs.get(), m, s);
@@ -128,8 +127,7 @@ struct Pcg : Linsys {
       it++;
     }
     total_iters += it;
-    vec_copy(xz, xs.get(), n, s);
-    if (m > 0) vec_copy(xz + n, Axs.get(), m, s);  // z~ = A x~
+    vec_copy2(xz, xs.get(), n, xz + n, Axs.get(), m, s);  // x~ and z~ = A x~
     return status;
   }
   int update_rho() override { precond(); carried_valid = false; have_prev = false; return 0; }
