@@ -298,47 +298,56 @@ struct RowPrefetch {
   double v[U], dinv;
   int c[U];
 };
-template <int U>
+// G lanes share a row (64: a wavefront per row -- long rows of a dense block; 16 or 4: several short rows per wavefront)
+template <int U, int G>
 __device__ __forceinline__ void prefetch_entries(RowPrefetch<U> &p, const int *__restrict__ idx, const double *__restrict__ val, int lane) {
   p.q0 = p.nq0; p.q1 = p.nq1;
 #pragma unroll
   for (int u = 0; u < U; u++) {
-    const int64_t a = p.q0 + 64 * u + lane;
+    const int64_t a = p.q0 + G * u + lane;
     p.v[u] = a < p.q1 ? val[a] : 0.0;
     p.c[u] = a < p.q1 ? idx[a] : -1;
   }
 }
-template <int U>
+template <int U, int G>
 __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
                                                                  const int64_t *__restrict__ Rsplit, const int64_t *__restrict__ Rp,
                                                                  const int *__restrict__ Rj, const double *__restrict__ Rx,
                                                                  double *__restrict__ b) {
   __shared__ double bl[kChainLdsRows];
   __shared__ int lp[kChainLdsLevels + 1];
-  constexpr int kStride = kChainThreads / 64;
+  constexpr int kStride = kChainThreads / G;  // rows in flight: one per group of G lanes
   const int c0 = level_ptr[l0], c1 = level_ptr[l1];
   for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) bl[i] = b[c0 + i];
   for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int next = c0 + wave;
+  const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+  int next = c0 + grp;
   RowPrefetch<U> pf;
   pf.nq0 = pf.nq1 = 0;
-  if (next < c1) { pf.nq0 = Rsplit[next]; pf.nq1 = Rp[next + 1]; prefetch_entries(pf, Rj, Rx, lane); }
+#pragma unroll
+  for (int u = 0; u < U; u++) { pf.v[u] = 0.0; pf.c[u] = -1; }
+  pf.q0 = pf.q1 = 0;
+  if (next < c1) { pf.nq0 = Rsplit[next]; pf.nq1 = Rp[next + 1]; prefetch_entries<U, G>(pf, Rj, Rx, lane); }
   if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
   __syncthreads();
   for (int l = 0; l < l1 - l0; l++) {
     const int r1 = lp[l + 1];
-    while (next < r1) {
+    while (__any(next < r1)) {  // the groups of a wavefront may differ by one row: idle ones ride along
+      const bool mine = next < r1;
       double acc = 0.0;
+      if (mine) {
 #pragma unroll
-      for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
-      for (int64_t q = pf.q0 + 64 * U + lane; q < pf.q1; q += 64) acc += Rx[q] * bl[Rj[q] - c0];
+        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
+        for (int64_t q = pf.q0 + G * U + lane; q < pf.q1; q += G) acc += Rx[q] * bl[Rj[q] - c0];
+      }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (lane == 0) bl[next - c0] -= acc;
-      next += kStride;
-      if (next < c1) prefetch_entries(pf, Rj, Rx, lane);
-      if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (mine) {
+        if (lane == 0) bl[next - c0] -= acc;
+        next += kStride;
+        if (next < c1) prefetch_entries<U, G>(pf, Rj, Rx, lane);
+        if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
+      }
     }
     lds_barrier();
   }
@@ -346,37 +355,45 @@ __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1,
 }
 // backward: the column of L below pivot k is row k of L'; its rows inside the chain are read from LDS, rows
 // above the chain (solved earlier in the backward pass) from global memory.  Pivots and levels descend.
-template <int U>
+template <int U, int G>
 __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
                                                                  const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                                  const double *__restrict__ Lx, const double *__restrict__ Dinv,
                                                                  double *__restrict__ b) {
   __shared__ double bl[kChainLdsRows];
   __shared__ int lp[kChainLdsLevels + 1];
-  constexpr int kStride = kChainThreads / 64;
+  constexpr int kStride = kChainThreads / G;
   const int c0 = level_ptr[l0], c1 = level_ptr[l1];
   for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) bl[i] = b[c0 + i];
   for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int next = c1 - 1 - wave;
+  const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+  int next = c1 - 1 - grp;
   RowPrefetch<U> pf;
   pf.nq0 = pf.nq1 = 0; pf.dinv = 0.0;
-  if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lp[next + 1]; pf.dinv = Dinv[next]; prefetch_entries(pf, Li, Lx, lane); }
+#pragma unroll
+  for (int u = 0; u < U; u++) { pf.v[u] = 0.0; pf.c[u] = -1; }
+  pf.q0 = pf.q1 = 0;
+  if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lp[next + 1]; pf.dinv = Dinv[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
   if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
   __syncthreads();
   for (int l = l1 - l0 - 1; l >= 0; l--) {
     const int r0 = lp[l];
-    while (next >= r0) {
+    while (__any(next >= r0)) {
+      const bool mine = next >= r0;
       double acc = 0.0;
+      if (mine) {
 #pragma unroll
-      for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * (pf.c[u] < c1 ? bl[pf.c[u] - c0] : b[pf.c[u]]);
-      for (int64_t t = pf.q0 + 64 * U + lane; t < pf.q1; t += 64) { const int i = Li[t]; acc += Lx[t] * (i < c1 ? bl[i - c0] : b[i]); }
+        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * (pf.c[u] < c1 ? bl[pf.c[u] - c0] : b[pf.c[u]]);
+        for (int64_t t = pf.q0 + G * U + lane; t < pf.q1; t += G) { const int i = Li[t]; acc += Lx[t] * (i < c1 ? bl[i - c0] : b[i]); }
+      }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (lane == 0) bl[next - c0] = bl[next - c0] * pf.dinv - acc;
-      next -= kStride;
-      if (next >= c0) { pf.dinv = Dinv[next]; prefetch_entries(pf, Li, Lx, lane); }
-      if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (mine) {
+        if (lane == 0) bl[next - c0] = bl[next - c0] * pf.dinv - acc;
+        next -= kStride;
+        if (next >= c0) { pf.dinv = Dinv[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
+        if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
+      }
     }
     lds_barrier();
   }
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double a
   }
 }
 
-struct Step { int kind; int a, b, G; int U = 2; };  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
+struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row inside an LDS chain  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
 
 // ------------------------------------------------------------------ factor object
@@ -568,6 +585,13 @@ struct LdlFactor {
             int64_t longest = 0;
             for (int r = c0; r < c1; r++) longest = std::max(longest, forward ? S.Rp[r + 1] - split[r] : S.Lp[r + 1] - S.Lp[r]);
             st.U = longest > 320 ? 8 : (longest > 224 ? 4 : 2);  // measured: 200-row blocks are fastest with 2, 500-row with 8
+            // short rows (the separators of a nested-dissection tree, banded factors): several rows per wavefront
+            int64_t inside = 0;
+            for (int r = c0; r < c1; r++) inside += forward ? S.Rp[r + 1] - split[r] : S.Lp[r + 1] - S.Lp[r];
+            const double mean = (double)inside / (double)std::max(1, c1 - c0);
+            const bool wide = (c1 - c0) > 2 * (l2 - l);  // more than two rows per level on average
+            if (wide && longest <= 64 && mean <= 12.0) { st.L = 4; st.U = longest > 8 ? 4 : 2; }
+            else if (wide && longest <= 256 && mean <= 48.0) { st.L = 16; st.U = longest > 64 ? 8 : (longest > 32 ? 4 : 2); }
           }
           steps.push_back(st);
           l = l2;
@@ -653,6 +677,24 @@ struct LdlFactor {
     Sinv = cur;
   }
 
+#define OQ_CHAIN_CASE(UU, LL)                                                                                                      \
+  if (t.U == UU && t.L == LL) {                                                                                                     \
+    if (fwd_) OQ_LAUNCH((k_fwd_chain_lds<UU, LL>), dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(),    \
+                        Rp.get(), Rj.get(), Rx.get(), bp.get());                                                                    \
+    else OQ_LAUNCH((k_bwd_chain_lds<UU, LL>), dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(),   \
+                   Lx.get(), Dinv.get(), bp.get());                                                                                 \
+    return;                                                                                                                         \
+  }
+  void launch_chain(const Step &t, bool fwd_, hipStream_t s) {
+    OQ_CHAIN_CASE(2, 64) OQ_CHAIN_CASE(4, 64) OQ_CHAIN_CASE(8, 64)
+    OQ_CHAIN_CASE(2, 16) OQ_CHAIN_CASE(4, 16) OQ_CHAIN_CASE(8, 16)
+    OQ_CHAIN_CASE(2, 4) OQ_CHAIN_CASE(4, 4)
+    throw Error(6, "internal: no chain kernel for this step");
+  }
+#undef OQ_CHAIN_CASE
+  void launch_fwd_chain(const Step &t, hipStream_t s) { launch_chain(t, true, s); }
+  void launch_bwd_chain(const Step &t, hipStream_t s) { launch_chain(t, false, s); }
+
   void run_steps() {
     hipStream_t s = e.stream;
     for (const Step &t : fwd) {
@@ -660,9 +702,7 @@ struct LdlFactor {
         const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
         if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), (double *)nullptr);
         else OQ_LAUNCH(k_fwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), (double *)nullptr);
-        if (t.U == 8) OQ_LAUNCH(k_fwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
-          else if (t.U == 4) OQ_LAUNCH(k_fwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
-          else OQ_LAUNCH(k_fwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(), Rp.get(), Rj.get(), Rx.get(), bp.get());
+        launch_fwd_chain(t, s);
         continue;
       }
       dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
@@ -680,9 +720,7 @@ struct LdlFactor {
     }
     for (const Step &t : bwd) {
       if (t.kind == 1) {
-        if (t.U == 8) OQ_LAUNCH(k_bwd_chain_lds<8>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
-          else if (t.U == 4) OQ_LAUNCH(k_bwd_chain_lds<4>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
-          else OQ_LAUNCH(k_bwd_chain_lds<2>, dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+        launch_bwd_chain(t, s);
         continue;
       }
       dim3 grid(blocks_for((int64_t)(t.b - t.a) * t.G)), block(kBlock);
