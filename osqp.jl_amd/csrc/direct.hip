@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N,
 // model, a data matrix) is a dense block: every pivot its own level, rows as long as the block.  Its triangular
 // solves are a chain of k dependent steps forward and k backward whatever the kernel.  So the last kD pivots are
 // not factorised at all: their Schur complement S0 = K22 - L21 D1 L21' is assembled as a dense kD x kD array,
-// inverted once per factorisation by kD Gauss-Jordan sweeps (one launch each, ping-pong buffers, the pivots
+// inverted once per factorisation by kD Gauss-Jordan sweeps (two per launch, ping-pong buffers, the pivots
 // are the same Schur complements LDL' would meet, so the inertia count is unchanged), and a solve replaces both
 // chains by one dense product x2 = S0^-1 (b2 - L21 y1).
 // wave per entry (i, k) of columns [b0, b1) of L's pattern inside the block; the work rows w_k hold L_kj d_j (k_ldl_wrow)
@@ -202,6 +202,37 @@ __global__ __launch_bounds__(kBlock) void k_dense_sweep(int kD, int p, const dou
   if (idx == 0) {
     if (piv == 0.0 || piv != piv) atomicOr(&status[0], 1);
     else if (piv > 0.0) atomicAdd(&status[1], 1);
+  }
+}
+// Two consecutive sweeps (pivots p, then q = p + 1) in one pass over the array: every thread recomputes the four
+// once-swept values its element needs (S'_ij, S'_iq, S'_qj, S'_qq) with the very expressions of k_dense_sweep, so
+// the result is bit-identical to two launches at half the traffic.  (A block sweep through the inverse of the 2 x 2
+// pivot block is NOT: on the quasi-definite Schur complement that block can be badly conditioned -- sigma next to a
+// large off-diagonal -- and the feasibility test of the reference lost its accuracy with it.)
+__device__ __forceinline__ double sweep_value(bool row_p, bool col_p, double xij, double xip, double xpj, double ip) {
+  if (row_p && col_p) return -ip;
+  if (row_p) return xpj * ip;
+  if (col_p) return xip * ip;
+  return xij - xip * xpj * ip;
+}
+__global__ __launch_bounds__(kBlock) void k_dense_sweep2(int kD, int p, const double *__restrict__ Sold, double *__restrict__ Snew,
+                                                         int *__restrict__ status) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (int64_t)kD * kD) return;
+  const int i = (int)(idx % kD), j = (int)(idx / kD), q = p + 1;
+  const size_t cp = (size_t)p * kD, cq = (size_t)q * kD, cj = (size_t)j * kD;
+  const double piv = Sold[cp + p], ip = 1.0 / piv;
+  const double sip = Sold[cp + i], spj = Sold[cj + p], siq = Sold[cq + i], sqj = Sold[cj + q];
+  const double spq = Sold[cq + p], sqp = Sold[cp + q], sqq = Sold[cq + q];
+  // after the first sweep
+  const double t_ij = sweep_value(i == p, j == p, Sold[idx], sip, spj, ip);
+  const double t_iq = sweep_value(i == p, false, siq, sip, spq, ip);
+  const double t_qj = sweep_value(false, j == p, sqj, sqp, spj, ip);
+  const double piv2 = sqq - sqp * spq * ip, ip2 = 1.0 / piv2;
+  Snew[idx] = sweep_value(i == q, j == q, t_ij, t_iq, t_qj, ip2);
+  if (idx == 0) {
+    if (piv == 0.0 || piv != piv || piv2 == 0.0 || piv2 != piv2) atomicOr(&status[0], 1);
+    else atomicAdd(&status[1], (piv > 0.0 ? 1 : 0) + (piv2 > 0.0 ? 1 : 0));
   }
 }
 // x2 = -(S v) with S = -S0^-1 as the sweeps leave it (symmetric: row a is read as column a, contiguous); wave per row
@@ -670,7 +701,12 @@ struct LdlFactor {
     }
     double *cur = S0a.get(), *nxt = S0b.get();
     const dim3 gs(blocks_for((int64_t)kD * kD));
-    for (int p = 0; p < kD; p++) {
+    int p = 0;
+    for (; p + 1 < kD; p += 2) {
+      OQ_LAUNCH(k_dense_sweep2, gs, dim3(kBlock), 0, s, kD, p, cur, nxt, status.get());
+      std::swap(cur, nxt);
+    }
+    for (; p < kD; p++) {
       OQ_LAUNCH(k_dense_sweep, gs, dim3(kBlock), 0, s, kD, p, cur, nxt, status.get());
       std::swap(cur, nxt);
     }
