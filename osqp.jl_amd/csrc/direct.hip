@@ -310,6 +310,33 @@ __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_
     }
   }
 }
+// Backward counterpart: the entries of column k of L with rows above the chain [c0, c1) (solved earlier in the
+// backward pass) are taken for all pivots of the chain at once, together with the D^-1 scaling:
+// b[k] = b[k] / d_k - sum_{i >= c1} L_ik b[i]; the chain then only walks the entries inside it.
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_bwd_far(int r0, int r1, const int64_t *__restrict__ Lsplit, const int64_t *__restrict__ Lp,
+                                                    const int *__restrict__ Li, const double *__restrict__ Lx,
+                                                    const double *__restrict__ Dinv, double *__restrict__ b) {
+  __shared__ double part[kBlock / 64];
+  const int lane = threadIdx.x & (T - 1);
+  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
+  double acc = 0.0;
+  if (row < r1)
+    for (int64_t t = Lsplit[row] + lane; t < Lp[row + 1]; t += T) acc += Lx[t] * b[Li[t]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (T == 64) {
+    if (lane == 0 && row < r1) b[row] = b[row] * Dinv[row] - acc;
+  } else {
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && row < r1) {
+      double t = 0.0;
+      for (int w = 0; w < kBlock / 64; w++) t += part[w];
+      b[row] = b[row] * Dinv[row] - t;
+    }
+  }
+}
 // LDS-resident chains.  A chain is cut so that its pivots [c0, c1) and its level table fit in LDS (build_schedule):
 // the segment of the solution lives there for the whole chain and the workgroup never touches global memory on the
 // critical path: row r belongs to wavefront (r - c0) mod 16 for good, so a wavefront knows its next row ahead of time and
@@ -320,13 +347,13 @@ __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_
 constexpr int kChainLdsRows = 8192, kChainLdsLevels = 8192;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Two rows ahead: the bounds of the row after next (so that fetching the entries of the next row never waits for
-// its own bounds), one row ahead: bounds, first 64 U entries and 1/d of the next row (U = 2, 4 or 8 by the
+// its own bounds), one row ahead: bounds and first G U entries of the next row (U = 2, 4 or 8 by the
 // longest row inside the chain: a dense trailing block has rows as long as the block).
 template <int U>
 struct RowPrefetch {
   int64_t q0, q1;    // entries of the next row inside the chain
   int64_t nq0, nq1;  // the same for the row after it
-  double v[U], dinv;
+  double v[U];
   int c[U];
 };
 // G lanes share a row (64: a wavefront per row -- long rows of a dense block; 16 or 4: several short rows per wavefront)
@@ -384,12 +411,12 @@ __global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1,
   }
   for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) b[c0 + i] = bl[i];
 }
-// backward: the column of L below pivot k is row k of L'; its rows inside the chain are read from LDS, rows
-// above the chain (solved earlier in the backward pass) from global memory.  Pivots and levels descend.
+// backward: the column of L below pivot k is row k of L'; only its rows inside the chain are left (k_bwd_far took
+// the rest and the D^-1 scaling).  Pivots and levels descend.
 template <int U, int G>
 __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
-                                                                 const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                                 const double *__restrict__ Lx, const double *__restrict__ Dinv,
+                                                                 const int64_t *__restrict__ Lp, const int64_t *__restrict__ Lsplit,
+                                                                 const int *__restrict__ Li, const double *__restrict__ Lx,
                                                                  double *__restrict__ b) {
   __shared__ double bl[kChainLdsRows];
   __shared__ int lp[kChainLdsLevels + 1];
@@ -400,12 +427,12 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1,
   const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
   int next = c1 - 1 - grp;
   RowPrefetch<U> pf;
-  pf.nq0 = pf.nq1 = 0; pf.dinv = 0.0;
+  pf.nq0 = pf.nq1 = 0;
 #pragma unroll
   for (int u = 0; u < U; u++) { pf.v[u] = 0.0; pf.c[u] = -1; }
   pf.q0 = pf.q1 = 0;
-  if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lp[next + 1]; pf.dinv = Dinv[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
-  if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
+  if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lsplit[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
+  if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lsplit[next - kStride]; }
   __syncthreads();
   for (int l = l1 - l0 - 1; l >= 0; l--) {
     const int r0 = lp[l];
@@ -414,16 +441,16 @@ __global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1,
       double acc = 0.0;
       if (mine) {
 #pragma unroll
-        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * (pf.c[u] < c1 ? bl[pf.c[u] - c0] : b[pf.c[u]]);
-        for (int64_t t = pf.q0 + G * U + lane; t < pf.q1; t += G) { const int i = Li[t]; acc += Lx[t] * (i < c1 ? bl[i - c0] : b[i]); }
+        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
+        for (int64_t t = pf.q0 + G * U + lane; t < pf.q1; t += G) acc += Lx[t] * bl[Li[t] - c0];
       }
 #pragma unroll
       for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (mine) {
-        if (lane == 0) bl[next - c0] = bl[next - c0] * pf.dinv - acc;
+        if (lane == 0) bl[next - c0] -= acc;
         next -= kStride;
-        if (next >= c0) { pf.dinv = Dinv[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
-        if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lp[next - kStride + 1]; }
+        if (next >= c0) prefetch_entries<U, G>(pf, Li, Lx, lane);
+        if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lsplit[next - kStride]; }
       }
     }
     lds_barrier();
@@ -487,7 +514,7 @@ struct LdlFactor {
   Symbolic S;
   int N = 0, n = 0, mr = 0, nlev = 0;
   double sigma = 0, cconst = 0;
-  DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit;
+  DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit, Lsplit;
   DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
   DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2;
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
@@ -589,7 +616,7 @@ struct LdlFactor {
   void build_schedule() {
     const auto &lp = S.level_ptr;
     // forward: level 0 rows have no predecessors (nothing to do); backward: every level (D^-1 applies everywhere)
-    std::vector<int64_t> split(S.Rp.begin(), S.Rp.end() - 1);
+    std::vector<int64_t> split(S.Rp.begin(), S.Rp.end() - 1), lsplit(S.Lp.begin() + 1, S.Lp.end());  // default: no far part
     auto make = [&](bool forward) {
       std::vector<Step> steps;
       int l = forward ? 1 : 0;
@@ -610,15 +637,25 @@ struct LdlFactor {
             }
             if (far / std::max(1, c1 - c0) > 1024) T = kBlock;
           }
+          if (!forward) {  // split the columns of the chain at its end
+            const int c0 = lp[l], c1 = lp[l2];
+            int64_t far = 0;
+            for (int r = c0; r < c1; r++) {
+              const int *beg = S.Li.data() + S.Lp[r], *end = S.Li.data() + S.Lp[r + 1];
+              lsplit[r] = S.Lp[r] + (std::lower_bound(beg, end, c1) - beg);
+              far += S.Lp[r + 1] - lsplit[r];
+            }
+            if (far / std::max(1, c1 - c0) > 1024) T = kBlock;
+          }
           Step st{1, l, l2, T};
           {  // longest row inside the chain decides how many entries a lane keeps prefetched
             const int c0 = lp[l], c1 = lp[l2];
             int64_t longest = 0;
-            for (int r = c0; r < c1; r++) longest = std::max(longest, forward ? S.Rp[r + 1] - split[r] : S.Lp[r + 1] - S.Lp[r]);
+            for (int r = c0; r < c1; r++) longest = std::max(longest, forward ? S.Rp[r + 1] - split[r] : lsplit[r] - S.Lp[r]);
             st.U = longest > 320 ? 8 : (longest > 224 ? 4 : 2);  // measured: 200-row blocks are fastest with 2, 500-row with 8
             // short rows (the separators of a nested-dissection tree, banded factors): several rows per wavefront
             int64_t inside = 0;
-            for (int r = c0; r < c1; r++) inside += forward ? S.Rp[r + 1] - split[r] : S.Lp[r + 1] - S.Lp[r];
+            for (int r = c0; r < c1; r++) inside += forward ? S.Rp[r + 1] - split[r] : lsplit[r] - S.Lp[r];
             const double mean = (double)inside / (double)std::max(1, c1 - c0);
             const bool wide = (c1 - c0) > 2 * (l2 - l);  // more than two rows per level on average
             if (wide && longest <= 64 && mean <= 12.0) { st.L = 4; st.U = longest > 8 ? 4 : 2; }
@@ -644,6 +681,8 @@ struct LdlFactor {
     }
     Rsplit.alloc(split.size());
     Rsplit.upload(split.data(), split.size(), e.stream);
+    Lsplit.alloc(lsplit.size());
+    Lsplit.upload(lsplit.data(), lsplit.size(), e.stream);
     e.sync();
   }
 
@@ -717,8 +756,8 @@ struct LdlFactor {
   if (t.U == UU && t.L == LL) {                                                                                                     \
     if (fwd_) OQ_LAUNCH((k_fwd_chain_lds<UU, LL>), dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Rsplit.get(),    \
                         Rp.get(), Rj.get(), Rx.get(), bp.get());                                                                    \
-    else OQ_LAUNCH((k_bwd_chain_lds<UU, LL>), dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(), Li.get(),   \
-                   Lx.get(), Dinv.get(), bp.get());                                                                                 \
+    else OQ_LAUNCH((k_bwd_chain_lds<UU, LL>), dim3(1), dim3(kChainThreads), 0, s, t.a, t.b, level_ptr.get(), Lp.get(),            \
+                   Lsplit.get(), Li.get(), Lx.get(), bp.get());                                                                     \
     return;                                                                                                                         \
   }
   void launch_chain(const Step &t, bool fwd_, hipStream_t s) {
@@ -756,6 +795,9 @@ struct LdlFactor {
     }
     for (const Step &t : bwd) {
       if (t.kind == 1) {
+        const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
+        if (t.G == kBlock) OQ_LAUNCH(k_bwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Lsplit.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
+        else OQ_LAUNCH(k_bwd_far<64>, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lsplit.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
         launch_bwd_chain(t, s);
         continue;
       }
