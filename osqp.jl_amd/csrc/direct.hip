@@ -589,25 +589,40 @@ struct LdlFactor {
   // The dense top block: the longest suffix of the top chain (levels of at most kChainRows pivots) with at most
   // kDenseMax pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when one dense
   // product costs less than its levels.
-  static constexpr int kDenseMax = 2048, kDenseMin = 32;
+  static constexpr int kDenseMax = 2048, kDenseSparseMax = 1024, kDenseMin = 32;
   void choose_dense_block() {
     const auto &lp = S.level_ptr;
     lD = nlev; cD = N; kD = 0;
     static const bool enabled = !(getenv("OSQP_AMD_DENSE_TOP") && atoi(getenv("OSQP_AMD_DENSE_TOP")) == 0);
     if (!enabled || nlev < 2) return;
-    int l = nlev;
-    while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && N - lp[l - 1] <= kDenseMax) l--;
-    const int c = lp[l], k = N - c;
+    auto suffix = [&](int limit) {
+      int l = nlev;
+      while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && N - lp[l - 1] <= limit) l--;
+      return l;
+    };
+    auto entries_inside = [&](int c) {
+      int64_t inside = 0;
+      for (int r = c; r < N; r++) {
+        const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
+        inside += end - std::lower_bound(beg, end, c);
+      }
+      return inside;
+    };
+    int l = suffix(kDenseMax);
+    int c = lp[l], k = N - c;
     if (k < kDenseMin) return;
-    int64_t inside = 0;
-    for (int r = c; r < N; r++) {
-      const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
-      inside += end - std::lower_bound(beg, end, c);
+    bool dense = entries_inside(c) * 8 >= (int64_t)k * k;
+    if (!dense && k > kDenseSparseMax) {
+      // a block-sparse top (the separators of a nested-dissection tree): the inversion costs k^3, the levels it
+      // replaces only k, so a smaller block is the better trade
+      l = suffix(kDenseSparseMax); c = lp[l]; k = N - c;
+      if (k < kDenseMin) return;
+      dense = entries_inside(c) * 8 >= (int64_t)k * k;
     }
     // worth it when the block is dense (then the chain rows are long) or when the dense product is cheaper than
-    // walking the block's levels one by one (a block-sparse top of a nested-dissection tree)
+    // walking the block's levels one by one
     const double dense_us = (double)k * (double)k * 8.0 / 4.0e6 + 10.0, chain_us = 1.4 * (double)(nlev - l);
-    if (inside * 8 < (int64_t)k * k && dense_us > chain_us) return;
+    if (!dense && dense_us > chain_us) return;
     lD = l; cD = c; kD = k;
   }
   // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
