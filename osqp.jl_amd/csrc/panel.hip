@@ -324,6 +324,15 @@ int64_t read_i64(const int64_t *dev, hipStream_t s) {
 
 }  // namespace
 
+// panels per workgroup tile: 4 when that still leaves > 1000 workgroups (measured at nnz = 1e9: 4 and 8 are equal,
+// 16 is slower), otherwise every panel on its own
+static int panel_group_size(const DevCsr &M, int B) {
+  const int want = env_int("OSQP_AMD_PANEL_GROUP", 0);
+  if (want > 0) return std::min(want, B);
+  if ((double)M.nnz / (4.0 * (double)panel_tile_nnz()) >= 1024.0) return std::min(4, B);
+  return 1;
+}
+
 bool panel_wanted(const DevCsr &M) {
   const int shift = panel_shift();
   if (const char *e = getenv("OSQP_AMD_PANEL")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return M.cols > (1 << shift); }
@@ -333,7 +342,10 @@ bool panel_wanted(const DevCsr &M) {
   const int B = (M.cols + (1 << shift) - 1) >> shift;
   if (B < 2 || M.nnz < 2000000) return false;
   if (M.nnz >= 4000000000LL) return false;  // 32-bit slot offsets
-  return (double)M.nnz / ((double)M.rows * B) >= 4.0;
+  // the partial sums cost 16 B per (row, group of panels): at least 4 entries behind each; and the slices need rows of
+  // more than an entry or two per panel to be worth their padding
+  const int Gp = panel_group_size(M, B), NG = (B + Gp - 1) / Gp;
+  return (double)M.nnz / ((double)M.rows * NG) >= 4.0 && (double)M.nnz / ((double)M.rows * B) >= 1.5;
 }
 
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s) {
@@ -353,14 +365,7 @@ void panel_build(DevCsr &M, hipStream_t s) {
   OQ_LAUNCH(k_panel_count, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.B, P.shift, M.rowptr.get(),
             M.col.get(), cnt.get());
   exclusive_scan(cnt.get(), off.get(), cells, s);
-  // groups of consecutive panels: 4 when that still leaves > 1000 workgroups (measured at nnz = 1e9: 4 and 8 are equal,
-  // 16 is slower), otherwise every panel on its own
-  P.Gp = 1;
-  {
-    const int want = env_int("OSQP_AMD_PANEL_GROUP", 0);
-    if (want > 0) P.Gp = std::min(want, P.B);
-    else if ((double)M.nnz / (4.0 * (double)panel_tile_nnz()) >= 1024.0) P.Gp = std::min(4, P.B);
-  }
+  P.Gp = panel_group_size(M, P.B);
   P.NG = (P.B + P.Gp - 1) / P.Gp;
   const int64_t gcells = (int64_t)P.NG * M.rows;
   // tiles of ~equal non-zero count inside each group (gcnt is reused: counts, costs, then tile-start flags)
