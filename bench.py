@@ -135,7 +135,8 @@ def main():
     nnzA, nnzPf = st[1], st[2]
     if st[0] == 2:   # indirect back-end: CSR SpMV y = A x
         variant = int(st[12]) if len(st) > 12 else 0
-        kname = ["k_spmv<G> (CSR, y = A x)", "k_spmv_panel (LDS-staged x panels, y = A x)", "k_spmv_sell (LDS-staged x panels, sliced-ELL tiles, y = A x)"][variant]
+        kname = ["k_spmv<G> (CSR, y = A x)", "k_spmv_panel (LDS-staged x panels, y = A x)", "k_spmv_sell (LDS-staged x panels, sliced-ELL tiles, y = A x)",
+                 "k_spmv_sell (wide x panels through L2, sliced-ELL tiles, y = A x)"][variant]
         which, abytes = 0, st[10]
     else:            # direct back-end: forward+backward triangular solve
         kname, which, abytes = "sptrsv forward+backward", 3, st[11]

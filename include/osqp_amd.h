@@ -260,7 +260,8 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *  6 total CG iterations so far              7 total ADMM iterations so far
  *  8 numeric factorisations so far           9 device bytes allocated
  * 10 algorithmic bytes of one SpMV with A   11 algorithmic bytes of one forward+backward trisolve
- * 12 SpMV kernel used for A: 0 CSR (k_spmv), 2 LDS-staged column panels with sliced-ELL tiles (k_spmv_sell)
+ * 12 SpMV kernel used for A: 0 CSR (k_spmv), 2 LDS-staged column panels with sliced-ELL tiles (k_spmv_sell),
+ *    3 the same tiles over wide panels gathered through L2 (n >> 1e6 at fixed nnz)
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
  * 16, 17 rows of the local blocks (n, m)
  * Returns the number of entries written. */

@@ -342,7 +342,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[9] = (c_float)g_device_bytes;
   v[10] = e.A.spmv_bytes();
   v[11] = e.lin->trisolve_bytes();
-  v[12] = e.A.panel.active ? 2.0 : 0.0;
+  v[12] = e.A.panel.active ? (e.A.panel.wide ? 3.0 : 2.0) : 0.0;
   v[13] = e.comm ? (c_float)e.comm->world : 1.0;
   v[14] = e.comm ? e.comm->exchanges : 0.0;
   v[15] = e.comm ? e.comm->bytes : 0.0;

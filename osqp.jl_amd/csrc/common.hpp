@@ -110,6 +110,8 @@ struct DevPanel {
   DevBuf<uint32_t> cellbase;                 // [B * rows] slot of the first entry of (panel, row): value refresh
   DevBuf<double> sval;
   DevBuf<uint16_t> scol;
+  bool wide = false;                         // panels of 2^18 columns gathered through L2 instead of staged in LDS
+  DevBuf<uint32_t> scol32;                   // their local column ids
   DevBuf<double> partial;                    // [NG * rows] per-group row sums, reduced in fixed order
   size_t padded = 0;                         // stored entries including padding
 };

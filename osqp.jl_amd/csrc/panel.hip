@@ -28,6 +28,11 @@
 // (A group-per-row CSR walk over the same panels moves fewer bytes but reached only 3.3 TB/s
 // of real traffic with its 8- and 2-byte loads on ~16-entry segments; profiles/r01_e_panel_sweep.md.)
 //
+// Wide mode (matrices with fewer than ~1.5 entries per row and 16384-column panel: n >> 1e6 at fixed nnz): the same
+// tiles and slices over panels of 2^18 columns, whose 2 MB of x are not staged in LDS but left to the L2 of the XCD --
+// the workgroups of a panel run side by side (tiles are launched panel-major), so their gathers hit the same lines;
+// 32-bit local column ids.  Slower per byte than the LDS scheme, several times faster than gathering from a 32 MB x.
+//
 // The whole layout is planned on the device (tile cuts, per-tile ordering, slice offsets): the
 // host only reads back three totals.
 //
@@ -218,9 +223,10 @@ __global__ __launch_bounds__(kThreads) void k_tile_layout(int rows, const int *_
 }
 
 // copy every entry of the CSR matrix to its sliced-ELL slot; with_cols = 0 refreshes the values only
+template <typename ColT>
 __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, const int64_t *__restrict__ rp, const int *__restrict__ col,
                                                          const double *__restrict__ val, const uint32_t *__restrict__ cellbase,
-                                                         uint16_t *__restrict__ scol, double *__restrict__ sval, int with_cols) {
+                                                         ColT *__restrict__ scol, double *__restrict__ sval, int with_cols) {
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (row >= rows) return;
@@ -232,25 +238,27 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
     const int64_t seg = lower_bound_col(col, s, k + 1, b << shift);  // first entry of this row in panel b
     const size_t dst = (size_t)cellbase[(size_t)b * rows + row] + (size_t)(k - seg) * 64;
     sval[dst] = val[k];
-    if (with_cols) scol[dst] = (uint16_t)(c & mask);
+    if (with_cols) scol[dst] = (ColT)(c & mask);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // the product
 // ---------------------------------------------------------------------------------------------
+template <typename ColT, bool kStageX>
 __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
                                                         const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
                                                         const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
                                                         const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
-                                                        const int *__restrict__ slice_rows, const uint16_t *__restrict__ scol,
+                                                        const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
                                                         const double *__restrict__ sval, const double *__restrict__ x,
                                                         double *__restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int t = blockIdx.x, g = tile_g[t];
   const int W = 1 << shift;
   const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
-  double *ys = xs + W;  // row sums of the tile: accumulated here over the panels of the group, stored as one contiguous block
+  double *xs_lds = lds;
+  double *ys = kStageX ? lds + W : lds;  // row sums of the tile: accumulated over the panels of the group, stored as one block
   for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   bool first = true;
@@ -259,23 +267,29 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
     if (b >= B) break;
     const int s0 = unit_s0[(size_t)t * Gp + j], ns = unit_ns[(size_t)t * Gp + j];
     if (ns == 0) continue;           // the same decision in every thread
-    if (!first) __syncthreads();     // the previous panel is no longer read
-    first = false;
     const int c0 = b << shift;
-    const int wlen = cols - c0 < W ? cols - c0 : W;
-    for (int i = threadIdx.x; i < wlen; i += kThreads) xs[i] = x[c0 + i];
-    __syncthreads();
+    const double *xs = x + c0;       // wide mode: the panel of x stays where it is (L2)
+    if (kStageX) {
+      if (!first) __syncthreads();   // the previous panel is no longer read
+      const int wlen = cols - c0 < W ? cols - c0 : W;
+      for (int i = threadIdx.x; i < wlen; i += kThreads) xs_lds[i] = x[c0 + i];
+      __syncthreads();
+      xs = xs_lds;
+    } else {
+      __syncthreads();               // first pass: the zeroes of ys are in place; later: the row sums of the previous panel are
+    }
+    first = false;
     for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
       const size_t base = (size_t)slice_base[sl] + lane;
       const int L = slice_len[sl];
       const int row = slice_rows[(size_t)sl * 64 + lane];
       const double *v = sval + base;
-      const uint16_t *c = scol + base;
+      const ColT *c = scol + base;
       double a0 = 0.0, a1 = 0.0;
       int k = 0;
       for (; k + 8 <= L; k += 8) {  // 16 loads in flight per lane before the first one is consumed
         double cv[8];
-        uint16_t cc[8];
+        ColT cc[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
 #pragma unroll
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
       }
       if (k + 4 <= L) {
         double cv[4];
-        uint16_t cc[4];
+        ColT cc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
 #pragma unroll
@@ -333,31 +347,49 @@ static int panel_group_size(const DevCsr &M, int B) {
   return 1;
 }
 
-bool panel_wanted(const DevCsr &M) {
+// 0: plain CSR kernel; 1: panels of 2^shift columns staged in LDS; 2: wide panels of 2^18 columns left to L2
+constexpr int kWideShift = 18;
+static int panel_mode(const DevCsr &M) {
   const int shift = panel_shift();
-  if (const char *e = getenv("OSQP_AMD_PANEL")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return M.cols > (1 << shift); }
+  if (const char *e = getenv("OSQP_AMD_PANEL")) {
+    if (atoi(e) == 0) return 0;
+    if (atoi(e) == 2) return M.cols > (1 << shift) ? 1 : 0;
+    if (atoi(e) == 3) return M.cols > (1 << shift) ? 2 : 0;  // wide mode forced (tests)
+  }
   // Worth it when the matrix is large enough to be bandwidth-bound, spans at least two panels and its row
   // segments per panel are long enough to pay for the partial sums.  Measured (tools/sweep_spmv.py): at
-  // n = 1e6 / 1000 per row 10.8 -> 2.1 ms per SpMV, at n = 1e5 / 100 per row 0.052 -> 0.027 ms.
+  // n = 1e6 / 1000 per row 10.8 -> 2.0 ms per SpMV, at n = 1e5 / 100 per row 0.052 -> 0.027 ms.
+  if (M.nnz < 2000000 || M.nnz >= 4000000000LL) return 0;  // 32-bit slot offsets
   const int B = (M.cols + (1 << shift) - 1) >> shift;
-  if (B < 2 || M.nnz < 2000000) return false;
-  if (M.nnz >= 4000000000LL) return false;  // 32-bit slot offsets
-  // the partial sums cost 16 B per (row, group of panels): at least 4 entries behind each; and the slices need rows of
-  // more than an entry or two per panel to be worth their padding
-  const int Gp = panel_group_size(M, B), NG = (B + Gp - 1) / Gp;
-  return (double)M.nnz / ((double)M.rows * NG) >= 4.0 && (double)M.nnz / ((double)M.rows * B) >= 1.5;
+  if (B >= 2) {
+    // the partial sums cost 16 B per (row, group of panels): at least 4 entries behind each; and the slices need rows of
+    // more than an entry or two per panel to be worth their padding
+    const int Gp = panel_group_size(M, B), NG = (B + Gp - 1) / Gp;
+    if ((double)M.nnz / ((double)M.rows * NG) >= 4.0 && (double)M.nnz / ((double)M.rows * B) >= 1.5) return 1;
+  }
+  // rows too thin for 16384-column panels: wide panels when x is far beyond L2 and the rows fill those
+  const int Bw = (M.cols + (1 << kWideShift) - 1) >> kWideShift;
+  if (Bw >= 4 && (double)M.nnz / ((double)M.rows * Bw) >= 4.0) return 2;
+  return 0;
 }
+
+bool panel_wanted(const DevCsr &M) { return panel_mode(M) != 0; }
 
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s) {
   DevPanel &P = M.panel;
-  OQ_LAUNCH(k_sell_scatter, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(), M.col.get(),
-            M.val.get(), P.cellbase.get(), P.scol.get(), P.sval.get(), with_cols ? 1 : 0);
+  if (P.wide)
+    OQ_LAUNCH(k_sell_scatter<uint32_t>, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(),
+              M.col.get(), M.val.get(), P.cellbase.get(), P.scol32.get(), P.sval.get(), with_cols ? 1 : 0);
+  else
+    OQ_LAUNCH(k_sell_scatter<uint16_t>, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(),
+              M.col.get(), M.val.get(), P.cellbase.get(), P.scol.get(), P.sval.get(), with_cols ? 1 : 0);
 }
 
 void panel_build(DevCsr &M, hipStream_t s) {
   DevPanel &P = M.panel;
-  P.shift = panel_shift(); P.W = 1 << P.shift;
-  if (P.shift > 15) throw Error(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
+  P.wide = panel_mode(M) == 2;
+  P.shift = P.wide ? kWideShift : panel_shift(); P.W = 1 << P.shift;
+  if (!P.wide && P.shift > 15) throw Error(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
   P.B = (M.cols + P.W - 1) >> P.shift;
   const int64_t cells = (int64_t)P.B * M.rows;
   // per-(panel, row) counts and their offsets
@@ -403,22 +435,31 @@ void panel_build(DevCsr &M, hipStream_t s) {
   P.cellbase.alloc((size_t)cells); P.cellbase.zero(s);
   OQ_LAUNCH(k_tile_layout, dim3((unsigned)nunits), dim3(kThreads), 0, s, M.rows, ub.get(), u0.get(), u1.get(), off.get(), slice0.get(),
             padded0.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), P.cellbase.get());
-  P.sval.alloc((size_t)padded); P.scol.alloc((size_t)padded);
-  P.sval.zero(s); P.scol.zero(s);  // padding slots: value 0 times x[panel column 0]
+  P.sval.alloc((size_t)padded);
+  P.sval.zero(s);  // padding slots: value 0 times x[panel column 0]
+  if (P.wide) { P.scol32.alloc((size_t)padded); P.scol32.zero(s); }
+  else { P.scol.alloc((size_t)padded); P.scol.zero(s); }
   P.partial.alloc((size_t)gcells);
   P.partial.zero(s);  // every (group, row) cell is rewritten by each product: the zeroes only matter before the first one
   panel_fill(M, true, s);
   HIP_CHECK(hipStreamSynchronize(s));
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spmv_lds_bytes(P.shift)));
+  if (!P.wide)
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)spmv_lds_bytes(P.shift)));
   P.active = true;
 }
 
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
                 hipStream_t s) {
   const DevPanel &P = M.panel;
-  OQ_LAUNCH(k_spmv_sell, dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B, P.Gp, P.tile_g.get(),
-            P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),
-            P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get());
+  if (P.wide)
+    OQ_LAUNCH((k_spmv_sell<uint32_t, false>), dim3(P.ntiles), dim3(kThreads), sizeof(double) * kTileRowsMax, s, M.rows, M.cols, P.shift, P.B,
+              P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
+              P.slice_len.get(), P.slice_rows.get(), P.scol32.get(), P.sval.get(), x, P.partial.get());
+  else
+    OQ_LAUNCH((k_spmv_sell<uint16_t, true>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B,
+              P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
+              P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get());
   OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v);
 }
 

@@ -136,11 +136,12 @@ def test_large_property_checks(product_lib):
     assert r2.info.status == "Solved" and r2.info.iter <= 25
 
 
-@pytest.mark.parametrize("group", ["1", "2", "4"])  # panels per workgroup tile: 1 below nnz = 2.7e8, 4 above (here forced)
-def test_panel_spmv_matches_scipy(product_lib, oracle_lib, monkeypatch, group):
-    """The LDS-staged column-panel SpMV (csrc/panel.hip, used when x does not fit the caches) against
-    scipy on the host-generated matrix, forced on at a size the test can hold (3 panels of 16384 columns)."""
-    monkeypatch.setenv("OSQP_AMD_PANEL", "2")
+@pytest.mark.parametrize("mode,group", [("2", "1"), ("2", "2"), ("2", "4"), ("3", "1")])
+def test_panel_spmv_matches_scipy(product_lib, oracle_lib, monkeypatch, mode, group):
+    """The column-panel SpMV (csrc/panel.hip, used when x does not fit the caches) against scipy on the host-generated
+    matrix, forced on at a size the test can hold: LDS-staged panels (3 panels of 16384 columns; 1, 2 or 4 panels per
+    workgroup tile -- 1 below nnz = 2.7e8, 4 above) and the wide panels gathered through L2 (mode 3)."""
+    monkeypatch.setenv("OSQP_AMD_PANEL", mode)
     monkeypatch.setenv("OSQP_AMD_PANEL_GROUP", group)
     n, k = 40000, 96
     d = oracle_lib.oracle_generate(0, n, k, 21)
