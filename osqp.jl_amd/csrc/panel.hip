@@ -348,13 +348,24 @@ static int panel_group_size(const DevCsr &M, int B) {
 }
 
 // 0: plain CSR kernel; 1: panels of 2^shift columns staged in LDS; 2: wide panels of 2^18 columns left to L2
-constexpr int kWideShift = 18;
+// width of the wide panels: 2^18 columns (2 MB of x, half an L2), up to 2^20 when the rows are so thin that a narrower
+// panel holds fewer than ~3.5 entries of a row (measured at n = 4e6 / 150 per row: 2^16..2^18 equal, 2^19 +25 %, 2^20 +55 %;
+// at n = 8e6 / 60 per row 2^19 is 5.2 ms against 8.9 ms of the CSR kernel).  0: no width is worth it.
+static int wide_shift(const DevCsr &M) {
+  if (const int forced = env_int("OSQP_AMD_WIDE_SHIFT", 0)) return forced;
+  for (int sh = 18; sh <= 20; sh++) {
+    const int Bw = (M.cols + (1 << sh) - 1) >> sh;
+    if (Bw < 4) return 0;
+    if ((double)M.nnz / ((double)M.rows * Bw) >= 3.5) return sh;
+  }
+  return 0;
+}
 static int panel_mode(const DevCsr &M) {
   const int shift = panel_shift();
   if (const char *e = getenv("OSQP_AMD_PANEL")) {
     if (atoi(e) == 0) return 0;
     if (atoi(e) == 2) return M.cols > (1 << shift) ? 1 : 0;
-    if (atoi(e) == 3) return M.cols > (1 << shift) ? 2 : 0;  // wide mode forced (tests)
+    if (atoi(e) == 3) return M.cols > (1 << shift) ? 2 : 0;  // wide mode forced (tests; width 2^18 unless OSQP_AMD_WIDE_SHIFT)
   }
   // Worth it when the matrix is large enough to be bandwidth-bound, spans at least two panels and its row
   // segments per panel are long enough to pay for the partial sums.  Measured (tools/sweep_spmv.py): at
@@ -368,9 +379,7 @@ static int panel_mode(const DevCsr &M) {
     if ((double)M.nnz / ((double)M.rows * NG) >= 4.0 && (double)M.nnz / ((double)M.rows * B) >= 1.5) return 1;
   }
   // rows too thin for 16384-column panels: wide panels when x is far beyond L2 and the rows fill those
-  const int Bw = (M.cols + (1 << kWideShift) - 1) >> kWideShift;
-  if (Bw >= 4 && (double)M.nnz / ((double)M.rows * Bw) >= 4.0) return 2;
-  return 0;
+  return wide_shift(M) ? 2 : 0;
 }
 
 bool panel_wanted(const DevCsr &M) { return panel_mode(M) != 0; }
@@ -388,7 +397,7 @@ void panel_fill(DevCsr &M, bool with_cols, hipStream_t s) {
 void panel_build(DevCsr &M, hipStream_t s) {
   DevPanel &P = M.panel;
   P.wide = panel_mode(M) == 2;
-  P.shift = P.wide ? kWideShift : panel_shift(); P.W = 1 << P.shift;
+  P.shift = P.wide ? (wide_shift(M) ? wide_shift(M) : 18) : panel_shift(); P.W = 1 << P.shift;
   if (!P.wide && P.shift > 15) throw Error(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
   P.B = (M.cols + P.W - 1) >> P.shift;
   const int64_t cells = (int64_t)P.B * M.rows;
