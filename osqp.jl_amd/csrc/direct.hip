@@ -505,6 +505,69 @@ __global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double a
   }
 }
 
+// The same two ends with the neighbouring level folded in (one thread per index; used when the rows of level 1 / the
+// columns of level 0 are short -- bound constraints, diagonal blocks): the right-hand side of a level-0 pivot is cheap
+// to recompute, so a level-1 row takes what it needs from the original vectors instead of waiting for a kernel that
+// writes them; and the update computes the solution of a level-0 pivot on the spot instead of reading it back.
+__device__ __forceinline__ double direct_rhs_value(int o, int n, double sigma, const double *__restrict__ x, const double *__restrict__ q,
+                                                   const double *__restrict__ z, const double *__restrict__ rho_inv,
+                                                   const double *__restrict__ y) {
+  if (o < n) return sigma * x[o] - q[o];
+  const int j = o - n;
+  return z[j] - rho_inv[j] * y[j];
+}
+__global__ __launch_bounds__(kBlock) void k_direct_rhs_fwd1(int n, int m, double sigma, const int *__restrict__ pinv, const int *__restrict__ perm,
+                                                            int l1_begin, int l1_end, const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                            const double *__restrict__ Rx, const double *__restrict__ x,
+                                                            const double *__restrict__ q, const double *__restrict__ z,
+                                                            const double *__restrict__ rho_inv, const double *__restrict__ y,
+                                                            double *__restrict__ bp) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n + m) return;
+  const int k = pinv[o];
+  double v = direct_rhs_value(o, n, sigma, x, q, z, rho_inv, y);
+  if (k >= l1_begin && k < l1_end) {
+    double acc = 0.0;
+    for (int64_t t = Rp[k]; t < Rp[k + 1]; t++) acc += Rx[t] * direct_rhs_value(perm[Rj[t]], n, sigma, x, q, z, rho_inv, y);
+    v -= acc;
+  }
+  bp[k] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_direct_bwd0_update(int n, int m, double alpha, const int *__restrict__ pinv, int l0_end,
+                                                               const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                               const double *__restrict__ Lx, const double *__restrict__ Dinv,
+                                                               const double *__restrict__ bp, const double *__restrict__ rho,
+                                                               const double *__restrict__ rho_inv, const double *__restrict__ l,
+                                                               const double *__restrict__ u, double *__restrict__ x, double *__restrict__ z,
+                                                               double *__restrict__ y, double *__restrict__ delta_x,
+                                                               double *__restrict__ delta_y) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n + m) return;
+  const int k = pinv[o];
+  double sol = bp[k];
+  if (k < l0_end) {  // level 0: the last backward step, done here
+    double acc = 0.0;
+    for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) acc += Lx[t] * bp[Li[t]];
+    sol = sol * Dinv[k] - acc;
+  }
+  if (o < n) {
+    double xp = x[o];
+    double xn = alpha * sol + (1.0 - alpha) * xp;
+    x[o] = xn;
+    delta_x[o] = xn - xp;
+  } else {
+    int j = o - n;
+    double zp = z[j], yj = y[j], ri = rho_inv[j];
+    double zt = (zp - ri * yj) + ri * sol;
+    double zh = alpha * zt + (1.0 - alpha) * zp;
+    double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
+    z[j] = zn;
+    double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    y[j] = yj + dy;
+  }
+}
+
 struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row inside an LDS chain  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
 
@@ -785,9 +848,12 @@ struct LdlFactor {
   void launch_fwd_chain(const Step &t, hipStream_t s) { launch_chain(t, true, s); }
   void launch_bwd_chain(const Step &t, hipStream_t s) { launch_chain(t, false, s); }
 
-  void run_steps() {
+  // skip_first_fwd / skip_last_bwd: those two level steps are folded into the kernels around the solve (fused_ends)
+  void run_steps(bool skip_first_fwd = false, bool skip_last_bwd = false) {
     hipStream_t s = e.stream;
-    for (const Step &t : fwd) {
+    for (size_t si = 0; si < fwd.size(); si++) {
+      const Step &t = fwd[si];
+      if (si == 0 && skip_first_fwd) continue;
       if (t.kind == 1) {
         const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
         if (t.G == kBlock) OQ_LAUNCH(k_fwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), (double *)nullptr);
@@ -808,7 +874,9 @@ struct LdlFactor {
       OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), x2.get());
       OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, Sinv, x2.get(), bp.get() + cD);
     }
-    for (const Step &t : bwd) {
+    for (size_t si = 0; si < bwd.size(); si++) {
+      const Step &t = bwd[si];
+      if (si + 1 == bwd.size() && skip_last_bwd) continue;
       if (t.kind == 1) {
         const int c0 = S.level_ptr[t.a], c1 = S.level_ptr[t.b];
         if (t.G == kBlock) OQ_LAUNCH(k_bwd_far<kBlock>, dim3(c1 - c0), dim3(kBlock), 0, s, c0, c1, Lsplit.get(), Lp.get(), Li.get(), Lx.get(), Dinv.get(), bp.get());
@@ -834,6 +902,14 @@ struct LdlFactor {
     OQ_LAUNCH(k_perm_out, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, n, pinv.get(), bp.get(), rho_inv, b);
   }
 
+  // level 1 forward / level 0 backward are plain level steps over short rows: they can ride with the iteration's ends
+  bool can_fuse_fwd1() const {
+    return nlev >= 2 && !fwd.empty() && fwd[0].kind == 0 && fwd[0].a == S.level_ptr[1] && fwd[0].b == S.level_ptr[2] && fwd[0].G <= 4;
+  }
+  bool can_fuse_bwd0() const {
+    return !bwd.empty() && bwd.back().kind == 0 && bwd.back().a == 0 && bwd.back().b == S.level_ptr[1] && bwd.back().G <= 4;
+  }
+
   double trisolve_bytes() const { return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N; }
 };
 
@@ -846,11 +922,23 @@ struct Direct : Linsys {
   bool fused_step() override {
     hipStream_t s = e.stream;
     const int N = e.n + e.m;
-    OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), e.x.get(), e.q.get(),
-              e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
-    F->run_steps();
-    OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->bp.get(),
-              e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
+    static const bool fuse_ends = !(getenv("OSQP_AMD_FUSE_ENDS") && atoi(getenv("OSQP_AMD_FUSE_ENDS")) == 0);
+    const bool f1 = fuse_ends && F->can_fuse_fwd1(), b0 = fuse_ends && F->can_fuse_bwd0();
+    if (f1)
+      OQ_LAUNCH(k_direct_rhs_fwd1, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), F->perm.get(),
+                F->S.level_ptr[1], F->S.level_ptr[2], F->Rp.get(), F->Rj.get(), F->Rx.get(), e.x.get(), e.q.get(), e.z.get(),
+                e.rho_inv.get(), e.y.get(), F->bp.get());
+    else
+      OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), e.x.get(), e.q.get(),
+                e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
+    F->run_steps(f1, b0);
+    if (b0)
+      OQ_LAUNCH(k_direct_bwd0_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->S.level_ptr[1],
+                F->Lp.get(), F->Li.get(), F->Lx.get(), F->Dinv.get(), F->bp.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(),
+                e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
+    else
+      OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->bp.get(),
+                e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     return true;
   }
   int update_rho() override { return F->refactor(e.rho_inv.get()); }
