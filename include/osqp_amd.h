@@ -176,6 +176,53 @@ typedef struct OSQPWorkspace {
   void         *impl;          /* 240  library-private (engine handle) */
 } OSQPWorkspace;
 
+/* Layout contract, checked at compile time by every translation unit that includes this header (the library
+ * itself and tests/c_harness.c): the byte offsets the Julia mirrors imply [REF src/types.jl:11-19, 74-77,
+ * 81-99, 101-109, 111-134, 173-217] and that interface.jl reads through `unsafe_load`
+ * [REF src/interface.jl:176-205, 744-746]. */
+#if defined(__cplusplus)
+#define OSQP_AMD_STATIC_ASSERT(c, msg) static_assert(c, msg)
+#else
+#define OSQP_AMD_STATIC_ASSERT(c, msg) _Static_assert(c, msg)
+#endif
+#define OSQP_AMD_OFFSET(T, f, o) OSQP_AMD_STATIC_ASSERT(offsetof(T, f) == (o), #T "." #f " must sit at byte " #o)
+OSQP_AMD_STATIC_ASSERT(sizeof(c_int) == 8 && sizeof(c_float) == 8 && sizeof(void *) == 8, "64-bit c_int / c_float / pointers");
+OSQP_AMD_STATIC_ASSERT(sizeof(csc) == 56, "csc is 56 bytes");
+OSQP_AMD_OFFSET(csc, nzmax, 0); OSQP_AMD_OFFSET(csc, m, 8); OSQP_AMD_OFFSET(csc, n, 16); OSQP_AMD_OFFSET(csc, p, 24);
+OSQP_AMD_OFFSET(csc, i, 32); OSQP_AMD_OFFSET(csc, x, 40); OSQP_AMD_OFFSET(csc, nz, 48);
+OSQP_AMD_STATIC_ASSERT(sizeof(OSQPData) == 56, "OSQPData is 56 bytes");
+OSQP_AMD_OFFSET(OSQPData, n, 0); OSQP_AMD_OFFSET(OSQPData, m, 8); OSQP_AMD_OFFSET(OSQPData, P, 16); OSQP_AMD_OFFSET(OSQPData, A, 24);
+OSQP_AMD_OFFSET(OSQPData, q, 32); OSQP_AMD_OFFSET(OSQPData, l, 40); OSQP_AMD_OFFSET(OSQPData, u, 48);
+OSQP_AMD_STATIC_ASSERT(sizeof(OSQPSettings) == 176, "OSQPSettings is 176 bytes");
+OSQP_AMD_OFFSET(OSQPSettings, rho, 0); OSQP_AMD_OFFSET(OSQPSettings, sigma, 8); OSQP_AMD_OFFSET(OSQPSettings, scaling, 16);
+OSQP_AMD_OFFSET(OSQPSettings, adaptive_rho, 24); OSQP_AMD_OFFSET(OSQPSettings, adaptive_rho_interval, 32);
+OSQP_AMD_OFFSET(OSQPSettings, adaptive_rho_tolerance, 40); OSQP_AMD_OFFSET(OSQPSettings, adaptive_rho_fraction, 48);
+OSQP_AMD_OFFSET(OSQPSettings, max_iter, 56); OSQP_AMD_OFFSET(OSQPSettings, eps_abs, 64); OSQP_AMD_OFFSET(OSQPSettings, eps_rel, 72);
+OSQP_AMD_OFFSET(OSQPSettings, eps_prim_inf, 80); OSQP_AMD_OFFSET(OSQPSettings, eps_dual_inf, 88); OSQP_AMD_OFFSET(OSQPSettings, alpha, 96);
+OSQP_AMD_OFFSET(OSQPSettings, linsys_solver, 104); OSQP_AMD_OFFSET(OSQPSettings, delta, 112); OSQP_AMD_OFFSET(OSQPSettings, polish, 120);
+OSQP_AMD_OFFSET(OSQPSettings, polish_refine_iter, 128); OSQP_AMD_OFFSET(OSQPSettings, verbose, 136);
+OSQP_AMD_OFFSET(OSQPSettings, scaled_termination, 144); OSQP_AMD_OFFSET(OSQPSettings, check_termination, 152);
+OSQP_AMD_OFFSET(OSQPSettings, warm_start, 160); OSQP_AMD_OFFSET(OSQPSettings, time_limit, 168);
+OSQP_AMD_STATIC_ASSERT(sizeof(OSQPInfo) == 136, "OSQPInfo is 136 bytes");
+OSQP_AMD_OFFSET(OSQPInfo, iter, 0); OSQP_AMD_OFFSET(OSQPInfo, status, 8); OSQP_AMD_OFFSET(OSQPInfo, status_val, 40);
+OSQP_AMD_OFFSET(OSQPInfo, status_polish, 48); OSQP_AMD_OFFSET(OSQPInfo, obj_val, 56); OSQP_AMD_OFFSET(OSQPInfo, pri_res, 64);
+OSQP_AMD_OFFSET(OSQPInfo, dua_res, 72); OSQP_AMD_OFFSET(OSQPInfo, setup_time, 80); OSQP_AMD_OFFSET(OSQPInfo, solve_time, 88);
+OSQP_AMD_OFFSET(OSQPInfo, update_time, 96); OSQP_AMD_OFFSET(OSQPInfo, polish_time, 104); OSQP_AMD_OFFSET(OSQPInfo, run_time, 112);
+OSQP_AMD_OFFSET(OSQPInfo, rho_updates, 120); OSQP_AMD_OFFSET(OSQPInfo, rho_estimate, 128);
+OSQP_AMD_STATIC_ASSERT(sizeof(OSQPSolution) == 16, "OSQPSolution is 16 bytes");
+OSQP_AMD_OFFSET(OSQPSolution, x, 0); OSQP_AMD_OFFSET(OSQPSolution, y, 8);
+OSQP_AMD_OFFSET(OSQPWorkspace, data, 0); OSQP_AMD_OFFSET(OSQPWorkspace, linsys_solver, 8); OSQP_AMD_OFFSET(OSQPWorkspace, pol, 16);
+OSQP_AMD_OFFSET(OSQPWorkspace, rho_vec, 24); OSQP_AMD_OFFSET(OSQPWorkspace, rho_inv_vec, 32); OSQP_AMD_OFFSET(OSQPWorkspace, constr_type, 40);
+OSQP_AMD_OFFSET(OSQPWorkspace, x, 48); OSQP_AMD_OFFSET(OSQPWorkspace, y, 56); OSQP_AMD_OFFSET(OSQPWorkspace, z, 64);
+OSQP_AMD_OFFSET(OSQPWorkspace, xz_tilde, 72); OSQP_AMD_OFFSET(OSQPWorkspace, x_prev, 80); OSQP_AMD_OFFSET(OSQPWorkspace, z_prev, 88);
+OSQP_AMD_OFFSET(OSQPWorkspace, Ax, 96); OSQP_AMD_OFFSET(OSQPWorkspace, Px, 104); OSQP_AMD_OFFSET(OSQPWorkspace, Aty, 112);
+OSQP_AMD_OFFSET(OSQPWorkspace, delta_y, 120); OSQP_AMD_OFFSET(OSQPWorkspace, Atdelta_y, 128); OSQP_AMD_OFFSET(OSQPWorkspace, delta_x, 136);
+OSQP_AMD_OFFSET(OSQPWorkspace, Pdelta_x, 144); OSQP_AMD_OFFSET(OSQPWorkspace, Adelta_x, 152); OSQP_AMD_OFFSET(OSQPWorkspace, D_temp, 160);
+OSQP_AMD_OFFSET(OSQPWorkspace, D_temp_A, 168); OSQP_AMD_OFFSET(OSQPWorkspace, E_temp, 176); OSQP_AMD_OFFSET(OSQPWorkspace, settings, 184);
+OSQP_AMD_OFFSET(OSQPWorkspace, scaling, 192); OSQP_AMD_OFFSET(OSQPWorkspace, solution, 200); OSQP_AMD_OFFSET(OSQPWorkspace, info, 208);
+OSQP_AMD_OFFSET(OSQPWorkspace, timer, 216); OSQP_AMD_OFFSET(OSQPWorkspace, first_run, 224); OSQP_AMD_OFFSET(OSQPWorkspace, summary_printed, 232);
+OSQP_AMD_OFFSET(OSQPWorkspace, impl, 240); /* past everything the reference mirror declares (240 bytes) */
+
 /* ------------------------------------------------------------------------- */
 /* Part 1c: the 30 symbols OSQP.jl binds                                      */
 /* ------------------------------------------------------------------------- */
@@ -264,7 +311,8 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *    3 the same tiles over wide panels gathered through L2 (n >> 1e6 at fixed nnz)
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
  * 16, 17 rows of the local blocks (n, m)
- * Returns the number of entries written. */
+ * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
+#define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 
 /* Time `reps` launches of one hot-path kernel with HIP events on the engine's

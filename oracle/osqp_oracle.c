@@ -1004,8 +1004,8 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
 c_int osqp_update_max_iter(OSQPWorkspace *w, c_int v) { if (!w) return 7; if (v <= 0) return 1; w->settings->max_iter = v; return 0; }
 c_int osqp_update_eps_abs(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_abs = v; return 0; }
 c_int osqp_update_eps_rel(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_rel = v; return 0; }
-c_int osqp_update_eps_prim_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_prim_inf = v; return 0; }
-c_int osqp_update_eps_dual_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_dual_inf = v; return 0; }
+c_int osqp_update_eps_prim_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->eps_prim_inf = v; return 0; }
+c_int osqp_update_eps_dual_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->eps_dual_inf = v; return 0; }
 c_int osqp_update_alpha(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0. || v >= 2.) return 1; w->settings->alpha = v; return 0; }
 c_int osqp_update_delta(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->delta = v; return 0; }
 c_int osqp_update_polish(OSQPWorkspace *w, c_int v) { if (!w) return 7; if (v != 0 && v != 1) return 1; w->settings->polish = v; w->info->polish_time = 0.0; return 0; }

@@ -19,6 +19,21 @@ struct Impl {
 };
 
 Engine *E(OSQPWorkspace *w) { return &((Impl *)w->impl)->eng; }
+
+// Every entry point that takes a workspace runs on the device the workspace was set up on, whatever device the
+// calling thread has current, and leaves the caller's device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int want) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    if (prev == want) { prev = -1; return; }
+    if (hipSetDevice(want) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define OQ_ON_DEVICE(w) DeviceGuard _dev_guard(E(w)->device)
 const Engine *E(const OSQPWorkspace *w) { return &((const Impl *)w->impl)->eng; }
 
 int validate_data(const OSQPData *d) {
@@ -229,47 +244,57 @@ c_int osqp_amd_setup_generated_sharded(OSQPWorkspace **workp, c_int kind, c_int 
 
 c_int osqp_solve(OSQPWorkspace *w) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->solve(); });
 }
 
 c_int osqp_cleanup(OSQPWorkspace *w) {
   if (!w) return 0;  // finalizer of a never-set-up Model [REF src/interface.jl:24-25, 223-229]
+  OQ_ON_DEVICE(w);
   try { destroy(w); } catch (...) { return 1; }
   return 0;
 }
 
 c_int osqp_update_lin_cost(OSQPWorkspace *w, const c_float *q_new) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_lin_cost(q_new); });
 }
 c_int osqp_update_bounds(OSQPWorkspace *w, const c_float *l_new, const c_float *u_new) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_bounds(l_new, u_new); });
 }
 c_int osqp_update_lower_bound(OSQPWorkspace *w, const c_float *l_new) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_bounds(l_new, nullptr); });
 }
 c_int osqp_update_upper_bound(OSQPWorkspace *w, const c_float *u_new) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_bounds(nullptr, u_new); });
 }
 c_int osqp_update_P(OSQPWorkspace *w, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_PA(Px_new, Px_new_idx, P_new_n, nullptr, nullptr, 0, true, false); });
 }
 c_int osqp_update_A(OSQPWorkspace *w, const c_float *Ax_new, const c_int *Ax_new_idx, c_int A_new_n) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_PA(nullptr, nullptr, 0, Ax_new, Ax_new_idx, A_new_n, false, true); });
 }
 c_int osqp_update_P_A(OSQPWorkspace *w, const c_float *Px_new, const c_int *Px_new_idx, c_int P_new_n, const c_float *Ax_new,
                       const c_int *Ax_new_idx, c_int A_new_n) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->update_PA(Px_new, Px_new_idx, P_new_n, Ax_new, Ax_new_idx, A_new_n, true, true); });
 }
 
 c_int osqp_update_rho(OSQPWorkspace *w, c_float rho_new) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   if (rho_new <= 0) return 1;
   return guarded([&]() {
     Engine &e = *E(w);
@@ -285,15 +310,17 @@ c_int osqp_update_rho(OSQPWorkspace *w, c_float rho_new) {
   c_int fn(OSQPWorkspace *w, type v) {                    \
     if (!w) return 7;                                     \
     if (!(cond)) return 1;                                \
+    OQ_ON_DEVICE(w);                                      \
     E(w)->st.field = v;                                   \
+    E(w)->settings_changed();                             \
     w->settings->field = v;                               \
     return 0;                                             \
   }
 OQ_SETTING(osqp_update_max_iter, c_int, max_iter, v > 0)
 OQ_SETTING(osqp_update_eps_abs, c_float, eps_abs, v >= 0.)
 OQ_SETTING(osqp_update_eps_rel, c_float, eps_rel, v >= 0.)
-OQ_SETTING(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v >= 0.)
-OQ_SETTING(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v >= 0.)
+OQ_SETTING(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v > 0.)  // as setup validation (validate_settings)
+OQ_SETTING(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v > 0.)
 OQ_SETTING(osqp_update_alpha, c_float, alpha, v > 0. && v < 2.)
 OQ_SETTING(osqp_update_delta, c_float, delta, v > 0.)
 OQ_SETTING(osqp_update_polish_refine_iter, c_int, polish_refine_iter, v >= 0)
@@ -305,6 +332,7 @@ OQ_SETTING(osqp_update_time_limit, c_float, time_limit, v >= 0.)
 
 c_int osqp_update_polish(OSQPWorkspace *w, c_int v) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   if (v != 0 && v != 1) return 1;
   E(w)->st.polish = v;
   w->settings->polish = v;
@@ -314,14 +342,17 @@ c_int osqp_update_polish(OSQPWorkspace *w, c_int v) {
 
 c_int osqp_warm_start(OSQPWorkspace *w, const c_float *x, const c_float *y) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->warm_start(x, y); });
 }
 c_int osqp_warm_start_x(OSQPWorkspace *w, const c_float *x) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->warm_start(x, nullptr); });
 }
 c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->warm_start(nullptr, y); });
 }
 
@@ -329,7 +360,7 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
 c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   if (!w || !out) return 0;
   const Engine &e = *E(w);
-  c_float v[18] = {0};
+  c_float v[OSQP_AMD_STATS_COUNT] = {0};
   v[0] = (c_float)e.lin->kind();
   v[1] = (c_float)e.nnzA;
   v[2] = (c_float)e.Pf.nnz;
@@ -349,12 +380,13 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[16] = (c_float)e.n;  // local block sizes
   v[17] = (c_float)e.m;
   c_int k = 0;
-  for (; k < count && k < 18; k++) out[k] = v[k];
+  for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;
 }
 
 c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
   if (!w || reps <= 0) return -1.0;
+  OQ_ON_DEVICE(w);
   c_float result = -1.0;
   guarded([&]() {
     Engine &e = *E(w);
@@ -393,11 +425,13 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
 
 c_int osqp_amd_iterate(OSQPWorkspace *w, c_int iters) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->iterate(iters); });
 }
 
 c_int osqp_amd_apply(OSQPWorkspace *w, c_int op, const c_float *in, c_float *out) {
   if (!w) return 7;
+  OQ_ON_DEVICE(w);
   return guarded([&]() {
     Engine &e = *E(w);
     if (e.comm) throw Error(6, "osqp_amd_apply is not available on a row-sharded workspace");

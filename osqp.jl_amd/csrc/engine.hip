@@ -359,6 +359,7 @@ int Engine::update_rho(double rho_new) {
   if (rho_new <= 0) return 1;
   st.rho = std::min(std::max(rho_new, RHO_MIN), RHO_MAX);
   rho_vec_update(m, l.get(), u.get(), ctype.get(), rho.get(), rho_inv.get(), st.rho, 2, flag.get(), stream);
+  settings_changed();
   return lin ? lin->update_rho() : 0;
 }
 
@@ -397,6 +398,10 @@ bool Engine::can_chunk(long long iter, long long max_iter) const {
   if ((iter - 1) % k != 0 || iter + k - 1 > max_iter) return false;
   if (st.adaptive_rho && (st.adaptive_rho_interval == 0 || st.adaptive_rho_interval % k != 0)) return false;
   return true;
+}
+
+void Engine::settings_changed() {
+  if (chunk_exec) { (void)hipGraphExecDestroy(chunk_exec); chunk_exec = nullptr; chunk_len = 0; }
 }
 
 void Engine::run_chunk() {
@@ -806,6 +811,7 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
   if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
   if (st.scaling) scale_data();
   refresh_panels();
+  settings_changed();
   int e = lin->update_matrices();
   reset_info(ws->info);
   end_update();
@@ -820,6 +826,9 @@ int Engine::warm_start(const double *xw, const double *yw) {
     if (st.scaling) vec_ew_prod(x.get(), x.get(), Dinv.get(), n, stream);
     if (m > 0) spmv(A, full_n(x.get()), z.get(), nullptr, 0.0, 0.0, nullptr, stream);
   } else {
+    // The single-vector forms reset the other block: "setting warm start for x only zeroes the stored warm start
+    // for y and vice versa" [REF src/modcaches.jl:196] -- the reference's own statement of what the pinned
+    // libosqp does, and the reason its MOI layer sends both vectors together when both are dirty.
     x.zero(stream); z.zero(stream);
   }
   if (yw) {

@@ -124,6 +124,9 @@ struct Engine {
   int admm_step();
   bool can_chunk(long long iter, long long max_iter) const;
   void run_chunk();
+  // The captured chunk bakes the scalar launch arguments (alpha, sigma) and the kernel choice into its nodes:
+  // whatever changes a setting, rho or the matrices drops it, and the next chunk is captured afresh.
+  void settings_changed();
   int kkt_solve();
   void residual_evaluation();
   void update_info(long long iter, bool compute_objective);

@@ -109,6 +109,29 @@ def test_iterates_match_oracle_early(product_lib, oracle_lib):
     assert abs(res[0].info.dua_res - res[1].info.dua_res) <= 1e-9
 
 
+def test_alpha_update_after_a_solve_is_honoured(product_lib, oracle_lib):
+    """The `check_termination` iterations of the direct back-end are replayed from a captured hipGraph whose nodes
+    hold alpha as a launch argument: `update_settings!(model, alpha=...)` [REF src/interface.jl:552-563] after a first
+    solve must reach the replayed iterations (the graph is dropped and captured again).  Direct back-end on both
+    sides: identical iteration counts, before and after the update."""
+    opts = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, adaptive_rho_interval=50, check_termination=25, linsys_solver="qdldl")
+    ms = []
+    for lib in (product_lib, oracle_lib):
+        m = oq.Model(lib); oq.setup_generated(m, 1, 4000, 0, 3, **opts); ms.append(m)
+    r1 = [oq.solve(m) for m in ms]
+    assert r1[0].info.status == r1[1].info.status == "Solved" and r1[0].info.iter == r1[1].info.iter
+    for m in ms:
+        oq.update_settings(m, alpha=1.0, warm_start=False)
+    r2 = [oq.solve(m) for m in ms]
+    assert r2[0].info.status == r2[1].info.status == "Solved"
+    assert r2[0].info.iter == r2[1].info.iter and r2[0].info.iter != r1[0].info.iter
+    assert np.max(np.abs(r2[0].x - r2[1].x)) <= 1e-7 and np.max(np.abs(r2[0].y - r2[1].y)) <= 1e-7
+    for m in ms:  # rho and the matrices change what the replayed kernels read as well
+        oq.update_settings(m, rho=0.3, alpha=1.6)
+    r3 = [oq.solve(m) for m in ms]
+    assert r3[0].info.iter == r3[1].info.iter and np.max(np.abs(r3[0].x - r3[1].x)) <= 1e-7
+
+
 def test_large_property_checks(product_lib):
     """BASELINE-size-independent properties on a larger generated problem: the returned
     point satisfies OSQP's own stopping criteria when re-evaluated on the host from
