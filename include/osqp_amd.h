@@ -343,6 +343,9 @@ c_int osqp_amd_comm_unique_id(void *out128, const char *librccl_path);
 c_int osqp_amd_comm_create_rccl(osqp_amd_comm **out, c_int rank, c_int world, const void *unique_id,
                                 const char *librccl_path);
 c_int osqp_amd_comm_destroy(osqp_amd_comm *comm);
+/* The communicator's one primitive, exposed: in-place all-gather of `count` doubles per rank on a DEVICE buffer of
+ * world*count doubles whose chunk `rank` is filled in; blocks until done. */
+c_int osqp_amd_comm_all_gather(osqp_amd_comm *comm, c_float *dev_buf, c_int count);
 /* as osqp_setup [REF src/interface.jl:147-162] / osqp_amd_setup_generated, keeping this rank's row block */
 c_int osqp_amd_setup_sharded(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings,
                              osqp_amd_comm *comm);
@@ -380,6 +383,26 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m,
 c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long long seed,
                                      const OSQPSettings *settings,
                                      c_float *x_dev, c_float *y_dev, c_float *info_dev, c_int device);
+
+/* The batched path over several GPUs (SURVEY.md 8e, rows K11 + K12): `total` MPC instances of the mpc-batch family
+ * (seed `seed`) cut into contiguous equal blocks, instance i -> rank floor(i / (total / world)); one process per GPU.
+ * create(): this rank's block is generated in HBM (`comm` NULL = a single rank owning everything; `total` must be
+ * divisible by the communicator's size).  solve(): one workgroup per instance writes its row
+ * [x (100) | y (200) | iter, status_val, pri_res, dua_res] straight into the packed DEVICE array
+ * `packed_dev` [total x 304], then ONE in-place all-gather of the rank blocks over the communicator (RCCL over xGMI,
+ * or the host callback) fills in the other ranks' rows; returns when the whole array is valid on this rank.  No other
+ * communication. */
+typedef struct osqp_amd_batch osqp_amd_batch;
+c_int osqp_amd_batch_mpc_create(osqp_amd_batch **out, c_int total, unsigned long long seed, const OSQPSettings *settings,
+                                osqp_amd_comm *comm, c_int device);
+c_int osqp_amd_batch_mpc_solve(osqp_amd_batch *batch, c_float *packed_dev);
+c_int osqp_amd_batch_destroy(osqp_amd_batch *batch);
+
+/* Differences between the batched path and osqp_setup / osqp_solve: instances share one sparsity pattern, n <= 192,
+ * fewer than 65536 rows and non-zeros, everything must fit 160 KB of LDS; `adaptive_rho_interval` = 0 (automatic) means
+ * every 100 iterations (there is no per-instance clock); `polish`, `time_limit`, `warm_start`, `verbose` and
+ * `linsys_solver` are ignored (always a cold start, the reduced KKT system factorised in LDS); data and settings are
+ * validated as by osqp_setup (1 = data, 2 = settings). */
 
 /* Select the HIP device for workspaces created afterwards by this process
  * (one process per GPU: pass LOCAL_RANK). */

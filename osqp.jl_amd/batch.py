@@ -4,8 +4,10 @@
 workgroup on the device (csrc/batch.hip).  Across GPUs the instance range is cut
 into contiguous equal blocks, one per rank (one process per GPU); there is no
 communication during the solve.  The only collective is the final gather of
-the packed per-rank results [x | y | info] (RCCL `all_gather_into_tensor` when
-the process group is `nccl`; the same code runs on `gloo` in the CPU tests).
+the packed per-rank results [x | y | info]: an in-place all-gather on the
+library's own communicator (`sharded.RcclComm`: ncclAllGather over xGMI issued by
+libosqp_amd.so itself; `sharded.HostComm`: pinned-host staging + a caller callback)
+-- `MpcBatch` below.  torch is only the allocator of the device array here.
 """
 import ctypes as C
 
@@ -76,19 +78,66 @@ def device_mpc_solver(lib, device, **settings):
     return solve
 
 
-def solve_mpc_sharded(solver, count, seed, rank=0, world=1, dist=None):
-    """Each rank solves its block with `solver(first, count, seed)`; one all-gather of the
-    packed block returns the whole batch on every rank.  Returns (x, y, info) views."""
+def split_packed(full):
+    """(x, y, info) views of a packed [count x (n + m + 4)] array."""
+    return full[:, :MPC_N], full[:, MPC_N:MPC_N + MPC_M], full[:, MPC_N + MPC_M:]
+
+
+def solve_mpc_sharded(solver, count, seed, rank=0, world=1, gather=None):
+    """The host logic of the sharded batch with the two device steps passed in: each rank solves its block with
+    `solver(first, count, seed)` -> packed [per x 304]; `gather(full, rank, per)` fills the other ranks' rows of
+    `full` in place (one collective).  Returns (x, y, info) views of the whole batch.  `MpcBatch` is the product form
+    of the same steps (both inside libosqp_amd.so); the CPU tests drive this one with the oracle and gloo."""
     first, per = shard_range(count, rank, world)
     mine = solver(first, per, seed)
     if world > 1:
-        import torch
-
-        full = torch.empty((count, mine.shape[1]), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(full, mine.contiguous())
+        full = mine.new_empty((count, mine.shape[1]))
+        full[first:first + per] = mine
+        gather(full, rank, per)
     else:
         full = mine
-    return full[:, :MPC_N], full[:, MPC_N:MPC_N + MPC_M], full[:, MPC_N + MPC_M:]
+    return split_packed(full)
+
+
+class MpcBatch:
+    """`total` MPC instances cut over the ranks of `comm` (None: one rank), resident in HBM; `solve()` = rows K11 + K12
+    in one library call (osqp_amd_batch_mpc_solve): this rank's block, one workgroup per instance, written in place into
+    the packed device array, then one in-place all-gather on the library's communicator."""
+
+    def __init__(self, lib, total, seed=1, device=0, comm=None, **settings):
+        self.lib, self.total, self.device, self.comm = lib, int(total), int(device), comm
+        self.world = comm.world if comm is not None else 1
+        self.rank = comm.rank if comm is not None else 0
+        self.first, self.per = shard_range(self.total, self.rank, self.world)
+        stgs = make_settings(lib, settings)
+        self.handle = C.c_void_p()
+        rc = lib.osqp_amd_batch_mpc_create(C.byref(self.handle), self.total, seed, C.byref(stgs),
+                                           comm.handle if comm is not None else None, self.device)
+        if rc != 0:
+            raise OSQPError("Error in batched setup: " + lib.osqp_amd_last_error().decode())
+
+    def alloc(self):
+        import torch
+
+        return torch.empty((self.total, MPC_N + MPC_M + INFO_COLS), dtype=torch.float64, device=f"cuda:{self.device}")
+
+    def solve(self, out=None):
+        packed = self.alloc() if out is None else out
+        rc = self.lib.osqp_amd_batch_mpc_solve(self.handle, packed.data_ptr())
+        if rc != 0:
+            raise OSQPError("Error in batched solve: " + self.lib.osqp_amd_last_error().decode())
+        return packed
+
+    def close(self):
+        if self.handle:
+            self.lib.osqp_amd_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def status_names(info):

@@ -36,6 +36,10 @@ struct DeviceGuard {
 #define OQ_ON_DEVICE(w) DeviceGuard _dev_guard(E(w)->device)
 const Engine *E(const OSQPWorkspace *w) { return &((const Impl *)w->impl)->eng; }
 
+}  // namespace
+
+namespace oq {
+
 int validate_data(const OSQPData *d) {
   if (!d || !d->P || !d->A || !d->q) return 1;
   if (d->n <= 0 || d->m < 0) return 1;
@@ -72,6 +76,10 @@ int validate_settings(const OSQPSettings *s) {
   if (s->time_limit < 0.0) return 1;
   return 0;
 }
+
+}  // namespace oq
+
+namespace {
 
 OSQPWorkspace *new_workspace() {
   OSQPWorkspace *w = (OSQPWorkspace *)calloc(1, sizeof(OSQPWorkspace));
@@ -224,6 +232,14 @@ c_int osqp_amd_comm_create_rccl(osqp_amd_comm **out, c_int rank, c_int world, co
   return guarded([&]() {
     require_device();
     *out = (osqp_amd_comm *)make_rccl_comm((int)rank, (int)world, unique_id, librccl_path);
+    return 0;
+  });
+}
+c_int osqp_amd_comm_all_gather(osqp_amd_comm *c, c_float *dev_buf, c_int count) {
+  if (!c || !dev_buf || count < 0) return 1;
+  return guarded([&]() {
+    ((Comm *)c)->all_gather(dev_buf, (size_t)count, nullptr);
+    HIP_CHECK(hipStreamSynchronize(nullptr));
     return 0;
   });
 }

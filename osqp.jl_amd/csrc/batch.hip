@@ -310,7 +310,8 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
                                                     const double *__restrict__ Ax_all, const double *__restrict__ q_all,
                                                     const double *__restrict__ l_all, const double *__restrict__ u_all,
                                                     double *__restrict__ x_out, double *__restrict__ y_out,
-                                                    double *__restrict__ info_out, int info_stride) {
+                                                    double *__restrict__ info_out, int x_stride, int y_stride, int info_stride,
+                                                    int info_cols) {
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   const int inst = blockIdx.x;
   if (inst >= count) return;
@@ -564,12 +565,12 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   PROF_PRINT
   // ---- store -----------------------------------------------------
   const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
-  for (int j = tid; j < n; j += NT) x_out[(size_t)inst * n + j] = has_sol ? s.D[j] * x[j] : NAN;
-  for (int i = tid; i < m; i += NT) y_out[(size_t)inst * m + i] = has_sol ? cinv * s.E[i] * s.y[i] : NAN;
+  for (int j = tid; j < n; j += NT) x_out[(size_t)inst * x_stride + j] = has_sol ? s.D[j] * x[j] : NAN;
+  for (int i = tid; i < m; i += NT) y_out[(size_t)inst * y_stride + i] = has_sol ? cinv * s.E[i] * s.y[i] : NAN;
   if (tid == 0) {
     double *o = info_out + (size_t)inst * info_stride;
     o[0] = (double)iter; o[1] = (double)status; o[2] = pri_res; o[3] = dua_res;
-    if (info_stride > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
+    if (info_cols > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
   }
 }
 
@@ -696,15 +697,31 @@ struct DevicePattern {
   }
 };
 
+// outputs: row i of x / y / info at x + i * x_stride etc. (packed layouts put all three in one row); info_cols 4 or 6
 void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, const double *Px, const double *Ax, const double *q,
-                  const double *l, const double *u, double *x, double *y, double *info, int info_stride, hipStream_t s) {
+                  const double *l, const double *u, double *x, double *y, double *info, int x_stride, int y_stride, int info_stride,
+                  int info_cols, hipStream_t s) {
   const Pattern &P = dp.P;
   size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF);
   if (P.n > 192 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 192 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
   HIP_CHECK(hipFuncSetAttribute((const void *)k_batch_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  OQ_LAUNCH(k_batch_solve, dim3(count), dim3(NT), bytes, s, P, st, count, Px, Ax, q, l, u, x, y, info, info_stride);
+  OQ_LAUNCH(k_batch_solve, dim3(count), dim3(NT), bytes, s, P, st, count, Px, Ax, q, l, u, x, y, info, x_stride, y_stride, info_stride,
+            info_cols);
 }
+
+// A batch of MPC instances resident in HBM, cut into contiguous equal blocks over the ranks of a communicator
+// (instance i -> rank floor(i / (total / world))).  solve() = this rank's block, one workgroup per
+// instance, results written straight into their rows of the packed [total x (n + m + 4)] array, then the one
+// collective of the path: an in-place all-gather of the rank blocks (rows K11 + K12 in one library call).
+struct BatchPlan {
+  int device = 0, total = 0, first = 0, count = 0;
+  Comm *comm = nullptr;  // not owned; nullptr = one rank
+  OSQPSettings st;
+  DevicePattern dp;
+  DevBuf<double> Px, Ax, q, l, u;
+  static constexpr int kRow = MPC_N + MPC_M + 4;
+};
 
 }  // namespace
 }  // namespace oq
@@ -717,8 +734,19 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
                            const c_int *Ai, const c_float *Ax_all, const c_float *q_all, const c_float *l_all, const c_float *u_all,
                            const OSQPSettings *settings, c_float *x_out, c_float *y_out, OSQPInfo *info_out, c_int device) {
   try {
-    if (count <= 0 || n <= 0 || m < 0 || !settings) return 1;
-    HIP_CHECK(hipSetDevice((int)device));
+    // the same checks osqp_setup makes [REF src/interface.jl:47-100 + the C side's validate_data / validate_settings]
+    if (count <= 0 || n <= 0 || m < 0 || !Pp || !Pi || !Ap || !Ai || !q_all || (m > 0 && (!l_all || !u_all))) { set_last_error("invalid batch data"); return 1; }
+    if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
+    if (n > 192 || m > 65535 || Pp[0] != 0 || Ap[0] != 0 || Pp[n] < 0 || Ap[n] < 0 || Pp[n] > 65535 || Ap[n] > 65535) {
+      set_last_error("the batched path supports n <= 192 and fewer than 65536 rows / non-zeros"); return 1;
+    }
+    for (c_int j = 0; j < n; j++) {
+      if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) { set_last_error("column pointers must not decrease"); return 1; }
+      for (c_int k = Pp[j]; k < Pp[j + 1]; k++) if (Pi[k] < 0 || Pi[k] > j) { set_last_error("P must be upper triangular with row indices in range"); return 1; }
+      for (c_int k = Ap[j]; k < Ap[j + 1]; k++) if (Ai[k] < 0 || Ai[k] >= m) { set_last_error("row index of A out of range"); return 1; }
+    }
+    for (c_int i = 0; i < count * m; i++) if (l_all[i] > u_all[i]) { set_last_error("lower bound greater than upper bound"); return 1; }
+    DeviceScope on_device((int)device);
     hipStream_t s = nullptr;
     std::vector<int> hPp(Pp, Pp + n + 1), hAp(Ap, Ap + n + 1);
     std::vector<int> hPi(Pi, Pi + Pp[n]), hAi(Ai, Ai + Ap[n]);
@@ -730,7 +758,8 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
     dPx.upload(Px_all, (size_t)count * nnzP, s); dAx.upload(Ax_all, (size_t)count * nnzA, s);
     dq.upload(q_all, (size_t)count * n, s); dl.upload(l_all, (size_t)count * m, s); du.upload(u_all, (size_t)count * m, s);
     auto t0 = std::chrono::steady_clock::now();
-    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), dx.get(), dy.get(), dinfo.get(), 6, s);
+    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), dx.get(), dy.get(), dinfo.get(), (int)n,
+                 (int)m, 6, 6, s);
     HIP_CHECK(hipDeviceSynchronize());
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::vector<double> hinfo((size_t)count * 6);
@@ -759,8 +788,9 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
 c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long long seed, const OSQPSettings *settings, c_float *x_dev,
                                      c_float *y_dev, c_float *info_dev, c_int device) {
   try {
-    if (count <= 0 || !settings) return 1;
-    HIP_CHECK(hipSetDevice((int)device));
+    if (count <= 0 || first < 0) return 1;
+    if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
+    DeviceScope on_device((int)device);
     hipStream_t s = nullptr;
     const int nnzA = mpc_nnzA();
     // shared pattern from instance `first` on the host
@@ -777,7 +807,7 @@ c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long lon
         du((size_t)count * MPC_M);
     OQ_LAUNCH(k_gen_mpc, dim3(blocks_for(count, 64)), dim3(64), 0, s, (long long)first, (int)count, seed, nnzA, dAx.get(), dPx.get(),
               dq.get(), dl.get(), du.get());
-    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), x_dev, y_dev, info_dev, 4, s);
+    launch_batch(dp, *settings, (int)count, dPx.get(), dAx.get(), dq.get(), dl.get(), du.get(), x_dev, y_dev, info_dev, MPC_N, MPC_M, 4, 4, s);
     HIP_CHECK(hipDeviceSynchronize());
     return 0;
   } catch (const Error &er) {
@@ -787,6 +817,75 @@ c_int osqp_amd_batch_solve_generated(c_int first, c_int count, unsigned long lon
     set_last_error(ex.what());
     return 6;
   }
+}
+
+// ---- sharded MPC batch: K11 + K12 behind one handle -------------------------------------------------------
+c_int osqp_amd_batch_mpc_create(osqp_amd_batch **out, c_int total, unsigned long long seed, const OSQPSettings *settings,
+                                osqp_amd_comm *comm, c_int device) {
+  if (!out) return 1;
+  *out = nullptr;
+  try {
+    if (total <= 0) { set_last_error("empty batch"); return 1; }
+    if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
+    Comm *c = (Comm *)comm;
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    if (total % world != 0) { set_last_error("instance count must be divisible by the number of ranks"); return 1; }
+    DeviceScope on_device((int)device);
+    std::unique_ptr<BatchPlan> b(new BatchPlan());
+    b->device = (int)device; b->total = (int)total; b->count = (int)(total / world); b->first = rank * b->count;
+    b->comm = c; b->st = *settings;
+    hipStream_t s = nullptr;
+    const int nnzA = mpc_nnzA();
+    std::vector<int> hAp(MPC_N + 1), hAi(nnzA), hPp(MPC_N + 1), hPi(MPC_N);
+    {
+      std::vector<double> ax(nnzA), pd(MPC_N), q(MPC_N), l(MPC_M), u(MPC_M);
+      mpc_fill(0, seed, hAp.data(), hAi.data(), ax.data(), pd.data(), q.data(), l.data(), u.data());  // the pattern is the same for every instance
+      for (int j = 0; j <= MPC_N; j++) hPp[j] = j;
+      for (int j = 0; j < MPC_N; j++) hPi[j] = j;
+    }
+    b->dp.build(MPC_N, MPC_M, hPp, hPi, hAp, hAi, s);
+    const size_t cnt = (size_t)b->count;
+    b->Px.alloc(cnt * MPC_N); b->Ax.alloc(cnt * nnzA); b->q.alloc(cnt * MPC_N); b->l.alloc(cnt * MPC_M); b->u.alloc(cnt * MPC_M);
+    OQ_LAUNCH(k_gen_mpc, dim3(blocks_for(b->count, 64)), dim3(64), 0, s, (long long)b->first, b->count, seed, nnzA, b->Ax.get(),
+              b->Px.get(), b->q.get(), b->l.get(), b->u.get());
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = (osqp_amd_batch *)b.release();
+    return 0;
+  } catch (const Error &er) {
+    set_last_error(er.what());
+    return er.code ? er.code : 6;
+  } catch (const std::exception &ex) {
+    set_last_error(ex.what());
+    return 6;
+  }
+}
+
+c_int osqp_amd_batch_mpc_solve(osqp_amd_batch *handle, c_float *packed_dev) {
+  if (!handle || !packed_dev) return 1;
+  BatchPlan &b = *(BatchPlan *)handle;
+  try {
+    DeviceScope on_device(b.device);
+    hipStream_t s = nullptr;
+    double *mine = packed_dev + (size_t)b.first * BatchPlan::kRow;
+    launch_batch(b.dp, b.st, b.count, b.Px.get(), b.Ax.get(), b.q.get(), b.l.get(), b.u.get(), mine, mine + MPC_N, mine + MPC_N + MPC_M,
+                 BatchPlan::kRow, BatchPlan::kRow, BatchPlan::kRow, 4, s);
+    if (b.comm && b.comm->world > 1) b.comm->all_gather(packed_dev, (size_t)b.count * BatchPlan::kRow, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+  } catch (const Error &er) {
+    set_last_error(er.what());
+    return er.code ? er.code : 6;
+  } catch (const std::exception &ex) {
+    set_last_error(ex.what());
+    return 6;
+  }
+}
+
+c_int osqp_amd_batch_destroy(osqp_amd_batch *handle) {
+  if (!handle) return 0;
+  BatchPlan *b = (BatchPlan *)handle;
+  try { DeviceScope on_device(b->device); delete b; } catch (...) { return 1; }
+  return 0;
 }
 
 }  // extern "C"

@@ -181,5 +181,21 @@ void generate_problem(int kind, int n, int per_row, unsigned long long seed, hip
                       DevBuf<double> &Ax, DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u);
 
 void update_status(OSQPInfo *info, c_int status_val);
+// the checks of osqp_setup (abi.hip); 0 = valid
+int validate_data(const OSQPData *d);
+int validate_settings(const OSQPSettings *s);
+void set_last_error(const std::string &m);
+
+// runs the enclosing scope on `device` and puts the caller's current device back on exit
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int want) {
+    HIP_CHECK(hipGetDevice(&prev));
+    if (prev != want) HIP_CHECK(hipSetDevice(want)); else prev = -1;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 }  // namespace oq

@@ -3,7 +3,7 @@
 usage: _sharded_worker.py RANK WORLD PORT OUT_JSON TRANSPORT CASE
   TRANSPORT: host (gloo, any number of ranks on one GPU) | rccl
   CASE: gen:<kind>:<n>:<per_row>:<seed> | cases:<name,name,...> (functions of tests/qp_cases.py, run with every
-        setup routed through the communicator)
+        setup routed through the communicator) | batch:<total>:<seed> (the sharded MPC batch, osqp_jl_amd.batch.MpcBatch)
 """
 import json
 import os
@@ -26,6 +26,22 @@ def main():
     torch.cuda.set_device(0)
     lib = oq.load_library()
     comm = sharded.HostComm(lib=lib) if transport == "host" else sharded.RcclComm(lib=lib)
+    if case.startswith("batch:"):
+        from osqp_jl_amd import batch
+
+        _, total, seed = case.split(":")
+        b = batch.MpcBatch(lib, int(total), int(seed), device=0, comm=comm, **settings)
+        packed = b.solve()
+        again = b.solve(packed.clone())  # a second solve of the resident batch gives the same bits
+        np.save("%s.%d.npy" % (out, rank), packed.cpu().numpy())
+        with open("%s.%d" % (out, rank), "w") as f:
+            json.dump({"first": b.first, "per": b.per, "same": bool((again == packed).all().item()),
+                       "exchanges": 0}, f)
+        b.close()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     m = oq.Model(lib)
     if case.startswith("gen:"):
         _, kind, n, per_row, seed = case.split(":")

@@ -65,6 +65,51 @@ def test_batch_generated_matches_host_fed(product_lib, oracle_lib):
     assert np.max(np.abs(yg.cpu().numpy() - y)) <= 1e-12
 
 
+def test_mpc_batch_handle_matches_generated_path(product_lib):
+    """osqp_amd_batch_mpc_create / _solve (instances resident in HBM, packed rows written in place) against the
+    one-shot osqp_amd_batch_solve_generated: same kernel, same bits."""
+    total, seed = 96, 9
+    solver = batch.device_mpc_solver(product_lib, 0, **OPTS)
+    xg, yg, ig = batch.solve_mpc_sharded(solver, total, seed)
+    b = batch.MpcBatch(product_lib, total, seed, device=0, **OPTS)
+    x, y, info = batch.split_packed(b.solve())
+    assert (x == xg).all().item() and (y == yg).all().item() and (info == ig).all().item()
+    b.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mpc_batch_sharded_over_ranks_on_one_gpu(product_lib, tmp_path, world):
+    """K11 + K12 with `world` ranks sharing the test box's one GPU over the host-staged communicator (gloo): every rank
+    ends up with the whole packed array, bit-identical to the single-rank solve (instances are independent)."""
+    from test_sharded_gpu import run_ranks
+
+    total, seed = 64, 3
+    b = batch.MpcBatch(product_lib, total, seed, device=0, **OPTS)
+    ref = b.solve().cpu().numpy()
+    b.close()
+    recs = run_ranks(tmp_path, world, "host", "batch:%d:%d" % (total, seed), OPTS)
+    for r, rec in enumerate(recs):
+        assert (rec["first"], rec["per"]) == (r * (total // world), total // world) and rec["same"]
+        got = np.load(str(tmp_path / ("out.json.%d.npy" % r)))
+        assert np.array_equal(got, ref)
+    assert np.all(ref[:, 301] == 1)
+
+
+def test_batch_rejects_bad_input(product_lib, oracle_lib):
+    """The batched entry point validates like osqp_setup: bad settings -> OSQPError, indices out of range -> OSQPError."""
+    probs = _mpc_instances(oracle_lib, 0, 2, 2)
+    P0, _, A0, _, _ = probs[0]
+    Px = np.array([sp.triu(p[0]).tocsc().data for p in probs]); Ax = np.array([p[2].data for p in probs])
+    q = np.array([p[1] for p in probs]); l = np.array([p[3] for p in probs]); u = np.array([p[4] for p in probs])
+    with pytest.raises(oq.OSQPError):
+        batch.solve_batch(product_lib, P0, A0, Px, Ax, q, l, u, **dict(OPTS, alpha=2.5))
+    lbad = l.copy(); lbad[1, 3] = u[1, 3] + 1.0
+    with pytest.raises(oq.OSQPError):
+        batch.solve_batch(product_lib, P0, A0, Px, Ax, q, lbad, u, **OPTS)
+    with pytest.raises(oq.OSQPError):
+        batch.MpcBatch(product_lib, 10, 1, comm=None, **dict(OPTS, rho=-1.0))
+
+
 def test_batch_detects_infeasible_instance(product_lib, oracle_lib):
     probs = _mpc_instances(oracle_lib, 0, 4, 2)
     P0, _, A0, _, _ = probs[0]

@@ -42,7 +42,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from osqp_jl_amd import batch
 
-    x, y, info = batch.solve_mpc_sharded(oracle_solver, COUNT, SEED, rank=rank, world=world, dist=dist)
+    def gather(full, rank, per):  # in place, like the library's communicator: chunk `rank` is filled in on entry
+        dist.all_gather_into_tensor(full, full[rank * per:(rank + 1) * per].clone())
+
+    x, y, info = batch.solve_mpc_sharded(oracle_solver, COUNT, SEED, rank=rank, world=world, gather=gather)
     q.put((rank, x.numpy().copy(), y.numpy().copy(), info.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
