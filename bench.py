@@ -253,8 +253,9 @@ def replica_bench(ctx):
                  "k_spmv_sell + k_panel_reduce (wide x panels through L2, sliced-ELL tiles, y = A x)"][variant]
         pmc_names = ["k_spmv_sell", "k_panel_reduce"] if variant >= 2 else ["k_spmv"]
         which, abytes = 0, st[10]
-    else:            # direct back-end: the iteration's kernels around the forward+backward triangular solve
-        kname, which, abytes = "sptrsv forward+backward", 3, st[11]
+    else:            # direct back-end: the kernels of one iteration (right-hand side | triangular solves | update, fused as the factor allows)
+        kname, which = "direct ADMM iteration: rhs + forward | backward + update around the LDL' factor (k_direct2_fwd + k_direct2_bwd_update on a two-level factor)", 5
+        abytes = st[11] + 8.0 * (6 * n + 12 * int(oq.dimensions(model)[1]))  # trisolve bytes + the vector updates
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

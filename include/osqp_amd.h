@@ -318,7 +318,8 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 /* Time `reps` launches of one hot-path kernel with HIP events on the engine's
  * own stream; returns the mean milliseconds per launch, <0 on error.
  * which: 0 SpMV A*x, 1 SpMV A'*y, 2 SpMV P*x, 3 forward+backward trisolve,
- *        4 fused ADMM vector update, 7 one all-gather of an n-vector (sharded workspaces). */
+ *        4 fused ADMM vector update, 5 one whole ADMM iteration of the back-end in use without the residual
+ *        evaluation (advances the iterate), 7 one all-gather of an n-vector (sharded workspaces). */
 c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
 
 /* ---- Row-sharded workspaces: ONE large QP over several GPUs, indirect back-end ----

@@ -416,6 +416,7 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *w, c_int which, c_int reps) {
       case 1: spmv(e.At, yin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 2: spmv(e.Pf, xin, e.tn2.get(), nullptr, 0.0, 0.0, nullptr, s); break;
       case 7: if (!e.comm) throw Error(1, "not a sharded workspace"); e.full_n(e.tn.get()); break;
+      case 5: e.admm_step(); break;  // one whole ADMM iteration of the back-end in use (advances the iterate)
       case 4:
         admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.rho.get(), e.rho_inv.get(), e.l.get(),
                     e.u.get(), e.tn.get(), e.tm.get(), e.tm2.get(), e.tn2.get(), e.Ax.get(), s);

@@ -568,6 +568,67 @@ __global__ __launch_bounds__(kBlock) void k_direct_bwd0_update(int n, int m, dou
   }
 }
 
+// Two-level factors (every constraint row a leaf under the variable it bounds: lasso, box-constrained problems; KKT
+// systems whose fill-free elimination has height 1) need no level kernel at all -- the whole iteration is two launches:
+//   k_direct2_fwd         thread per level-1 pivot k: the right-hand sides of k and of its level-0 columns are
+//                         recomputed from (x, q, z, rho^-1, y) -- a level-0 right-hand side is never stored -- the
+//                         forward step and, level 1 being the top of the tree, the D^-1 scaling: bp[k] is final;
+//   k_direct2_bwd_update  thread per KKT index o: a level-0 pivot takes its right-hand side from the same vectors the
+//                         ADMM update reads anyway, does its backward step against the level-1 solutions and goes
+//                         straight into the update of x / z / y.
+// Same operations in the same order as k_direct_rhs_fwd1 | k_bwd_level | k_direct_bwd0_update: bit-identical iterates.
+__global__ __launch_bounds__(kBlock) void k_direct2_fwd(int n, int N, double sigma, const int *__restrict__ perm, int l1_begin,
+                                                        const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
+                                                        const double *__restrict__ Rx, const double *__restrict__ Dinv,
+                                                        const double *__restrict__ x, const double *__restrict__ q,
+                                                        const double *__restrict__ z, const double *__restrict__ rho_inv,
+                                                        const double *__restrict__ y, double *__restrict__ bp) {
+  const int k = l1_begin + blockIdx.x * kBlock + threadIdx.x;
+  if (k >= N) return;
+  double v = direct_rhs_value(perm[k], n, sigma, x, q, z, rho_inv, y);
+  double acc = 0.0;
+  for (int64_t t = Rp[k]; t < Rp[k + 1]; t++) acc += Rx[t] * direct_rhs_value(perm[Rj[t]], n, sigma, x, q, z, rho_inv, y);
+  v -= acc;
+  bp[k] = v * Dinv[k] - 0.0;
+}
+__global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, double sigma, double alpha, const int *__restrict__ pinv,
+                                                               int l1_begin, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                               const double *__restrict__ Lx, const double *__restrict__ Dinv,
+                                                               const double *__restrict__ bp, const double *__restrict__ q,
+                                                               const double *__restrict__ rho, const double *__restrict__ rho_inv,
+                                                               const double *__restrict__ l, const double *__restrict__ u,
+                                                               double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
+                                                               double *__restrict__ delta_x, double *__restrict__ delta_y) {
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n + m) return;
+  const int k = pinv[o];
+  const bool leaf = k < l1_begin;
+  double acc = 0.0, dk = 0.0;
+  if (leaf) {
+    for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) acc += Lx[t] * bp[Li[t]];
+    dk = Dinv[k];
+  }
+  if (o < n) {
+    const double xp = x[o];
+    const double sol = leaf ? (sigma * xp - q[o]) * dk - acc : bp[k];
+    const double xn = alpha * sol + (1.0 - alpha) * xp;
+    x[o] = xn;
+    delta_x[o] = xn - xp;
+  } else {
+    const int j = o - n;
+    const double zp = z[j], yj = y[j], ri = rho_inv[j];
+    const double rhs = zp - ri * yj;
+    const double sol = leaf ? rhs * dk - acc : bp[k];
+    const double zt = rhs + ri * sol;  // z~ = rhs_z + rho^-1 nu  
+    const double zh = alpha * zt + (1.0 - alpha) * zp;
+    const double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
+    z[j] = zn;
+    const double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    y[j] = yj + dy;
+  }
+}
+
 struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row inside an LDS chain  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
 
@@ -599,6 +660,14 @@ struct LdlFactor {
       Symbolic S2;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
       if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
+    }
+    // A short level schedule is launch-bound: the tie-breaking variant of the same ordering (symbolic.hpp, ordering 2)
+    // often folds it further (bound constraints: row - variable - row chains of height 2 become height 1).
+    static const bool try_fifo = !(getenv("OSQP_AMD_MD_FIFO") && atoi(getenv("OSQP_AMD_MD_FIFO")) == 0);
+    if (try_fifo && (int)S.level_ptr.size() - 1 >= 3 && (int)S.level_ptr.size() - 1 <= 400) {
+      Symbolic S3;
+      symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 2, S3);
+      if (!S3.too_large && S3.nnzL <= S.nnzL + S.nnzL / 10 && solve_cost_us(S3) < 0.9 * solve_cost_us(S)) S = std::move(S3);
     }
     hipStream_t s = e.stream;
     N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
@@ -910,6 +979,13 @@ struct LdlFactor {
     return !bwd.empty() && bwd.back().kind == 0 && bwd.back().a == 0 && bwd.back().b == S.level_ptr[1] && bwd.back().G <= 4;
   }
 
+  // the whole iteration in two launches (k_direct2_fwd / k_direct2_bwd_update): a two-level factor with short rows
+  bool can_fuse2() const {
+    if (nlev != 2 || kD != 0 || fwd.size() != 1 || bwd.size() != 2) return false;
+    if (fwd[0].kind != 0 || fwd[0].G > 4 || bwd[0].kind != 0 || bwd[1].kind != 0 || bwd[1].G > 4) return false;
+    return S.Lp[N] == S.Lp[S.level_ptr[1]];  // nothing above level 1: its backward step is the D^-1 scaling alone
+  }
+
   double trisolve_bytes() const { return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N; }
 };
 
@@ -924,6 +1000,16 @@ struct Direct : Linsys {
     const int N = e.n + e.m;
     static const bool fuse_ends = !(getenv("OSQP_AMD_FUSE_ENDS") && atoi(getenv("OSQP_AMD_FUSE_ENDS")) == 0);
     const bool f1 = fuse_ends && F->can_fuse_fwd1(), b0 = fuse_ends && F->can_fuse_bwd0();
+    static const bool fuse2 = !(getenv("OSQP_AMD_FUSE2") && atoi(getenv("OSQP_AMD_FUSE2")) == 0);
+    if (fuse_ends && fuse2 && F->can_fuse2()) {
+      const int l1 = F->S.level_ptr[1];
+      OQ_LAUNCH(k_direct2_fwd, dim3(blocks_for(N - l1)), dim3(kBlock), 0, s, e.n, N, e.st.sigma, F->perm.get(), l1, F->Rp.get(), F->Rj.get(),
+                F->Rx.get(), F->Dinv.get(), e.x.get(), e.q.get(), e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
+      OQ_LAUNCH(k_direct2_bwd_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, e.st.alpha, F->pinv.get(), l1, F->Lp.get(),
+                F->Li.get(), F->Lx.get(), F->Dinv.get(), F->bp.get(), e.q.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(),
+                e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
+      return true;
+    }
     if (f1)
       OQ_LAUNCH(k_direct_rhs_fwd1, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), F->perm.get(),
                 F->S.level_ptr[1], F->S.level_ptr[2], F->Rp.get(), F->Rj.get(), F->Rx.get(), e.x.get(), e.q.get(), e.z.get(),

@@ -160,7 +160,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipHostMalloc((void **)&h_slots, sizeof(double) * S_COUNT));
   slots.alloc(S_COUNT); slots.zero(stream);
-  partials.alloc(2 * kReduceBlocks);
+  partials.alloc(16 * kReduceBlocks);
   flag.alloc(4); flag.zero(stream);
 
   int64_t ends[2] = {0, 0};

@@ -38,7 +38,9 @@ struct Symbolic {
 // nnzL_limit / flops_limit (0 = none): stop and set too_large as soon as the factor is known to have more entries
 // than the first or a sum of squared column counts above the second (checked while the ordering runs, so that a
 // hopeless problem is handed to the indirect back-end without paying for the whole analysis).
-// ordering: 0 approximate minimum degree, 1 nested dissection by level structures (banded / chain-like graphs).
+// ordering: 0 approximate minimum degree, 1 nested dissection by level structures (banded / chain-like graphs),
+// 2 approximate minimum degree with updated nodes queued behind their equals (multiple-elimination tie-breaking:
+// flatter elimination trees on graphs with many degree-1 nodes, e.g. bound constraints).
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
                       double flops_limit, int ordering, Symbolic &out);
 
