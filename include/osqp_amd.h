@@ -399,7 +399,7 @@ c_int osqp_amd_batch_mpc_create(osqp_amd_batch **out, c_int total, unsigned long
 c_int osqp_amd_batch_mpc_solve(osqp_amd_batch *batch, c_float *packed_dev);
 c_int osqp_amd_batch_destroy(osqp_amd_batch *batch);
 
-/* Differences between the batched path and osqp_setup / osqp_solve: instances share one sparsity pattern, n <= 192,
+/* Differences between the batched path and osqp_setup / osqp_solve: instances share one sparsity pattern, n <= 128,
  * fewer than 65536 rows and non-zeros, everything must fit 160 KB of LDS; `adaptive_rho_interval` = 0 (automatic) means
  * every 100 iterations (there is no per-instance clock); `polish`, `time_limit`, `warm_start`, `verbose` and
  * `linsys_solver` are ignored (always a cold start, the reduced KKT system factorised in LDS); data and settings are

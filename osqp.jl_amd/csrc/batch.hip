@@ -1,15 +1,18 @@
 // batch.hip -- batched small-QP path (rows K11/K12 of SURVEY.md section 8a,
 // BASELINE.json config 5: 4096 independent MPC QPs, n = 100, m = 200).
 //
-// One workgroup solves one QP from start to finish with everything in LDS:
-//   * the instance's values of A (shared sparsity pattern, CSC order) and of the
-//     full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates;
-//   * the reduced KKT matrix M = P + sigma I + A' diag(rho) A (n x n, 80 KB at
-//     n = 100; the 300 x 300 KKT matrix would not fit), inverted in place by
-//     Gauss-Jordan sweeps and rebuilt whenever adaptive rho changes rho.
-// Per iteration: b = sigma x - q + A'(rho z - y); x~ = M^-1 b (dense product,
-// lane = row); z~ = A x~ consumed row by row by the x/z/y update; every `check_termination`
-// iterations the same residual / infeasibility tests as the large-problem path.
+// One workgroup solves one QP from start to finish out of LDS and registers:
+//   * LDS (~46 KB at n = 100, m = 200: three workgroups fit a CU): the instance's values of A (shared sparsity
+//     pattern, CSC order) and of the full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates;
+//   * REGISTERS: the inverse of the reduced KKT matrix M = P + sigma I + A' diag(rho) A -- thread (row i, column part c)
+//     of the 512 holds M^-1[i, c*n/4 .. (c+1)*n/4) (25 doubles at n = 100) -- and the thread's share of the entries of A
+//     in both orientations (value + index), so that an iteration's products are one LDS gather deep;
+//   * M is assembled from host-precomputed term lists through a per-instance scratch in global memory (L2-resident, written
+//     and read once per factorisation) and inverted by n Gauss-Jordan sweeps on the register tiles: a sweep is one LDS
+//     broadcast of the pivot column + one barrier + 25 fused multiply-adds per thread.
+// Per iteration: b = sigma x - q + A'(rho z - y); x~ = M^-1 b (registers x LDS broadcast); z~ = A x~ consumed row by
+// row by the x/z/y update; every `check_termination` iterations the same residual / infeasibility tests as the
+// large-problem path.
 // Same algorithm as oracle/osqp_oracle.c with the KKT system in reduced form.
 // There is no communication between instances: the multi-GPU path shards the
 // instance range over ranks and gathers the packed results once (batch.py).
@@ -43,14 +46,63 @@ struct Pattern {        // shared by all instances; device pointers
   int npair;
   const int *Tp;
   const unsigned short *Ti, *Tj, *Tr, *Ta, *Tb;
+  int max_col, max_row;             // longest column / row of A
 };
+
+// LDS pointers carry their address space in the type: a plain `double *` into LDS is a 64-bit generic pointer whose
+// accesses compile to flat_load / flat_store (the slow path into LDS, and two registers per pointer) -- with these
+// every access is a ds_read / ds_write on a 32-bit offset.
+typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) unsigned short lshort;
+typedef __attribute__((address_space(3))) int lint;
+typedef __attribute__((address_space(3))) char lchar;
 
 __device__ __forceinline__ double nmax(double a, double b) { return (a > b || a != a) ? a : b; }
 __device__ __forceinline__ double lim(double v) { v = v < B_MIN_SCALING ? 1.0 : v; return v > B_MAX_SCALING ? B_MAX_SCALING : v; }
 
+// a value every lane holds identically, moved to scalar registers (the compiler cannot see that an LDS broadcast is uniform)
+__device__ __forceinline__ double uni(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
+// Hides where a (wave-uniform) pointer comes from: address arithmetic on it cannot be hoisted out of the enclosing loop.
+// The rarely taken phases of the ADMM loop (factorisation, residual evaluation) would otherwise park dozens of
+// precomputed addresses in registers -- or spill them -- across the iterations that never use them.
+template <typename T>
+__device__ __forceinline__ T *opaque(T *p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// The same for per-thread values: the thread id as a value the optimiser cannot trace (every use site gets its own copy, so
+// nothing derived from it -- row ids, LDS addresses, predicates -- is a loop invariant worth keeping), and a register word.
+__device__ __forceinline__ int mytid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ unsigned opaque_word(unsigned w) {
+  asm volatile("" : "+v"(w));
+  return w;
+}
+
+// lane `lane` (a compile-time constant) of v, as a wave-uniform value: two v_readlane into scalar registers.  A vector of up
+// to 64 doubles that every lane of a wavefront needs (a pivot row, a right-hand side) is read from LDS ONCE -- lane l takes
+// element l -- and handed round this way: no vector registers, no further LDS traffic.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  union { double d; int i[2]; } a;
+  a.d = v;
+  a.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+  a.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+  return a.d;
+}
+
 // K simultaneous block reductions (max for op 0, sum for op 1); result broadcast to every thread
 template <int K>
-__device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
+__device__ __forceinline__ void block_reduce(double *v, int op, ldouble *red) {
 #pragma unroll
   for (int k = 0; k < K; k++) {
     double a = v[k];
@@ -59,8 +111,8 @@ __device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
     v[k] = a;
   }
   __syncthreads();
-  if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < K; k++) red[(threadIdx.x >> 6) * K + k] = v[k];
+  if ((mytid() & 63) == 0)
+    for (int k = 0; k < K; k++) red[(mytid() >> 6) * K + k] = v[k];
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -72,13 +124,13 @@ __device__ __forceinline__ void block_reduce(double *v, int op, double *red) {
 }
 
 struct Lds {
-  double *M, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv;
-  int *ctype;
-  unsigned short *Ap, *Ai, *Rp, *Rc, *Rmap, *Fp, *Fc;  // shared pattern, staged into LDS as 16-bit indices
+  ldouble *part, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv, *nrm;
+  lint *ctype;
+  lshort *Ap, *Ai, *Rp, *Rc, *Rmap, *Fp, *Fc;  // shared pattern, staged into LDS as 16-bit indices
   int ld;
 };
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (size_t)n * (n + 1) + (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW;
+  return (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW + 24;
 }
 __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
   return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
@@ -86,20 +138,21 @@ __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
 __host__ __device__ inline size_t lds_bytes(int n, int m, int nnzA, int nnzF) {
   return lds_doubles(n, m, nnzA, nnzF) * 8 + (((size_t)m * 4 + 15) / 16) * 16 + lds_shorts(n, m, nnzA, nnzF) * 2 + 16;
 }
-__device__ inline Lds carve(double *base, const Pattern &P) {
+__device__ __forceinline__ Lds carve(ldouble *base, const Pattern &P) {
   Lds s;
   const int n = P.n, m = P.m;
   s.ld = n + 1;
-  double *p = base;
-  s.M = p; p += (size_t)n * s.ld + (NT / 128) * (size_t)n;  // the array + the partial sums of the dense product
+  ldouble *p = base;
+  s.part = p; p += (NT / 128) * (size_t)n;  // the column parts of the dense product meet here
   s.Av = p; p += P.nnzA; s.Pv = p; p += P.nnzF;
   s.q = p; p += n; s.D = p; p += n; s.x = p; p += n; s.xp = p; p += n; s.xt = p; p += n; s.dx = p; p += n;
   s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n; s.ldinv = p; p += n;
   s.l = p; p += m; s.u = p; p += m; s.E = p; p += m; s.rho = p; p += m; s.rhoi = p; p += m; s.z = p; p += m; s.y = p; p += m;
   s.zp = p; p += m; s.zt = p; p += m; s.dy = p; p += m; s.Ax = p; p += m; s.tm = p; p += m;
   s.red = p; p += 16 * NW;  // NW * K doubles of block_reduce, K <= 14
-  s.ctype = (int *)p;
-  unsigned short *h = (unsigned short *)((char *)p + (((size_t)m * 4 + 15) / 16) * 16);
+  s.nrm = p; p += 24;
+  s.ctype = (lint *)p;
+  lshort *h = (lshort *)((lchar *)p + (((size_t)m * 4 + 15) / 16) * 16);
   s.Ap = h; h += n + 1; s.Fp = h; h += n + 1; s.Rp = h; h += m + 1;
   s.Ai = h; h += P.nnzA; s.Rc = h; h += P.nnzA; s.Rmap = h; h += P.nnzA; s.Fc = h;
   return s;
@@ -110,10 +163,10 @@ __device__ inline Lds carve(double *base, const Pattern &P) {
 // and add up with xor shuffles, so every thread of the workgroup reaches the shuffles whether it has a row or not.
 // finish(r, sum) runs on one lane per row.
 template <int L, typename F, typename G>
-__device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restrict__ ptr, F term, G finish) {
-  const int lane = threadIdx.x & (L - 1);
+__device__ __forceinline__ void rows_dot(int rows, const lshort *ptr, F term, G finish) {
+  const int lane = mytid() & (L - 1);
   for (int base = 0; base < rows; base += NT / L) {
-    const int r = base + threadIdx.x / L;
+    const int r = base + mytid() / L;
     double a = 0.0;
     if (r < rows)
       for (int q = ptr[r] + lane; q < ptr[r + 1]; q += L) a += term(q);
@@ -122,18 +175,12 @@ __device__ __forceinline__ void rows_dot(int rows, const unsigned short *__restr
     if (lane == 0 && r < rows) finish(r, a);
   }
 }
-__device__ __forceinline__ void mul_A(const Pattern &P, const Lds &s, const double *x, double *y) {
-  rows_dot<2>(P.m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * x[s.Rc[q]]; }, [&](int r, double a) { y[r] = a; });
-}
-__device__ __forceinline__ void mul_At(const Pattern &P, const Lds &s, const double *x, double *y) {
-  rows_dot<4>(P.n, s.Ap, [&](int k) { return s.Av[k] * x[s.Ai[k]]; }, [&](int r, double a) { y[r] = a; });
-}
-__device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const double *x, double *y) {
+__device__ __forceinline__ void mul_P(const Pattern &P, const Lds &s, const ldouble *x, ldouble *y) {
   rows_dot<4>(P.n, s.Fp, [&](int q) { return s.Pv[q] * x[s.Fc[q]]; }, [&](int r, double a) { y[r] = a; });
 }
 
-__device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classify) {
-  for (int i = threadIdx.x; i < P.m; i += NT) {
+__device__ __forceinline__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classify) {
+  for (int i = mytid(); i < P.m; i += NT) {
     int t;
     if (classify) {
       if (s.l[i] < -B_INF && s.u[i] > B_INF) t = -1;
@@ -147,176 +194,391 @@ __device__ void set_rho(const Pattern &P, const Lds &s, double rho, bool classif
   __syncthreads();
 }
 
-// M = P + sigma I + A' diag(rho) A, then M <- M^-1 in place.  Returns false if M is not positive definite.
+// ---------------------------------------------------------------------------------------------------------
+// The reduced KKT matrix and its inverse, in registers.
 //
-// The inverse is applied to thousands of right-hand sides (one per ADMM iteration) between two rho updates,
-// and a dense product M^-1 b keeps every row independent while a triangular solve is a chain of 2n dependent
-// steps; so the factorisation step is an explicit symmetric inversion by n Gauss-Jordan sweeps (Goodnight's
-// sweep operator): every sweep is one rank-1 update of the whole n x n array, spread over the workgroup, with
-// two barriers -- no serial column loop anywhere.  The pivots are the Schur complements of M, so the
+// Thread t = part * 128 + lane owns row `lane` (lanes >= n idle) and the NC = ceil(n / PARTS) columns
+// [part * NC, (part + 1) * NC) of the n x n array: Mr[u] = M[row, j0 + u].  NCT is the compile-time bound of NC.
+//
+// Why an explicit inverse: it is applied to thousands of right-hand sides (one per ADMM iteration) between two rho
+// updates, and a dense product M^-1 b keeps every row independent while a triangular solve is a chain of 2n dependent
+// steps.  Why Gauss-Jordan sweeps (Goodnight's sweep operator): one sweep is a rank-1 update of the whole array --
+// every thread updates its own registers, the only shared data is the pivot column (n doubles through LDS, one barrier,
+// double-buffered) -- no serial column loop anywhere.  The pivots are the Schur complements of M, so the
 // positive-definiteness test of the Cholesky factorisation carries over unchanged.
-__device__ bool build_and_factor(const Pattern &P, const Lds &s, double sigma) {
-  const int n = P.n, ld = s.ld;
-  // A' rho A from the pre-computed term lists (the intersections of the columns of A do not depend on the instance)
-  for (int e = threadIdx.x; e < n * ld; e += NT) s.M[e] = 0.0;
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PARTS = NT / 128;
+
+template <int NCT>
+struct MTile {
+  double v[NCT];
+};
+
+// M = P + sigma I + A' diag(rho) A: the lower triangle from the host-precomputed term lists (the intersections of the
+// columns of A do not depend on the instance), both triangles into the instance's scratch (global memory, n x ld,
+// column-major), then every thread picks up its tile.
+// Addressing rule of the three routines below: ONE base register per array (array + j0, resp. scratch + row + j0 ld)
+// and compile-time offsets u / u ld -- a column test is `u == k - j0` against the constant u.  (Written with the global
+// column j = j0 + u, the 25 column ids and 25 clamped addresses are loop invariants that the compiler precomputes
+// and then has to keep in -- or spill from -- registers across the whole ADMM loop.)  EXACT: PARTS * NCT == n, no
+// column of a tile lies outside the matrix; otherwise columns u >= ncv of the last part are masked.
+template <int NCT, bool EXACT>
+__device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, double sigma, double *__restrict__ scratch, MTile<NCT> &T) {
+  const int n = P.n, ld = n;
+  scratch = opaque(scratch);
+  for (int e = mytid(); e < n * ld; e += NT) scratch[e] = 0.0;
   __syncthreads();
-  for (int t = threadIdx.x; t < P.npair; t += NT) {
+  for (int t = mytid(); t < P.npair; t += NT) {
     double acc = 0.0;
     for (int q = P.Tp[t]; q < P.Tp[t + 1]; q++) acc += s.rho[P.Tr[q]] * s.Av[P.Ta[q]] * s.Av[P.Tb[q]];
     const int i = P.Ti[t], j = P.Tj[t];
-    s.M[i + j * ld] = acc;
-    s.M[j + i * ld] = acc;
+    scratch[i + j * ld] = acc;
+    scratch[j + i * ld] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += NT) s.M[i + i * ld] += sigma;
+  for (int i = mytid(); i < n; i += NT) scratch[i + i * ld] += sigma;
   __syncthreads();
-  for (int r = threadIdx.x; r < n; r += NT)
-    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) s.M[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
+  for (int r = mytid(); r < n; r += NT)
+    for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) scratch[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
   __syncthreads();
+  const int row = mytid() & 127, part = mytid() >> 7;
+  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
+  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
+  const bool live = row < n;
+  const double *src = scratch + (live ? row : 0) + (size_t)min(j0, n - 1) * ld;
+#pragma unroll
+  for (int u = 0; u < NCT; u++) T.v[u] = (live && (EXACT || u < ncv)) ? src[(size_t)u * ld] : 0.0;
+}
+
+// T <- (the matrix it holds)^-1.  Returns false if the matrix is not positive definite.  c0, c1: two LDS vectors of n
+// doubles (scratch: the pivot column of the current and of the next sweep), followed in LDS by at least NCT more doubles.
+template <int NCT, bool EXACT>
+__device__ __forceinline__ bool invert_tile(int n, MTile<NCT> &T, ldouble *c0, ldouble *c1) {
+  const int row = mytid() & 127, part = mytid() >> 7;
+  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
+  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
+  const bool live = row < n;
+  const int lane = mytid() & 63;
   bool ok = true;
-  // Only the lower triangle (i >= j) is swept; the rest of the array is filled in by symmetry at the end.  Thread
-  // layout: rows r and n-1-r form a pair with n+1 lower-triangle elements together, so every pair is the same
-  // amount of work: pair = tid % PAIRS_PAD, position inside the pair p = tid / PAIRS_PAD, + PS, ...
-  //   p <= r: element (r, p)          p > r: element (n-1-r, n-p)    (column independent of r: no bank conflicts)
-  const int npairs = (n + 1) >> 1;  // for odd n the middle row pairs with itself and is taken once (p <= r only)
-  constexpr int PP = 64;            // pairs handled side by side (lanes of a wavefront = consecutive pairs)
-  constexpr int PS = NT / PP;       // positions handled side by side
-  const int tr = threadIdx.x % PP, tp = threadIdx.x / PP;
-  // Two pivots per pass (a block sweep on {k, k+1}: the same result as two single sweeps, with half the passes over
-  // the array and half the barriers):  M_ij -= [c0_i c1_i] B^-1 [c0_j; c1_j],  columns k, k+1 <- [c0 c1] B^-1,
-  // pivot block <- -B^-1, with B = [a b; b c] the 2 x 2 pivot block and c0, c1 the two columns.
-  double *c0 = s.tn, *c1 = s.Px;  // scratch: Px is only live inside a residual evaluation
-  int k = 0;
-  for (; k + 1 < n; k += 2) {
-    for (int i = threadIdx.x; i < n; i += NT) {
-      c0[i] = i >= k ? s.M[i + k * ld] : s.M[k + i * ld];
-      c1[i] = i >= k + 1 ? s.M[i + (k + 1) * ld] : s.M[k + 1 + i * ld];
-    }
-    __syncthreads();
-    const double pa = c0[k], pb = c0[k + 1], pc = c1[k + 1];
-    const double det = pa * pc - pb * pb;
-    if (!(pa > 0.0) || !(det > 0.0)) ok = false;  // both pivots (a and c - b^2 / a) positive
-    const double idet = 1.0 / det;
-    for (int r = tr; r < npairs; r += PP) {
-      const int r2 = n - 1 - r;
-      const double g0a = (c0[r] * pc - c1[r] * pb) * idet, g1a = (c1[r] * pa - c0[r] * pb) * idet;
-      const double g0b = (c0[r2] * pc - c1[r2] * pb) * idet, g1b = (c1[r2] * pa - c0[r2] * pb) * idet;
-      const int last = (r2 == r) ? r : n;
-      int q = tp;
-      for (; q + 3 * PS <= last; q += 4 * PS) {  // 4 independent read-modify-writes in flight
-        int idx[4];
-        double mv[4], fv[4];
+  for (int k = 0; k < n; k++) {
+    ldouble *c = (k & 1) ? c1 : c0;
+    const int kl = k - j0;  // column k inside this tile (when 0 <= kl < ncv)
+    // Publish the pivot column.  The array stays symmetric under the sweeps, so column k is row k: the PARTS threads of
+    // row k write their tiles with compile-time register indices (extracting register kl from the tile that holds
+    // column k is a dynamic index -- the compiler parks the whole tile in scratch memory for it, every sweep).
+    if (row == k) {
+      ldouble *cw = c + j0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int qq = q + u * PS;
-          const bool first = qq <= r;
-          const int i = first ? r : r2, j = first ? qq : n - qq;
-          idx[u] = i + j * ld;
-          mv[u] = s.M[idx[u]];
-          fv[u] = (first ? g0a : g0b) * c0[j] + (first ? g1a : g1b) * c1[j];
-        }
+      for (int u = 0; u < NCT; u++) if (EXACT || u < ncv) cw[u] = T.v[u];
+    }
+    __syncthreads();  // (the buffer written two sweeps ago is free: every thread passed the barrier in between)
+    const double piv = c[k];
+    if (!(piv > 0.0)) ok = false;
+    const double ip = 1.0 / piv;
+    const double ci = live ? c[row] : 0.0;
+    const double f = ci * ip;
+    const ldouble *cb = c + j0;
+    const double mine = cb[lane < NCT ? lane : NCT - 1];  // element `lane` of this part's stretch of the pivot row
+    // the common case is one fused multiply-add per element; the pivot row (one thread per part) and the pivot column (the
+    // waves of one part) are fixed up under branches that the other wavefronts skip
+    if (row == k) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) s.M[idx[u]] = mv[u] - fv[u];
-      }
-      for (; q <= last; q += PS) {
-        const bool first = q <= r;
-        const int i = first ? r : r2, j = first ? q : n - q;
-        s.M[i + j * ld] -= (first ? g0a : g0b) * c0[j] + (first ? g1a : g1b) * c1[j];
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
-      if (i == k) {
-        s.M[k + k * ld] = -pc * idet;
-        s.M[k + 1 + k * ld] = pb * idet;
-        s.M[k + 1 + (k + 1) * ld] = -pa * idet;
-      } else if (i != k + 1) {
-        const double v0 = (c0[i] * pc - c1[i] * pb) * idet, v1 = (c1[i] * pa - c0[i] * pb) * idet;
-        if (i > k) { s.M[i + k * ld] = v0; s.M[i + (k + 1) * ld] = v1; }
-        else { s.M[k + i * ld] = v0; s.M[k + 1 + i * ld] = v1; }
-      }
-    }
-    __syncthreads();
-  }
-  for (; k < n; k++) {  // odd n: the last pivot alone
-    // column k of the symmetric matrix: below the diagonal from column k, above it from row k
-    for (int i = threadIdx.x; i < n; i += NT) s.tn[i] = i >= k ? s.M[i + k * ld] : s.M[k + i * ld];
-    __syncthreads();
-    const double d = s.tn[k];
-    if (!(d > 0.0)) ok = false;
-    const double p = 1.0 / d;
-    // rank-1 update of the lower triangle (row and column k are overwritten right after)
-    for (int r = tr; r < npairs; r += PP) {
-      const int r2 = n - 1 - r;
-      const double f1 = s.tn[r] * p, f2 = s.tn[r2] * p;
-      const int last = (r2 == r) ? r : n;  // positions 0..last
-      int q = tp;
-      for (; q + 3 * PS <= last; q += 4 * PS) {  // 4 independent read-modify-writes in flight
-        int idx[4];
-        double mv[4], fv[4];
+      for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? -ip : lane_bcast(mine, u) * ip;   // row k: M_kj / p, pivot: -1 / p
+    } else {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int qq = q + u * PS;
-          const bool first = qq <= r;
-          const int i = first ? r : r2, j = first ? qq : n - qq;
-          idx[u] = i + j * ld;
-          mv[u] = s.M[idx[u]];
-          fv[u] = (first ? f1 : f2) * s.tn[j];
-        }
+      for (int u = 0; u < NCT; u++) T.v[u] = __builtin_fma(-f, lane_bcast(mine, u), T.v[u]);  // M_ij - M_ik M_kj / p
+      if (kl >= 0 && kl < NCT) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) s.M[idx[u]] = mv[u] - fv[u];
-      }
-      for (; q <= last; q += PS) {
-        const bool first = q <= r;
-        const int i = first ? r : r2, j = first ? q : n - q;
-        s.M[i + j * ld] -= (first ? f1 : f2) * s.tn[j];
+        for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? f : T.v[u];        // column k: M_ik / p
       }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
-      const double v = (i == k) ? -p : s.tn[i] * p;
-      if (i >= k) s.M[i + k * ld] = v; else s.M[k + i * ld] = v;
-    }
-    __syncthreads();
-  }
-  // negate and mirror: M^-1 as a full array for the row-wise products of the iterations
-  for (int r = tr; r < npairs; r += PP) {
-    const int r2 = n - 1 - r;
-    const int last = (r2 == r) ? r : n;
-    for (int q = tp; q <= last; q += PS) {
-      const bool first = q <= r;
-      const int i = first ? r : r2, j = first ? q : n - q;
-      const double v = -s.M[i + j * ld];
-      s.M[i + j * ld] = v;
-      s.M[j + i * ld] = v;
+    if (!EXACT) {
+#pragma unroll
+      for (int u = 0; u < NCT; u++) T.v[u] = (u < ncv) ? T.v[u] : 0.0;
     }
   }
-  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NCT; u++) T.v[u] = -T.v[u];  // the sweeps leave -M^-1
+  __syncthreads();  // c0 / c1 are scratch of the caller again
   return ok;
 }
 
+// xt <- M^-1 xt: registers x LDS broadcast, the PARTS column parts meet in LDS
+template <int NCT, bool EXACT>
+__device__ __forceinline__ void apply_tile(int n, const MTile<NCT> &T, const Lds &s) {
+  const int row = mytid() & 127, part = mytid() >> 7;
+  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
+  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
+  const ldouble *xb = s.xt + j0;
+  const int lane = mytid() & 63;
+  const double mine = xb[lane < NCT ? lane : NCT - 1];  // one LDS read per wavefront; the elements go round by lane_bcast
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < NCT; u++) {
+    const double xj = (EXACT || u < ncv) ? lane_bcast(mine, u) : 0.0;
+    if (u & 1) a1 = __builtin_fma(T.v[u], xj, a1); else a0 = __builtin_fma(T.v[u], xj, a0);
+  }
+  if (row < n) s.part[part * n + row] = a0 + a1;
+  __syncthreads();
+  for (int i = mytid(); i < n; i += NT) {
+    double a = s.part[i];
+#pragma unroll
+    for (int q = 1; q < PARTS; q++) a += s.part[q * n + i];
+    s.xt[i] = a;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The thread's share of the pattern of A in registers, both orientations:
+//   column side (A' v):  4 lanes per column, lane l of column c walks entries Ap[c] + l, + 4, ...   (KT per lane)
+//   row side    (A v):   2 lanes per row,    lane l of row r    walks entries Rp[r] + l, + 2, ...   (KR per lane)
+// A register holds (position of the value, index of the operand): both LDS reads of an entry are independent, where the
+// walk through the pattern arrays is a chain of three dependent ones.
+// Same lane-strided order and the same xor-shuffle reduction as rows_dot<4> / rows_dot<2>: bit-identical sums.  Used
+// when the pattern fits (at most 4 KT per column, 2 KR per row, 4 n and 2 m threads); rows_dot on the LDS copy otherwise.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KT = 4, KR = 6;
+struct SparseRegs {
+  unsigned ce[KT], re[KR];  // (position in the value array) << 16 | (row resp. column index)
+  int ccnt, rcnt, col, row;  // col / row = -1: no work on that side
+};
+__device__ __forceinline__ bool sparse_fits(const Pattern &P) {
+  return 4 * P.n <= NT && 2 * P.m <= NT && P.max_col <= 4 * KT && P.max_row <= 2 * KR;
+}
+__device__ __forceinline__ void load_sparse(const Pattern &P, const Lds &s, SparseRegs &R) {
+  const int t = mytid();
+  R.col = (t >> 2) < P.n ? (t >> 2) : -1;
+  R.row = (t >> 1) < P.m ? (t >> 1) : -1;
+  R.ccnt = R.rcnt = 0;
+#pragma unroll
+  for (int e = 0; e < KT; e++) {
+    R.ce[e] = 0;
+    if (R.col >= 0) {
+      const int k = s.Ap[R.col] + (t & 3) + 4 * e;
+      if (k < s.Ap[R.col + 1]) { R.ce[e] = ((unsigned)k << 16) | s.Ai[k]; R.ccnt = e + 1; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < KR; e++) {
+    R.re[e] = 0;
+    if (R.row >= 0) {
+      const int q = s.Rp[R.row] + (t & 1) + 2 * e;
+      if (q < s.Rp[R.row + 1]) { R.re[e] = ((unsigned)s.Rmap[q] << 16) | s.Rc[q]; R.rcnt = e + 1; }
+    }
+  }
+}
+// finish(col, sum over the column of A of value * v[row]) on one lane per column; every thread reaches the shuffles
+template <typename G>
+__device__ __forceinline__ void col_dot(const SparseRegs &R, const ldouble *Av, const ldouble *v, G finish) {
+  double a = 0.0;
+#pragma unroll
+  for (int e = 0; e < KT; e++) if (e < R.ccnt) { const unsigned w = opaque_word(R.ce[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
+  a += __shfl_xor(a, 2, 64);
+  a += __shfl_xor(a, 1, 64);
+  if ((mytid() & 3) == 0 && R.col >= 0) finish(R.col, a);
+}
+template <typename G>
+__device__ __forceinline__ void row_dot(const SparseRegs &R, const ldouble *Av, const ldouble *v, G finish) {
+  double a = 0.0;
+#pragma unroll
+  for (int e = 0; e < KR; e++) if (e < R.rcnt) { const unsigned w = opaque_word(R.re[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
+  a += __shfl_xor(a, 1, 64);
+  if ((mytid() & 1) == 0 && R.row >= 0) finish(R.row, a);
+}
 
 #ifdef OQ_BATCH_PROFILE
-#define PROF_DECL long long pt0 = clock64(), pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL long long pt0 = clock64(), pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF(k) { long long pt1 = clock64(); pacc[k] += pt1 - pt0; pt0 = pt1; }
-#define PROF_PRINT if (inst == 0 && tid == 0) printf("cycles: load %lld scale %lld factor %lld rhs %lld solve %lld mulA+upd %lld check %lld rho %lld iters %d\n", pacc[0], pacc[1], pacc[2], pacc[3], pacc[4], pacc[5], pacc[6], pacc[7], iter);
+#define PROF_PRINT if (inst == 0 && tid == 0) printf("cycles: load %lld scale %lld assemble %lld invert %lld rhs %lld solve %lld mulA+upd %lld check %lld rho %lld iters %d\n", pacc[0], pacc[1], pacc[8], pacc[2], pacc[3], pacc[4], pacc[5], pacc[6], pacc[7], iter);
 #else
 #define PROF_DECL
 #define PROF(k)
 #define PROF_PRINT
 #endif
 
-__global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, int count, const double *__restrict__ Px_all,
+// ---------------------------------------------------------------------------------------------------------
+// Residual evaluation + termination tests, every `check_termination` iterations.  NOT inlined on purpose: the ADMM
+// loop holds the inverse in registers; as a separate function this phase gets its own register allocation (the call
+// saves / restores what is live around it -- once per 25 iterations) instead of dragging 100+ temporaries into the
+// allocation of the hot loop.  Everything it needs is in LDS (products walk the LDS copy of A); results go back through
+// the nrm[] block: the 14 norms (Slot order of the large-problem path), then pri_res, dua_res, obj and the status code
+// (0: keep iterating).
+// ---------------------------------------------------------------------------------------------------------
+enum { N_PRI = 14, N_DUA = 15, N_OBJ = 16, N_STATUS = 17, N_COUNT = 24 };
+struct CheckArgs {
+  int n, m, nnzA, nnzF, swapped, uns, passes, last;
+  double ea, er, epi, edi, c, cinv;
+};
+extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+
+// K values per thread -> K block results in out[0..K) (max for op 0, sum for op 1); two barriers, a few registers
+template <int K>
+__device__ __forceinline__ void block_reduce_to(double *v, int op, ldouble *red, ldouble *out) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double b = __shfl_xor(a, o, 64); a = op ? a + b : nmax(a, b); }
+    v[k] = a;
+  }
+  __syncthreads();
+  const int t = mytid();
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) red[(t >> 6) * K + k] = v[k];
+  }
+  __syncthreads();
+  if (t < K) {
+    double a = red[t];
+#pragma unroll 1
+    for (int w = 1; w < NW; w++) a = op ? a + red[w * K + t] : nmax(a, red[w * K + t]);
+    out[t] = a;
+  }
+  __syncthreads();
+}
+
+template <int CN, int CM, int CA, int CF>
+__device__ __noinline__ void residual_phase(CheckArgs a) {
+  Pattern P;
+  P.n = CN ? CN : a.n; P.m = CN ? CM : a.m; P.nnzA = CN ? CA : a.nnzA; P.nnzF = CN ? CF : a.nnzF;
+  const Lds s = carve((ldouble *)lds_raw, P);
+  const int n = P.n, m = P.m, tid = mytid();
+  ldouble *x = a.swapped ? s.xp : s.x, *z = a.swapped ? s.zp : s.z;
+  ldouble *nrm = s.nrm, *tmp = s.nrm + 18;  // tmp: 6 scratch results of the small reductions
+  const bool uns = a.uns;
+  const double c = a.c, cinv = a.cinv;
+  auto a_rows = [&](const ldouble *v, auto finish) {
+    rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * v[s.Rc[q]]; }, finish);
+  };
+  auto a_cols = [&](const ldouble *v, auto finish) {
+    rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * v[s.Ai[k]]; }, finish);
+  };
+  // ---- residual evaluation (K8): nrm[0..14), pri_res, dua_res, obj ----
+  {
+    a_rows(x, [&](int r, double v) { s.Ax[r] = v; });
+    mul_P(P, s, x, s.Px);
+    a_cols(s.y, [&](int j, double v) { s.Aty[j] = v; });
+    __syncthreads();
+    double v[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) v[k] = 0.0;
+    double sm[2] = {0.0, 0.0};
+    for (int i = tid; i < m; i += NT) {
+      double ax = s.Ax[i], zi = z[i], e = 1.0 / s.E[i], r = ax - zi;
+      v[0] = nmax(v[0], fabs(r)); v[1] = nmax(v[1], fabs(e * r)); v[2] = nmax(v[2], fabs(zi)); v[3] = nmax(v[3], fabs(ax));
+      v[4] = nmax(v[4], fabs(e * zi)); v[5] = nmax(v[5], fabs(e * ax));
+    }
+    for (int j = tid; j < n; j += NT) {
+      double px = s.Px[j], qj = s.q[j], at = s.Aty[j], d = 1.0 / s.D[j], xj = x[j], r = (qj + px) + at;
+      v[6] = nmax(v[6], fabs(r)); v[7] = nmax(v[7], fabs(d * r)); v[8] = nmax(v[8], fabs(qj)); v[9] = nmax(v[9], fabs(at));
+      v[10] = nmax(v[10], fabs(px)); v[11] = nmax(v[11], fabs(d * qj)); v[12] = nmax(v[12], fabs(d * at)); v[13] = nmax(v[13], fabs(d * px));
+      sm[0] += xj * px; sm[1] += qj * xj;
+    }
+    block_reduce_to<14>(v, 0, s.red, nrm);
+    block_reduce_to<2>(sm, 1, s.red, tmp);
+    if (tid == 0) {
+      nrm[N_PRI] = m == 0 ? 0.0 : (uns ? nrm[1] : nrm[0]);
+      nrm[N_DUA] = uns ? cinv * nrm[7] : nrm[6];
+      nrm[N_OBJ] = cinv * (0.5 * tmp[0] + tmp[1]);
+      nrm[N_STATUS] = 0.0;
+    }
+    __syncthreads();
+  }
+  const double pri_res = nrm[N_PRI], dua_res = nrm[N_DUA];
+  // ---- termination tests: the requested accuracy when a check is due or the iteration limit is reached,
+  //      then -- at the limit only -- the 10x-relaxed ones ----
+  int status = 0;
+  for (int pass = 0; pass < a.passes && status == 0; pass++) {
+    const bool approx = pass == 1;
+    double ea = a.ea, er = a.er, epi = a.epi, edi = a.edi;
+    if (!(pri_res <= OSQP_INFTY) || !(dua_res <= OSQP_INFTY)) { status = OSQP_NON_CVX; break; }
+    if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+    bool pc = false, dc = false, pinf = false, dinf = false;
+    if (m == 0) pc = true;
+    else {
+      double eps_p = ea + er * (uns ? nmax(nrm[4], nrm[5]) : nmax(nrm[2], nrm[3]));
+      if (pri_res < eps_p) pc = true;
+      else {  // primal infeasibility on delta_y
+        double v[1] = {0.0}, sm[1] = {0.0};
+        for (int i = tid; i < m; i += NT) {
+          double d = s.dy[i];
+          if (s.u[i] > B_INF) { if (s.l[i] < -B_INF) d = 0.0; else d = fmin(d, 0.0); }
+          else if (s.l[i] < -B_INF) d = fmax(d, 0.0);
+          s.dy[i] = d;
+          v[0] = nmax(v[0], fabs(uns ? s.E[i] * d : d));
+          sm[0] += s.u[i] * fmax(d, 0.0) + s.l[i] * fmin(d, 0.0);
+        }
+        block_reduce_to<1>(v, 0, s.red, tmp);
+        block_reduce_to<1>(sm, 1, s.red, tmp + 1);
+        const double nv = tmp[0], lhs = tmp[1];
+        if (nv > epi && lhs < -epi * nv) {
+          a_cols(s.dy, [&](int j, double t) { s.tn[j] = t; });
+          __syncthreads();
+          double w[1] = {0.0};
+          for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
+          block_reduce_to<1>(w, 0, s.red, tmp + 2);
+          pinf = tmp[2] < epi * nv;
+        }
+      }
+    }
+    double eps_d = ea + er * (uns ? cinv * nmax(nrm[11], nmax(nrm[12], nrm[13])) : nmax(nrm[8], nmax(nrm[9], nrm[10])));
+    if (dua_res < eps_d) dc = true;
+    else {  // dual infeasibility on delta_x
+      double v[1] = {0.0}, sm[1] = {0.0};
+      for (int j = tid; j < n; j += NT) { v[0] = nmax(v[0], fabs(uns ? s.D[j] * s.dx[j] : s.dx[j])); sm[0] += s.q[j] * s.dx[j]; }
+      block_reduce_to<1>(v, 0, s.red, tmp + 3);
+      block_reduce_to<1>(sm, 1, s.red, tmp + 4);
+      const double nv = tmp[3], qdx = tmp[4];
+      double cs = uns ? c : 1.0;
+      if (nv > edi && qdx < -cs * edi * nv) {
+        mul_P(P, s, s.dx, s.tn);
+        __syncthreads();
+        double w[1] = {0.0};
+        for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
+        block_reduce_to<1>(w, 0, s.red, tmp + 5);
+        if (tmp[5] < cs * edi * nv) {
+          a_rows(s.dx, [&](int r, double t) { s.tm[r] = t; });
+          __syncthreads();
+          double bad[1] = {0.0};
+          for (int i = tid; i < m; i += NT) {
+            double t = uns ? s.tm[i] / s.E[i] : s.tm[i];
+            if ((s.u[i] < B_INF && t > edi * nv) || (s.l[i] > -B_INF && t < -edi * nv) || t != t) bad[0] = 1.0;
+          }
+          block_reduce_to<1>(bad, 0, s.red, tmp + 5);
+          dinf = tmp[5] == 0.0;
+        }
+      }
+    }
+    if (pc && dc) status = approx ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED;
+    else if (pinf) status = approx ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE;
+    else if (dinf) status = approx ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE;
+  }
+  if (a.last && a.passes && status == 0) status = OSQP_MAX_ITER_REACHED;
+  __syncthreads();
+  if (tid == 0) nrm[N_STATUS] = (double)status;
+  __syncthreads();
+}
+
+
+// CN > 0: the instance shape (n, m, nnz(A), nnz(P full)) = (CN, CM, CA, CF) is known at compile time -- every LDS address
+// becomes an immediate and every vector loop a fixed trip count (the registers otherwise spent on ~35 LDS pointers are
+// what the inverse needs); CN = 0: the same source with the shape read from the pattern at run time.
+template <int NCT, int CN, int CM, int CA, int CF>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_batch_solve(Pattern Pin, OSQPSettings st, int count, double *__restrict__ scratch_all,
+                                                    const double *__restrict__ Px_all,
                                                     const double *__restrict__ Ax_all, const double *__restrict__ q_all,
                                                     const double *__restrict__ l_all, const double *__restrict__ u_all,
                                                     double *__restrict__ x_out, double *__restrict__ y_out,
                                                     double *__restrict__ info_out, int x_stride, int y_stride, int info_stride,
                                                     int info_cols) {
-  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   const int inst = blockIdx.x;
   if (inst >= count) return;
-  const int n = P.n, m = P.m, tid = threadIdx.x;
-  Lds s = carve(lds_raw, P);
+  Pattern P = Pin;
+  if (CN > 0) { P.n = CN; P.m = CM; P.nnzA = CA; P.nnzF = CF; }
+  constexpr bool EXACT = CN > 0 && PARTS * NCT == CN;
+  const int n = P.n, m = P.m, tid = mytid();
+  Lds s = carve((ldouble *)lds_raw, P);
   PROF_DECL
   // ---- stage the shared pattern (16-bit) and load the instance -----------------
   for (int k = tid; k <= n; k += NT) { s.Ap[k] = (unsigned short)P.Ap[k]; s.Fp[k] = (unsigned short)P.Fp[k]; }
@@ -382,186 +644,110 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
   __syncthreads();
   PROF(1)
   // ---- K1, K2 ----------------------------------------------------------------
-  double rho = fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX);
+  double rho = uni(fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX));
   set_rho(P, s, rho, true);
   int status = OSQP_UNSOLVED;
-  if (!build_and_factor(P, s, st.sigma)) status = OSQP_NON_CVX;
+  double *scratch = scratch_all + (size_t)inst * n * n;
+  MTile<NCT> Minv;
+  ldouble *gj0 = s.tn, *gj1 = s.Px;  // scratch of the sweeps: Px is only live inside a residual evaluation
+  // the thread's share of the entries of A, both orientations (positions and indices in registers, values from LDS)
+  const bool regs = sparse_fits(P);
+  SparseRegs R;
+  if (regs) load_sparse(P, s, R);
+  // y = A v / y = A' v through whichever walk of A applies
+  auto a_rows = [&](const ldouble *v, auto finish) {
+    if (regs) row_dot(R, s.Av, v, finish);
+    else rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * v[s.Rc[q]]; }, finish);
+  };
+  auto a_cols = [&](const ldouble *v, auto finish) {
+    if (regs) col_dot(R, s.Av, v, finish);
+    else rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * v[s.Ai[k]]; }, finish);
+  };
   PROF(2)
   const bool uns = st.scaling && !st.scaled_termination;
   const int check = (int)st.check_termination;
   const int rho_interval = st.adaptive_rho ? (st.adaptive_rho_interval ? (int)st.adaptive_rho_interval : 100) : 0;
   const double alpha = st.alpha, sigma = st.sigma;
   double pri_res = 0.0, dua_res = 0.0, obj = 0.0;
-  double nrm[14];
+  ldouble *nrm = s.nrm;  // the 14 norms of the last residual evaluation (the same in every thread: kept in LDS, not in registers)
   int iter = 0, rho_updates = 0;
-  bool checked_last = false;
-  double *x = s.x, *xp = s.xp, *z = s.z, *zp = s.zp;
+  ldouble *x = s.x, *xp = s.xp, *z = s.z, *zp = s.zp;
 
-  // residual evaluation (K8): fills nrm[], pri_res, dua_res, obj
-  auto update_info = [&]() {
-    mul_A(P, s, x, s.Ax); mul_P(P, s, x, s.Px); mul_At(P, s, s.y, s.Aty);
-    __syncthreads();
-    double v[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) v[k] = 0.0;
-    double sm[2] = {0.0, 0.0};
-    for (int i = tid; i < m; i += NT) {
-      double ax = s.Ax[i], zi = z[i], e = 1.0 / s.E[i], r = ax - zi;
-      v[0] = nmax(v[0], fabs(r)); v[1] = nmax(v[1], fabs(e * r)); v[2] = nmax(v[2], fabs(zi)); v[3] = nmax(v[3], fabs(ax));
-      v[4] = nmax(v[4], fabs(e * zi)); v[5] = nmax(v[5], fabs(e * ax));
-    }
-    for (int j = tid; j < n; j += NT) {
-      double px = s.Px[j], qj = s.q[j], at = s.Aty[j], d = 1.0 / s.D[j], xj = x[j], r = (qj + px) + at;
-      v[6] = nmax(v[6], fabs(r)); v[7] = nmax(v[7], fabs(d * r)); v[8] = nmax(v[8], fabs(qj)); v[9] = nmax(v[9], fabs(at));
-      v[10] = nmax(v[10], fabs(px)); v[11] = nmax(v[11], fabs(d * qj)); v[12] = nmax(v[12], fabs(d * at)); v[13] = nmax(v[13], fabs(d * px));
-      sm[0] += xj * px; sm[1] += qj * xj;
-    }
-    block_reduce<14>(v, 0, s.red);
-    block_reduce<2>(sm, 1, s.red);
-#pragma unroll
-    for (int k = 0; k < 14; k++) nrm[k] = v[k];
-    pri_res = m == 0 ? 0.0 : (uns ? v[1] : v[0]);
-    dua_res = uns ? cinv * v[7] : v[6];
-    obj = cinv * (0.5 * sm[0] + sm[1]);
-  };
-  // termination tests; returns true when a status was set
-  auto check_termination = [&](bool approx) -> bool {
-    double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
-    if (!(pri_res <= OSQP_INFTY) || !(dua_res <= OSQP_INFTY)) { status = OSQP_NON_CVX; return true; }
-    if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
-    bool pc = false, dc = false, pinf = false, dinf = false;
-    if (m == 0) pc = true;
-    else {
-      double eps_p = ea + er * (uns ? nmax(nrm[4], nrm[5]) : nmax(nrm[2], nrm[3]));
-      if (pri_res < eps_p) pc = true;
-      else {  // primal infeasibility on delta_y
-        double v[1] = {0.0}, sm[1] = {0.0};
-        for (int i = tid; i < m; i += NT) {
-          double d = s.dy[i];
-          if (s.u[i] > B_INF) { if (s.l[i] < -B_INF) d = 0.0; else d = fmin(d, 0.0); }
-          else if (s.l[i] < -B_INF) d = fmax(d, 0.0);
-          s.dy[i] = d;
-          v[0] = nmax(v[0], fabs(uns ? s.E[i] * d : d));
-          sm[0] += s.u[i] * fmax(d, 0.0) + s.l[i] * fmin(d, 0.0);
-        }
-        block_reduce<1>(v, 0, s.red);
-        block_reduce<1>(sm, 1, s.red);
-        if (v[0] > epi && sm[0] < -epi * v[0]) {
-          mul_At(P, s, s.dy, s.tn);
-          __syncthreads();
-          double w[1] = {0.0};
-          for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
-          block_reduce<1>(w, 0, s.red);
-          pinf = w[0] < epi * v[0];
-        }
-      }
-    }
-    double eps_d = ea + er * (uns ? cinv * nmax(nrm[11], nmax(nrm[12], nrm[13])) : nmax(nrm[8], nmax(nrm[9], nrm[10])));
-    if (dua_res < eps_d) dc = true;
-    else {  // dual infeasibility on delta_x
-      double v[1] = {0.0}, sm[1] = {0.0};
-      for (int j = tid; j < n; j += NT) { v[0] = nmax(v[0], fabs(uns ? s.D[j] * s.dx[j] : s.dx[j])); sm[0] += s.q[j] * s.dx[j]; }
-      block_reduce<1>(v, 0, s.red);
-      block_reduce<1>(sm, 1, s.red);
-      double cs = uns ? c : 1.0;
-      if (v[0] > edi && sm[0] < -cs * edi * v[0]) {
-        mul_P(P, s, s.dx, s.tn);
-        __syncthreads();
-        double w[1] = {0.0};
-        for (int j = tid; j < n; j += NT) w[0] = nmax(w[0], fabs(uns ? s.tn[j] / s.D[j] : s.tn[j]));
-        block_reduce<1>(w, 0, s.red);
-        if (w[0] < cs * edi * v[0]) {
-          mul_A(P, s, s.dx, s.tm);
-          __syncthreads();
-          double bad[1] = {0.0};
-          for (int i = tid; i < m; i += NT) {
-            double a = uns ? s.tm[i] / s.E[i] : s.tm[i];
-            if ((s.u[i] < B_INF && a > edi * v[0]) || (s.l[i] > -B_INF && a < -edi * v[0]) || a != a) bad[0] = 1.0;
-          }
-          block_reduce<1>(bad, 0, s.red);
-          dinf = bad[0] == 0.0;
-        }
-      }
-    }
-    if (pc && dc) { status = approx ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED; return true; }
-    if (pinf) { status = approx ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE; return true; }
-    if (dinf) { status = approx ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE; return true; }
-    return false;
-  };
-
+  // Every phase below appears ONCE in the code (the loop is arranged around that): the kernel is one long function
+  // whose register allocation has to hold the inverse (2 NCT registers) across all of it.
   // ---- ADMM loop --------------------------------------------------------------
-  if (status == OSQP_UNSOLVED) {
-    const int max_iter = (int)st.max_iter;
-    for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];
+  const int max_iter = (int)st.max_iter;
+  bool need_factor = true;
+  for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];
+  __syncthreads();
+  for (iter = 1; iter <= max_iter; iter++) {
+    const int tid = mytid();  // shadows the outer one: nothing derived from the thread id outlives an iteration
+    if (need_factor) {  // first iteration and after every rho update
+      assemble_tile<NCT, EXACT>(P, s, st.sigma, scratch, Minv);
+      PROF(8)
+      if (!invert_tile<NCT, EXACT>(n, Minv, gj0, gj1)) { status = OSQP_NON_CVX; iter--; break; }
+      need_factor = false;
+      PROF(2)
+    }
+    { ldouble *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
+    // b = sigma x_prev - q + A'(rho z_prev - y); s.zt = rho z_prev - y was left behind by the previous z / y update
+    a_cols(s.zt, [&](int j, double a) { s.xt[j] = sigma * xp[j] - s.q[j] + a; });
     __syncthreads();
-    for (iter = 1; iter <= max_iter; iter++) {
-      { double *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
-      // b = sigma x_prev - q + A'(rho z_prev - y); s.zt = rho z_prev - y was left behind by the previous z / y update
-      rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * s.zt[s.Ai[k]]; },
-                  [&](int j, double a) { s.xt[j] = sigma * xp[j] - s.q[j] + a; });
-      __syncthreads();
-      PROF(3)
-      // x~ = M^-1 b: lane = row (consecutive lanes read consecutive LDS words: no bank conflicts, b[j] is a broadcast),
-      // the columns cut into NT / 128 parts whose partial sums meet in LDS
-      {
-        constexpr int PARTS = NT / 128;
-        const int part = tid >> 7;
-        const int qn = (n + PARTS - 1) / PARTS;
-        const int j0 = part * qn, j1 = (j0 + qn < n) ? j0 + qn : n;
-        double *partial = s.M + (size_t)n * s.ld;  // PARTS * n doubles behind the array (see lds_doubles)
-        for (int row = tid & 127; row < n; row += 128) {
-          double a0 = 0.0, a1 = 0.0;
-          int j = j0;
-          for (; j + 1 < j1; j += 2) { a0 += s.M[row + j * s.ld] * s.xt[j]; a1 += s.M[row + (j + 1) * s.ld] * s.xt[j + 1]; }
-          if (j < j1) a0 += s.M[row + j * s.ld] * s.xt[j];
-          partial[part * n + row] = a0 + a1;
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) {
-          double a = partial[i];
-#pragma unroll
-          for (int q = 1; q < PARTS; q++) a += partial[q * n + i];
-          s.xt[i] = a;
-        }
-        __syncthreads();
-      }
-      PROF(4)
-      // z~ = A x~ row by row, each row finished on the spot: z, y, delta_y and s.zt = rho z - y for the next right-hand side
-      rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * s.xt[s.Rc[q]]; }, [&](int i, double zt) {
-        const double zh = alpha * zt + (1.0 - alpha) * zp[i];
-        const double yo = s.y[i];
-        const double zn = fmin(fmax(zh + s.rhoi[i] * yo, s.l[i]), s.u[i]);
-        z[i] = zn;
-        const double d = s.rho[i] * (zh - zn);
-        s.dy[i] = d; s.y[i] = yo + d;
-        s.zt[i] = s.rho[i] * zn - (yo + d);
-      });
-      for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
-      __syncthreads();
-      PROF(5)
-      checked_last = check && (iter % check == 0);
-      if (checked_last) { update_info(); if (check_termination(false)) break; }
-      PROF(6)
-      if (rho_interval && (iter % rho_interval == 0)) {
-        if (!checked_last) update_info();
-        double pr = m == 0 ? 0.0 : nrm[0] / (nmax(nrm[2], nrm[3]) + 1e-10);
-        double du = nrm[6] / (nmax(nmax(nrm[8], nrm[9]), nrm[10]) + 1e-10);
-        double est = fmin(fmax(rho * sqrt(pr / (du + 1e-10)), B_RHO_MIN), B_RHO_MAX);
-        if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
-          rho = est; rho_updates++;
-          set_rho(P, s, rho, false);
-          for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];  // the carried vector follows rho
-          if (!build_and_factor(P, s, st.sigma)) { status = OSQP_NON_CVX; break; }
-        }
-      }
-      PROF(7)
+    PROF(3)
+    // x~ = M^-1 b: the thread's tile of the inverse against b from LDS (every lane of a wavefront reads the same word:
+    // a broadcast), the column parts meet in LDS
+    apply_tile<NCT, EXACT>(n, Minv, s);
+    PROF(4)
+    // z~ = A x~ row by row, each row finished on the spot: z, y, delta_y and s.zt = rho z - y for the next right-hand side
+    a_rows(s.xt, [&](int i, double zt) {
+      const double zh = alpha * zt + (1.0 - alpha) * zp[i];
+      const double yo = s.y[i];
+      const double zn = fmin(fmax(zh + s.rhoi[i] * yo, s.l[i]), s.u[i]);
+      z[i] = zn;
+      const double d = s.rho[i] * (zh - zn);
+      s.dy[i] = d; s.y[i] = yo + d;
+      s.zt[i] = s.rho[i] * zn - (yo + d);
+    });
+    for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
+    __syncthreads();
+    PROF(5)
+    const bool last = iter == max_iter;
+    const bool due = check && (iter % check == 0);
+    const bool rho_due = rho_interval && (iter % rho_interval == 0);
+    if (!(due || rho_due || last)) continue;
+
+    // ---- residual evaluation (K8) and termination tests: a call, not inlined (see residual_phase) ----
+    {
+      CheckArgs ca;
+      ca.n = n; ca.m = m; ca.nnzA = P.nnzA; ca.nnzF = P.nnzF;
+      ca.swapped = (x != s.x); ca.uns = uns; ca.passes = (due || last) ? (last ? 2 : 1) : 0; ca.last = last;
+      ca.ea = st.eps_abs; ca.er = st.eps_rel; ca.epi = st.eps_prim_inf; ca.edi = st.eps_dual_inf; ca.c = c; ca.cinv = cinv;
+      residual_phase<CN, CM, CA, CF>(ca);
     }
-    if (status == OSQP_UNSOLVED) {  // max_iter reached: last residual evaluation, then the 10x-relaxed tests
-      iter = max_iter;
-      if (!checked_last) { update_info(); check_termination(false); }
-      if (status == OSQP_UNSOLVED && !check_termination(true)) status = OSQP_MAX_ITER_REACHED;
+    bool done = false;
+    {
+      const int code = (int)nrm[N_STATUS];
+      if (code != 0) { status = code; done = true; }
+      pri_res = uni(nrm[N_PRI]); dua_res = uni(nrm[N_DUA]); obj = uni(nrm[N_OBJ]);
     }
+    PROF(6)
+    if (done) break;
+    // ---- adaptive rho ----
+    if (rho_due) {
+      double pr = m == 0 ? 0.0 : nrm[0] / (nmax(nrm[2], nrm[3]) + 1e-10);
+      double du = nrm[6] / (nmax(nmax(nrm[8], nrm[9]), nrm[10]) + 1e-10);
+      double est = uni(fmin(fmax(rho * sqrt(pr / (du + 1e-10)), B_RHO_MIN), B_RHO_MAX));
+      if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
+        rho = est; rho_updates++;
+        set_rho(P, s, rho, false);
+        for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];  // the carried vector follows rho
+        __syncthreads();
+        need_factor = true;  // picked up at the top of the next iteration
+      }
+    }
+    PROF(7)
   }
+  if (iter > max_iter) iter = max_iter;
   PROF_PRINT
   // ---- store -----------------------------------------------------
   const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
@@ -580,11 +766,12 @@ __global__ __launch_bounds__(NT) void k_batch_solve(Pattern P, OSQPSettings st, 
 // shared sparsity pattern.
 // ---------------------------------------------------------------------------
 constexpr int NX = 6, NU = 4, TT = 10, NS = NX + NU, MPC_N = NS * TT, MPC_M = NX * TT + MPC_N + NU * TT;
-__host__ __device__ inline int mpc_nnzA() {
+__host__ __device__ constexpr int mpc_nnzA() {
   int c = 0;
   for (int t = 0; t < TT; t++) c += NX * (2 + (t + 1 < TT ? NX : 0)) + NU * (NX + 2 + (t + 1 < TT ? 1 : 0));
   return c;
 }
+constexpr int kMpcNnzA = mpc_nnzA();
 __host__ __device__ inline void mpc_fill(long long inst, unsigned long long seed, int *Ap, int *Ai, double *Ax, double *Pd,
                                          double *q, double *l, double *u) {
   const int row_box = NX * TT, row_rate = NX * TT + MPC_N;
@@ -649,6 +836,7 @@ struct DevicePattern {
   Pattern P;
   DevBuf<int> Ap, Ai, Rp, Rc, Rmap, Fp, Fc, Fmap, Tp;
   DevBuf<unsigned short> Ti, Tj, Tr, Ta, Tb;
+  mutable DevBuf<double> scratch;  // [instances x n x n]: where a workgroup assembles its reduced KKT matrix (launch_batch sizes it)
   void build(int n, int m, const std::vector<int> &hPp, const std::vector<int> &hPi, const std::vector<int> &hAp,
              const std::vector<int> &hAi, hipStream_t s) {
     const int nnzA = hAp[n], nnzP = hPp[n];
@@ -692,8 +880,11 @@ struct DevicePattern {
     auto up16 = [&](DevBuf<unsigned short> &d, const std::vector<unsigned short> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
     up(Tp, tp); up16(Ti, ti); up16(Tj, tj); up16(Tr, tr); up16(Ta, ta); up16(Tb, tb);
     HIP_CHECK(hipStreamSynchronize(s));
+    int max_col = 0, max_row = 0;
+    for (int j = 0; j < n; j++) max_col = std::max(max_col, hAp[j + 1] - hAp[j]);
+    for (int i = 0; i < m; i++) max_row = std::max(max_row, rp[i + 1] - rp[i]);
     P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get(),
-                (int)ti.size(), Tp.get(), Ti.get(), Tj.get(), Tr.get(), Ta.get(), Tb.get()};
+                (int)ti.size(), Tp.get(), Ti.get(), Tj.get(), Tr.get(), Ta.get(), Tb.get(), max_col, max_row};
   }
 };
 
@@ -703,11 +894,23 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
                   int info_cols, hipStream_t s) {
   const Pattern &P = dp.P;
   size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF);
-  if (P.n > 192 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 192 and fewer than 65536 rows / non-zeros");
+  if (P.n > 128 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 128 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
-  HIP_CHECK(hipFuncSetAttribute((const void *)k_batch_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  OQ_LAUNCH(k_batch_solve, dim3(count), dim3(NT), bytes, s, P, st, count, Px, Ax, q, l, u, x, y, info, x_stride, y_stride, info_stride,
-            info_cols);
+  const size_t need = (size_t)count * P.n * P.n;
+  if (dp.scratch.n < need) { HIP_CHECK(hipStreamSynchronize(s)); dp.scratch.alloc(need); }
+  const int nc = (P.n + PARTS - 1) / PARTS;  // columns of the inverse per thread: the register tile is sized at compile time
+#define OQ_BATCH_LAUNCH(...)                                                                                                          \
+  do {                                                                                                                                 \
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_batch_solve<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));  \
+    OQ_LAUNCH((k_batch_solve<__VA_ARGS__>), dim3(count), dim3(NT), bytes, s, P, st, count, dp.scratch.get(), Px, Ax, q, l, u, x, y, info, \
+              x_stride, y_stride, info_stride, info_cols);                                                                             \
+  } while (0)
+  // shapes compiled in (same source, constants folded): the MPC family of BASELINE.json config 5
+  if (P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N);
+  else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0);
+  else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0);
+  else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0);
+#undef OQ_BATCH_LAUNCH
 }
 
 // A batch of MPC instances resident in HBM, cut into contiguous equal blocks over the ranks of a communicator
@@ -737,8 +940,8 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
     // the same checks osqp_setup makes [REF src/interface.jl:47-100 + the C side's validate_data / validate_settings]
     if (count <= 0 || n <= 0 || m < 0 || !Pp || !Pi || !Ap || !Ai || !q_all || (m > 0 && (!l_all || !u_all))) { set_last_error("invalid batch data"); return 1; }
     if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
-    if (n > 192 || m > 65535 || Pp[0] != 0 || Ap[0] != 0 || Pp[n] < 0 || Ap[n] < 0 || Pp[n] > 65535 || Ap[n] > 65535) {
-      set_last_error("the batched path supports n <= 192 and fewer than 65536 rows / non-zeros"); return 1;
+    if (n > 128 || m > 65535 || Pp[0] != 0 || Ap[0] != 0 || Pp[n] < 0 || Ap[n] < 0 || Pp[n] > 65535 || Ap[n] > 65535) {
+      set_last_error("the batched path supports n <= 128 and fewer than 65536 rows / non-zeros"); return 1;
     }
     for (c_int j = 0; j < n; j++) {
       if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) { set_last_error("column pointers must not decrease"); return 1; }
