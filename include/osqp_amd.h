@@ -310,7 +310,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 12 SpMV kernel used for A: 0 CSR (k_spmv), 2 LDS-staged column panels with sliced-ELL tiles (k_spmv_sell),
  *    3 the same tiles over wide panels gathered through L2 (n >> 1e6 at fixed nnz)
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
- * 16, 17 rows of the local blocks (n, m)
+ * 16, 17 rows of the local blocks (n, m)          18 compact mode (CSR column / value arrays released) 0 / 1
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);

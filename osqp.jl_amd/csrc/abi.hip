@@ -395,6 +395,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[15] = e.comm ? e.comm->bytes : 0.0;
   v[16] = (c_float)e.n;  // local block sizes
   v[17] = (c_float)e.m;
+  v[18] = e.compact ? 1.0 : 0.0;
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

@@ -123,6 +123,7 @@ struct DevCsr {
   DevBuf<int> col;
   DevBuf<double> val;
   DevPanel panel;
+  bool compact = false;  // col / val released: the sliced-ELL copy in `panel` is the only one (panel.hip, compact mode)
   int group = 64;  // lanes per row chosen for the SpMV kernel (1..64)
   double spmv_bytes() const {  // algorithmic bytes of one y = M x
     return 12.0 * (double)nnz + 4.0 * ((double)rows + 1.0) + 8.0 * ((double)rows + (double)cols);

@@ -1106,6 +1106,7 @@ __global__ __launch_bounds__(kBlock) void k_normal_cone(int m, double *__restric
 }
 
 int polish_run(Engine &e) {
+  if (e.compact) return -1;  // the reduced KKT system is assembled from the CSR arrays, which a compact workspace has released
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;
   OSQPInfo *info = e.ws->info;

@@ -233,6 +233,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   if (const char *e = getenv("OSQP_AMD_PCG_LAMBDA")) lambda0 = atof(e);
   lambda = lambda0;
   select_linsys();
+  compact_matrices();
   sync();
 }
 
@@ -317,10 +318,50 @@ void Engine::scale_data() {
 // LDS-staged panel copies of the matrices whose x vector does not fit the caches (panel.hip)
 void Engine::refresh_panels() {
   for (DevCsr *M : {&A, &At, &Pf}) {
-    if (M->rows == 0 || M->nnz == 0) continue;
+    if (M->rows == 0 || M->nnz == 0 || M->compact) continue;  // compact: the values were changed in place
     if (M->panel.active) panel_fill(*M, false, stream);
     else if (panel_wanted(*M)) panel_build(*M, stream);
   }
+}
+
+// Large problems on the indirect back-end: once the sliced-ELL copies exist, the CSR column / value arrays of A, A' and P
+// (12 B per stored entry, 36 GB of the 79 GB of rand-1e6) are only ever read by maintenance passes -- Ruiz scaling
+// inside osqp_update_P / _A, the Jacobi diagonal after a rho update, value updates by nnz index.  Those walk the slices
+// instead (panel.hip, compact mode), the nnz-index maps are rewritten as positions in the slice arrays, and the CSR
+// arrays go.  Row pointers stay (8 B per row).
+__global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const int *__restrict__ k2pos, const uint32_t *__restrict__ pos2slot,
+                                                             uint32_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= k) return;
+  const int p = k2pos ? k2pos[i] : (int)i;
+  out[i] = p >= 0 ? pos2slot[p] : 0xFFFFFFFFu;
+}
+void Engine::compact_matrices() {
+  const double limit = getenv("OSQP_AMD_COMPACT_NNZ") ? atof(getenv("OSQP_AMD_COMPACT_NNZ")) : 5e7;  // stored entries of A + P (< 0: never)
+  if (compact || !lin || lin->kind() != 2) return;
+  if (limit < 0.0 || (double)nnzA + (double)Pf.nnz < limit) return;
+  if (!panel_can_compact(Pf) || (m > 0 && !(panel_can_compact(A) && panel_can_compact(At)))) return;
+  const bool maps = A_k2pos.n > 0 || nnzA == 0;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
+  auto slots = [&](const DevCsr &M, DevBuf<uint32_t> &tmp) { tmp.alloc((size_t)M.nnz); panel_slot_of_pos(M, tmp.get(), stream); };
+  auto compose = [&](int64_t k, const int *k2pos, const DevBuf<uint32_t> &p2s, DevBuf<uint32_t> &out) {
+    out.alloc((size_t)k);
+    if (k > 0) OQ_LAUNCH(k_compose_slot_map, dim3(blocks_for(k)), dim3(kBlock), 0, stream, k, k2pos, p2s.get(), out.get());
+  };
+  if (maps) {
+    DevBuf<uint32_t> p2s;
+    if (m > 0) {
+      slots(A, p2s); compose(nnzA, A_k2pos.get(), p2s, A_k2slot); sync(); A_k2pos.release();
+      slots(At, p2s); compose(nnzA, nullptr, p2s, At_k2slot); sync();
+    }
+    slots(Pf, p2s);
+    compose(nnzPtriu, P_k2lo.get(), p2s, P_k2slot_lo); compose(nnzPtriu, P_k2up.get(), p2s, P_k2slot_up);
+    sync();
+    P_k2lo.release(); P_k2up.release();
+  }
+  Pi_keep.release();  // the direct back-end's symbolic phase is out of reach at this size
+  if (m > 0) { panel_compact(A); panel_compact(At); }
+  panel_compact(Pf);
+  compact = true;
 }
 
 void Engine::unscale_data() {
@@ -402,6 +443,7 @@ bool Engine::can_chunk(long long iter, long long max_iter) const {
 
 void Engine::settings_changed() {
   if (chunk_exec) { (void)hipGraphExecDestroy(chunk_exec); chunk_exec = nullptr; chunk_len = 0; }
+  if (lin) { if (int rc = lin->flush()) deferred_error = rc; lin->invalidate(); }
 }
 
 void Engine::run_chunk() {
@@ -426,6 +468,7 @@ void Engine::run_chunk() {
 // --------------------------------------------------------------------------
 // Ax, Px, A'y at the current iterate and the 16 norms / sums of Slot order into h_slots
 void Engine::residual_evaluation() {
+  if (int rc = lin->flush()) deferred_error = rc;  // the iterate must be the one the host believes it is
   const double *xg = full_n(x.get());
   spmv(A, xg, Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
   spmv(Pf, xg, Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);
@@ -659,6 +702,7 @@ int Engine::solve() {
     can_print = st.verbose && ((iter % 200 == 0) || iter == 1);
     if (can_check_termination || can_print) {
       update_info(iter, compute_cost_function);
+      if (deferred_error) { deferred_error = 0; update_status(info, OSQP_NON_CVX); info->obj_val = NAN; info->iter = iter; break; }
       if (can_print && rank() == 0) printf("%4lld  %11.4e  %9.2e  %9.2e  %9.2e\n", iter, info->obj_val, info->pri_res, info->dua_res, st.rho);
       if (can_check_termination && check_termination(false)) break;
     }
@@ -676,13 +720,15 @@ int Engine::solve() {
     }
     if (st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0)) {
       if (!can_check_termination && !can_print) update_info(iter, compute_cost_function);
+      if (deferred_error) { deferred_error = 0; update_status(info, OSQP_NON_CVX); info->obj_val = NAN; info->iter = iter; break; }
       if (adapt_rho()) { update_status(info, OSQP_NON_CVX); break; }
     }
   }
 
   if (!can_check_termination && info->status_val != OSQP_NON_CVX) {
     if (!can_print) update_info(iter - 1, compute_cost_function);
-    check_termination(false);
+    if (deferred_error) { deferred_error = 0; update_status(info, OSQP_NON_CVX); info->obj_val = NAN; }
+    else check_termination(false);
   }
   if (!compute_cost_function && has_solution(info)) info->obj_val = obj_from_slots_fresh();
   if (info->status_val == OSQP_UNSOLVED) {
@@ -729,6 +775,7 @@ int Engine::iterate(long long iters) {
   }
   update_info(iters, true);
   sync();
+  if (deferred_error) { int rc = deferred_error; deferred_error = 0; return rc; }
   return 0;
 }
 
@@ -788,6 +835,18 @@ __global__ __launch_bounds__(kBlock) void k_scatter_vals(int64_t k, const long l
   if (t2) { int p = map2[e]; if (p >= 0) t2[p] = val; }
 }
 
+__global__ __launch_bounds__(kBlock) void k_scatter_vals_slot(int64_t k, const long long *__restrict__ idx, const double *__restrict__ v,
+                                                              double *__restrict__ t1, const uint32_t *__restrict__ map1,
+                                                              double *__restrict__ t2, const uint32_t *__restrict__ map2) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= k) return;
+  const int64_t e = idx ? idx[i] : i;
+  const double val = v[i];
+  const uint32_t p1 = map1[e], p2 = map2[e];
+  if (p1 != 0xFFFFFFFFu) t1[p1] = val;
+  if (p2 != 0xFFFFFFFFu) t2[p2] = val;
+}
+
 int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const double *Ax_new, const c_int *Aidx, c_int An,
                       bool doP, bool doA) {
   if (comm) throw Error(6, "osqp_update_P / osqp_update_A are not available on a row-sharded workspace");
@@ -807,8 +866,23 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
                        dv.get(), t1, map1, t2, map2);
     sync();
   };
-  if (doP) scatter(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
-  if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
+  auto scatter_slots = [&](const double *vals, const c_int *idx, c_int k, double *t1, const uint32_t *map1, double *t2, const uint32_t *map2) {
+    if (k <= 0) return;
+    DevBuf<double> dv((size_t)k);
+    DevBuf<long long> di;
+    dv.upload(vals, (size_t)k, stream);
+    if (idx) { di.alloc((size_t)k); di.upload((const long long *)idx, (size_t)k, stream); }
+    OQ_LAUNCH(k_scatter_vals_slot, dim3(blocks_for(k)), dim3(kBlock), 0, stream, (int64_t)k, idx ? di.get() : (const long long *)nullptr,
+              dv.get(), t1, map1, t2, map2);
+    sync();
+  };
+  if (compact) {
+    if (doP) scatter_slots(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.panel.sval.get(), P_k2slot_lo.get(), Pf.panel.sval.get(), P_k2slot_up.get());
+    if (doA) scatter_slots(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.panel.sval.get(), At_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
+  } else {
+    if (doP) scatter(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
+    if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
+  }
   if (st.scaling) scale_data();
   refresh_panels();
   settings_changed();

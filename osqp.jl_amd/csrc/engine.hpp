@@ -34,6 +34,10 @@ struct Linsys {
   virtual void set_guess(const double *x) {}
   // one whole ADMM iteration with back-end specific fusion; false = not provided (generic path runs)
   virtual bool fused_step() { return false; }
+  // back-ends that enqueue work ahead of the host (pcg.hip): wait for it; 0, or 5 when negative curvature was met
+  virtual int flush() { return 0; }
+  // a scalar the enqueued / captured work holds by value changed (alpha, sigma)
+  virtual void invalidate() {}
   virtual double nnzL() const { return 0.0; }
   virtual double levels() const { return 0.0; }
   virtual double trisolve_bytes() const { return 0.0; }
@@ -65,6 +69,9 @@ struct Engine {
 
   DevCsr A, At, Pf;
   DevBuf<int> A_k2pos, P_k2lo, P_k2up;
+  // compact mode (compact_matrices): the same maps as positions in the sliced-ELL value arrays (0xFFFFFFFF: none)
+  DevBuf<uint32_t> A_k2slot, At_k2slot, P_k2slot_lo, P_k2slot_up;
+  bool compact = false;
   DevBuf<int64_t> Pp_keep;  // caller's triu(P) CSC pattern, kept for the direct back-end's symbolic phase
   DevBuf<int> Pi_keep;
   int64_t nnzA = 0, nnzPtriu = 0;
@@ -88,6 +95,7 @@ struct Engine {
   bool have_res = false, have_ref = false, have_seed = false;
   double g_seed = 0;
 
+  int deferred_error = 0;  // an asynchronous back-end met negative curvature some iterations ago (reported at the next check)
   // statistics
   long long admm_iters_total = 0;
   // graph of `check_termination` iterations (direct back-end)
@@ -116,6 +124,7 @@ struct Engine {
   void scale_data();
   void unscale_data();
   void refresh_panels();
+  void compact_matrices();
   void set_rho_vec();
   int update_rho_vec_from_bounds();
   void cold_start();

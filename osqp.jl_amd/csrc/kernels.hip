@@ -12,6 +12,7 @@
 namespace oq {
 
 size_t g_device_bytes = 0;
+thread_local const int *g_skip = nullptr;
 int g_debug_sync = getenv("OSQP_AMD_DEBUG") ? atoi(getenv("OSQP_AMD_DEBUG")) : 0;
 
 // --------------------------------------------------------------------------
@@ -286,7 +287,8 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void k_spmv(int rows, const int64_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ va, const double *__restrict__ x,
                                                  double *__restrict__ y, const double *__restrict__ rscale, double beta,
-                                                 double gamma, const double *__restrict__ v) {
+                                                 double gamma, const double *__restrict__ v, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const int lane = threadIdx.x & (G - 1);
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
   if (row >= rows) return;
@@ -317,7 +319,7 @@ void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, dou
   const int G = M.group;
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
 #define OQ_SPMV(GG) \
-  OQ_LAUNCH(k_spmv<GG>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), x, y, rscale, beta, gamma, v)
+  OQ_LAUNCH(k_spmv<GG>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), x, y, rscale, beta, gamma, v, g_skip)
   switch (G) {
   case 1: OQ_SPMV(1); break;
   case 2: OQ_SPMV(2); break;
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_row_absmax(int rows, const int64_t *
 }
 void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s) {
   if (M.rows == 0) return;
+  if (M.compact) { panel_row_absmax(M, out, accumulate, s); return; }
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
   if (G == 64) OQ_LAUNCH(k_row_absmax<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.val.get(), out, (int)accumulate);
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int6
 void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmetric_order, double scalar, hipStream_t s,
                          int row0) {
   if (M.rows == 0 || M.nnz == 0) return;
+  if (M.compact) { panel_scale(M, r, c, symmetric_order, scalar, s, row0); return; }
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
   if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
@@ -399,7 +403,8 @@ void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmet
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
 __global__ __launch_bounds__(kBlock) void k_vec_op(int op, double *__restrict__ out, const double *__restrict__ a,
-                                                   const double *__restrict__ b, double sc, double sc2, int n) {
+                                                   const double *__restrict__ b, double sc, double sc2, int n, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   switch (op) {
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_vec_op(int op, double *__restrict__ 
 }
 static void vec_op(int op, double *out, const double *a, const double *b, double sc, double sc2, int n, hipStream_t s) {
   if (n <= 0) return;
-  OQ_LAUNCH(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n);
+  OQ_LAUNCH(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n, g_skip);
 }
 void vec_limit_rsqrt(double *d, int n, hipStream_t s) { vec_op(0, d, nullptr, nullptr, 0, 0, n, s); }
 void vec_limit(double *d, int n, hipStream_t s) { vec_op(1, d, nullptr, nullptr, 0, 0, n, s); }
@@ -436,7 +441,8 @@ void vec_clamp(double *x, double lo, double hi, int n, hipStream_t s) { vec_op(9
 void zero_slots(double *slots, hipStream_t s) { HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(double) * S_COUNT, s)); }
 
 __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ x, const double *__restrict__ scale, int n,
-                                                   double *__restrict__ slot) {
+                                                   double *__restrict__ slot, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double m = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     m = nanmax(m, fabs(scale ? scale[i] * x[i] : x[i]));
@@ -446,22 +452,24 @@ __global__ __launch_bounds__(kBlock) void k_absmax(const double *__restrict__ x,
 void reduce_absmax(const double *x, const double *scale, int n, double *slot, hipStream_t s) {
   if (n <= 0) return;
   int grid = blocks_for(n); if (grid > kReduceBlocks) grid = kReduceBlocks;
-  OQ_LAUNCH(k_absmax, dim3(grid), dim3(kBlock), 0, s, x, scale, n, slot);
+  OQ_LAUNCH(k_absmax, dim3(grid), dim3(kBlock), 0, s, x, scale, n, slot, g_skip);
 }
 __global__ __launch_bounds__(kBlock) void k_dot_partial(const double *__restrict__ a, const double *__restrict__ b, int n,
-                                                        double *__restrict__ partials) {
+                                                        double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double v = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v += b ? a[i] * b[i] : a[i];
   v = block_sum(v);
   if (threadIdx.x == 0) partials[blockIdx.x] = v;
 }
-__global__ __launch_bounds__(kBlock) void k_sum_partials(const double *__restrict__ partials, double *__restrict__ slot) {
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const double *__restrict__ partials, double *__restrict__ slot, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double v = sum_partials(partials);
   if (threadIdx.x == 0) *slot = v;
 }
 void reduce_dot(const double *a, const double *b, int n, double *partials, double *slot, hipStream_t s) {
-  OQ_LAUNCH(k_dot_partial, dim3(kReduceBlocks), dim3(kBlock), 0, s, a, b, n, partials);
-  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot);
+  OQ_LAUNCH(k_dot_partial, dim3(kReduceBlocks), dim3(kBlock), 0, s, a, b, n, partials, g_skip);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot, g_skip);
 }
 void reduce_sum(const double *x, int n, double *partials, double *slot, hipStream_t s) { reduce_dot(x, nullptr, n, partials, slot, s); }
 
@@ -503,14 +511,15 @@ void rho_vec_update(int m, const double *l, const double *u, int *ctype, double 
 __global__ __launch_bounds__(kBlock) void k_admm_rhs(int n, int m, double sigma, const double *__restrict__ x_prev,
                                                      const double *__restrict__ q, const double *__restrict__ z_prev,
                                                      const double *__restrict__ rho_inv, const double *__restrict__ y,
-                                                     double *__restrict__ xz) {
+                                                     double *__restrict__ xz, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) xz[i] = sigma * x_prev[i] - q[i];
   else if (i < n + m) { int j = i - n; xz[i] = z_prev[j] - rho_inv[j] * y[j]; }
 }
 void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q, const double *z_prev, const double *rho_inv,
               const double *y, double *xz, hipStream_t s) {
-  OQ_LAUNCH(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz);
+  OQ_LAUNCH(k_admm_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, sigma, x_prev, q, z_prev, rho_inv, y, xz, g_skip);
 }
 // in place: x and z hold the previous iterate on entry and the new one on exit (no x_prev / z_prev copies,
 // no pointer swap -- which also keeps every launch argument constant, so the iteration can be graph-captured)
@@ -518,7 +527,8 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
                                                         const double *__restrict__ rho, const double *__restrict__ rho_inv,
                                                         const double *__restrict__ l, const double *__restrict__ u,
                                                         double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
-                                                        double *__restrict__ delta_x, double *__restrict__ delta_y) {
+                                                        double *__restrict__ delta_x, double *__restrict__ delta_y, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
     double xp = x[i];
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
 void admm_update(int n, int m, double alpha, const double *xz, const double *rho, const double *rho_inv, const double *l,
                  const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s) {
   OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, rho, rho_inv, l, u, x, z, y,
-            delta_x, delta_y);
+            delta_x, delta_y, g_skip);
 }
 
 // --------------------------------------------------------------------------
@@ -602,7 +612,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_finish(const double *__rest
   const double b = sum_partials(partials + (size_t)S_QX * kReduceBlocks);
   if (threadIdx.x == 0) { slots[S_XPX] = a; slots[S_QX] = b; }
 }
-__global__ __launch_bounds__(kBlock) void k_sum_partials2(const double *__restrict__ partials, double *__restrict__ s0, double *__restrict__ s1) {
+__global__ __launch_bounds__(kBlock) void k_sum_partials2(const double *__restrict__ partials, double *__restrict__ s0, double *__restrict__ s1, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double a = sum_partials(partials);
   double b = sum_partials(partials + kReduceBlocks);
   if (threadIdx.x == 0) { *s0 = a; *s1 = b; }
@@ -637,7 +648,7 @@ void prim_infeas_prep(int m, double *dy, const double *l, const double *u, const
                       hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(slots + S_T0, 0, sizeof(double) * 6, s));
   OQ_LAUNCH(k_prim_infeas_prep, dim3(kReduceBlocks), dim3(kBlock), 0, s, m, dy, l, u, E, slots, partials);
-  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slots + S_T1);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slots + S_T1, g_skip);
 }
 __global__ __launch_bounds__(kBlock) void k_dual_infeas_rows(int m, const double *__restrict__ Adx, const double *__restrict__ Einv,
                                                              const double *__restrict__ l, const double *__restrict__ u, double thr,
@@ -678,8 +689,21 @@ __global__ __launch_bounds__(kBlock) void k_pcg_precond(int n, const int64_t *__
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) dinv[j] = 1.0 / (sigma + acc);
 }
+// compact matrices: dinv = 1 / (sigma + diag(P) + (A' .* A') rho), both pieces from the sliced-ELL copies
+__global__ __launch_bounds__(kBlock) void k_precond_finish(int n, double sigma, const double *__restrict__ acc, double *__restrict__ dinv) {
+  int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < n) dinv[j] = 1.0 / (sigma + acc[j]);
+}
 void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s, int row0) {
   int n = Pf.rows;
+  if (At.compact || Pf.compact) {
+    if (!(Pf.compact && (At.compact || At.rows == 0 || At.cols == 0)))
+      throw Error(6, "internal: P and A' must be compacted together");
+    panel_diag(Pf, dinv, row0, s);                                          // dinv <- diag(P)
+    if (At.rows > 0 && At.cols > 0) spmv_panel_squared(At, rho, dinv, 1.0, dinv, s);  // dinv <- (A' .* A') rho + diag(P)
+    OQ_LAUNCH(k_precond_finish, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, sigma, dinv, dinv);
+    return;
+  }
   OQ_LAUNCH(k_pcg_precond, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n,
                      At.cols > 0 && At.rows > 0 ? At.rowptr.get() : (const int64_t *)nullptr, At.col.get(), At.val.get(),
                      Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, sigma, dinv, row0);
@@ -687,7 +711,8 @@ void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double s
 
 __global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ w,
                                                      const double *__restrict__ dinv, double *__restrict__ r, double *__restrict__ zz,
-                                                     double *__restrict__ p, double *__restrict__ partials, double *__restrict__ slot_rn) {
+                                                     double *__restrict__ p, double *__restrict__ partials, double *__restrict__ slot_rn, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double rz = 0.0, mx = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     double ri = b[i] - w[i];
@@ -703,14 +728,15 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(int n, const double *__rest
 void pcg_init_residual(int n, const double *b, const double *w, const double *dinv, double *r, double *zz, double *p,
                        double *partials, double *slot_rz, double *slot_rn, hipStream_t s) {
   // *slot_rn must be zero on entry (the caller clears its slot block once per solve)
-  OQ_LAUNCH(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn);
-  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz);
+  OQ_LAUNCH(k_pcg_init, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, b, w, dinv, r, zz, p, partials, slot_rn, g_skip);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz, g_skip);
 }
 __global__ __launch_bounds__(kBlock) void k_pcg_update_xr(int n, const double *__restrict__ slot_rz, const double *__restrict__ slot_pw,
                                                           double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
                                                           const double *__restrict__ w, const double *__restrict__ dinv,
                                                           double *__restrict__ zz, double *__restrict__ partials,
-                                                          double *__restrict__ slot_rn) {
+                                                          double *__restrict__ slot_rn, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const double alpha = *slot_rz / *slot_pw;
   double rz = 0.0, mx = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -725,20 +751,28 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update_xr(int n, const double *_
   mx = block_max(mx);
   if (threadIdx.x == 0) { partials[blockIdx.x] = rz; atomic_max_nonneg(slot_rn, mx); }
 }
+__global__ void k_fill_slots(double *slots, int count, double value, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  if ((int)threadIdx.x < count) slots[threadIdx.x] = value;
+}
+void fill_slots(double *slots, int count, double value, hipStream_t s) {
+  OQ_LAUNCH(k_fill_slots, dim3(1), dim3(64), 0, s, slots, count, value, g_skip);
+}
 void pcg_update_xr(int n, const double *slot_rz, const double *slot_pw, double *x, const double *p, double *r, const double *w,
                    const double *dinv, double *zz, double *partials, double *slot_rz_new, double *slot_rn, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(slot_rn, 0, sizeof(double), s));
-  OQ_LAUNCH(k_pcg_update_xr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, slot_rz, slot_pw, x, p, r, w, dinv, zz, partials, slot_rn);
-  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz_new);
+  fill_slots(slot_rn, 1, 0.0, s);
+  OQ_LAUNCH(k_pcg_update_xr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, slot_rz, slot_pw, x, p, r, w, dinv, zz, partials, slot_rn, g_skip);
+  OQ_LAUNCH(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, slot_rz_new, g_skip);
 }
 __global__ __launch_bounds__(kBlock) void k_pcg_update_p(int n, const double *__restrict__ slot_rz_new, const double *__restrict__ slot_rz,
-                                                         const double *__restrict__ zz, double *__restrict__ p) {
+                                                         const double *__restrict__ zz, double *__restrict__ p, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const double beta = *slot_rz_new / *slot_rz;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) p[i] = zz[i] + beta * p[i];
 }
 void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const double *zz, double *p, hipStream_t s) {
-  OQ_LAUNCH(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p);
+  OQ_LAUNCH(k_pcg_update_p, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, slot_rz_new, slot_rz, zz, p, g_skip);
 }
 // Start vector of a CG solve from the last two solutions x1 (newest), x0: the point x1 + theta (x1 - x0) that is
 // closest to the new solution in the energy norm, theta = e'r / e'Me with e = x1 - x0, r = b - M x1 (M x1, M x0
@@ -746,7 +780,8 @@ void pcg_update_p(int n, const double *slot_rz_new, const double *slot_rz, const
 // two solutions coincide, clamped to [-1, 4]) to x, M x and A x and rotates the pairs.
 __global__ __launch_bounds__(kBlock) void k_extrap_dots(int n, const double *__restrict__ x1, const double *__restrict__ x0,
                                                         const double *__restrict__ Mx1, const double *__restrict__ Mx0,
-                                                        const double *__restrict__ b, double *__restrict__ partials) {
+                                                        const double *__restrict__ b, double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   double num = 0.0, den = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const double e = x1[i] - x0[i], m1 = Mx1[i];
@@ -759,14 +794,15 @@ __global__ __launch_bounds__(kBlock) void k_extrap_dots(int n, const double *__r
 }
 void pcg_extrap_dots(int n, const double *x1, const double *x0, const double *Mx1, const double *Mx0, const double *b,
                      double *partials, double *slot_num, double *slot_den, hipStream_t s) {
-  OQ_LAUNCH(k_extrap_dots, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, x1, x0, Mx1, Mx0, b, partials);
-  OQ_LAUNCH(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slot_num, slot_den);
+  OQ_LAUNCH(k_extrap_dots, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, x1, x0, Mx1, Mx0, b, partials, g_skip);
+  OQ_LAUNCH(k_sum_partials2, dim3(1), dim3(kBlock), 0, s, partials, slot_num, slot_den, g_skip);
 }
 // the three vector pairs of a CG start (x, M x over n; A x over m) in one launch
 __global__ __launch_bounds__(kBlock) void k_extrapolate3_dev(double *__restrict__ a1, double *__restrict__ a0, double *__restrict__ b1,
                                                              double *__restrict__ b0, int n, double *__restrict__ c1,
                                                              double *__restrict__ c0, int m, const double *__restrict__ num,
-                                                             const double *__restrict__ den) {
+                                                             const double *__restrict__ den, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const double d = *den;
   double theta = d > 0.0 ? *num / d : 0.0;
   theta = theta != theta ? 0.0 : fmin(fmax(theta, -1.0), 4.0);
@@ -781,22 +817,24 @@ __global__ __launch_bounds__(kBlock) void k_extrapolate3_dev(double *__restrict_
 }
 void pcg_extrapolate3(double *x1, double *x0, double *Mx1, double *Mx0, int n, double *Ax1, double *Ax0, int m,
                       const double *slot_num, const double *slot_den, hipStream_t s) {
-  OQ_LAUNCH(k_extrapolate3_dev, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, x1, x0, Mx1, Mx0, n, Ax1, Ax0, m, slot_num, slot_den);
+  OQ_LAUNCH(k_extrapolate3_dev, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, x1, x0, Mx1, Mx0, n, Ax1, Ax0, m, slot_num, slot_den, g_skip);
 }
 __global__ __launch_bounds__(kBlock) void k_copy2(double *__restrict__ d1, const double *__restrict__ s1, int n1, double *__restrict__ d2,
-                                                  const double *__restrict__ s2, int n2) {
+                                                  const double *__restrict__ s2, int n2, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n1) d1[i] = s1[i];
   else if (i < n1 + n2) d2[i - n1] = s2[i - n1];
 }
 void vec_copy2(double *d1, const double *s1, int n1, double *d2, const double *s2, int n2, hipStream_t s) {
   if (n1 + n2 <= 0) return;
-  OQ_LAUNCH(k_copy2, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, d1, s1, n1, d2, s2, n2);
+  OQ_LAUNCH(k_copy2, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, d1, s1, n1, d2, s2, n2, g_skip);
 }
 // y1 += (num/den) x1 over n1 and y2 += (num/den) x2 over n2 in one launch
 __global__ __launch_bounds__(kBlock) void k_axpy2_dev(double *__restrict__ y1, const double *__restrict__ x1, int n1, double *__restrict__ y2,
                                                       const double *__restrict__ x2, int n2, const double *__restrict__ num,
-                                                      const double *__restrict__ den) {
+                                                      const double *__restrict__ den, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const double a = *num / *den;
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n1) y1[i] += a * x1[i];
@@ -805,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy2_dev(double *__restrict__ y1, c
 void vec_axpy2_dev(double *y1, const double *x1, int n1, double *y2, const double *x2, int n2, const double *slot_num,
                    const double *slot_den, hipStream_t s) {
   if (n1 + n2 <= 0) return;
-  OQ_LAUNCH(k_axpy2_dev, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, y1, x1, n1, y2, x2, n2, slot_num, slot_den);
+  OQ_LAUNCH(k_axpy2_dev, dim3(blocks_for((int64_t)n1 + n2)), dim3(kBlock), 0, s, y1, x1, n1, y2, x2, n2, slot_num, slot_den, g_skip);
 }
 
 // ---------------- row blocks of a CSR matrix and rank-ordered scalar combination (sharded path, row N4) ----------------

@@ -5,6 +5,19 @@
 
 namespace oq {
 
+// Predication of the kernels of the conjugate-gradient path.  While a SkipScope is alive, every launcher below passes its
+// flag to the kernel, which returns at once when the flag is set: the host can enqueue CG iterations (or whole ADMM
+// iterations) ahead of the convergence test that runs on the device, without a round trip per iteration (pcg.hip).
+extern thread_local const int *g_skip;
+struct SkipScope {
+  const int *prev;
+  explicit SkipScope(const int *flag) : prev(g_skip) { g_skip = flag; }
+  ~SkipScope() { g_skip = prev; }
+  SkipScope(const SkipScope &) = delete;
+  SkipScope &operator=(const SkipScope &) = delete;
+};
+void fill_slots(double *slots, int count, double value, hipStream_t s);  // slots[0..count) = value, count <= 64 (predicated)
+
 // ---------------- sparse structure (setup only) ----------------
 // out[k] = column id of CSC entry k (binary search in colptr)
 void expand_colptr(int cols, const int64_t *colptr, int64_t nnz, int *out, hipStream_t s);
@@ -31,6 +44,14 @@ void panel_build(DevCsr &M, hipStream_t s);                    // structure + va
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s);     // refresh the values after the CSR values changed
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
                 const double *v, hipStream_t s);
+// compact mode: the CSR column / value arrays released, every maintenance pass on the sliced-ELL copy (panel.hip)
+bool panel_can_compact(const DevCsr &M);
+void panel_compact(DevCsr &M);
+void panel_slot_of_pos(const DevCsr &M, uint32_t *slot, hipStream_t s);  // before panel_compact
+void panel_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);
+void panel_scale(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0);
+void panel_diag(const DevCsr &M, double *diag, int row0, hipStream_t s);
+void spmv_panel_squared(const DevCsr &M, const double *x, double *y, double gamma, const double *v, hipStream_t s);
 
 // ---------------- K0: Ruiz equilibration pieces ----------------
 void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);  // out[i] = max(|row i|) (or max with old)

@@ -245,15 +245,17 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
 // ---------------------------------------------------------------------------------------------
 // the product
 // ---------------------------------------------------------------------------------------------
-template <typename ColT, bool kStageX>
+// kSquare: y = (M .* M) x -- the Jacobi diagonal of A' diag(rho) A is this product of A' with rho (compact mode)
+template <typename ColT, bool kStageX, bool kSquare = false>
 __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
                                                         const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
                                                         const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
                                                         const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
                                                         const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
                                                         const double *__restrict__ sval, const double *__restrict__ x,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial, const int *__restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (skip && *skip) return;
   const int t = blockIdx.x, g = tile_g[t];
   const int W = 1 << shift;
   const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
 #pragma unroll
         for (int u = 0; u < 8; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) a0 += cv[u] * xs[cc[u]];
+        for (int u = 0; u < 8; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
       }
       if (k + 4 <= L) {
         double cv[4];
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
 #pragma unroll
         for (int u = 0; u < 4; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) a0 += cv[u] * xs[cc[u]];
+        for (int u = 0; u < 4; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
         k += 4;
       }
-      for (; k < L; k++) a1 += v[(size_t)k * 64] * xs[c[(size_t)k * 64]];
+      for (; k < L; k++) { const double e = v[(size_t)k * 64]; a1 += (kSquare ? e * e : e) * xs[c[(size_t)k * 64]]; }
       if (row >= 0) ys[row - r0] += a0 + a1;  // a row appears once per panel; panels are separated by barriers
     }
   }
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
 // y[i] = (rscale ? rscale[i] : 1) * sum_g partial[g][i] + beta * y[i] + gamma * v[i]   (group order is fixed)
 __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
                                                          const double *__restrict__ rscale, double beta, double gamma,
-                                                         const double *__restrict__ v) {
+                                                         const double *__restrict__ v, const int *__restrict__ skip) {
+  if (skip && *skip) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= rows) return;
   double acc = 0.0;
@@ -325,6 +328,90 @@ __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const 
   if (beta != 0.0) acc += beta * y[i];
   if (v) acc += gamma * v[i];
   y[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Compact mode (panel_compact): the CSR column / value arrays of a matrix have been released and the sliced-ELL copy
+// is the only one.  What the CSR arrays were still used for after setup -- Ruiz passes (row maxima, row / column
+// scaling), the Jacobi diagonal, value updates by nnz index -- walks the slices instead: same tiles, same units as the
+// product, lane = row, global column = panel base + local id.
+// ---------------------------------------------------------------------------------------------------------
+// op 0: val <- ((val * a) * b) * scalar with the three orders of k_scale_rows_cols; op 1: partial[g][row] = max |val|;
+// op 2: diag[row] = val where column == row + row0
+template <typename ColT, int kOp>
+__global__ __launch_bounds__(kThreads) void k_sell_visit(int rows, int shift, int B, int Gp, const int *__restrict__ tile_g,
+                                                         const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                                         const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
+                                                         const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
+                                                         const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
+                                                         double *__restrict__ sval, const double *__restrict__ r, const double *__restrict__ c,
+                                                         int order, double scalar, int row0, double *__restrict__ out) {
+  __shared__ double ys[kOp == 1 ? kTileRowsMax : 1];
+  const int t = blockIdx.x, g = tile_g[t];
+  const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (kOp == 1) for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
+  for (int j = 0; j < Gp; j++) {
+    const int b = g * Gp + j;
+    if (b >= B) break;
+    const int s0 = unit_s0[(size_t)t * Gp + j], ns = unit_ns[(size_t)t * Gp + j];
+    if (kOp == 1) __syncthreads();  // a row appears once per panel; panels are separated by barriers
+    const int c0 = b << shift;
+    for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
+      const size_t base = (size_t)slice_base[sl] + lane;
+      const int L = slice_len[sl];
+      const int row = slice_rows[(size_t)sl * 64 + lane];
+      if (row < 0) continue;
+      double mx = 0.0;
+      for (int k = 0; k < L; k++) {
+        const size_t at = base + (size_t)k * 64;
+        double v = sval[at];
+        if (kOp == 0) {
+          if (r) {
+            const int col = c0 + (int)scol[at];
+            double a, bb;
+            if (order == 1) { const int gi = row + row0; const int lo = col < gi ? col : gi, hi = col < gi ? gi : col; a = c[lo]; bb = c[hi]; }
+            else if (order == 2) { a = c[col]; bb = r[row]; }
+            else { a = r[row]; bb = c[col]; }
+            v = (v * a) * bb;
+          }
+          if (scalar != 1.0) v *= scalar;
+          if (v != 0.0 || sval[at] != 0.0) sval[at] = v;  // padding slots (value 0 at local column 0) stay exact zeros
+        } else if (kOp == 1) {
+          mx = fmax(mx, fabs(v));
+        } else {
+          if (c0 + (int)scol[at] == row + row0 && v != 0.0) out[row] = v;
+        }
+      }
+      if (kOp == 1) ys[row - r0] = fmax(ys[row - r0], mx);
+    }
+  }
+  if (kOp == 1) {
+    __syncthreads();
+    double *o = out + (size_t)g * rows + r0;
+    for (int i = threadIdx.x; i < nrows; i += kThreads) o[i] = ys[i];
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_panel_reduce_max(int rows, int NG, const double *__restrict__ partial, double *__restrict__ out,
+                                                             int accumulate) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= rows) return;
+  double m = 0.0;
+  for (int g = 0; g < NG; g++) m = fmax(m, partial[(size_t)g * rows + i]);
+  out[i] = accumulate ? fmax(out[i], m) : m;
+}
+// slot of every CSR position (the address computation of k_sell_scatter, recorded instead of used)
+__global__ __launch_bounds__(kBlock) void k_sell_slot_of_pos(int rows, int shift, const int64_t *__restrict__ rp, const int *__restrict__ col,
+                                                             const uint32_t *__restrict__ cellbase, uint32_t *__restrict__ slot) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int64_t s = rp[row], e = rp[row + 1];
+  for (int64_t k = s + lane; k < e; k += 64) {
+    const int b = col[k] >> shift;
+    const int64_t seg = lower_bound_col(col, s, k + 1, b << shift);
+    slot[k] = (uint32_t)((size_t)cellbase[(size_t)b * rows + row] + (size_t)(k - seg) * 64);
+  }
 }
 
 size_t spmv_lds_bytes(int shift) { return (sizeof(double) << shift) + sizeof(double) * kTileRowsMax; }
@@ -464,12 +551,63 @@ void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscal
   if (P.wide)
     OQ_LAUNCH((k_spmv_sell<uint32_t, false>), dim3(P.ntiles), dim3(kThreads), sizeof(double) * kTileRowsMax, s, M.rows, M.cols, P.shift, P.B,
               P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
-              P.slice_len.get(), P.slice_rows.get(), P.scol32.get(), P.sval.get(), x, P.partial.get());
+              P.slice_len.get(), P.slice_rows.get(), P.scol32.get(), P.sval.get(), x, P.partial.get(), g_skip);
   else
     OQ_LAUNCH((k_spmv_sell<uint16_t, true>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B,
               P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
-              P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get());
-  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v);
+              P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get(), g_skip);
+  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v, g_skip);
+}
+
+// ---- compact mode: host side -------------------------------------------------------------------------------------------
+#define OQ_SELL_VISIT(OP, ...)                                                                                                              \
+  do {                                                                                                                                      \
+    if (P.wide) OQ_LAUNCH((k_sell_visit<uint32_t, OP>), dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.shift, P.B, P.Gp, P.tile_g.get(),    \
+                          P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),        \
+                          P.slice_rows.get(), P.scol32.get(), P.sval.get(), __VA_ARGS__);                                                    \
+    else OQ_LAUNCH((k_sell_visit<uint16_t, OP>), dim3(P.ntiles), dim3(kThreads), 0, s, M.rows, P.shift, P.B, P.Gp, P.tile_g.get(),           \
+                   P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),               \
+                   P.slice_rows.get(), P.scol.get(), P.sval.get(), __VA_ARGS__);                                                             \
+  } while (0)
+
+void panel_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s) {
+  const DevPanel &P = M.panel;
+  OQ_SELL_VISIT(1, (const double *)nullptr, (const double *)nullptr, 0, 1.0, 0, P.partial.get());
+  OQ_LAUNCH(k_panel_reduce_max, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), out, (int)accumulate);
+}
+void panel_scale(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0) {
+  const DevPanel &P = M.panel;
+  OQ_SELL_VISIT(0, r, c, order, scalar, row0, (double *)nullptr);
+}
+void panel_diag(const DevCsr &M, double *diag, int row0, hipStream_t s) {
+  const DevPanel &P = M.panel;
+  HIP_CHECK(hipMemsetAsync(diag, 0, sizeof(double) * (size_t)M.rows, s));
+  OQ_SELL_VISIT(2, (const double *)nullptr, (const double *)nullptr, 0, 1.0, row0, diag);
+}
+#undef OQ_SELL_VISIT
+// y = (M .* M) x + gamma v  (LDS-staged panels only; the wide mode keeps its CSR arrays)
+void spmv_panel_squared(const DevCsr &M, const double *x, double *y, double gamma, const double *v, hipStream_t s) {
+  const DevPanel &P = M.panel;
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell<uint16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)spmv_lds_bytes(P.shift)));
+  OQ_LAUNCH((k_spmv_sell<uint16_t, true, true>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B,
+            P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
+            P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get(), (const int *)nullptr);
+  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, (const double *)nullptr, 0.0, gamma, v,
+            (const int *)nullptr);
+}
+// slot[k] = position of CSR entry k inside sval (needs the CSR arrays: call before panel_compact)
+void panel_slot_of_pos(const DevCsr &M, uint32_t *slot, hipStream_t s) {
+  const DevPanel &P = M.panel;
+  OQ_LAUNCH(k_sell_slot_of_pos, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.shift, M.rowptr.get(), M.col.get(),
+            P.cellbase.get(), slot);
+}
+bool panel_can_compact(const DevCsr &M) { return M.panel.active && !M.panel.wide; }
+void panel_compact(DevCsr &M) {
+  M.col.release();
+  M.val.release();
+  M.panel.cellbase.release();  // only the value refresh from the CSR arrays needed it
+  M.compact = true;
 }
 
 }  // namespace oq

@@ -199,6 +199,89 @@ def test_panel_spmv_matches_scipy(product_lib, oracle_lib, monkeypatch, mode, gr
     assert np.max(np.abs(rp.x - rc.x)) <= 1e-9 and np.max(np.abs(rp.y - rc.y)) <= 1e-9
 
 
+def test_compact_mode(product_lib, oracle_lib, monkeypatch):
+    """Compact workspaces (the CSR column / value arrays released once the sliced-ELL copies exist; automatic above 5e7
+    stored entries, forced here at a size the test can hold): the products, osqp_update_P_A through the slot maps, Ruiz
+    scaling and the Jacobi diagonal on the slices -- against scipy and against the same solve on a non-compact workspace."""
+    monkeypatch.setenv("OSQP_AMD_PANEL", "2")
+    n, k = 40000, 96
+    d = oracle_lib.oracle_generate(0, n, k, 21)
+    P, q, A, l, u = _data_to_scipy(d.contents)
+    oracle_lib.oracle_data_free(d)
+    Pu = sp.triu(P, format="csc")
+    rng = np.random.default_rng(5)
+    xv, yv = rng.standard_normal(n), rng.standard_normal(n)
+    f = oq.interface._fptr
+
+    def products(model, Pu_, A_):
+        Pfull = Pu_ + sp.triu(Pu_, 1).T
+        for op, mat, vec in ((0, A_, xv), (1, A_.T, yv), (2, Pfull, xv)):
+            out = np.zeros(n)
+            assert product_lib.osqp_amd_apply(model.workspace, op, f(vec), f(out)) == 0
+            ref = mat @ vec
+            assert np.max(np.abs(out - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+    monkeypatch.setenv("OSQP_AMD_COMPACT_NNZ", "0")
+    m0 = oq.Model(product_lib)
+    oq.setup_generated(m0, 0, n, k, 21, scaling=0, verbose=False, linsys_solver="pcg")
+    assert oq.stats(m0)[18] == 1.0
+    bytes_compact = oq.stats(m0)[9]
+    products(m0, Pu, A)
+    # partial updates by index, then everything
+    idxA = np.sort(rng.choice(A.nnz, 5000, replace=False)); idxP = np.sort(rng.choice(Pu.nnz, 3000, replace=False))
+    A2 = A.copy(); A2.data[idxA] *= -2.0
+    Pu2 = Pu.copy(); offdiag = Pu2.tocoo().row[idxP] != Pu2.tocoo().col[idxP]
+    Pu2.data[idxP[offdiag]] *= 0.25
+    oq.update(m0, Px=Pu2.data[idxP], Px_idx=idxP, Ax=A2.data[idxA], Ax_idx=idxA)  # 0-based positions in the Python mirror
+    products(m0, Pu2, A2)
+    oq.update(m0, Px=Pu.data * 0.5, Ax=A.data * 1.5)
+    Pu3 = Pu.copy(); Pu3.data = Pu.data * 0.5
+    A3 = A.copy(); A3.data = A.data * 1.5
+    products(m0, Pu3, A3)
+    oq.clean(m0)
+    # whole solves with scaling, before and after a value update, against a workspace that kept its CSR arrays
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, linsys_solver="pcg")
+    res = {}
+    for mode, limit in (("compact", "0"), ("csr", "-1")):
+        monkeypatch.setenv("OSQP_AMD_COMPACT_NNZ", limit)
+        m = oq.Model(product_lib); oq.setup_generated(m, 0, n, k, 21, **opts)
+        assert oq.stats(m)[18] == (1.0 if mode == "compact" else 0.0)
+        if mode == "csr":
+            assert oq.stats(m)[9] > bytes_compact + 12 * 2 * A.nnz  # what the three CSR copies weigh (roughly)
+        r1 = oq.solve(m)
+        oq.update(m, Px=Pu.data * 1.25, Ax=A.data * 0.8)
+        oq.update_settings(m, warm_start=False)
+        r2 = oq.solve(m)
+        res[mode] = (r1, r2)
+        oq.clean(m)
+    for a, b in zip(res["compact"], res["csr"]):
+        assert a.info.status == b.info.status == "Solved" and abs(a.info.iter - b.info.iter) <= 25
+        assert np.max(np.abs(a.x - b.x)) <= 1e-5 * max(1.0, np.max(np.abs(b.x)))
+        assert np.max(np.abs(a.y - b.y)) <= 1e-5 * max(1.0, np.max(np.abs(b.y)))
+
+
+@pytest.mark.parametrize("kind,n,k", [(0, 20000, 40), (0, 3000, 12)])
+def test_async_pcg_is_the_host_loop_bit_for_bit(product_lib, monkeypatch, kind, n, k):
+    """The asynchronous form of the CG back-end (convergence test on the device, predicated kernels, one hipGraph per
+    ADMM iteration, stalled steps finished by the host loop; pcg.hip) performs the arithmetic of the host-driven loop:
+    same iteration counts, same CG totals, bit-identical solutions -- including solves that stall (speculation depth 1)."""
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, linsys_solver="pcg")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_PCG_ASYNC", mode)
+        m = oq.Model(product_lib); oq.setup_generated(m, kind, n, k, 5, **opts)
+        r1 = oq.solve(m)
+        oq.update_q(m, np.random.default_rng(1).standard_normal(n))
+        r2 = oq.solve(m)
+        out[mode] = (r1, r2, oq.stats(m)[6])
+        oq.clean(m)
+    for a, b in zip(out["0"][:2], out["1"][:2]):
+        assert a.info.status == b.info.status == "Solved" and a.info.iter == b.info.iter
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
+        assert a.info.pri_res == b.info.pri_res and a.info.dua_res == b.info.dua_res
+    assert out["0"][2] == out["1"][2]  # the same number of CG iterations in total
+
+
 def test_dense_row_and_arrow_P(product_lib, oracle_lib):
     """Rows longer than the LDS sort tile (4096): a dense budget row sum(x) = 1 in A and an arrow-shaped P (dense
     first row / column) go through the global-memory row sort of the CSR build; products against scipy, 30 ADMM iterations
