@@ -82,7 +82,9 @@ struct Engine {
   DevBuf<int> ctype, flag;
   DevBuf<double> x, z, y, xz, dx, dy, Ax, Px_, Aty, tn, tm, tn2, tm2;
   DevBuf<double> slots, partials;
-  double *h_slots = nullptr;  // pinned
+  double *h_slots = nullptr;  // pinned; read_slots publishes into it through its device mapping
+  double *h_slots_dev = nullptr;
+  unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, publish_seq = 0;
   double res[16] = {0};       // norms of the last residual evaluation (Slot order)
   double c = 1.0, cinv = 1.0;
   std::vector<double> h_l, h_u;  // unscaled bounds on the host (validation of bound updates)

@@ -349,6 +349,7 @@ struct Pcg : Linsys {
     int cur = it0 & 1, it = it0;
     double tol = 0.0;
     HIP_CHECK(hipMemcpyAsync(&tol, dctl.get() + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     e.read_slots(S_T0, 5);
     double rn = e.h_slots[S_T1 + 2 * cur];
     while (it < max_iter) {

@@ -214,4 +214,42 @@ function setup_sharded!(model::OSQP.Model, comm::Comm; P::SparseMatrixCSC, q::Ve
     return model
 end
 
+# ---------------------------------------------------------------------------------------------------------
+# The batched path over several GPUs (include/osqp_amd.h: osqp_amd_batch_mpc_*): `total` MPC instances cut into
+# contiguous blocks over the ranks of a communicator, resident in HBM; `batch_mpc_solve!` = every rank its block
+# (one workgroup per instance) + ONE in-place all-gather of the packed rows [x (100) | y (200) | iter, status, pri, dua]
+# on the library's own RCCL communicator.  `packed` is a DEVICE pointer to total * 304 doubles (e.g. from AMDGPU.jl's
+# allocator or hipMalloc through ccall); nothing else crosses ranks.
+# ---------------------------------------------------------------------------------------------------------
+mutable struct MpcBatch
+    handle::Ptr{Cvoid}
+    total::Int
+end
+
+function batch_mpc_create(total::Integer; seed::Integer = 1, comm::Ptr{Cvoid} = C_NULL, device::Integer = 0, settings...)
+    stgs = OSQP.Settings(Dict{Symbol,Any}(settings))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    flag = ccall((:osqp_amd_batch_mpc_create, lib), Cc_int,
+                 (Ptr{Ptr{Cvoid}}, Cc_int, Culonglong, Ptr{OSQP.Settings}, Ptr{Cvoid}, Cc_int),
+                 h, total, seed, Ref(stgs), comm, device)
+    flag == 0 || error("Error in batched setup: $(last_error())")
+    b = MpcBatch(h[], total)
+    finalizer(x -> ccall((:osqp_amd_batch_destroy, lib), Cc_int, (Ptr{Cvoid},), x.handle), b)
+    return b
+end
+
+function batch_mpc_solve!(b::MpcBatch, packed::Ptr{Cdouble})
+    flag = ccall((:osqp_amd_batch_mpc_solve, lib), Cc_int, (Ptr{Cvoid}, Ptr{Cdouble}), b.handle, packed)
+    flag == 0 || error("Error in batched solve: $(last_error())")
+    return nothing
+end
+
+"In-place all-gather of `count` doubles per rank on a device buffer, on the library's communicator."
+function comm_all_gather!(comm::Ptr{Cvoid}, buf::Ptr{Cdouble}, count::Integer)
+    flag = ccall((:osqp_amd_comm_all_gather, lib), Cc_int, (Ptr{Cvoid}, Ptr{Cdouble}, Cc_int), comm, buf, count)
+    flag == 0 || error("Error in all-gather: $(last_error())")
+    return nothing
+end
+
+
 end # module
