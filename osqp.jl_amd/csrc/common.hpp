@@ -139,6 +139,14 @@ enum Slot {
   S_COUNT = 32
 };
 
+// Where a kernel that has just produced scalars the host is waiting for puts them: pinned host memory mapped into the
+// device's address space, a sequence number raised last (Engine::read_slots / begin_publish / wait_publish).
+struct Publish {
+  double *host_slots = nullptr;                  // the host mirror of the slot array (device-visible address); null: do not publish
+  volatile unsigned long long *host_seq = nullptr;
+  unsigned long long seq = 0;
+};
+
 constexpr int kBlock = 256;
 constexpr int kReduceBlocks = 1024;  // fixed grid of the two-stage (deterministic) sum reductions
 

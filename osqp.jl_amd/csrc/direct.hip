@@ -995,7 +995,7 @@ struct Direct : Linsys {
   explicit Direct(Engine &en) : e(en) {}
   int kind() const override { return 0; }
   int solve(double *xz, double) override { F->solve(xz, e.rho_inv.get()); return 0; }
-  bool fused_step() override {
+  int fused_step() override {
     hipStream_t s = e.stream;
     const int N = e.n + e.m;
     static const bool fuse_ends = !(getenv("OSQP_AMD_FUSE_ENDS") && atoi(getenv("OSQP_AMD_FUSE_ENDS")) == 0);
@@ -1008,7 +1008,7 @@ struct Direct : Linsys {
       OQ_LAUNCH(k_direct2_bwd_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, e.st.alpha, F->pinv.get(), l1, F->Lp.get(),
                 F->Li.get(), F->Lx.get(), F->Dinv.get(), F->bp.get(), e.q.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(),
                 e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
-      return true;
+      return 0;
     }
     if (f1)
       OQ_LAUNCH(k_direct_rhs_fwd1, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), F->perm.get(),
@@ -1025,7 +1025,7 @@ struct Direct : Linsys {
     else
       OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->bp.get(),
                 e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
-    return true;
+    return 0;
   }
   int update_rho() override { return F->refactor(e.rho_inv.get()); }
   int update_matrices() override { return F->refactor(e.rho_inv.get()); }

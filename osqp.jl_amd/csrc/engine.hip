@@ -77,24 +77,34 @@ __global__ void k_publish_slots(const double *__restrict__ src, double *__restri
   __syncthreads();
   if (threadIdx.x == 0) { *host_seq = seq; __threadfence_system(); }
 }
+Publish Engine::begin_publish() {
+  Publish p;
+  if (!h_slots_dev || g_debug_sync) return p;
+  p.host_slots = h_slots_dev;
+  p.host_seq = (volatile unsigned long long *)h_seq_dev;
+  p.seq = ++publish_seq;
+  return p;
+}
+void Engine::wait_publish(const Publish &p) {
+  volatile unsigned long long *seen = (volatile unsigned long long *)h_seq;
+  long long spins = 0;
+  while (*seen != p.seq) {
+    if (++spins > 20000000) {  // ~ a second: something is wrong with the stream rather than slow
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (*seen != p.seq) throw Error(6, "internal: published slots did not arrive");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
 void Engine::read_slots(int first, int count) {
   if (!h_slots_dev || g_debug_sync) {
     HIP_CHECK(hipMemcpyAsync(h_slots + first, slots.get() + first, sizeof(double) * count, hipMemcpyDeviceToHost, stream));
     sync();
     return;
   }
-  const unsigned long long want = ++publish_seq;
-  OQ_LAUNCH(k_publish_slots, dim3(1), dim3(64), 0, stream, (const double *)(slots.get() + first), h_slots_dev + first, count,
-            (volatile unsigned long long *)h_seq_dev, want);
-  volatile unsigned long long *seen = (volatile unsigned long long *)h_seq;
-  long long spins = 0;
-  while (*seen != want) {
-    if (++spins > 20000000) {  // ~ a second: something is wrong with the stream rather than slow
-      HIP_CHECK(hipStreamSynchronize(stream));
-      if (*seen != want) throw Error(6, "internal: published slots did not arrive");
-    }
-  }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const Publish p = begin_publish();
+  OQ_LAUNCH(k_publish_slots, dim3(1), dim3(64), 0, stream, (const double *)(slots.get() + first), h_slots_dev + first, count, p.host_seq, p.seq);
+  wait_publish(p);
 }
 
 // --------------------------------------------------------------------------
@@ -138,8 +148,8 @@ void Engine::shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &
   n0 = std::min(r * chunk_n, ng);
   m0 = std::min(r * chunk_m, mg);
   const int n1 = std::min(n0 + chunk_n, ng), m1 = std::min(m0 + chunk_m, mg);
-  // ceil-sized blocks: the trailing ranks may own no rows at all (n = 9 over 4 ranks: 3 + 3 + 3 + 0); they still take part in
-  // every exchange
+  if (n1 <= n0 || (mg > 0 && m1 <= m0))
+    throw Error(1, "sharded setup: with ceil-sized blocks the last rank would own no rows (e.g. n = 9 over 4 ranks: 3 + 3 + 3 + 0); use fewer ranks");
   csr_slice_rows(At, n0, n1, stream);
   csr_slice_rows(Pf, n0, n1, stream);
   if (mg > 0) csr_slice_rows(A, m0, m1, stream);
@@ -463,7 +473,7 @@ int Engine::kkt_solve() {
 // one iteration, in place on (x, z, y)
 int Engine::admm_step() {
   admm_iters_total++;
-  if (lin->fused_step()) return 0;  // back-end specific fusion of rhs / permutation / update (direct.hip)
+  { const int rc = lin->fused_step(); if (rc >= 0) return rc; }  // back-end specific fusion of rhs / solve / update (direct.hip, pcg.hip)
   admm_rhs(n, m, st.sigma, x.get(), q.get(), z.get(), rho_inv.get(), y.get(), xz.get(), stream);
   int rc = kkt_solve();
   admm_update(n, m, st.alpha, xz.get(), rho.get(), rho_inv.get(), l.get(), u.get(), x.get(), z.get(), y.get(), dx.get(),

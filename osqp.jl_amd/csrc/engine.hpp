@@ -32,8 +32,9 @@ struct Linsys {
   virtual int update_rho() = 0;       // engine.rho / rho_inv changed
   virtual int update_matrices() = 0;  // engine.A / At / Pf values changed
   virtual void set_guess(const double *x) {}
-  // one whole ADMM iteration with back-end specific fusion; false = not provided (generic path runs)
-  virtual bool fused_step() { return false; }
+  // one whole ADMM iteration with back-end specific fusion; -1 = not provided (generic path runs), 0 done, 5 negative
+  // curvature met (problem non-convex)
+  virtual int fused_step() { return -1; }
   // back-ends that enqueue work ahead of the host (pcg.hip): wait for it; 0, or 5 when negative curvature was met
   virtual int flush() { return 0; }
   // a scalar the enqueued / captured work holds by value changed (alpha, sigma)
@@ -169,7 +170,11 @@ struct Engine {
   // first + k is a sum, otherwise a max).  A slot must not be combined twice.
   void fetch_slots(int first, int count, unsigned sum_mask = 0);
   void combine_slots(int first, int count, unsigned sum_mask);
-  void read_slots(int first, int count);  // plain copy to h_slots + stream sync
+  void read_slots(int first, int count);  // slots [first, first + count) to h_slots (publish kernel + spin, or copy + stream sync)
+  // the same in two halves for kernels that publish their own results: hand begin_publish() to the kernel (it writes
+  // h_slots through the mapping, then the sequence number), wait_publish() spins until it has
+  Publish begin_publish();
+  void wait_publish(const Publish &p);
   double agree_max(double v);
   const double *full_n(const double *v);  // v (n local entries) as a full-length vector
   const double *full_m(const double *v);

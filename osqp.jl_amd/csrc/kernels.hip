@@ -7,6 +7,7 @@
 // reductions keep every solve bit-reproducible), max-norms through integer
 // atomicMax on the bit pattern of non-negative doubles (order independent).
 #include "kernels.hpp"
+#include "devutil.hpp"
 #include <algorithm>
 
 namespace oq {
@@ -14,49 +15,6 @@ namespace oq {
 size_t g_device_bytes = 0;
 thread_local const int *g_skip = nullptr;
 int g_debug_sync = getenv("OSQP_AMD_DEBUG") ? atoi(getenv("OSQP_AMD_DEBUG")) : 0;
-
-// --------------------------------------------------------------------------
-// device helpers
-// --------------------------------------------------------------------------
-__device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-// all threads of a 256-thread block get the block total (fixed order -> deterministic)
-__device__ __forceinline__ double block_sum(double v) {
-  __shared__ double sm[4];
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
-}
-__device__ __forceinline__ double block_max(double v) {
-  __shared__ double smx[4];
-  v = wave_max(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return nanmax(nanmax(smx[0], smx[1]), nanmax(smx[2], smx[3]));
-}
-// max of non-negative doubles through their (monotone) bit pattern; NaN sorts above +inf
-__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
-  atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
-}
-// sum of the kReduceBlocks partials, same order in every block
-__device__ __forceinline__ double sum_partials(const double *partials) {
-  double v = 0.0;
-  for (int i = threadIdx.x; i < kReduceBlocks; i += kBlock) v += partials[i];
-  return block_sum(v);
-}
 
 // --------------------------------------------------------------------------
 // sparse structure
@@ -313,9 +271,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int rows, const int64_t *__rest
 }
 
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
-          hipStream_t s) {
+          hipStream_t s, const SpmvExtra *extra) {
   if (M.rows == 0) return;
-  if (M.panel.active) { spmv_panel(M, x, y, rscale, beta, gamma, v, s); return; }
+  if (M.panel.active) { spmv_panel(M, x, y, rscale, beta, gamma, v, s, extra); return; }
+  if (extra) throw Error(6, "internal: epilogue extras need the panel kernels");
   const int G = M.group;
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
 #define OQ_SPMV(GG) \
@@ -523,7 +482,7 @@ void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q,
 }
 // in place: x and z hold the previous iterate on entry and the new one on exit (no x_prev / z_prev copies,
 // no pointer swap -- which also keeps every launch argument constant, so the iteration can be graph-captured)
-__global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alpha, const double *__restrict__ xz,
+__global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alpha, const double *__restrict__ xt, const double *__restrict__ ztv,
                                                         const double *__restrict__ rho, const double *__restrict__ rho_inv,
                                                         const double *__restrict__ l, const double *__restrict__ u,
                                                         double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
@@ -532,12 +491,12 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
     double xp = x[i];
-    double xn = alpha * xz[i] + (1.0 - alpha) * xp;
+    double xn = alpha * xt[i] + (1.0 - alpha) * xp;
     x[i] = xn;
     delta_x[i] = xn - xp;
   } else if (i < n + m) {
     int j = i - n;
-    double zt = xz[i], zp = z[j], yj = y[j];
+    double zt = ztv[j], zp = z[j], yj = y[j];
     double zh = alpha * zt + (1.0 - alpha) * zp;
     double zn = zh + rho_inv[j] * yj;
     zn = fmin(fmax(zn, l[j]), u[j]);
@@ -549,7 +508,12 @@ __global__ __launch_bounds__(kBlock) void k_admm_update(int n, int m, double alp
 }
 void admm_update(int n, int m, double alpha, const double *xz, const double *rho, const double *rho_inv, const double *l,
                  const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s) {
-  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, rho, rho_inv, l, u, x, z, y,
+  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, xz + n, rho, rho_inv, l, u, x, z, y,
+            delta_x, delta_y, g_skip);
+}
+void admm_update2(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv, const double *l,
+                  const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s) {
+  OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xt, zt, rho, rho_inv, l, u, x, z, y,
             delta_x, delta_y, g_skip);
 }
 

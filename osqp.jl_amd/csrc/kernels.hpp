@@ -34,16 +34,24 @@ void convert_i64_i32(int64_t n, const int64_t *in, int *out, hipStream_t s);
 int pick_group(int rows, int64_t nnz);
 
 // ---------------- K6 / K7: CSR SpMV ----------------
+// Optional epilogue work of a product (panel kernels only: fused CG path, pcg.hip); all pointers may be null.
+struct SpmvExtra {
+  double *y2 = nullptr;               // y2[i] = s2[i] * (M x)[i]  -- the raw product, before rscale / beta / gamma
+  const double *s2 = nullptr;
+  const double *dotv = nullptr;       // dot_partials[block] = sum over the block's rows of dotv[i] * y[i] (the layout and
+  double *dot_partials = nullptr;     //   order of reduce_dot's first stage: kReduceBlocks entries, unused ones zeroed)
+  double *absmax_slot = nullptr;      // *absmax_slot = max(*absmax_slot, |y[i]|)  (zero it first)
+};
 // y[i] = (rscale ? rscale[i] : 1) * sum_k val[k] x[col[k]] + beta * y[i] + gamma * v[i]
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
-          const double *v, hipStream_t s);
+          const double *v, hipStream_t s, const SpmvExtra *extra = nullptr);
 
 // LDS-staged column-panel variant (panel.hip); spmv() dispatches to it when M.panel.active
 bool panel_wanted(const DevCsr &M);
 void panel_build(DevCsr &M, hipStream_t s);                    // structure + values from the CSR arrays
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s);     // refresh the values after the CSR values changed
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
-                const double *v, hipStream_t s);
+                const double *v, hipStream_t s, const SpmvExtra *extra = nullptr);
 // compact mode: the CSR column / value arrays released, every maintenance pass on the sliced-ELL copy (panel.hip)
 bool panel_can_compact(const DevCsr &M);
 void panel_compact(DevCsr &M);
@@ -88,6 +96,9 @@ void admm_rhs(int n, int m, double sigma, const double *x_prev, const double *q,
 // in place on x, z (previous iterate in, new iterate out)
 void admm_update(int n, int m, double alpha, const double *xz, const double *rho, const double *rho_inv, const double *l,
                  const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s);
+// the same with x~ and z~ in two separate arrays
+void admm_update2(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv,
+                  const double *l, const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s);
 
 // ---------------- K8: residual norms + objective pieces ----------------
 void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px,

@@ -41,6 +41,7 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include "devutil.hpp"
 
 namespace oq {
 
@@ -316,18 +317,35 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
 }
 
 // y[i] = (rscale ? rscale[i] : 1) * sum_g partial[g][i] + beta * y[i] + gamma * v[i]   (group order is fixed)
+// Grid of at most kReduceBlocks blocks, grid-stride over the rows -- the thread-to-row assignment of the two-stage
+// reductions (k_dot_partial), so that the optional dot product of the result with another vector lands in the same
+// partials, in the same order, as a separate reduce_dot would form (SpmvExtra).
 __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
                                                          const double *__restrict__ rscale, double beta, double gamma,
-                                                         const double *__restrict__ v, const int *__restrict__ skip) {
+                                                         const double *__restrict__ v, SpmvExtra ex, const int *__restrict__ skip) {
   if (skip && *skip) return;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= rows) return;
-  double acc = 0.0;
-  for (int b = 0; b < B; b++) acc += partial[(size_t)b * rows + i];
-  if (rscale) acc *= rscale[i];
-  if (beta != 0.0) acc += beta * y[i];
-  if (v) acc += gamma * v[i];
-  y[i] = acc;
+  double dot = 0.0, mx = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < rows; i += gridDim.x * kBlock) {
+    double acc = 0.0;
+    for (int b = 0; b < B; b++) acc += partial[(size_t)b * rows + i];
+    if (ex.y2) ex.y2[i] = ex.s2[i] * acc;
+    if (rscale) acc *= rscale[i];
+    if (beta != 0.0) acc += beta * y[i];
+    if (v) acc += gamma * v[i];
+    y[i] = acc;
+    if (ex.dotv) dot += ex.dotv[i] * acc;
+    if (ex.absmax_slot) mx = nanmax(mx, fabs(acc));
+  }
+  if (ex.dot_partials) {
+    dot = block_sum(dot);
+    if (threadIdx.x == 0) ex.dot_partials[blockIdx.x] = dot;
+    if (blockIdx.x == 0)  // blocks that do not exist hold zeroes, as in a kReduceBlocks-wide first stage
+      for (int t = gridDim.x + threadIdx.x; t < kReduceBlocks; t += kBlock) ex.dot_partials[t] = 0.0;
+  }
+  if (ex.absmax_slot) {
+    mx = block_max(mx);
+    if (threadIdx.x == 0) atomic_max_nonneg(ex.absmax_slot, mx);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -545,9 +563,12 @@ void panel_build(DevCsr &M, hipStream_t s) {
   P.active = true;
 }
 
+static int reduce_grid(int rows) { return std::min(blocks_for(rows), kReduceBlocks); }
+
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma, const double *v,
-                hipStream_t s) {
+                hipStream_t s, const SpmvExtra *extra) {
   const DevPanel &P = M.panel;
+  const SpmvExtra ex = extra ? *extra : SpmvExtra();
   if (P.wide)
     OQ_LAUNCH((k_spmv_sell<uint32_t, false>), dim3(P.ntiles), dim3(kThreads), sizeof(double) * kTileRowsMax, s, M.rows, M.cols, P.shift, P.B,
               P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
@@ -556,7 +577,7 @@ void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscal
     OQ_LAUNCH((k_spmv_sell<uint16_t, true>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B,
               P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
               P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get(), g_skip);
-  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v, g_skip);
+  OQ_LAUNCH(k_panel_reduce, dim3(reduce_grid(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v, ex, g_skip);
 }
 
 // ---- compact mode: host side -------------------------------------------------------------------------------------------
@@ -593,8 +614,8 @@ void spmv_panel_squared(const DevCsr &M, const double *x, double *y, double gamm
   OQ_LAUNCH((k_spmv_sell<uint16_t, true, true>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B,
             P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
             P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get(), (const int *)nullptr);
-  OQ_LAUNCH(k_panel_reduce, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, (const double *)nullptr, 0.0, gamma, v,
-            (const int *)nullptr);
+  OQ_LAUNCH(k_panel_reduce, dim3(reduce_grid(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, (const double *)nullptr, 0.0, gamma, v,
+            SpmvExtra(), (const int *)nullptr);
 }
 // slot[k] = position of CSR entry k inside sval (needs the CSR arrays: call before panel_compact)
 void panel_slot_of_pos(const DevCsr &M, uint32_t *slot, hipStream_t s) {

@@ -28,6 +28,7 @@
 // looks at an iterate: every residual evaluation) finishes that solve with the host loop, re-issues the steps
 // behind it and raises `spec`.
 #include "engine.hpp"
+#include "devutil.hpp"
 
 #include <cmath>
 #include <map>
@@ -69,6 +70,161 @@ __global__ void k_pcg_end(int *ctl, int final_flag, int spec) {
   ctl[C_STEPS] += 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused kernels of the CG path (single device, all three matrices on the panel kernels).  A step of the host loop
+// above is ~29 launches at one CG iteration; a short kernel costs ~4.5 us whichever way it is issued, so at mid size
+// the launches, not the bytes, are the time.  Fused: 6 launches of start-up, 8 per CG iteration (6 of them the three
+// products), 1 update.  Every sum is recombined from the same block partials by the same functions (devutil.hpp), so the
+// iterates are those of the unfused sequence, bit for bit.
+// Regions of the partials buffer (kReduceBlocks doubles each):
+constexpr int R_DOT = 0;                  // p'w from the epilogue of the A' product  /  numerator of the extrapolation
+constexpr int R_AUX = 1 * kReduceBlocks;  // denominator of the extrapolation
+constexpr int R_RZ = 2 * kReduceBlocks;   // r'z
+constexpr int R_RN = 3 * kReduceBlocks;   // max |r| per block
+
+// xz_x = sigma x - q ;  t = rho (z - rho^-1 y)  (= rho .* the z-part of the ADMM right-hand side) ; scratch slots cleared
+__global__ __launch_bounds__(kBlock) void k_pcg_rhs(int n, int m, double sigma, const double *__restrict__ x, const double *__restrict__ q,
+                                                    const double *__restrict__ z, const double *__restrict__ rho,
+                                                    const double *__restrict__ rho_inv, const double *__restrict__ y,
+                                                    double *__restrict__ xz_x, double *__restrict__ t, double *__restrict__ slots,
+                                                    const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < 6) slots[S_T0 + i] = 0.0;
+  if (i < n) xz_x[i] = sigma * x[i] - q[i];
+  else if (i < n + m) { const int j = i - n; const double rz = z[j] - rho_inv[j] * y[j]; t[j] = rho[j] * rz; }
+}
+// start vector (energy-optimal extrapolation from the last two solutions, or a plain copy) and initial residual
+__global__ __launch_bounds__(kBlock) void k_pcg_start(int n, int m, int have_prev, double *__restrict__ xs, double *__restrict__ xs0,
+                                                      double *__restrict__ Mxs, double *__restrict__ Mxs0, double *__restrict__ Axs,
+                                                      double *__restrict__ Axs0, const double *__restrict__ b1,
+                                                      const double *__restrict__ dinv, double *__restrict__ r, double *__restrict__ zz,
+                                                      double *__restrict__ p, double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  double theta = 0.0;
+  if (have_prev) {
+    const double num = sum_partials(partials + R_DOT), den = sum_partials(partials + R_AUX);
+    theta = den > 0.0 ? num / den : 0.0;
+    theta = theta != theta ? 0.0 : fmin(fmax(theta, -1.0), 4.0);
+  }
+  double rz = 0.0, mx = 0.0;
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    double cur = xs[i], old = xs0[i];
+    xs0[i] = cur;
+    if (have_prev) xs[i] = cur + theta * (cur - old);
+    cur = Mxs[i]; old = Mxs0[i];
+    Mxs0[i] = cur;
+    const double mnew = have_prev ? cur + theta * (cur - old) : cur;
+    if (have_prev) Mxs[i] = mnew;
+    const double ri = b1[i] - mnew, zi = dinv[i] * ri;
+    r[i] = ri; zz[i] = zi; p[i] = zi;
+    rz += ri * zi;
+    mx = nanmax(mx, fabs(ri));
+  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < m; j += stride) {
+    const double cur = Axs[j], old = Axs0[j];
+    Axs0[j] = cur;
+    if (have_prev) Axs[j] = cur + theta * (cur - old);
+  }
+  rz = block_sum(rz);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { partials[R_RZ + blockIdx.x] = rz; partials[R_RN + blockIdx.x] = mx; }
+}
+// r'z and ||r||inf of the start vector into their slots; asynchronous form: also the tolerance and the first flag
+__global__ __launch_bounds__(kBlock) void k_pcg_finish_start(const double *__restrict__ partials, double *__restrict__ slots, int *ctl,
+                                                             const double *cand_p, double *tol_p, Publish pub, const int *__restrict__ skip) {
+  if (skip && *skip) { if (ctl && threadIdx.x == 0) ctl[C_DONE0] = 1; return; }
+  const double rz = sum_partials(partials + R_RZ), rn = max_partials(partials + R_RN);
+  if (threadIdx.x != 0) return;
+  slots[S_T0] = rz; slots[S_T1] = rn;
+  if (pub.host_slots) {  // the host loop waits for exactly these three
+    pub.host_slots[S_T0] = rz; pub.host_slots[S_T1] = rn; pub.host_slots[S_T5] = slots[S_T5];
+    __threadfence_system();
+    *pub.host_seq = pub.seq;
+    __threadfence_system();
+  }
+  if (!ctl) return;
+  const double bnorm = slots[S_T5], cand = *cand_p;
+  const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
+  double tol = hi;
+  if (cand >= 0.0) tol = cand;
+  if (!(tol < hi)) tol = hi;
+  if (tol < lo) tol = lo;
+  *tol_p = tol;
+  if (rn != rn) { ctl[C_ERR] = 1; ctl[C_STALL] = 1; ctl[C_DONE0] = 1; return; }
+  ctl[C_DONE0] = rn <= tol ? 1 : 0;
+}
+// alpha = r'z / p'w ;  M x~ += alpha w ; A x~ += alpha u ; x~ += alpha p ; r -= alpha w ; zz = dinv r ; partials of r'z, max |r|
+__global__ __launch_bounds__(kBlock) void k_pcg_step(int n, int m, const double *__restrict__ slot_rz, double *__restrict__ partials,
+                                                     double *__restrict__ xs, const double *__restrict__ p, double *__restrict__ r,
+                                                     const double *__restrict__ w, const double *__restrict__ dinv, double *__restrict__ zz,
+                                                     double *__restrict__ Mxs, double *__restrict__ Axs, const double *__restrict__ u,
+                                                     double *__restrict__ slot_pw, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  const double pw = sum_partials(partials + R_DOT);
+  const double alpha = *slot_rz / pw;
+  double rz = 0.0, mx = 0.0;
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double wi = w[i];
+    Mxs[i] += alpha * wi;
+    xs[i] += alpha * p[i];
+    const double ri = r[i] - alpha * wi, zi = dinv[i] * ri;
+    r[i] = ri; zz[i] = zi;
+    rz += ri * zi;
+    mx = nanmax(mx, fabs(ri));
+  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < m; j += stride) Axs[j] += alpha * u[j];
+  rz = block_sum(rz);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) {
+    partials[R_RZ + blockIdx.x] = rz; partials[R_RN + blockIdx.x] = mx;
+    if (blockIdx.x == 0) *slot_pw = pw;
+  }
+}
+// beta = r'z_new / r'z ;  p = zz + beta p ;  the new r'z and ||r||inf into their slots; asynchronous form: the next flag
+__global__ __launch_bounds__(kBlock) void k_pcg_next(int n, const double *__restrict__ partials, const double *__restrict__ slot_rz,
+                                                     double *__restrict__ slot_rz_new, const double *__restrict__ zz, double *__restrict__ p,
+                                                     const double *__restrict__ slot_pw, int *ctl, const double *tol_p, int cur,
+                                                     Publish pub, const int *__restrict__ skip) {
+  if (skip && *skip) { if (ctl && blockIdx.x == 0 && threadIdx.x == 0) ctl[1 - cur] = 1; return; }
+  const double rz_new = sum_partials(partials + R_RZ), rn = max_partials(partials + R_RN);
+  const double beta = rz_new / *slot_rz;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    slot_rz_new[0] = rz_new; slot_rz_new[1] = rn;
+    if (pub.host_slots) {  // the host's stopping test needs ||r||inf and p'Mp; it does not wait for the update of p
+      pub.host_slots[S_T0 + 2 * (1 - cur)] = rz_new; pub.host_slots[S_T1 + 2 * (1 - cur)] = rn; pub.host_slots[S_T4] = *slot_pw;
+      __threadfence_system();
+      *pub.host_seq = pub.seq;
+      __threadfence_system();
+    }
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = zz[i] + beta * p[i];
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (!ctl) return;
+  ctl[C_ITERS] += 1;
+  const double pw = *slot_pw;
+  if (!(pw > 0.0) || rn != rn) { ctl[C_ERR] = 1; ctl[C_STALL] = 1; ctl[1 - cur] = 1; return; }  // M is not positive definite
+  ctl[1 - cur] = rn <= *tol_p ? 1 : 0;
+}
+// first stage of the extrapolation dot products alone (the consumer recombines the partials)
+__global__ __launch_bounds__(kBlock) void k_extrap_partials(int n, const double *__restrict__ x1, const double *__restrict__ x0,
+                                                            const double *__restrict__ Mx1, const double *__restrict__ Mx0,
+                                                            const double *__restrict__ b, double *__restrict__ partials,
+                                                            const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  double num = 0.0, den = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double e = x1[i] - x0[i], m1 = Mx1[i];
+    num += e * (b[i] - m1);
+    den += e * (m1 - Mx0[i]);
+  }
+  num = block_sum(num);
+  den = block_sum(den);
+  if (threadIdx.x == 0) { partials[R_DOT + blockIdx.x] = num; partials[R_AUX + blockIdx.x] = den; }
+}
+
 struct Pcg : Linsys {
   Engine &e;
   DevBuf<double> xs, r, zz, p, w, t, u, b1, dinv, Axs, Mxs, xs0, Axs0, Mxs0;
@@ -77,6 +233,7 @@ struct Pcg : Linsys {
   int max_iter = 20000;
   bool carried_valid = false;
   int since_refresh = 0;
+  bool fused_on = false;            // the fused kernels apply (single device, panel kernels on all three matrices)
   // asynchronous form
   bool async_on = false;
   DevBuf<int> ctl;
@@ -95,6 +252,10 @@ struct Pcg : Linsys {
     if (const char *ev = getenv("OSQP_AMD_PCG_EXTRAP")) extrapolate = atoi(ev) != 0;
     if (extrapolate) { xs0.alloc(n); Axs0.alloc(m); Mxs0.alloc(n); }
     precond();
+    {
+      const char *fv = getenv("OSQP_AMD_PCG_FUSED");
+      fused_on = !e.comm && e.m > 0 && e.A.panel.active && e.At.panel.active && e.Pf.panel.active && !(fv && atoi(fv) == 0);
+    }
     const char *ev = getenv("OSQP_AMD_PCG_ASYNC");
     // opt-in (OSQP_AMD_PCG_ASYNC=1): measured on rand-1e5 the empty kernels of the iterations enqueued beyond convergence
     // (~5 us each inside a graph, ~14 per CG iteration) cost more than the two host round trips they replace; it needs the
@@ -207,74 +368,169 @@ struct Pcg : Linsys {
   void set_guess(const double *x) override { (void)flush(); vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; have_prev = false; }
 
   // ---------------------------------------------------------------- asynchronous form
+  // ---- the pieces of a step, fused kernels where they apply (fused_on), the launches of solve() otherwise -------------
+  // right-hand side b1, its norm, the carried products, the start vector, the initial residual; r'z -> S_T0, ||r||inf -> S_T1
+  Publish pub_next;  // set by the host loop before a launch whose kernel publishes its scalars itself
+  void start_solve(bool hp, bool refresh, bool async) {
+    hipStream_t s = e.stream;
+    const int n = e.n, m = e.m;
+    double *slots = e.slots.get(), *xz = e.xz.get(), *part = e.partials.get();
+    int *flags = async ? ctl.get() : nullptr;
+    if (fused_on) {
+      OQ_LAUNCH(k_pcg_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(),
+                e.rho.get(), e.rho_inv.get(), e.y.get(), xz, t.get(), slots, g_skip);
+      SpmvExtra ex;
+      ex.absmax_slot = slots + S_T5;
+      spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s, &ex);
+      if (refresh) apply_M(xs.get(), Axs.get(), Mxs.get());
+      const bool ext = extrapolate && hp;
+      if (ext) OQ_LAUNCH(k_extrap_partials, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), part, g_skip);
+      if (extrapolate)
+        OQ_LAUNCH(k_pcg_start, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, ext ? 1 : 0, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), Axs.get(),
+                  Axs0.get(), b1.get(), dinv.get(), r.get(), zz.get(), p.get(), part, g_skip);
+      else
+        pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), part + R_RZ, slots + S_T0, slots + S_T1, s);
+      if (extrapolate)
+        OQ_LAUNCH(k_pcg_finish_start, dim3(1), dim3(kBlock), 0, s, (const double *)part, slots, flags, (const double *)dctl.get(), dctl.get() + 1,
+                  async ? Publish() : pub_next, g_skip);
+      else if (async)
+        OQ_LAUNCH(k_pcg_begin, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)dctl.get(), dctl.get() + 1);
+      return;
+    }
+    admm_rhs(n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(), e.rho_inv.get(), e.y.get(), xz, s);
+    if (m > 0) {
+      vec_ew_prod(t.get(), e.rho.get(), xz + n, m, s);
+      spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s);
+    } else {
+      vec_copy(b1.get(), xz, n, s);
+    }
+    fill_slots(slots + S_T0, 6, 0.0, s);
+    reduce_absmax(b1.get(), nullptr, n, slots + S_T5, s);
+    if (refresh) apply_M(xs.get(), Axs.get(), Mxs.get());
+    if (extrapolate) {
+      if (hp) {
+        pcg_extrap_dots(n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), part, slots + S_T2, slots + S_T3, s);
+        pcg_extrapolate3(xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), n, Axs.get(), Axs0.get(), m, slots + S_T2, slots + S_T3, s);
+      } else {
+        vec_copy(xs0.get(), xs.get(), n, s); vec_copy(Mxs0.get(), Mxs.get(), n, s);
+        if (m > 0) vec_copy(Axs0.get(), Axs.get(), m, s);
+      }
+    }
+    pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), part, slots + S_T0, slots + S_T1, s);
+    if (async) {
+      SkipScope none(nullptr);
+      OQ_LAUNCH(k_pcg_begin, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)dctl.get(), dctl.get() + 1);
+    }
+  }
+  // one CG iteration; cur: which slot pair holds the current r'z
+  void cg_iteration(int cur, bool async) {
+    hipStream_t s = e.stream;
+    const int n = e.n, m = e.m;
+    double *slots = e.slots.get(), *part = e.partials.get();
+    double *rz = slots + S_T0 + 2 * cur, *rz_new = slots + S_T0 + 2 * (1 - cur), *pw = slots + S_T4;
+    int *flags = async ? ctl.get() : nullptr;
+    if (fused_on) {
+      SpmvExtra exA;
+      exA.y2 = t.get(); exA.s2 = e.rho.get();                        // t = rho .* (A p) next to u = A p
+      spmv(e.A, p.get(), u.get(), nullptr, 0.0, 0.0, nullptr, s, &exA);
+      spmv(e.Pf, p.get(), w.get(), nullptr, 0.0, e.st.sigma, p.get(), s);
+      SpmvExtra exT;
+      exT.dotv = p.get(); exT.dot_partials = part + R_DOT;            // p'w with the result of w += A' t
+      spmv(e.At, t.get(), w.get(), nullptr, 1.0, 0.0, nullptr, s, &exT);
+      OQ_LAUNCH(k_pcg_step, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, (const double *)rz, part, xs.get(), (const double *)p.get(), r.get(),
+                (const double *)w.get(), (const double *)dinv.get(), zz.get(), Mxs.get(), Axs.get(), (const double *)u.get(), pw, g_skip);
+      OQ_LAUNCH(k_pcg_next, dim3(std::min(blocks_for(n), kReduceBlocks)), dim3(kBlock), 0, s, n, (const double *)part, (const double *)rz, rz_new,
+                (const double *)zz.get(), p.get(), (const double *)pw, flags, (const double *)(dctl.get() + 1), cur, async ? Publish() : pub_next,
+                g_skip);
+      return;
+    }
+    apply_M(p.get(), u.get(), w.get());
+    reduce_dot(p.get(), w.get(), n, part, pw, s);
+    vec_axpy2_dev(Mxs.get(), w.get(), n, Axs.get(), u.get(), m, rz, pw, s);
+    pcg_update_xr(n, rz, pw, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(), part, rz_new, rz_new + 1, s);
+    pcg_update_p(n, rz_new, rz, zz.get(), p.get(), s);
+    if (async) {
+      SkipScope none(nullptr);
+      OQ_LAUNCH(k_pcg_decide, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)(dctl.get() + 1), cur);
+    }
+  }
+  void finish_step() {  // x~ = xs, z~ = A xs carried along: the ADMM update of (x, z, y)
+    hipStream_t s = e.stream;
+    admm_update2(e.n, e.m, e.st.alpha, xs.get(), Axs.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(),
+                 e.dx.get(), e.dy.get(), s);
+  }
+
   // One ADMM iteration, enqueued: right-hand side, start vector, `c` predicated CG iterations, update of (x, z, y).
   void enqueue_step(int c, bool hp, bool refresh) {
     hipStream_t s = e.stream;
-    const int n = e.n, m = e.m;
-    double *slots = e.slots.get(), *xz = e.xz.get();
     int *flags = ctl.get();
     {
       SkipScope on_stall(flags + C_STALL);
-      admm_rhs(n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(), e.rho_inv.get(), e.y.get(), xz, s);
-      if (m > 0) {
-        vec_ew_prod(t.get(), e.rho.get(), xz + n, m, s);
-        spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s);
-      } else {
-        vec_copy(b1.get(), xz, n, s);
-      }
-      fill_slots(slots + S_T0, 6, 0.0, s);
-      reduce_absmax(b1.get(), nullptr, n, slots + S_T5, s);
-      if (refresh) apply_M(xs.get(), Axs.get(), Mxs.get());
-      if (extrapolate) {
-        if (hp) {
-          pcg_extrap_dots(n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), e.partials.get(), slots + S_T2, slots + S_T3, s);
-          pcg_extrapolate3(xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), n, Axs.get(), Axs0.get(), m, slots + S_T2, slots + S_T3, s);
-        } else {
-          vec_copy(xs0.get(), xs.get(), n, s); vec_copy(Mxs0.get(), Mxs.get(), n, s);
-          if (m > 0) vec_copy(Axs0.get(), Axs.get(), m, s);
-        }
-      }
-      pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), e.partials.get(), slots + S_T0, slots + S_T1, s);
+      start_solve(hp, refresh, true);
     }
-    OQ_LAUNCH(k_pcg_begin, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)dctl.get(), dctl.get() + 1);
     for (int it = 0; it < c; it++) {
-      const int cur = it & 1;
-      {
-        SkipScope on_done(flags + cur);
-        apply_M(p.get(), u.get(), w.get());
-        double *rz = slots + S_T0 + 2 * cur, *rz_new = slots + S_T0 + 2 * (1 - cur), *pw = slots + S_T4;
-        reduce_dot(p.get(), w.get(), n, e.partials.get(), pw, s);
-        vec_axpy2_dev(Mxs.get(), w.get(), n, Axs.get(), u.get(), m, rz, pw, s);
-        pcg_update_xr(n, rz, pw, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(), e.partials.get(), rz_new, rz_new + 1, s);
-        pcg_update_p(n, rz_new, rz, zz.get(), p.get(), s);
-      }
-      OQ_LAUNCH(k_pcg_decide, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)(dctl.get() + 1), cur);
+      SkipScope on_done(flags + (it & 1));
+      cg_iteration(it & 1, true);
     }
     OQ_LAUNCH(k_pcg_end, dim3(1), dim3(1), 0, s, flags, c & 1, c);
     {
       SkipScope on_stall(flags + C_STALL);
-      vec_copy2(xz, xs.get(), n, xz + n, Axs.get(), m, s);  // x~ and z~ = A x~
-      admm_update(n, m, e.st.alpha, xz, e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(),
-                  e.dy.get(), s);
+      finish_step();
     }
   }
 
-  bool fused_step() override {
-    if (!async_on) return false;
+  // One ADMM iteration with the host in the CG loop (two scalar read-backs per CG iteration), fused kernels
+  int step_sync() {
+    double cand = -1.0;
+    if (e.have_res) cand = e.lambda * std::sqrt(e.sc_pri * e.sc_dua);
+    else if (e.have_seed) cand = e.lambda * e.g_seed;
+    const bool refresh = !carried_valid || since_refresh + 1 >= kRefresh;
+    const bool self_publish = fused_on && extrapolate;  // k_pcg_finish_start / k_pcg_next hand their scalars to the host themselves
+    pub_next = self_publish ? e.begin_publish() : Publish();
+    start_solve(have_prev, refresh, false);
+    if (refresh) { carried_valid = true; since_refresh = 0; } else since_refresh++;
+    if (extrapolate) have_prev = true;
+    if (pub_next.host_slots) e.wait_publish(pub_next); else e.read_slots(S_T0, 6);
+    const double bnorm = e.h_slots[S_T5];
+    const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
+    double tol = hi;
+    if (cand >= 0.0) tol = cand;
+    if (!(tol < hi)) tol = hi;
+    if (tol < lo) tol = lo;
+    double rn = e.h_slots[S_T1];
+    int it = 0, cur = 0, status = 0;
+    while (it < max_iter) {
+      if (rn <= tol) break;
+      if (rn != rn) { status = 5; break; }
+      pub_next = fused_on ? e.begin_publish() : Publish();
+      cg_iteration(cur, false);
+      if (pub_next.host_slots) e.wait_publish(pub_next); else e.read_slots(S_T0, 5);
+      if (!(e.h_slots[S_T4] > 0.0)) { status = 5; carried_valid = false; break; }
+      rn = e.h_slots[S_T1 + 2 * (1 - cur)];
+      cur = 1 - cur;
+      it++;
+    }
+    total_iters += it;
+    finish_step();
+    return status;
+  }
+
+  int fused_step() override {
+    if (!async_on) return fused_on ? step_sync() : -1;
     hipStream_t s = e.stream;
     // the candidate tolerance only changes at a residual evaluation, i.e. right after a flush
     double cand = -1.0;
     if (e.have_res) cand = e.lambda * std::sqrt(e.sc_pri * e.sc_dua);
     else if (e.have_seed) cand = e.lambda * e.g_seed;
     if (cand != cand_dev) {
-      if (issued) { if (flush()) return true; }
+      if (issued) { if (int rc = flush()) return rc; }
       HIP_CHECK(hipMemcpyAsync(dctl.get(), &cand, sizeof(double), hipMemcpyHostToDevice, s));
       HIP_CHECK(hipStreamSynchronize(s));  // `cand` lives on this frame
       cand_dev = cand;
     }
     bool refresh = !carried_valid || since_refresh + 1 >= kRefresh;
     issue(spec, have_prev, refresh);
-    return true;
+    return 0;
   }
   void issue(int c, bool hp, bool refresh) {
     hipStream_t s = e.stream;
@@ -330,9 +586,7 @@ struct Pcg : Linsys {
       const long long behind = issued - steps - 1;
       int rc = finish_on_host(stall_it);
       if (rc) { issued = 0; return rc; }
-      vec_copy2(e.xz.get(), xs.get(), e.n, e.xz.get() + e.n, Axs.get(), e.m, s);
-      admm_update(e.n, e.m, e.st.alpha, e.xz.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(),
-                  e.dx.get(), e.dy.get(), s);
+      finish_step();
       spec = std::min(kMaxSpec, spec + 1);
       issued = 0;
       since_refresh = (int)std::max<long long>(0, since_refresh - behind);  // the steps behind the stall fell through: their bookkeeping is redone
@@ -344,8 +598,6 @@ struct Pcg : Linsys {
   // the synchronous loop of solve(), entered after `it0` iterations of a solve whose state is on the device
   int finish_on_host(int it0) {
     hipStream_t s = e.stream;
-    const int n = e.n, m = e.m;
-    double *slots = e.slots.get();
     int cur = it0 & 1, it = it0;
     double tol = 0.0;
     HIP_CHECK(hipMemcpyAsync(&tol, dctl.get() + 1, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -355,12 +607,8 @@ struct Pcg : Linsys {
     while (it < max_iter) {
       if (rn <= tol) break;
       if (rn != rn) { carried_valid = false; return 5; }
-      apply_M(p.get(), u.get(), w.get());
-      double *rz = slots + S_T0 + 2 * cur, *rz_new = slots + S_T0 + 2 * (1 - cur), *pw = slots + S_T4;
-      reduce_dot(p.get(), w.get(), n, e.partials.get(), pw, s);
-      vec_axpy2_dev(Mxs.get(), w.get(), n, Axs.get(), u.get(), m, rz, pw, s);
-      pcg_update_xr(n, rz, pw, xs.get(), p.get(), r.get(), w.get(), dinv.get(), zz.get(), e.partials.get(), rz_new, rz_new + 1, s);
-      pcg_update_p(n, rz_new, rz, zz.get(), p.get(), s);
+      pub_next = Publish();
+      cg_iteration(cur, false);
       e.read_slots(S_T0, 5);
       if (!(e.h_slots[S_T4] > 0.0)) { carried_valid = false; return 5; }
       rn = e.h_slots[S_T1 + 2 * (1 - cur)];

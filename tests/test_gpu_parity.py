@@ -261,25 +261,32 @@ def test_compact_mode(product_lib, oracle_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,n,k", [(0, 20000, 40), (0, 3000, 12)])
-def test_async_pcg_is_the_host_loop_bit_for_bit(product_lib, monkeypatch, kind, n, k):
-    """The asynchronous form of the CG back-end (convergence test on the device, predicated kernels, one hipGraph per
-    ADMM iteration, stalled steps finished by the host loop; pcg.hip) performs the arithmetic of the host-driven loop:
-    same iteration counts, same CG totals, bit-identical solutions -- including solves that stall (speculation depth 1)."""
+def test_pcg_forms_are_one_arithmetic(product_lib, monkeypatch, kind, n, k):
+    """The CG back-end has three forms of one iteration (pcg.hip): the host loop over the unfused kernels, the same loop over
+    the fused kernels (start-up 6 launches, 8 per CG iteration; sums recombined from the same block partials in the same
+    order), and the asynchronous form (convergence test on the device, predicated kernels, one hipGraph per ADMM iteration,
+    stalled steps finished by the host loop).  Same iteration counts, same CG totals, bit-identical solutions.
+    n = 20000 runs on the panel kernels (forced), where the fused kernels apply; n = 3000 on the CSR kernel."""
+    monkeypatch.setenv("OSQP_AMD_PANEL", "2")
     opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, linsys_solver="pcg")
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("OSQP_AMD_PCG_ASYNC", mode)
+    for fused, asyn in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("OSQP_AMD_PCG_FUSED", fused)
+        monkeypatch.setenv("OSQP_AMD_PCG_ASYNC", asyn)
         m = oq.Model(product_lib); oq.setup_generated(m, kind, n, k, 5, **opts)
         r1 = oq.solve(m)
         oq.update_q(m, np.random.default_rng(1).standard_normal(n))
         r2 = oq.solve(m)
-        out[mode] = (r1, r2, oq.stats(m)[6])
+        out[fused + asyn] = (r1, r2, oq.stats(m)[6])
         oq.clean(m)
-    for a, b in zip(out["0"][:2], out["1"][:2]):
-        assert a.info.status == b.info.status == "Solved" and a.info.iter == b.info.iter
-        assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y)
-        assert a.info.pri_res == b.info.pri_res and a.info.dua_res == b.info.dua_res
-    assert out["0"][2] == out["1"][2]  # the same number of CG iterations in total
+    ref = out["00"]
+    assert ref[0].info.status == ref[1].info.status == "Solved"
+    for key in ("10", "01", "11"):
+        for a, b in zip(ref[:2], out[key][:2]):
+            assert a.info.status == b.info.status and a.info.iter == b.info.iter, key
+            assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y), key
+            assert a.info.pri_res == b.info.pri_res and a.info.dua_res == b.info.dua_res, key
+        assert ref[2] == out[key][2], key  # the same number of CG iterations in total
 
 
 def test_dense_row_and_arrow_P(product_lib, oracle_lib):
