@@ -5,7 +5,10 @@ Layout (only what the hot path needs):
   types.py     ctypes mirrors of the ABI structs      [REF src/types.jl]
   constants.py status codes, updatable lists          [REF src/constants.jl]
   interface.py Model / setup / solve / update / ...   [REF src/interface.jl]
+  modcaches.py modification / warm-start caches       [REF src/modcaches.jl]
+  moi.py       the MathOptInterface face              [REF src/MOI_wrapper.jl]
   batch.py     batched small-QP path + multi-GPU shard/gather
+  sharded.py   communicators of the row-sharded / batched multi-GPU paths
   julia/       the same host layer in Julia (cannot be executed in this image)
 """
 from .constants import *  # noqa: F401,F403

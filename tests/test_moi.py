@@ -1,0 +1,16 @@
+"""the MathOptInterface face restated (osqp.jl_amd/moi.py) and the reference's hand-written tests of it
+[REF test/MOI_wrapper.jl:280-812] -- against the CPU oracle here, against the HIP engine through the C ABI on the GPU."""
+import pytest
+
+import moi_cases
+
+
+@pytest.mark.parametrize("case", moi_cases.ALL, ids=lambda f: f.__name__)
+def test_moi_face_on_oracle(oracle_lib, case):
+    case(oracle_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", moi_cases.ALL, ids=lambda f: f.__name__)
+def test_moi_face_on_product(product_lib, case):
+    case(product_lib)
