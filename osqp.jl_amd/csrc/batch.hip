@@ -100,6 +100,18 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return a.d;
 }
 
+// v of the lane whose id differs in bit 0 (kXor = 1) or bit 1 (kXor = 2): a DPP quad permutation on the two halves -- a
+// plain VALU move, where __shfl_xor goes through the LDS crossbar (ds_bpermute) and its queue
+template <int kXor>
+__device__ __forceinline__ double quad_xor(double v) {
+  constexpr int ctrl = kXor == 1 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+  union { double d; int i[2]; } a;
+  a.d = v;
+  a.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], ctrl, 0xF, 0xF, true);
+  a.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], ctrl, 0xF, 0xF, true);
+  return a.d;
+}
+
 // K simultaneous block reductions (max for op 0, sum for op 1); result broadcast to every thread
 template <int K>
 __device__ __forceinline__ void block_reduce(double *v, int op, ldouble *red) {
@@ -260,9 +272,12 @@ __device__ __forceinline__ bool invert_tile(int n, MTile<NCT> &T, ldouble *c0, l
   const bool live = row < n;
   const int lane = mytid() & 63;
   bool ok = true;
+  // c0 / c1 hold n + 1 doubles each: the pivot row and, behind it, the reciprocal of the pivot (computed once by the
+  // publishing thread instead of once per wavefront)
   for (int k = 0; k < n; k++) {
     ldouble *c = (k & 1) ? c1 : c0;
-    const int kl = k - j0;  // column k inside this tile (when 0 <= kl < ncv)
+    // column k inside this tile (when 0 <= kl < ncv); wave-uniform, so the fix-up below is a scalar jump, not NCT compares
+    const int kl = __builtin_amdgcn_readfirstlane(k - j0);
     // Publish the pivot column.  The array stays symmetric under the sweeps, so column k is row k: the PARTS threads of
     // row k write their tiles with compile-time register indices (extracting register kl from the tile that holds
     // column k is a dynamic index -- the compiler parks the whole tile in scratch memory for it, every sweep).
@@ -270,26 +285,42 @@ __device__ __forceinline__ bool invert_tile(int n, MTile<NCT> &T, ldouble *c0, l
       ldouble *cw = c + j0;
 #pragma unroll
       for (int u = 0; u < NCT; u++) if (EXACT || u < ncv) cw[u] = T.v[u];
+      if (kl >= 0 && kl < ncv) {  // this thread holds the pivot itself
+        double piv = T.v[0];
+#pragma unroll
+        for (int u = 1; u < NCT; u++) piv = (u == kl) ? T.v[u] : piv;
+        c[n] = 1.0 / piv;
+      }
     }
     __syncthreads();  // (the buffer written two sweeps ago is free: every thread passed the barrier in between)
-    const double piv = c[k];
+    const double piv = c[k], ip = c[n];
     if (!(piv > 0.0)) ok = false;
-    const double ip = 1.0 / piv;
     const double ci = live ? c[row] : 0.0;
     const double f = ci * ip;
     const ldouble *cb = c + j0;
     const double mine = cb[lane < NCT ? lane : NCT - 1];  // element `lane` of this part's stretch of the pivot row
+    // the elements of the pivot row as wave-uniform values (scalar registers), all of them before the arithmetic
+    double cj[NCT];
+#pragma unroll
+    for (int u = 0; u < NCT; u++) cj[u] = lane_bcast(mine, u);
     // the common case is one fused multiply-add per element; the pivot row (one thread per part) and the pivot column (the
     // waves of one part) are fixed up under branches that the other wavefronts skip
     if (row == k) {
 #pragma unroll
-      for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? -ip : lane_bcast(mine, u) * ip;   // row k: M_kj / p, pivot: -1 / p
+      for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? -ip : cj[u] * ip;   // row k: M_kj / p, pivot: -1 / p
     } else {
 #pragma unroll
-      for (int u = 0; u < NCT; u++) T.v[u] = __builtin_fma(-f, lane_bcast(mine, u), T.v[u]);  // M_ij - M_ik M_kj / p
-      if (kl >= 0 && kl < NCT) {
-#pragma unroll
-        for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? f : T.v[u];        // column k: M_ik / p
+      for (int u = 0; u < NCT; u++) T.v[u] = __builtin_fma(-f, cj[u], T.v[u]);  // M_ij - M_ik M_kj / p
+      if (kl >= 0 && kl < NCT) {                                                // column k: M_ik / p
+        switch (kl) {
+#define OQ_COLFIX(U) case U: if (U < NCT) T.v[U < NCT ? U : 0] = f; break;
+          OQ_COLFIX(0) OQ_COLFIX(1) OQ_COLFIX(2) OQ_COLFIX(3) OQ_COLFIX(4) OQ_COLFIX(5) OQ_COLFIX(6) OQ_COLFIX(7)
+          OQ_COLFIX(8) OQ_COLFIX(9) OQ_COLFIX(10) OQ_COLFIX(11) OQ_COLFIX(12) OQ_COLFIX(13) OQ_COLFIX(14) OQ_COLFIX(15)
+          OQ_COLFIX(16) OQ_COLFIX(17) OQ_COLFIX(18) OQ_COLFIX(19) OQ_COLFIX(20) OQ_COLFIX(21) OQ_COLFIX(22) OQ_COLFIX(23)
+          OQ_COLFIX(24) OQ_COLFIX(25) OQ_COLFIX(26) OQ_COLFIX(27) OQ_COLFIX(28) OQ_COLFIX(29) OQ_COLFIX(30) OQ_COLFIX(31)
+#undef OQ_COLFIX
+          default: break;
+        }
       }
     }
     if (!EXACT) {
@@ -374,8 +405,8 @@ __device__ __forceinline__ void col_dot(const SparseRegs &R, const ldouble *Av, 
   double a = 0.0;
 #pragma unroll
   for (int e = 0; e < KT; e++) if (e < R.ccnt) { const unsigned w = opaque_word(R.ce[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
-  a += __shfl_xor(a, 2, 64);
-  a += __shfl_xor(a, 1, 64);
+  a += quad_xor<2>(a);
+  a += quad_xor<1>(a);
   if ((mytid() & 3) == 0 && R.col >= 0) finish(R.col, a);
 }
 template <typename G>
@@ -383,7 +414,7 @@ __device__ __forceinline__ void row_dot(const SparseRegs &R, const ldouble *Av, 
   double a = 0.0;
 #pragma unroll
   for (int e = 0; e < KR; e++) if (e < R.rcnt) { const unsigned w = opaque_word(R.re[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
-  a += __shfl_xor(a, 1, 64);
+  a += quad_xor<1>(a);
   if ((mytid() & 1) == 0 && R.row >= 0) finish(R.row, a);
 }
 
@@ -649,7 +680,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   int status = OSQP_UNSOLVED;
   double *scratch = scratch_all + (size_t)inst * n * n;
   MTile<NCT> Minv;
-  ldouble *gj0 = s.tn, *gj1 = s.Px;  // scratch of the sweeps: Px is only live inside a residual evaluation
+  // scratch of the sweeps, n + 1 doubles each: tn runs on into ldinv (unused by this kernel), Px into Aty -- Px and Aty are
+  // only live inside a residual evaluation
+  ldouble *gj0 = s.tn, *gj1 = s.Px;
   // the thread's share of the entries of A, both orientations (positions and indices in registers, values from LDS)
   const bool regs = sparse_fits(P);
   SparseRegs R;
