@@ -311,6 +311,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  *    3 the same tiles over wide panels gathered through L2 (n >> 1e6 at fixed nnz)
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
  * 16, 17 rows of the local blocks (n, m)          18 compact mode (CSR column / value arrays released) 0 / 1
+ * 19 levels of the supernode graph when the triangular solves run by supernodes (0: by the level schedule)
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
@@ -408,6 +409,15 @@ c_int osqp_amd_batch_destroy(osqp_amd_batch *batch);
 /* Select the HIP device for workspaces created afterwards by this process
  * (one process per GPU: pass LOCAL_RANK). */
 c_int osqp_amd_set_device(c_int device);
+
+/* Host-only: the symbolic analysis of the direct back-end on the pattern of a QP (triu(P) and A in CSC form), no
+ * device needed -- what the CPU tests of the ordering / level schedule / supernode partition call.
+ * ordering: 0 minimum degree, 1 nested dissection, 2 minimum degree with queued ties; smax: largest supernode.
+ * out[0..12]: N, nnz(L), pivot levels, supernodes, supernode levels, entries outside the diagonal blocks,
+ *            doubles in the inverted blocks, largest supernode, 1 if every structural invariant holds, nnz in blocks,
+ *            modelled microseconds of a solve by levels / by supernodes, 1 if the engine would take supernodes */
+c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_int *Ap, const c_int *Ai,
+                              c_int ordering, c_int smax, c_float *out, c_int count);
 
 /* Last error message of the calling thread ("" if none). */
 const char *osqp_amd_last_error(void);

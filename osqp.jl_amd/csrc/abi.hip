@@ -3,6 +3,7 @@
 // extension entry points.  Exceptions stop here and become the integer exit
 // flags the Julia side tests with `!= 0` [REF src/interface.jl:157-159].
 #include "engine.hpp"
+#include "symbolic.hpp"
 
 #include <cmath>
 
@@ -243,6 +244,64 @@ c_int osqp_amd_comm_all_gather(osqp_amd_comm *c, c_float *dev_buf, c_int count) 
     return 0;
   });
 }
+c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_int *Ap, const c_int *Ai,
+                              c_int ordering, c_int smax, c_float *out, c_int count) {
+  if (n <= 0 || m < 0 || !Pp || !Ap || !out || count < 13 || smax < 1) return 1;
+  return guarded([&]() {
+    HostCsc P, A;
+    P.rows = (int)n; P.cols = (int)n; P.p.assign(Pp, Pp + n + 1); P.i.assign(Pi, Pi + Pp[n]);
+    A.rows = (int)m; A.cols = (int)n; A.p.assign(Ap, Ap + n + 1); A.i.assign(Ai, Ai + Ap[n]);
+    std::vector<int> ident((size_t)m);
+    for (int i = 0; i < (int)m; i++) ident[i] = i;
+    Symbolic S;
+    symbolic_analyse(P, A, ident, (int)m, (int64_t)4000000000LL, 0.0, (int)ordering, S);
+    if (S.too_large) return 2;
+    Supernodes T;
+    build_supernodes(S, (int)smax, T);
+    // invariants: slots are a permutation; supernodes are numbered level by level; every entry of L is either inside
+    // a diagonal block (below its diagonal) or points from a supernode to one of a strictly lower level
+    bool ok = (int)T.piv.size() == S.N && T.ptr.back() == S.N && T.lvl_ptr.back() == T.count;
+    std::vector<int> owner(S.N, -1), lvl(T.count, -1);
+    for (int L = 0; L < T.nlev; L++)
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) lvl[J] = L;
+    int largest = 0;
+    for (int J = 0; J < T.count && ok; J++) {
+      largest = std::max(largest, T.ptr[J + 1] - T.ptr[J]);
+      for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) {
+        ok = ok && T.slot[T.piv[q]] == q && (q == T.ptr[J] || T.piv[q] > T.piv[q - 1]);
+        owner[q] = J;
+      }
+    }
+    ok = ok && largest <= (int)smax;
+    int64_t inside = 0;
+    for (int J = 0; J < T.count && ok; J++) {
+      const int s = T.ptr[J + 1] - T.ptr[J];
+      for (int a = 0; a < s; a++)
+        for (int b = 0; b < s; b++) {
+          const int64_t t = T.wmap[T.woff[J] + (int64_t)a * s + b];
+          if (t < 0) continue;
+          inside++;
+          const int col = T.piv[T.ptr[J] + b], row = T.piv[T.ptr[J] + a];
+          ok = ok && a > b && t >= S.Lp[col] && t < S.Lp[col + 1] && S.Li[t] == row;
+        }
+    }
+    for (int q = 0; q < S.N && ok; q++) {
+      for (int64_t i = T.Fp[q]; i < T.Fp[q + 1]; i++)
+        ok = ok && lvl[owner[T.Fj[i]]] < lvl[owner[q]] && S.Li[T.Fpos[i]] == T.piv[q] && (i == T.Fp[q] || T.Fj[i] > T.Fj[i - 1]) &&
+             ((i < T.Fsplit[q]) == (lvl[owner[T.Fj[i]]] == 0));
+      for (int64_t i = T.Gp[q]; i < T.Gp[q + 1]; i++)
+        ok = ok && lvl[owner[T.Gi[i]]] > lvl[owner[q]] && S.Li[T.Gpos[i]] == T.piv[T.Gi[i]] && (i == T.Gp[q] || T.Gi[i] > T.Gi[i - 1]);
+    }
+    ok = ok && inside + T.Fp[S.N] == S.nnzL && T.Gp[S.N] == T.Fp[S.N];
+    out[0] = S.N; out[1] = (double)S.nnzL; out[2] = (double)S.level_ptr.size() - 1; out[3] = T.count; out[4] = T.nlev;
+    out[5] = (double)T.Fp[S.N]; out[6] = (double)T.woff[T.count]; out[7] = largest; out[8] = ok ? 1.0 : 0.0; out[9] = (double)inside;
+    int lD, cD, kD;
+    choose_dense_top(S, 512, 2048, 1024, 32, lD, cD, kD);
+    out[10] = level_solve_cost_us(S, 512, lD, kD); out[11] = supernode_solve_cost_us(T, 256);
+    out[12] = supernodes_pay(S, T, 512, lD, kD, 256) ? 1.0 : 0.0;
+    return 0;
+  });
+}
 c_int osqp_amd_comm_destroy(osqp_amd_comm *c) {
   if (!c) return 0;
   try { delete (Comm *)c; } catch (...) { return 1; }
@@ -396,6 +455,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[16] = (c_float)e.n;  // local block sizes
   v[17] = (c_float)e.m;
   v[18] = e.compact ? 1.0 : 0.0;
+  v[19] = e.lin->supernode_levels();
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

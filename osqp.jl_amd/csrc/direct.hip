@@ -629,6 +629,178 @@ __global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, dou
   }
 }
 
+
+// ------------------------------------------------------------------ supernodal triangular solves
+// (symbolic.hpp, Supernodes) One workgroup per supernode, one launch per level of the supernode graph.  With
+// W = L_JJ^-1 (unit lower triangular, dense s x s, stored twice: Wc[j*s+a] = W(a,j), Wr[j*s+a] = W(j,a)):
+//   forward   t = b_J - F_J y (entries of the rows of J outside its block),  y_J = W t
+//   backward  u = D_J^-1 y_J - G_J x (entries of the columns of J outside its block),  x_J = W' u
+// A deep elimination tree (nested dissection of a long banded problem: 300 pivot levels) is 15 such levels.
+constexpr int kSnMax = 64, kSnThreads = 256;
+
+__global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                          const int64_t *__restrict__ wmap, const double *__restrict__ Lx,
+                                                          double *__restrict__ Wc, double *__restrict__ Wr) {
+  __shared__ double Ld[kSnMax * kSnMax], Wd[kSnMax * kSnMax];
+  const int J = blockIdx.x, s = ptr[J + 1] - ptr[J];
+  const int64_t w0 = woff[J];
+  for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
+    const int64_t t = wmap[w0 + e];
+    Ld[e] = t >= 0 ? Lx[t] : 0.0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < s) {  // column j of the inverse by forward substitution: W(i,j) = -sum_{k=j}^{i-1} L(i,k) W(k,j)
+    const int j = threadIdx.x;
+    for (int i = 0; i < s; i++) {
+      double w = 0.0;
+      if (i == j) w = 1.0;
+      else if (i > j) {
+        for (int k = j; k < i; k++) w -= Ld[i * s + k] * Wd[k * s + j];
+      }
+      Wd[i * s + j] = w;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
+    const int j = e / s, a = e - j * s;
+    Wc[w0 + e] = Wd[a * s + j];
+    Wr[w0 + e] = Wd[j * s + a];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sn_gather(int64_t nf, const int64_t *__restrict__ Fpos, double *__restrict__ Fx, int64_t ng,
+                                                      const int64_t *__restrict__ Gpos, double *__restrict__ Gx, int N,
+                                                      const int *__restrict__ piv, const double *__restrict__ Dinv,
+                                                      double *__restrict__ Dinv_s, const double *__restrict__ Lx) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nf) Fx[i] = Lx[Fpos[i]];
+  if (i < ng) Gx[i] = Lx[Gpos[i]];
+  if (i < N) Dinv_s[i] = Dinv[piv[i]];
+}
+
+// LA lanes per row for the entries outside the block, 4 lanes per row for the block product
+template <int LA, bool kForward>
+__global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                         const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
+                                                         const double *__restrict__ Ex, const double *__restrict__ W,
+                                                         const double *__restrict__ Dinv_s, double *__restrict__ b) {
+  __shared__ double t[kSnMax];
+  const int J = J0 + blockIdx.x, q0 = ptr[J], s = ptr[J + 1] - q0;
+  {
+    const int lane = threadIdx.x % LA;
+    for (int a = threadIdx.x / LA; a < s; a += kSnThreads / LA) {
+      const int q = q0 + a;
+      double acc = 0.0;
+      for (int64_t i = Ep[q] + lane; i < Ep[q + 1]; i += LA) acc += Ex[i] * b[Ej[i]];
+#pragma unroll
+      for (int o = LA / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
+    }
+  }
+  __syncthreads();
+  const double *Wj = W + woff[J];
+  const int part = threadIdx.x & 3;
+  for (int a = threadIdx.x >> 2; a < s; a += kSnThreads / 4) {
+    double acc = 0.0;
+    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s + a] * t[j]; }
+    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * s + a] * t[j]; }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0) b[q0 + a] = acc;
+  }
+}
+
+// The supernodes of level >= 1 in ONE launch per direction: workgroup = supernode, started in level order, each
+// waiting on a counter for the supernodes below it (forward: `pending[J]` children still running; backward: the
+// supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
+// their resting values when the launch ends, so a captured graph can replay it.  Workgroups are dispatched in
+// blockIdx order per XCD and a workgroup only waits on lower blockIdx values, so the lowest unfinished one is always
+// resident and never waits on an unscheduled one; a wait that still exceeds one second sets *fault (mapped host memory)
+// and carries on, so a broken assumption is a reported error, not a hang.
+constexpr int kSnTreeThreads = 1024;
+__device__ __forceinline__ int sn_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sum of Ex[i] * b[Ej[i]] over i = i0 + lane, i0 + lane + la, ... < i1, four gathers in flight per lane
+template <bool kCoherent>
+__device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, int la, const int *__restrict__ Ej,
+                                            const double *__restrict__ Ex, const double *b) {
+  auto ld = [&](int j) { return kCoherent ? __hip_atomic_load(&b[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : b[j]; };
+  double acc = 0.0;
+  int64_t i = i0 + lane;
+  for (; i + 3 * (int64_t)la < i1; i += 4 * (int64_t)la) {
+    const int j0 = Ej[i], j1 = Ej[i + la], j2 = Ej[i + 2 * la], j3 = Ej[i + 3 * la];
+    const double x0 = Ex[i], x1 = Ex[i + la], x2 = Ex[i + 2 * la], x3 = Ex[i + 3 * la];
+    const double b0 = ld(j0), b1 = ld(j1), b2 = ld(j2), b3 = ld(j3);
+    acc += x0 * b0; acc += x1 * b1; acc += x2 * b2; acc += x3 * b3;
+  }
+  for (; i < i1; i += la) acc += Ex[i] * ld(Ej[i]);
+  return acc;
+}
+template <bool kForward>
+__global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                            const int64_t *__restrict__ Ep, const int64_t *__restrict__ Es,
+                                                            const int *__restrict__ Ej, const double *__restrict__ Ex,
+                                                            const double *__restrict__ W, const double *__restrict__ Dinv_s,
+                                                            const int *__restrict__ up, const int *__restrict__ waits,
+                                                            int *__restrict__ sync, int *__restrict__ fault, double *b) {
+  __shared__ double t[kSnMax];
+  const int J = kForward ? J0 + (int)blockIdx.x : count - 1 - (int)blockIdx.x;
+  const int P = up[J];
+  const int q0 = ptr[J], s = ptr[J + 1] - q0;
+  const int64_t mean = (Ep[q0 + s] - Ep[q0]) / s;
+  const int la = mean <= 8 ? 4 : (mean <= 64 ? 16 : 64);  // lanes per row
+  const int lane = threadIdx.x & (la - 1);
+  // Entries of b written inside this launch (slots of level >= 1) are stored and loaded at device scope, past the
+  // per-XCD L2s, so no cache write-back / invalidate is needed around the counters; everything else (level-0 slots, L,
+  // W) was written by earlier launches and is read through the caches -- and, in the forward direction, before the
+  // wait: the part of each row that points at level 0 does not depend on anything in this launch.
+  for (int a = threadIdx.x / la; a < s; a += kSnTreeThreads / la) {
+    const int q = q0 + a;
+    double acc = kForward ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
+    for (int o = la >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
+  }
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    if (kForward) {
+      while (sn_load(&sync[J]) != 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+      }
+      sync[J] = waits[J];  // resting value for the next solve (its children are all past their decrement)
+    } else if (P >= 0) {
+      while (sn_load(&sync[P]) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+      }
+      __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  for (int a = threadIdx.x / la; a < s; a += kSnTreeThreads / la) {
+    const int q = q0 + a;
+    double acc = sn_gather<true>(kForward ? Es[q] : Ep[q], Ep[q + 1], lane, la, Ej, Ex, b);
+    for (int o = la >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) t[a] -= acc;
+  }
+  __syncthreads();
+  const double *Wj = W + woff[J];
+  const int part = threadIdx.x & 15;
+  for (int a = threadIdx.x >> 4; a < s; a += kSnTreeThreads / 16) {
+    double acc = 0.0;
+    if (kForward) { for (int j = part; j <= a; j += 16) acc += Wj[j * s + a] * t[j]; }
+    else { for (int j = a + part; j < s; j += 16) acc += Wj[j * s + a] * t[j]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (part == 0) __hip_atomic_store(&b[q0 + a], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (kForward) { if (P >= 0) __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (waits[J] > 0) __hip_atomic_store(&sync[J], waits[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row inside an LDS chain  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
 
@@ -646,6 +818,20 @@ struct LdlFactor {
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
   std::vector<Step> fwd, bwd;
   long long factorizations = 0;
+  // supernodal solves (k_sn_*): chosen when the level schedule is deep and the supernode graph is shallow
+  bool sn = false;
+  Supernodes T;
+  DevBuf<int> sn_ptr, sn_piv, perm_s, pinv_s, sn_Fj, sn_Gi, sn_up, sn_waits, sn_pending, sn_ready;
+  int *sn_fault = nullptr, *sn_fault_host = nullptr;  // mapped host memory: a wait inside k_sn_tree timed out
+  ~LdlFactor() { if (sn_fault_host) (void)hipHostFree(sn_fault_host); }
+  bool faulted() const { return sn_fault_host && *(volatile int *)sn_fault_host != 0; }
+  bool sn_tree = false;     // levels >= 1 in one launch per direction (k_sn_tree) instead of one per level
+  DevBuf<int64_t> sn_woff, sn_wmap, sn_Fp, sn_Fpos, sn_Gp, sn_Gpos, sn_Fsplit;
+  DevBuf<double> sn_Wc, sn_Wr, sn_Fx, sn_Gx, sn_Dinv;
+  std::vector<int> sn_lanes_f, sn_lanes_b;  // per level: lanes per row for the entries outside the blocks
+  const int *vec_perm() const { return sn ? perm_s.get() : perm.get(); }   // order of the solve vector bp
+  const int *vec_pinv() const { return sn ? pinv_s.get() : pinv.get(); }
+  int solve_levels() const { return sn ? T.nlev : lD; }
 
   LdlFactor(Engine &en, const std::vector<int> &row_map, int mr_, double sigma_, double cconst_, int64_t limit,
             double flops_limit = 0.0)
@@ -677,6 +863,8 @@ struct LdlFactor {
     up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
     Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
     choose_dense_block();
+    choose_supernodes();
+    if (sn) { lD = nlev; cD = N; kD = 0; }
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
@@ -684,7 +872,7 @@ struct LdlFactor {
         const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1], width = c1 - c0;
         if (width == 0 || S.Lp[c1] == S.Lp[c0]) continue;
         const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)width;
-        if (mean >= 128.0 && (size_t)width * (size_t)N * sizeof(double) <= ((size_t)256 << 20)) {
+        if (mean >= long_row_mean() && (size_t)width * (size_t)N * sizeof(double) <= ((size_t)256 << 20)) {
           long_rows[l] = 1;
           wmax = std::max(wmax, (size_t)width * (size_t)N);
         }
@@ -700,62 +888,67 @@ struct LdlFactor {
     std::vector<int64_t>().swap(S.PtoL); std::vector<int64_t>().swap(S.AtoL);
   }
 
-  static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
-
-  // Rough time of one forward + backward solve: a launch per wide level, a chain step per narrow level below the
-  // dense top block, the bytes of L at 2 TB/s, the dense block's product.  Only used to compare two orderings.
-  static double solve_cost_us(const Symbolic &Y) {
-    const auto &lp = Y.level_ptr;
-    const int nl = (int)lp.size() - 1, NN = Y.N;
-    int l = nl;
-    while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && NN - lp[l - 1] <= kDenseMax) l--;
-    const int k = NN - lp[l];
-    const int top = k >= kDenseMin ? l : nl;
-    double us = 0.0;
-    for (int q = 0; q < top; q++) us += (lp[q + 1] - lp[q] > kChainRows) ? 6.0 : 1.4;
-    us += (double)Y.nnzL * 24.0 / 2.0e6;
-    if (top < nl) us += (double)k * (double)k * 8.0 / 4.0e6 + 10.0;
-    return us;
+  // Supernodal solves when their modelled time (a launch per level; the slowest workgroup of each level walks its
+  // entries outside the blocks with 256 threads, then its s x s block) is well below the level schedule's.
+  // OSQP_AMD_SNODE = 0 never, 2 always (tests), otherwise by the model.
+  void choose_supernodes() {
+    const int mode = getenv("OSQP_AMD_SNODE") ? atoi(getenv("OSQP_AMD_SNODE")) : 1;
+    if (mode == 0 || N < 2) return;
+    if (mode != 2 && nlev < 48) return;
+    int smax = kSnMax;  // OSQP_AMD_SNODE_MAX: smaller supernodes (tests: many levels on small problems)
+    if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
+    build_supernodes(S, smax, T);
+    sn_lanes_f.assign(T.nlev, 1); sn_lanes_b.assign(T.nlev, 1);
+    for (int L = 0; L < T.nlev; L++) {
+      int64_t ef = 0, eb = 0, rows = 0;
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+        const int q0 = T.ptr[J], q1 = T.ptr[J + 1];
+        ef += T.Fp[q1] - T.Fp[q0]; eb += T.Gp[q1] - T.Gp[q0]; rows += q1 - q0;
+      }
+      sn_lanes_f[L] = pick((double)ef / (double)std::max<int64_t>(1, rows));
+      sn_lanes_b[L] = pick((double)eb / (double)std::max<int64_t>(1, rows));
+    }
+    sn = mode == 2 || supernodes_pay(S, T, kChainRows, lD, kD, kSnThreads);
+    if (!sn) { T = Supernodes(); return; }
+    hipStream_t s = e.stream;
+    auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    up32(sn_ptr, T.ptr); up32(sn_piv, T.piv); up32(sn_Fj, T.Fj); up32(sn_Gi, T.Gi);
+    up32(sn_up, T.up); up32(sn_waits, T.waits); up32(sn_pending, T.waits);
+    sn_ready.alloc(T.count); sn_ready.zero(s);
+    sn_tree = T.nlev > 2 && !(getenv("OSQP_AMD_SNODE_TREE") && atoi(getenv("OSQP_AMD_SNODE_TREE")) == 0);
+    if (sn_tree) {
+      HIP_CHECK(hipHostMalloc((void **)&sn_fault_host, sizeof(int), hipHostMallocMapped));
+      *sn_fault_host = 0;
+      HIP_CHECK(hipHostGetDevicePointer((void **)&sn_fault, sn_fault_host, 0));
+    }
+    up64(sn_woff, T.woff); up64(sn_wmap, T.wmap); up64(sn_Fp, T.Fp); up64(sn_Fpos, T.Fpos); up64(sn_Gp, T.Gp); up64(sn_Gpos, T.Gpos); up64(sn_Fsplit, T.Fsplit);
+    std::vector<int> ps(N), pis(N);
+    for (int q = 0; q < N; q++) { ps[q] = S.perm[T.piv[q]]; pis[ps[q]] = q; }
+    up32(perm_s, ps); up32(pinv_s, pis);
+    sn_Wc.alloc(T.woff[T.count]); sn_Wr.alloc(T.woff[T.count]);
+    sn_Fx.alloc(std::max<size_t>(1, T.Fj.size())); sn_Gx.alloc(std::max<size_t>(1, T.Gi.size())); sn_Dinv.alloc(N);
+    e.sync();
+    // only the shapes are needed on the host from here on
+    std::vector<int64_t>().swap(T.wmap); std::vector<int64_t>().swap(T.Fpos); std::vector<int64_t>().swap(T.Gpos);
+    std::vector<int>().swap(T.Fj); std::vector<int>().swap(T.Gi);
   }
 
-  // The dense top block: the longest suffix of the top chain (levels of at most kChainRows pivots) with at most
-  // kDenseMax pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when one dense
-  // product costs less than its levels.
+  // rows at least this long (mean over a level) go through the work-row form of phase 2: the thread-per-entry merge
+  // of two rows of 50-300 entries is ~100 us of dependent loads, the wave-per-entry product ~7 us (control, T = 800)
+  static double long_row_mean() { const char *v = getenv("OSQP_AMD_LONG_ROW_MEAN"); return v ? atof(v) : 24.0; }
+  static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
+
+  static double solve_cost_us(const Symbolic &Y, double chain_level_us = 1.4) {
+    return level_solve_cost_us(Y, kChainRows, kDenseMax, kDenseMin, chain_level_us);
+  }
+
+  // The dense top block (symbolic.hpp, choose_dense_top)
   static constexpr int kDenseMax = 2048, kDenseSparseMax = 1024, kDenseMin = 32;
   void choose_dense_block() {
-    const auto &lp = S.level_ptr;
     lD = nlev; cD = N; kD = 0;
     static const bool enabled = !(getenv("OSQP_AMD_DENSE_TOP") && atoi(getenv("OSQP_AMD_DENSE_TOP")) == 0);
-    if (!enabled || nlev < 2) return;
-    auto suffix = [&](int limit) {
-      int l = nlev;
-      while (l > 1 && lp[l] - lp[l - 1] <= kChainRows && N - lp[l - 1] <= limit) l--;
-      return l;
-    };
-    auto entries_inside = [&](int c) {
-      int64_t inside = 0;
-      for (int r = c; r < N; r++) {
-        const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
-        inside += end - std::lower_bound(beg, end, c);
-      }
-      return inside;
-    };
-    int l = suffix(kDenseMax);
-    int c = lp[l], k = N - c;
-    if (k < kDenseMin) return;
-    bool dense = entries_inside(c) * 8 >= (int64_t)k * k;
-    if (!dense && k > kDenseSparseMax) {
-      // a block-sparse top (the separators of a nested-dissection tree): the inversion costs k^3, the levels it
-      // replaces only k, so a smaller block is the better trade
-      l = suffix(kDenseSparseMax); c = lp[l]; k = N - c;
-      if (k < kDenseMin) return;
-      dense = entries_inside(c) * 8 >= (int64_t)k * k;
-    }
-    // worth it when the block is dense (then the chain rows are long) or when the dense product is cheaper than
-    // walking the block's levels one by one
-    const double dense_us = (double)k * (double)k * 8.0 / 4.0e6 + 10.0, chain_us = 1.4 * (double)(nlev - l);
-    if (!dense && dense_us > chain_us) return;
-    lD = l; cD = c; kD = k;
+    if (enabled) choose_dense_top(S, kChainRows, kDenseMax, kDenseSparseMax, kDenseMin, lD, cD, kD);
   }
   // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
   int dense_batch() const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)kD, ((size_t)256 << 20) / ((size_t)N * sizeof(double)))); }
@@ -860,6 +1053,12 @@ struct LdlFactor {
                   Rj.get(), Rmap.get(), D.get(), Dinv.get());
     }
     if (kD) factor_dense_block();
+    if (sn) {
+      const int64_t nf = T.Fp[N], big = std::max<int64_t>(N, nf);
+      OQ_LAUNCH(k_sn_gather, dim3(blocks_for(big)), dim3(kBlock), 0, s, nf, sn_Fpos.get(), sn_Fx.get(), nf, sn_Gpos.get(), sn_Gx.get(), N,
+                sn_piv.get(), Dinv.get(), sn_Dinv.get(), Lx.get());
+      OQ_LAUNCH(k_sn_invert, dim3(T.count), dim3(kSnThreads), 0, s, sn_ptr.get(), sn_woff.get(), sn_wmap.get(), Lx.get(), sn_Wc.get(), sn_Wr.get());
+    }
     if (S.nnzL > 0) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
     int st[2] = {0, 0};
     status.download(st, 2, s);
@@ -918,8 +1117,53 @@ struct LdlFactor {
   void launch_bwd_chain(const Step &t, hipStream_t s) { launch_chain(t, false, s); }
 
   // skip_first_fwd / skip_last_bwd: those two level steps are folded into the kernels around the solve (fused_ends)
+#define OQ_SN_LEVEL(LA, FWD, L)                                                                                                   \
+  OQ_LAUNCH((k_sn_level<LA, FWD>), dim3(T.lvl_ptr[L + 1] - T.lvl_ptr[L]), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(),     \
+            sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),      \
+            FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get())
+#define OQ_SN_TREE(FWD)                                                                                                           \
+  OQ_LAUNCH((k_sn_tree<FWD>), dim3(T.count - T.lvl_ptr[1]), dim3(kSnTreeThreads), 0, s, T.lvl_ptr[1], T.count, sn_ptr.get(),    \
+            sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
+            FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
+            FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get())
+  void run_supernodes() {
+    hipStream_t s = e.stream;
+    if (sn_tree) {
+      switch (sn_lanes_f[0]) {
+      case 1: OQ_SN_LEVEL(1, true, 0); break;
+      case 4: OQ_SN_LEVEL(4, true, 0); break;
+      case 16: OQ_SN_LEVEL(16, true, 0); break;
+      default: OQ_SN_LEVEL(64, true, 0); break;
+      }
+      OQ_SN_TREE(true);
+      OQ_SN_TREE(false);
+      switch (sn_lanes_b[0]) {
+      case 1: OQ_SN_LEVEL(1, false, 0); break;
+      case 4: OQ_SN_LEVEL(4, false, 0); break;
+      case 16: OQ_SN_LEVEL(16, false, 0); break;
+      default: OQ_SN_LEVEL(64, false, 0); break;
+      }
+      return;
+    }
+    for (int L = 0; L < T.nlev; L++) switch (sn_lanes_f[L]) {
+      case 1: OQ_SN_LEVEL(1, true, L); break;
+      case 4: OQ_SN_LEVEL(4, true, L); break;
+      case 16: OQ_SN_LEVEL(16, true, L); break;
+      default: OQ_SN_LEVEL(64, true, L); break;
+    }
+    for (int L = T.nlev - 1; L >= 0; L--) switch (sn_lanes_b[L]) {
+      case 1: OQ_SN_LEVEL(1, false, L); break;
+      case 4: OQ_SN_LEVEL(4, false, L); break;
+      case 16: OQ_SN_LEVEL(16, false, L); break;
+      default: OQ_SN_LEVEL(64, false, L); break;
+    }
+  }
+#undef OQ_SN_LEVEL
+#undef OQ_SN_TREE
+
   void run_steps(bool skip_first_fwd = false, bool skip_last_bwd = false) {
     hipStream_t s = e.stream;
+    if (sn) { run_supernodes(); return; }
     for (size_t si = 0; si < fwd.size(); si++) {
       const Step &t = fwd[si];
       if (si == 0 && skip_first_fwd) continue;
@@ -966,27 +1210,30 @@ struct LdlFactor {
   // in place on b (length N, KKT order).  rho_inv != nullptr: the ADMM form with the z~ fix-up.
   void solve(double *b, const double *rho_inv) {
     hipStream_t s = e.stream;
-    OQ_LAUNCH(k_perm_in, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, perm.get(), b, bp.get());
+    OQ_LAUNCH(k_perm_in, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, vec_perm(), b, bp.get());
     run_steps();
-    OQ_LAUNCH(k_perm_out, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, n, pinv.get(), bp.get(), rho_inv, b);
+    OQ_LAUNCH(k_perm_out, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, n, vec_pinv(), bp.get(), rho_inv, b);
   }
 
   // level 1 forward / level 0 backward are plain level steps over short rows: they can ride with the iteration's ends
   bool can_fuse_fwd1() const {
-    return nlev >= 2 && !fwd.empty() && fwd[0].kind == 0 && fwd[0].a == S.level_ptr[1] && fwd[0].b == S.level_ptr[2] && fwd[0].G <= 4;
+    return !sn && nlev >= 2 && !fwd.empty() && fwd[0].kind == 0 && fwd[0].a == S.level_ptr[1] && fwd[0].b == S.level_ptr[2] && fwd[0].G <= 4;
   }
   bool can_fuse_bwd0() const {
-    return !bwd.empty() && bwd.back().kind == 0 && bwd.back().a == 0 && bwd.back().b == S.level_ptr[1] && bwd.back().G <= 4;
+    return !sn && !bwd.empty() && bwd.back().kind == 0 && bwd.back().a == 0 && bwd.back().b == S.level_ptr[1] && bwd.back().G <= 4;
   }
 
   // the whole iteration in two launches (k_direct2_fwd / k_direct2_bwd_update): a two-level factor with short rows
   bool can_fuse2() const {
-    if (nlev != 2 || kD != 0 || fwd.size() != 1 || bwd.size() != 2) return false;
+    if (sn || nlev != 2 || kD != 0 || fwd.size() != 1 || bwd.size() != 2) return false;
     if (fwd[0].kind != 0 || fwd[0].G > 4 || bwd[0].kind != 0 || bwd[1].kind != 0 || bwd[1].G > 4) return false;
     return S.Lp[N] == S.Lp[S.level_ptr[1]];  // nothing above level 1: its backward step is the D^-1 scaling alone
   }
 
-  double trisolve_bytes() const { return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N; }
+  double trisolve_bytes() const {
+    if (sn) return 2.0 * (12.0 * (double)T.Fp[N] + 8.0 * (double)T.woff[T.count] + 8.0 * ((double)N + 1.0)) + 40.0 * (double)N;
+    return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N;
+  }
 };
 
 struct Direct : Linsys {
@@ -1015,7 +1262,7 @@ struct Direct : Linsys {
                 F->S.level_ptr[1], F->S.level_ptr[2], F->Rp.get(), F->Rj.get(), F->Rx.get(), e.x.get(), e.q.get(), e.z.get(),
                 e.rho_inv.get(), e.y.get(), F->bp.get());
     else
-      OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), e.x.get(), e.q.get(),
+      OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->vec_pinv(), e.x.get(), e.q.get(),
                 e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
     F->run_steps(f1, b0);
     if (b0)
@@ -1023,14 +1270,16 @@ struct Direct : Linsys {
                 F->Lp.get(), F->Li.get(), F->Lx.get(), F->Dinv.get(), F->bp.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(),
                 e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     else
-      OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->bp.get(),
+      OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->vec_pinv(), F->bp.get(),
                 e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     return 0;
   }
+  int flush() override { return F->faulted() ? 6 : 0; }  // a supernode waited a second for its children: internal error
   int update_rho() override { return F->refactor(e.rho_inv.get()); }
   int update_matrices() override { return F->refactor(e.rho_inv.get()); }
   double nnzL() const override { return (double)F->S.nnzL; }
   double levels() const override { return (double)F->nlev; }
+  double supernode_levels() const override { return F->sn ? (double)F->T.nlev : 0.0; }
   double trisolve_bytes() const override { return F->trisolve_bytes(); }
   double factorizations() const override { return (double)F->factorizations; }
   float time_solve(int reps) override {
@@ -1077,7 +1326,7 @@ std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
   // (sum of squared column counts ~ multiply-adds of one numeric factorisation; it is redone at every rho update)
   // or when the level schedule below the dense top block is so deep that the triangular solves are a serial chain
   // (measured, n = m = 5000 with 10 per row: 4623 levels, 60 ms per iteration -- PCG needs a fraction of a millisecond there)
-  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->lD > level_limit())) { *err = -1; return nullptr; }
+  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->solve_levels() > level_limit())) { *err = -1; return nullptr; }
   int rc = d->F->refactor(e.rho_inv.get());
   if (rc) { *err = rc; return nullptr; }
   return std::unique_ptr<Linsys>(d.release());

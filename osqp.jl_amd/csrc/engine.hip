@@ -520,7 +520,10 @@ void Engine::run_chunk() {
 // --------------------------------------------------------------------------
 // Ax, Px, A'y at the current iterate and the 16 norms / sums of Slot order into h_slots
 void Engine::residual_evaluation() {
-  if (int rc = lin->flush()) deferred_error = rc;  // the iterate must be the one the host believes it is
+  if (int rc = lin->flush()) {  // the iterate must be the one the host believes it is
+    if (rc == 6) throw Error(6, "internal: a supernode of the triangular solve waited a second for its children");
+    deferred_error = rc;
+  }
   const double *xg = full_n(x.get());
   spmv(A, xg, Ax.get(), nullptr, 0.0, 0.0, nullptr, stream);
   spmv(Pf, xg, Px_.get(), nullptr, 0.0, 0.0, nullptr, stream);

@@ -41,6 +41,7 @@ struct Linsys {
   virtual void invalidate() {}
   virtual double nnzL() const { return 0.0; }
   virtual double levels() const { return 0.0; }
+  virtual double supernode_levels() const { return 0.0; }  // 0: the solves walk the level schedule
   virtual double trisolve_bytes() const { return 0.0; }
   virtual double factorizations() const { return 0.0; }
   virtual double cg_iters() const { return 0.0; }

@@ -395,6 +395,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   for (int k = 0; k < N; k++) S.pinv[S.perm[k]] = k;
   build_cols(S.pinv, cp, ci);
   etree_of(cp, ci, parent);
+  S.parent = parent;
 
   // ---- 4. pattern of L: row patterns by climbing the tree from each entry of the row ----
   std::vector<int64_t> colcount(N, 0);
@@ -452,6 +453,202 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       }
       if (org >= 0) S.PtoL[org] = target; else S.AtoL[-(org + 2)] = target;
     }
+}
+
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
+  const int N = S.N;
+  const std::vector<int> &parent = S.parent;
+  out = Supernodes();
+  out.smax = smax;
+  // subtree sizes (parents have larger indices than their children)
+  std::vector<int> size(N, 1), big_children(N, 0);
+  for (int v = 0; v < N; v++)
+    if (parent[v] >= 0) size[parent[v]] += size[v];
+  auto big = [&](int v) { return size[v] > smax; };
+  for (int v = 0; v < N; v++)
+    if (parent[v] >= 0 && big(v)) big_children[parent[v]]++;
+  // roots first: a small node joins its parent's subtree supernode; a big node continues its parent's path segment
+  // when it is the only big child and the segment has room
+  std::vector<int> sn(N, -1), members;
+  for (int v = N - 1; v >= 0; v--) {
+    const int p = parent[v];
+    if (!big(v)) {
+      if (p >= 0 && !big(p)) sn[v] = sn[p];
+    } else if (p >= 0 && big_children[p] == 1 && members[sn[p]] < smax) sn[v] = sn[p];
+    if (sn[v] < 0) { sn[v] = (int)members.size(); members.push_back(0); }
+    members[sn[v]]++;
+  }
+  const int count = (int)members.size();
+  // levels of the supernode graph: one more than the deepest supernode holding a child of one of its nodes
+  std::vector<int> level(count, 0);
+  for (int v = 0; v < N; v++) {  // ascending: every child is final before its parent is looked at ...
+    const int p = parent[v];
+    if (p >= 0 && sn[p] != sn[v]) level[sn[p]] = std::max(level[sn[p]], level[sn[v]] + 1);
+  }
+  // ... except that a path segment's level can still grow after a lower node of it was used: iterate to a fixed point
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (int v = 0; v < N; v++) {
+      const int p = parent[v];
+      if (p >= 0 && sn[p] != sn[v] && level[sn[p]] < level[sn[v]] + 1) { level[sn[p]] = level[sn[v]] + 1; changed = true; }
+    }
+  }
+  int nlev = 0;
+  for (int J = 0; J < count; J++) nlev = std::max(nlev, level[J] + 1);
+  out.count = count; out.nlev = nlev;
+  out.lvl_ptr.assign(nlev + 1, 0);
+  for (int J = 0; J < count; J++) out.lvl_ptr[level[J] + 1]++;
+  for (int l = 0; l < nlev; l++) out.lvl_ptr[l + 1] += out.lvl_ptr[l];
+  std::vector<int> newid(count);
+  {
+    std::vector<int> f(out.lvl_ptr.begin(), out.lvl_ptr.end() - 1);
+    for (int J = 0; J < count; J++) newid[J] = f[level[J]]++;
+  }
+  out.ptr.assign(count + 1, 0);
+  for (int J = 0; J < count; J++) out.ptr[newid[J] + 1] = members[J];
+  for (int J = 0; J < count; J++) out.ptr[J + 1] += out.ptr[J];
+  out.piv.resize(N); out.slot.resize(N);
+  {
+    std::vector<int> f(out.ptr.begin(), out.ptr.end() - 1);
+    for (int v = 0; v < N; v++) { const int q = f[newid[sn[v]]]++; out.piv[q] = v; out.slot[v] = q; }
+  }
+  out.up.assign(count, -1); out.waits.assign(count, 0);
+  for (int v = 0; v < N; v++) {
+    const int p = parent[v];
+    if (p >= 0 && sn[p] != sn[v]) out.up[newid[sn[v]]] = newid[sn[p]];  // only the top node of a supernode leaves it
+  }
+  for (int J = out.lvl_ptr[std::min(1, nlev)]; J < count; J++)
+    if (out.up[J] >= 0) out.waits[out.up[J]]++;
+  out.woff.assign(count + 1, 0);
+  for (int J = 0; J < count; J++) {
+    const int64_t s = out.ptr[J + 1] - out.ptr[J];
+    out.woff[J + 1] = out.woff[J] + s * s;
+    out.flops += (double)(s * s);
+  }
+  out.wmap.assign(out.woff[count], -1);
+  // split the entries of L (column v, rows r > v) into block entries and the rest
+  out.Fp.assign(N + 1, 0); out.Gp.assign(N + 1, 0);
+  for (int v = 0; v < N; v++)
+    for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
+      const int r = S.Li[t];
+      if (sn[r] == sn[v]) {
+        const int J = newid[sn[v]], s = out.ptr[J + 1] - out.ptr[J];
+        out.wmap[out.woff[J] + (int64_t)(out.slot[r] - out.ptr[J]) * s + (out.slot[v] - out.ptr[J])] = t;
+      } else {
+        out.Fp[out.slot[r] + 1]++;
+        out.Gp[out.slot[v] + 1]++;
+      }
+    }
+  for (int q = 0; q < N; q++) { out.Fp[q + 1] += out.Fp[q]; out.Gp[q + 1] += out.Gp[q]; }
+  out.Fj.resize(out.Fp[N]); out.Fpos.resize(out.Fp[N]); out.Gi.resize(out.Gp[N]); out.Gpos.resize(out.Gp[N]);
+  {
+    // visiting the columns / rows in slot order leaves every list sorted by slot (= by level, then supernode)
+    std::vector<int64_t> ff(out.Fp.begin(), out.Fp.end() - 1), gf(out.Gp.begin(), out.Gp.end() - 1);
+    for (int qv = 0; qv < N; qv++) {
+      const int v = out.piv[qv];
+      for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
+        const int r = S.Li[t];
+        if (sn[r] == sn[v]) continue;
+        const int64_t a = ff[out.slot[r]]++;
+        out.Fj[a] = qv; out.Fpos[a] = t;
+      }
+    }
+    std::vector<std::pair<int, int64_t>> col;
+    for (int qv = 0; qv < N; qv++) {
+      const int v = out.piv[qv];
+      col.clear();
+      for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++)
+        if (sn[S.Li[t]] != sn[v]) col.push_back({out.slot[S.Li[t]], t});
+      std::sort(col.begin(), col.end());
+      int64_t b = gf[qv];
+      for (auto &c : col) { out.Gi[b] = c.first; out.Gpos[b] = c.second; b++; }
+    }
+  }
+  // forward rows: where the entries that point above level 0 begin
+  const int q_upper = nlev > 1 ? out.ptr[out.lvl_ptr[1]] : N;
+  out.Fsplit.resize(N);
+  for (int q = 0; q < N; q++)
+    out.Fsplit[q] = out.Fp[q] + (std::lower_bound(out.Fj.begin() + out.Fp[q], out.Fj.begin() + out.Fp[q + 1], q_upper) - (out.Fj.begin() + out.Fp[q]));
+  out.flops = 2.0 * (out.flops + (double)out.Fp[N]);
+}
+
+double level_solve_cost_us(const Symbolic &Y, int chain_rows, int dense_max, int dense_min, double chain_level_us) {
+  const auto &lp = Y.level_ptr;
+  const int nl = (int)lp.size() - 1, NN = Y.N;
+  int l = nl;
+  while (l > 1 && lp[l] - lp[l - 1] <= chain_rows && NN - lp[l - 1] <= dense_max) l--;
+  const int k = NN - lp[l];
+  const int top = k >= dense_min ? l : nl;
+  double us = 0.0;
+  for (int q = 0; q < top; q++) us += (lp[q + 1] - lp[q] > chain_rows) ? 6.0 : chain_level_us;
+  us += (double)Y.nnzL * 24.0 / 2.0e6;
+  if (top < nl) us += (double)k * (double)k * 8.0 / 4.0e6 + 10.0;
+  return us;
+}
+
+double supernode_solve_cost_us(const Supernodes &T, int threads) {
+  double cost = 0.0;
+  for (int L = 0; L < T.nlev; L++) {
+    double worst = 0.0;
+    for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+      const int q0 = T.ptr[J], q1 = T.ptr[J + 1];
+      const double f = (double)(T.Fp[q1] - T.Fp[q0]), g = (double)(T.Gp[q1] - T.Gp[q0]), blk = (double)(q1 - q0) * (q1 - q0);
+      worst = std::max(worst, (f + g + 2.0 * blk) / (double)threads * 0.05);  // ~50 ns per dependent gather of a thread
+    }
+    cost += 2.0 * 3.0 + worst;  // one hand-over between workgroups per level and direction (k_sn_tree)
+  }
+  return cost + 4.0 * 6.0;      // level 0 and the rest: two launches per direction
+}
+
+double level_solve_cost_us(const Symbolic &Y, int chain_rows, int lD, int kD) {
+  const auto &lp = Y.level_ptr;
+  double us = 0.0;
+  // a chain level: one barrier-separated step of a single workgroup, 2.4 us plus the passes its rows need
+  for (int q = 0; q < lD; q++) us += (lp[q + 1] - lp[q] > chain_rows) ? 6.0 : 2.4 + 0.01 * (double)(lp[q + 1] - lp[q]);
+  us += (double)Y.nnzL * 24.0 / 2.0e6;
+  if (kD) us += (double)kD * (double)kD * 8.0 / 4.0e6 + 10.0;
+  return us;
+}
+
+bool supernodes_pay(const Symbolic &S, const Supernodes &T, int chain_rows, int lD, int kD, int threads) {
+  const int nlev = (int)S.level_ptr.size() - 1;
+  return 4 * T.nlev <= nlev && supernode_solve_cost_us(T, threads) < 0.7 * level_solve_cost_us(S, chain_rows, lD, kD);
+}
+
+void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD) {
+  const auto &lp = S.level_ptr;
+  const int N = S.N, nlev = (int)lp.size() - 1;
+  lD = nlev; cD = N; kD = 0;
+  if (nlev < 2) return;
+  auto suffix = [&](int limit) {
+    int l = nlev;
+    while (l > 1 && lp[l] - lp[l - 1] <= chain_rows && N - lp[l - 1] <= limit) l--;
+    return l;
+  };
+  auto entries_inside = [&](int c) {
+    int64_t inside = 0;
+    for (int r = c; r < N; r++) {
+      const int *beg = S.Rj.data() + S.Rp[r], *end = S.Rj.data() + S.Rp[r + 1];
+      inside += end - std::lower_bound(beg, end, c);
+    }
+    return inside;
+  };
+  int l = suffix(dense_max);
+  int c = lp[l], k = N - c;
+  if (k < dense_min) return;
+  bool dense = entries_inside(c) * 8 >= (int64_t)k * k;
+  if (!dense && k > dense_sparse_max) {
+    // a block-sparse top (the separators of a nested-dissection tree): the inversion costs k^3, the levels it
+    // replaces only k, so a smaller block is the better trade
+    l = suffix(dense_sparse_max); c = lp[l]; k = N - c;
+    if (k < dense_min) return;
+    dense = entries_inside(c) * 8 >= (int64_t)k * k;
+  }
+  // worth it when the block is dense (then the chain rows are long) or when the dense product is cheaper than
+  // walking the block's levels one by one
+  const double dense_us = (double)k * (double)k * 8.0 / 4.0e6 + 10.0, chain_us = 1.4 * (double)(nlev - l);
+  if (!dense && dense_us > chain_us) return;
+  lD = l; cD = c; kD = k;
 }
 
 }  // namespace oq

@@ -25,6 +25,7 @@ struct Symbolic {
   std::vector<int> Rj;
   // level schedule: pivots are numbered so that level l is the index range [level_ptr[l], level_ptr[l+1])
   std::vector<int> level_ptr;
+  std::vector<int> parent;           // elimination tree of the final numbering (-1: root)
   // scatter maps: target >= 0 is a position in Lx, target < 0 encodes the diagonal entry D[-target-1]
   std::vector<int64_t> PtoL;         // one per nnz of triu(P) (caller's CSC order)
   std::vector<int64_t> AtoL;         // one per nnz of A (caller's CSC order); INT64_MIN for rows not selected
@@ -43,5 +44,46 @@ struct Symbolic {
 // flatter elimination trees on graphs with many degree-1 nodes, e.g. bound constraints).
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
                       double flops_limit, int ordering, Symbolic &out);
+
+// Supernodes for the triangular solves (direct.hip, k_sn_*): sets of at most `smax` pivots whose diagonal block of L is
+// inverted once per factorisation, so that a solve needs one step per supernode instead of one per pivot.  Two kinds:
+// a whole subtree of the elimination tree with at most smax nodes (the leaves of a nested-dissection tree), and a
+// segment of a path of the tree above those (a separator, cut into pieces of smax).  Everything the solves index is
+// in SLOT order: slot q = position of the pivot in `piv`, supernodes numbered level by level (a supernode's rows only
+// reference slots of lower levels outside its own block).
+struct Supernodes {
+  int count = 0, nlev = 0, smax = 0;
+  std::vector<int> lvl_ptr;   // level L = supernodes [lvl_ptr[L], lvl_ptr[L+1])
+  std::vector<int> ptr;       // supernode J = slots [ptr[J], ptr[J+1])
+  std::vector<int> piv;       // slot -> pivot (ascending inside a supernode)
+  std::vector<int> slot;      // pivot -> slot
+  std::vector<int> up;        // supernode holding the elimination-tree parent of its top node (-1: a root)
+  std::vector<int> waits;     // number of supernodes of level >= 1 that have it as `up`
+  std::vector<int64_t> woff;  // offset of the s x s block of supernode J in the W arrays (count + 1 entries)
+  std::vector<int64_t> wmap;  // per block entry a*s+b: position in Lx of L(slot a, slot b) for a > b, -1 if not in the pattern
+  // the entries of L outside the diagonal blocks, by row (forward solve) and by column (backward solve), rows and
+  // columns in slot order; the index stored is the slot of the other end, pos the position of the value in Lx
+  std::vector<int64_t> Fp, Fpos, Gp, Gpos;   // every list ascending by slot
+  std::vector<int64_t> Fsplit;               // per row: first entry that points at a slot of level >= 1
+  std::vector<int> Fj, Gi;
+  double flops = 0.0;         // multiply-adds of one forward + backward solve
+};
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out);
+
+// The dense top block of the level schedule: the longest suffix of the top chain (levels of at most chain_rows pivots)
+// with at most dense_max pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when
+// one dense product costs less than its levels.  lD = first level of the block, cD its first pivot, kD = N - cD (0: none).
+void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD);
+
+// Rough time of one forward + backward solve by the level schedule: a launch per wide level, a chain step per narrow
+// level below the dense top block, the bytes of L at 2 TB/s, the dense block's product.  Used to compare orderings
+// (chain_level_us = 1.4, the best case; the block guessed from dense_max / dense_min).
+double level_solve_cost_us(const Symbolic &Y, int chain_rows, int dense_max, int dense_min, double chain_level_us);
+// ... with the block that was actually chosen and 2.4 us per chain level (measured on deep nested-dissection trees)
+double level_solve_cost_us(const Symbolic &Y, int chain_rows, int lD, int kD);
+// ... and by supernodes: two launches per direction, inside them one hand-over between workgroups per level; the
+// slowest workgroup of each level walks its entries outside the blocks and its block with `threads` threads.
+double supernode_solve_cost_us(const Supernodes &T, int threads);
+bool supernodes_pay(const Symbolic &S, const Supernodes &T, int chain_rows, int lD, int kD, int threads);
 
 }  // namespace oq

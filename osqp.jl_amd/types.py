@@ -205,6 +205,7 @@ EXT_SYMBOLS = {
         c_int, [C.POINTER(Workspace_p), c_int, c_int, c_int, C.c_ulonglong, C.POINTER(Settings), C.c_void_p]),
     "osqp_amd_last_error": (C.c_char_p, []),
     "osqp_amd_set_device": (c_int, [c_int]),
+    "osqp_amd_symbolic_probe": (c_int, [c_int, c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int, c_int, c_float_p, c_int]),
     # oracle-only helpers
     "oracle_generate": (C.POINTER(Data), [c_int, c_int, c_int, C.c_ulonglong]),
     "oracle_data_free": (None, [C.POINTER(Data)]),

@@ -87,6 +87,40 @@ def test_random_small_problems_follow_the_oracle(product_lib, oracle_lib, block)
     assert solved > 0
 
 
+@pytest.mark.parametrize("smax", [3, 64])
+def test_supernodal_solves_follow_the_oracle(product_lib, oracle_lib, smax, monkeypatch):
+    """The same comparison with the triangular solves forced through supernodes (csrc/direct.hip k_sn_*; blocks of at
+    most `smax` pivots inverted once per factorisation): subtree and path supernodes, many levels at smax = 3."""
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    rng = np.random.default_rng(3000 + smax)
+    tally = {"exact": 0, "close": 0, "borderline": 0, "different": 0}
+    notes = []
+    deepest = 0
+    for k in range(25):
+        prob = random_problem(rng)
+        opts = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, max_iter=2000, adaptive_rho_interval=25,
+                    scaling=int(rng.choice([0, 1, 10])), alpha=float(rng.choice([1.0, 1.6])), polish=bool(k % 2))
+        res = []
+        for lib, ls in ((oracle_lib, "qdldl"), (product_lib, "direct")):
+            m = oq.Model(lib)
+            oq.setup(m, linsys_solver=ls, **prob, **opts)
+            res.append(oq.solve(m))
+            if lib is product_lib:
+                st = oq.stats(m)
+                assert st[19] >= 1  # the supernodal path is what ran
+                deepest = max(deepest, int(st[19]))
+            oq.clean(m)
+        verdict = compare(res[0], res[1], 1e-5)
+        tally[verdict] += 1
+        if verdict != "exact":
+            notes.append("problem %d (n=%d, m=%d): %s, oracle %s/%d, product %s/%d" % (
+                k, prob["P"].shape[0], prob["A"].shape[0], verdict, res[0].info.status, res[0].info.iter, res[1].info.status, res[1].info.iter))
+        assert res[0].info.status_polish == res[1].info.status_polish or verdict != "exact", notes
+    assert tally["different"] == 0 and tally["borderline"] <= 1 and tally["exact"] >= 22, (tally, notes)
+    assert deepest >= (4 if smax == 3 else 1)
+
+
 def feasible_problem(rng):
     n = int(rng.integers(2, 30))
     m = int(rng.integers(1, 40))

@@ -80,6 +80,7 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
         if lib is product_lib:
             levels = oq.stats(m)[5]
             assert 50 < levels < 1000  # min-degree leaves > 4000 levels here
+            assert 0 < oq.stats(m)[19] <= 20  # and the solves run by supernodes: a launch per level of the separator tree
         oq.clean(m)
     ro, rp = out
     assert ro.info.status == rp.info.status == "Solved"
