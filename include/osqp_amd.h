@@ -312,6 +312,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 13 ranks of the row partition (1: not sharded)   14 all-gathers issued so far   15 bytes received by them
  * 16, 17 rows of the local blocks (n, m)          18 compact mode (CSR column / value arrays released) 0 / 1
  * 19 levels of the supernode graph when the triangular solves run by supernodes (0: by the level schedule)
+ * 20 high-water mark of the device bytes allocated by this process (a sharded setup stays near 1/ranks of the whole)
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
@@ -329,7 +330,9 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
  * [r*ceil(m/R), ...) of A and of every m-vector.  Per product with A, P or A' the input vector is all-gathered
  * (n or m doubles); norms and dot products are all-gathered as scalars and combined in rank order, so all
  * ranks take identical decisions.  Every rank calls the same entry points in the same order with the same
- * arguments (full-length vectors; each rank reads its slice) and receives the full solution.  Not available on a
+ * arguments (full-length vectors; each rank reads its slice) and receives the full solution.  Setup walks the
+ * problem column range by column range and keeps only the rank's row blocks, so the peak device memory of a rank is
+ * about 1/R of the single-device workspace (stats[20]; the device generator never materialises the rest at all).  Not available on a
  * sharded workspace: the direct back-end, polish (skipped), osqp_update_P / _A / _P_A, osqp_amd_apply.
  *
  * The communicator is one in-place all-gather of doubles; it must outlive the workspaces that use it.

@@ -169,7 +169,8 @@ static c_int setup_from_host(OSQPWorkspace **workp, const OSQPData *data, const 
     Engine &e = *E(w);
     e.comm = comm;
     e.tic();
-    e.setup_host(data, *settings);
+    if (comm) { auto src = host_columns(data); e.setup_sharded(*src, *settings); }
+    else e.setup_host(data, *settings);
     finish_setup(w);
     w->info->setup_time = e.toc();
     return 0;
@@ -191,6 +192,14 @@ static c_int setup_from_generator(OSQPWorkspace **workp, c_int kind, c_int n, c_
     w = new_workspace();
     Engine &e = *E(w);
     e.comm = comm;
+    if (comm) {  // only this rank's row blocks are ever resident
+      e.tic();
+      auto src = generated_columns((int)kind, (int)n, (int)per_row, seed, nullptr);
+      e.setup_sharded(*src, *settings);
+      finish_setup(w);
+      w->info->setup_time = e.toc();
+      return 0;
+    }
     DevBuf<int64_t> Pp, Ap;
     DevBuf<int> Pi, Ai;
     DevBuf<double> Px, Ax, q, l, u;
@@ -456,6 +465,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[17] = (c_float)e.m;
   v[18] = e.compact ? 1.0 : 0.0;
   v[19] = e.lin->supernode_levels();
+  v[20] = (c_float)g_device_peak;
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

@@ -52,6 +52,7 @@ inline void post_launch(const char *name, hipStream_t s) {
 
 // ---- device buffers -------------------------------------------------------
 extern size_t g_device_bytes;  // bytes currently allocated through DevBuf
+extern size_t g_device_peak;   // high-water mark of the above since the process started
 
 template <typename T>
 struct DevBuf {
@@ -73,6 +74,7 @@ struct DevBuf {
     size_t bytes = (count ? count : 1) * sizeof(T);
     HIP_CHECK(hipMalloc((void **)&p, bytes));
     g_device_bytes += bytes;
+    if (g_device_bytes > g_device_peak) g_device_peak = g_device_bytes;
   }
   void release() {
     if (p) {

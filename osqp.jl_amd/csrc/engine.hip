@@ -140,19 +140,20 @@ const double *Engine::full_m(const double *v) {
   return gm.get();
 }
 
-// Keep block `rank` of the rows of A, A', P and the matching slices of q, l, u; drop everything else.
-void Engine::shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_) {
+// The row partition of a sharded workspace: ceil-sized contiguous blocks (include/osqp_amd.h).  Returns the local ranges.
+void Engine::shard_layout(int &n1, int &m1) {
   const int R = comm->world, r = comm->rank;
   chunk_n = (ng + R - 1) / R;
   chunk_m = mg > 0 ? (mg + R - 1) / R : 0;
   n0 = std::min(r * chunk_n, ng);
   m0 = std::min(r * chunk_m, mg);
-  const int n1 = std::min(n0 + chunk_n, ng), m1 = std::min(m0 + chunk_m, mg);
+  n1 = std::min(n0 + chunk_n, ng); m1 = std::min(m0 + chunk_m, mg);
   if (n1 <= n0 || (mg > 0 && m1 <= m0))
     throw Error(1, "sharded setup: with ceil-sized blocks the last rank would own no rows (e.g. n = 9 over 4 ranks: 3 + 3 + 3 + 0); use fewer ranks");
-  csr_slice_rows(At, n0, n1, stream);
-  csr_slice_rows(Pf, n0, n1, stream);
-  if (mg > 0) csr_slice_rows(A, m0, m1, stream);
+}
+// the matching slices of q, l, u and the gather buffers; n, m become the local sizes
+void Engine::shard_vectors(int n1, int m1, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_) {
+  const int R = comm->world;
   n = n1 - n0; m = m1 - m0;
   auto slice = [&](DevBuf<double> &b, int first, int count) {
     DevBuf<double> out((size_t)count);
@@ -167,6 +168,170 @@ void Engine::shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &
   gm.alloc((size_t)std::max(chunk_m, 1) * R); gm.zero(stream);
   gslots.alloc((size_t)S_COUNT * R); gslots.zero(stream);
 }
+// Keep block `rank` of the rows of matrices that were built whole (setup_device with a communicator; the entry points
+// go through setup_sharded, which never holds more than the block).
+void Engine::shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_) {
+  int n1 = 0, m1 = 0;
+  shard_layout(n1, m1);
+  csr_slice_rows(At, n0, n1, stream);
+  csr_slice_rows(Pf, n0, n1, stream);
+  if (mg > 0) csr_slice_rows(A, m0, m1, stream);
+  shard_vectors(n1, m1, q_, l_, u_);
+}
+
+// ---- sharded setup from column ranges ------------------------------------------------------------------------------
+// Stream compaction of the entries a rank keeps: a block counts its keepers (ballot + LDS), reserves a range of the
+// output list with one atomic and writes in thread order.  fill = 0 only counts (first pass sizes the lists exactly).
+__device__ __forceinline__ long long block_reserve(bool keep, unsigned long long *counter, bool fill) {
+  __shared__ int wave_total[kBlock / 64];
+  __shared__ long long base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long mask = __ballot(keep);
+  const int before = __popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_total[wave] = __popcll(mask);
+  __syncthreads();
+  int offset = 0, total = 0;
+  for (int w = 0; w < kBlock / 64; w++) { if (w < wave) offset += wave_total[w]; total += wave_total[w]; }
+  if (threadIdx.x == 0) base = total ? (long long)atomicAdd(counter, (unsigned long long)total) : 0;
+  __syncthreads();
+  const long long pos = base + offset + before;
+  __syncthreads();  // the shared words are reused by the caller's next reservation
+  return fill ? pos : -1;
+}
+// entries of columns [j0, ...) of A: list 0 = rows [n0, n1) of A' (entry (j, i)), list 1 = rows [m0, m1) of A (entry (i, j))
+__global__ __launch_bounds__(kBlock) void k_shard_pick_A(int64_t E, int j0, const int *__restrict__ colid, const int *__restrict__ Ai,
+                                                        const double *__restrict__ Ax, int n0, int n1, int m0, int m1, int fill,
+                                                        unsigned long long *__restrict__ counters, int *__restrict__ tr,
+                                                        int *__restrict__ tc, double *__restrict__ tv, int *__restrict__ ar,
+                                                        int *__restrict__ ac, double *__restrict__ av) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool in = e < E;
+  const int j = in ? j0 + colid[e] : -1, i = in ? Ai[e] : -1;
+  const double v = (in && fill) ? Ax[e] : 0.0;
+  const bool kt = in && j >= n0 && j < n1, ka = in && i >= m0 && i < m1;
+  long long p = block_reserve(kt, &counters[0], fill);
+  if (fill && kt) { tr[p] = j - n0; tc[p] = i; tv[p] = v; }
+  p = block_reserve(ka, &counters[1], fill);
+  if (fill && ka) { ar[p] = i - m0; ac[p] = j; av[p] = v; }
+}
+// entries (i, j), i <= j, of columns [j0, ...) of triu(P): rows [n0, n1) of the full symmetric P get (j, i) and, off the
+// diagonal, the mirror (i, j)
+__global__ __launch_bounds__(kBlock) void k_shard_pick_P(int64_t E, int j0, const int *__restrict__ colid, const int *__restrict__ Pi,
+                                                        const double *__restrict__ Px, int n0, int n1, int fill,
+                                                        unsigned long long *__restrict__ counter, int *__restrict__ pr,
+                                                        int *__restrict__ pc, double *__restrict__ pv, int *__restrict__ bad) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool in = e < E;
+  const int j = in ? j0 + colid[e] : -1, i = in ? Pi[e] : -1;
+  const double v = (in && fill) ? Px[e] : 0.0;
+  if (in && i > j) *bad = 1;  // not upper triangular
+  const bool kl = in && j >= n0 && j < n1, ku = in && i != j && i >= n0 && i < n1;
+  long long p = block_reserve(kl, counter, fill);
+  if (fill && kl) { pr[p] = j - n0; pc[p] = i; pv[p] = v; }
+  p = block_reserve(ku, counter, fill);
+  if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; }
+}
+
+void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
+  n = src.n; m = src.m; ng = src.n; mg = src.m; st = s;
+  nnzPtriu = src.nnzP; nnzA = src.nnzA;
+  open_device();
+  int n1 = 0, m1 = 0;
+  shard_layout(n1, m1);
+  // column ranges of about a quarter of a rank's share, at least 64 columns
+  const int step = std::max(64, (ng + 4 * comm->world - 1) / (4 * comm->world));
+  DevBuf<unsigned long long> counters(3);
+  counters.zero(stream);
+  DevBuf<int> tr, tc, ar, ac, pr, pc;
+  DevBuf<double> tv, av, pv;
+  unsigned long long total[3] = {0, 0, 0};
+  for (int fill = 0; fill < 2; fill++) {
+    if (fill) {
+      counters.download(total, 3, stream);
+      sync();
+      if (total[0] >= 2147483647ULL || total[1] >= 2147483647ULL || total[2] >= 2147483647ULL)
+        throw Error(6, "matrix block too large: more than 2^31-1 non-zeros on one rank");
+      tr.alloc(total[0]); tc.alloc(total[0]); tv.alloc(total[0]);
+      ar.alloc(total[1]); ac.alloc(total[1]); av.alloc(total[1]);
+      pr.alloc(total[2]); pc.alloc(total[2]); pv.alloc(total[2]);
+      counters.zero(stream);
+    }
+    for (int j0 = 0; j0 < ng; j0 += step) {
+      const int j1 = std::min(ng, j0 + step);
+      DevBuf<int64_t> p;
+      DevBuf<int> idx;
+      DevBuf<double> val;
+      {
+        const int64_t E = src.A_chunk(j0, j1, p, idx, val, stream);
+        if (E > 0) {
+          DevBuf<int> colid((size_t)E);
+          expand_colptr(j1 - j0, p.get(), E, colid.get(), stream);
+          OQ_LAUNCH(k_shard_pick_A, dim3(blocks_for(E)), dim3(kBlock), 0, stream, E, j0, colid.get(), idx.get(), val.get(), n0, n1, m0, m1, fill,
+                    counters.get(), tr.get(), tc.get(), tv.get(), ar.get(), ac.get(), av.get());
+          sync();
+        }
+      }
+      {
+        const int64_t E = src.P_chunk(j0, j1, p, idx, val, stream);
+        if (E > 0) {
+          DevBuf<int> colid((size_t)E);
+          expand_colptr(j1 - j0, p.get(), E, colid.get(), stream);
+          OQ_LAUNCH(k_shard_pick_P, dim3(blocks_for(E)), dim3(kBlock), 0, stream, E, j0, colid.get(), idx.get(), val.get(), n0, n1, fill,
+                    counters.get() + 2, pr.get(), pc.get(), pv.get(), flag.get());
+          sync();
+        }
+      }
+    }
+  }
+  int bad = 0;
+  flag.download(&bad, 1, stream);
+  sync();
+  if (bad) throw Error(1, "P is not upper triangular");
+  auto build = [&](DevCsr &M, int rows, int cols, unsigned long long E, DevBuf<int> &er, DevBuf<int> &ec, DevBuf<double> &ev) {
+    DevBuf<int> order;
+    csr_from_coo(rows, cols, (int64_t)E, er.get(), ec.get(), M, order, stream);
+    gather_values(M.nnz, order.get(), ev.get(), M.val.get(), 0, stream);
+    sync();
+    er.release(); ec.release(); ev.release();
+  };
+  build(At, n1 - n0, mg, total[0], tr, tc, tv);
+  build(A, m1 - m0, ng, total[1], ar, ac, av);
+  build(Pf, n1 - n0, ng, total[2], pr, pc, pv);
+  DevBuf<double> q_, l_, u_;
+  src.vectors(q_, l_, u_, stream);
+  sync();
+  shard_vectors(n1, m1, q_, l_, u_);
+  finish_setup(q_, l_, u_);
+}
+
+// the host caller's CSC arrays, uploaded range by range
+struct HostColumns : ColumnSource {
+  const OSQPData *d;
+  explicit HostColumns(const OSQPData *data) : d(data) {
+    n = (int)d->n; m = (int)d->m; nnzP = d->P->p[n]; nnzA = d->A->p[n];
+    if (nnzA >= 2147483647LL || 2 * nnzP >= 2147483647LL) throw Error(6, "matrix too large: more than 2^31-1 non-zeros");
+    for (int64_t k = 0; k < nnzA; k++) if (d->A->i[k] < 0 || d->A->i[k] >= m) throw Error(1, "row index of A out of range");
+  }
+  static int64_t chunk(const csc *M, int j0, int j1, DevBuf<int64_t> &p, DevBuf<int> &i, DevBuf<double> &x, hipStream_t s) {
+    const int64_t b = M->p[j0], e = M->p[j1];
+    std::vector<int64_t> hp((size_t)(j1 - j0) + 1);
+    for (int j = j0; j <= j1; j++) hp[j - j0] = M->p[j] - b;
+    std::vector<int> hi((size_t)(e - b));
+    for (int64_t k = b; k < e; k++) hi[k - b] = (int)M->i[k];
+    p.alloc(hp.size()); i.alloc(std::max<size_t>(1, hi.size())); x.alloc(std::max<size_t>(1, hi.size()));
+    p.upload(hp.data(), hp.size(), s); i.upload(hi.data(), hi.size(), s); x.upload(M->x + b, (size_t)(e - b), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    return e - b;
+  }
+  int64_t P_chunk(int j0, int j1, DevBuf<int64_t> &p, DevBuf<int> &i, DevBuf<double> &x, hipStream_t s) override { return chunk(d->P, j0, j1, p, i, x, s); }
+  int64_t A_chunk(int j0, int j1, DevBuf<int64_t> &p, DevBuf<int> &i, DevBuf<double> &x, hipStream_t s) override { return chunk(d->A, j0, j1, p, i, x, s); }
+  void vectors(DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u, hipStream_t s) override {
+    q.alloc(n); l.alloc(m); u.alloc(m);
+    q.upload(d->q, n, s); l.upload(d->l, m, s); u.upload(d->u, m, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+};
+std::unique_ptr<ColumnSource> host_columns(const OSQPData *data) { return std::unique_ptr<ColumnSource>(new HostColumns(data)); }
 
 // --------------------------------------------------------------------------
 // setup
@@ -189,10 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int *p, int v) {
   if (k < n) p[k] = v;
 }
 
-void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
-                          DevBuf<int> &Ai, DevBuf<double> &Ax_in, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
-                          const OSQPSettings &s) {
-  n = n_; m = m_; ng = n_; mg = m_; st = s;
+void Engine::open_device() {
   HIP_CHECK(hipGetDevice(&device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipHostMalloc((void **)&h_slots, sizeof(double) * (S_COUNT + 8)));
@@ -209,6 +371,13 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   slots.alloc(S_COUNT); slots.zero(stream);
   partials.alloc(16 * kReduceBlocks);
   flag.alloc(4); flag.zero(stream);
+}
+
+void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
+                          DevBuf<int> &Ai, DevBuf<double> &Ax_in, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
+                          const OSQPSettings &s) {
+  n = n_; m = m_; ng = n_; mg = m_; st = s;
+  open_device();
 
   int64_t ends[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(&ends[0], Pp.get() + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
@@ -256,6 +425,10 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   Px.release();
 
   if (comm) shard_rows(q_, l_, u_);  // from here on n, m are the local sizes
+  finish_setup(q_, l_, u_);
+}
+
+void Engine::finish_setup(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_) {
   q = std::move(q_); l = std::move(l_); u = std::move(u_);
   auto alloc0 = [&](DevBuf<double> &b, size_t cnt) { b.alloc(cnt); b.zero(stream); };
   alloc0(D, n); alloc0(Dinv, n); alloc0(E, m); alloc0(Einv, m); alloc0(rho, m); alloc0(rho_inv, m);

@@ -54,6 +54,20 @@ struct HostCsc {  // host copy of a sparsity pattern (for the symbolic phase of 
   std::vector<int> i;
 };
 
+// The caller's problem in column ranges of its CSC form (sharded setup: a rank looks at every column once or twice
+// but keeps only its row block, so its peak memory is the block plus one range).
+struct ColumnSource {
+  int n = 0, m = 0;
+  int64_t nnzP = 0, nnzA = 0;  // of triu(P) and A, whole problem
+  virtual ~ColumnSource() {}
+  // columns [j0, j1): pointers relative to the range (j1 - j0 + 1 of them), row indices, values; returns the entry count
+  virtual int64_t P_chunk(int j0, int j1, DevBuf<int64_t> &p, DevBuf<int> &i, DevBuf<double> &x, hipStream_t s) = 0;
+  virtual int64_t A_chunk(int j0, int j1, DevBuf<int64_t> &p, DevBuf<int> &i, DevBuf<double> &x, hipStream_t s) = 0;
+  virtual void vectors(DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u, hipStream_t s) = 0;  // full length
+};
+std::unique_ptr<ColumnSource> generated_columns(int kind, int n, int per_row, unsigned long long seed, hipStream_t s);
+std::unique_ptr<ColumnSource> host_columns(const OSQPData *data);
+
 struct Engine {
   int n = 0, m = 0;
   // Row-sharded mode (row N4, comm.hpp): `comm` is set before setup and this engine holds block `rank` of the
@@ -122,6 +136,12 @@ struct Engine {
                     DevBuf<int> &Ai, DevBuf<double> &Ax, DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u,
                     const OSQPSettings &s);
   void setup_host(const OSQPData *data, const OSQPSettings &s);
+  // row-sharded: builds this rank's row blocks of A, A' and the full symmetric P from column ranges of the source
+  void setup_sharded(ColumnSource &src, const OSQPSettings &s);
+  void shard_layout(int &n1, int &m1);
+  void shard_vectors(int n1, int m1, DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u);
+  void open_device();                                                       // stream, readback slots
+  void finish_setup(DevBuf<double> &q, DevBuf<double> &l, DevBuf<double> &u);  // everything after the matrices exist
   void fetch_host_pattern();
 
   // ---- algorithm ----

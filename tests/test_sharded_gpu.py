@@ -84,6 +84,19 @@ def test_sharded_matches_single(product_lib, tmp_path, world, kind, n, per_row):
         assert rec["x"] == recs[0]["x"] and rec["y"] == recs[0]["y"] and rec["iter"] == recs[0]["iter"]
 
 
+def test_sharded_setup_keeps_only_the_row_block(tmp_path):
+    """A rank looks at the problem column range by column range and keeps its row blocks of A, A' and P only
+    (csrc/engine.hip setup_sharded): the high-water mark of its device memory falls with the number of ranks."""
+    case = "gen:0:40000:256:7"
+    one = run_ranks(tmp_path, 1, "host", case, SETTINGS)[0]
+    four = run_ranks(tmp_path, 4, "host", case, SETTINGS)
+    assert one["status"] == "Solved" and all(r["status"] == "Solved" for r in four)
+    peak1 = one["stats"][20]
+    assert peak1 > 3e8  # ~1e7 non-zeros in each of A, A', P
+    for r in four:
+        assert r["stats"][20] <= 0.4 * peak1, (r["stats"][20], peak1)
+
+
 SHARDABLE_CASES = [
     "case_basic_qp", "case_update_q", "case_update_l", "case_update_u", "case_update_max_iter",
     "case_update_check_termination", "case_update_rho", "case_time_limit", "case_non_convex_big_sigma",
