@@ -61,6 +61,7 @@ __device__ __forceinline__ double nmax(double a, double b) { return (a > b || a 
 __device__ __forceinline__ double lim(double v) { v = v < B_MIN_SCALING ? 1.0 : v; return v > B_MAX_SCALING ? B_MAX_SCALING : v; }
 
 // a value every lane holds identically, moved to scalar registers (the compiler cannot see that an LDS broadcast is uniform)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v) {
   union { double d; int i[2]; } u;
   u.d = v;
@@ -136,13 +137,15 @@ __device__ __forceinline__ void block_reduce(double *v, int op, ldouble *red) {
 }
 
 struct Lds {
+  ldouble *gjc;  // 2 x (4 x 128): the four pivot rows of a block step of the MFMA inversion, double-buffered; behind them
+                 // 2 x 32: the inverse of the 4 x 4 pivot block and its positive-definite flag
   ldouble *part, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv, *nrm;
   lint *ctype;
   lshort *Ap, *Ai, *Rp, *Rc, *Rmap, *Fp, *Fc;  // shared pattern, staged into LDS as 16-bit indices
   int ld;
 };
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW + 24;
+  return (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW + 24 + 2 * 4 * 128 + 64;
 }
 __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
   return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
@@ -163,6 +166,7 @@ __device__ __forceinline__ Lds carve(ldouble *base, const Pattern &P) {
   s.zp = p; p += m; s.zt = p; p += m; s.dy = p; p += m; s.Ax = p; p += m; s.tm = p; p += m;
   s.red = p; p += 16 * NW;  // NW * K doubles of block_reduce, K <= 14
   s.nrm = p; p += 24;
+  s.gjc = p; p += 2 * 4 * 128 + 64;
   s.ctype = (lint *)p;
   lshort *h = (lshort *)((lchar *)p + (((size_t)m * 4 + 15) / 16) * 16);
   s.Ap = h; h += n + 1; s.Fp = h; h += n + 1; s.Rp = h; h += m + 1;
@@ -234,7 +238,20 @@ struct MTile {
 // column j = j0 + u, the 25 column ids and 25 clamped addresses are loop invariants that the compiler precomputes
 // and then has to keep in -- or spill from -- registers across the whole ADMM loop.)  EXACT: PARTS * NCT == n, no
 // column of a tile lies outside the matrix; otherwise columns u >= ncv of the last part are masked.
+// the thread's tile (row = tid & 127, NCT columns of part tid >> 7) of the n x n array in the instance's scratch
 template <int NCT, bool EXACT>
+__device__ __forceinline__ void load_tile(int n, const double *scratch, MTile<NCT> &T) {
+  scratch = opaque(scratch);
+  const int ld = n;
+  const int row = mytid() & 127, part = mytid() >> 7;
+  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
+  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
+  const bool live = row < n;
+  const double *src = scratch + (live ? row : 0) + (size_t)min(j0, n - 1) * ld;
+#pragma unroll
+  for (int u = 0; u < NCT; u++) T.v[u] = (live && (EXACT || u < ncv)) ? src[(size_t)u * ld] : 0.0;
+}
+template <int NCT, bool EXACT, bool LOAD>
 __device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, double sigma, double *__restrict__ scratch, MTile<NCT> &T) {
   const int n = P.n, ld = n;
   scratch = opaque(scratch);
@@ -253,13 +270,7 @@ __device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, do
   for (int r = mytid(); r < n; r += NT)
     for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) scratch[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
   __syncthreads();
-  const int row = mytid() & 127, part = mytid() >> 7;
-  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
-  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
-  const bool live = row < n;
-  const double *src = scratch + (live ? row : 0) + (size_t)min(j0, n - 1) * ld;
-#pragma unroll
-  for (int u = 0; u < NCT; u++) T.v[u] = (live && (EXACT || u < ncv)) ? src[(size_t)u * ld] : 0.0;
+  if (LOAD) load_tile<NCT, EXACT>(n, scratch, T);
 }
 
 // T <- (the matrix it holds)^-1.  Returns false if the matrix is not positive definite.  c0, c1: two LDS vectors of n
@@ -331,6 +342,142 @@ __device__ __forceinline__ bool invert_tile(int n, MTile<NCT> &T, ldouble *c0, l
 #pragma unroll
   for (int u = 0; u < NCT; u++) T.v[u] = -T.v[u];  // the sweeps leave -M^-1
   __syncthreads();  // c0 / c1 are scratch of the caller again
+  return ok;
+}
+
+
+// ---- the same inverse by block sweeps on the matrix cores ---------------------------------------------------------
+// Four pivots at a time: with K the pivot indices, C = M[K, :] (4 x n) and G = M[K, K]^-1 the sweep operator is
+//   M <- M - C' (G C),  then  M[K, R] <- G C (and its mirror),  M[K, K] <- -G,
+// i.e. one rank-4 update of the whole array -- v_mfma_f64_16x16x4_f64 per 16 x 16 tile -- and a patch of four rows and
+// columns, instead of four rank-1 updates whose pivot row has to be broadcast element by element (invert_tile: 50
+// v_readlane per 25 multiply-adds, ~10 % of the fp64 rate).  The array stays symmetric, so only the tiles on and below
+// the diagonal are kept, TPW per wavefront in accumulator layout (lane: column lane & 15, rows (lane >> 4) + 4 r);
+// indices >= n are padded with the identity and never swept.  One barrier per block step: the pivot rows go through two
+// alternating 4 x 128 LDS buffers.  In: M in the instance's scratch (both triangles, ld = n); out: M^-1 there.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <int TPW>
+__device__ __forceinline__ bool invert_mfma(int n, double *scratch, ldouble *cb) {
+  scratch = opaque(scratch);
+  const int lane = mytid() & 63, wave = uni(mytid() >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NB = (n + 15) >> 4, ntiles = NB * (NB + 1) / 2, steps = (n + 3) >> 2;
+  d4_t acc[TPW];
+  int TI[TPW], TJ[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    const int t = wave + s * NW;
+    int I = -1, J = -1;
+    if (t < ntiles) { I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++; J = t - I * (I + 1) / 2; }
+    TI[s] = uni(I); TJ[s] = uni(J);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = I * 16 + lr + 4 * r, col = J * 16 + lc;
+      double v = (row == col) ? 1.0 : 0.0;
+      if (I >= 0 && row < n && col < n) v = scratch[row + (size_t)col * n];
+      acc[s][r] = v;
+    }
+  }
+  bool ok = true;
+  for (int tb = 0; tb < NB; tb++) {
+#pragma unroll
+    for (int tq = 0; tq < 4; tq++) {
+      const int step = tb * 4 + tq;
+      if (step < steps) {
+        ldouble *C = cb + (step & 1) * 512;  // C[a][j] at a * 128 + j
+        ldouble *Gs = cb + 1024 + (step & 1) * 32;
+        // publish rows k0 .. k0 + 3: left of and inside block tb from the tiles of row block tb (register tq of every
+        // lane), right of it from column k0 + a of the tiles below (the array is symmetric).  The wavefront that owns the
+        // diagonal tile also inverts the 4 x 4 pivot block -- it sits in register tq of its lanes 16 a + 4 tq + b -- while
+        // the others wait at the barrier: one Gauss-Jordan per block step instead of one per wavefront.
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+          if (TI[s] == tb) C[lr * 128 + TJ[s] * 16 + lc] = acc[s][tq];
+          if (TJ[s] == tb && TI[s] > tb && (lc >> 2) == tq) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(lc & 3) * 128 + TI[s] * 16 + lr + 4 * r] = acc[s][r];
+          }
+          if (TI[s] == tb && TJ[s] == tb) {
+            double g[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int b = 0; b < 4; b++) g[a][b] = lane_bcast(acc[s][tq], 16 * a + 4 * tq + b);
+            bool pd = true;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+              if (!(g[p][p] > 0.0)) pd = false;
+              double d = __builtin_amdgcn_rcp(g[p][p]);                 // v_rcp_f64 and two Newton steps instead of the
+              d = __builtin_fma(__builtin_fma(-g[p][p], d, 1.0), d, d);  // ~40-instruction chain of the IEEE division
+              d = __builtin_fma(__builtin_fma(-g[p][p], d, 1.0), d, d);
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (j != p) g[p][j] *= d;
+#pragma unroll
+              for (int i = 0; i < 4; i++) if (i != p) {
+                const double f = g[i][p];
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j != p) g[i][j] = __builtin_fma(-f, g[p][j], g[i][j]);
+                g[i][p] = -f * d;
+              }
+              g[p][p] = d;
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) Gs[a * 4 + b] = g[a][b];
+              Gs[16] = pd ? 1.0 : 0.0;
+            }
+          }
+        }
+        __syncthreads();
+        if (Gs[16] == 0.0) ok = false;
+        double gl[4], gc[4];  // rows lane >> 4 and lane & 3 of G
+#pragma unroll
+        for (int b = 0; b < 4; b++) { gl[b] = Gs[lr * 4 + b]; gc[b] = Gs[(lc & 3) * 4 + b]; }
+        const double gdiag = Gs[lr * 4 + (lc & 3)];
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+          if (TI[s] < 0) continue;
+          const double aop = -C[lr * 128 + TI[s] * 16 + lc];  // A[i = lane & 15][k = lane >> 4] = -C[k][row i of block I]
+          const ldouble *cj = C + TJ[s] * 16 + lc;
+          double bop = gl[0] * cj[0];                          // B[k = lane >> 4][j = lane & 15] = (G C)[k][column j of block J]
+          bop = __builtin_fma(gl[1], cj[128], bop);
+          bop = __builtin_fma(gl[2], cj[256], bop);
+          bop = __builtin_fma(gl[3], cj[384], bop);
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[s], 0, 0, 0);
+          if (TI[s] == tb) acc[s][tq] = (TJ[s] == tb && (lc >> 2) == tq) ? -gdiag : bop;  // rows K: G C, and -G inside the block
+          if (TJ[s] == tb && (lc >> 2) == tq) {                                              // columns K: the mirror
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              if (TI[s] == tb && r == tq) continue;  // rows K of the diagonal tile were set above
+              const ldouble *ci = C + TI[s] * 16 + lr + 4 * r;
+              double w = gc[0] * ci[0];
+              w = __builtin_fma(gc[1], ci[128], w);
+              w = __builtin_fma(gc[2], ci[256], w);
+              w = __builtin_fma(gc[3], ci[384], w);
+              acc[s][r] = w;
+            }
+          }
+        }
+      }
+    }
+  }
+  // the sweeps leave -M^-1; both triangles back into the scratch
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    if (TI[s] < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = TI[s] * 16 + lr + 4 * r, col = TJ[s] * 16 + lc;
+      if (row < n && col < n) {
+        const double v = -acc[s][r];
+        scratch[row + (size_t)col * n] = v;
+        scratch[col + (size_t)row * n] = v;
+      }
+    }
+  }
+  __syncthreads();
   return ok;
 }
 
@@ -595,7 +742,7 @@ __device__ __noinline__ void residual_phase(CheckArgs a) {
 // CN > 0: the instance shape (n, m, nnz(A), nnz(P full)) = (CN, CM, CA, CF) is known at compile time -- every LDS address
 // becomes an immediate and every vector loop a fixed trip count (the registers otherwise spent on ~35 LDS pointers are
 // what the inverse needs); CN = 0: the same source with the shape read from the pattern at run time.
-template <int NCT, int CN, int CM, int CA, int CF>
+template <int NCT, int CN, int CM, int CA, int CF, bool MFMA>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_batch_solve(Pattern Pin, OSQPSettings st, int count, double *__restrict__ scratch_all,
                                                     const double *__restrict__ Px_all,
                                                     const double *__restrict__ Ax_all, const double *__restrict__ q_all,
@@ -716,9 +863,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   for (iter = 1; iter <= max_iter; iter++) {
     const int tid = mytid();  // shadows the outer one: nothing derived from the thread id outlives an iteration
     if (need_factor) {  // first iteration and after every rho update
-      assemble_tile<NCT, EXACT>(P, s, st.sigma, scratch, Minv);
+      assemble_tile<NCT, EXACT, !MFMA>(P, s, st.sigma, scratch, Minv);
       PROF(8)
-      if (!invert_tile<NCT, EXACT>(n, Minv, gj0, gj1)) { status = OSQP_NON_CVX; iter--; break; }
+      bool pd;
+      if (MFMA) {
+        pd = invert_mfma<(NCT <= 16 ? 2 : (NCT <= 25 ? 4 : 5))>(n, scratch, s.gjc);
+        load_tile<NCT, EXACT>(n, scratch, Minv);
+      } else pd = invert_tile<NCT, EXACT>(n, Minv, gj0, gj1);
+      if (!pd) { status = OSQP_NON_CVX; iter--; break; }
       need_factor = false;
       PROF(2)
     }
@@ -939,10 +1091,20 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
               x_stride, y_stride, info_stride, info_cols);                                                                             \
   } while (0)
   // shapes compiled in (same source, constants folded): the MPC family of BASELINE.json config 5
-  if (P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N);
-  else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0);
-  else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0);
-  else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0);
+  // OSQP_AMD_BATCH_MFMA=0: the inverse by rank-1 sweeps on the vector units (invert_tile) instead of the matrix cores
+  const bool mfma = !(getenv("OSQP_AMD_BATCH_MFMA") && atoi(getenv("OSQP_AMD_BATCH_MFMA")) == 0);
+  const bool mpc = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N;
+  if (mfma) {
+    if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N, true);
+    else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0, true);
+    else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0, true);
+    else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0, true);
+  } else {
+    if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N, false);
+    else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0, false);
+    else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0, false);
+    else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0, false);
+  }
 #undef OQ_BATCH_LAUNCH
 }
 
