@@ -49,6 +49,50 @@ def test_batch_host_api_matches_oracle(product_lib, oracle_lib):
         assert abs(info[i, 4] - r.info.obj_val) <= 1e-4 * max(1.0, abs(r.info.obj_val))
 
 
+@pytest.mark.parametrize("n,m", [(3, 2), (16, 40), (17, 0), (40, 25), (64, 100), (65, 30), (100, 60), (113, 20), (128, 90)])
+def test_batch_generic_shapes_match_oracle(product_lib, oracle_lib, n, m):
+    """Shapes other than the MPC family go through the run-time-sized instantiations (register tiles of 16 / 25 / 32
+    columns; 1 .. 8 blocks of 16 in the matrix-core inversion, padded with the identity): instances that share one random
+    pattern, each against the oracle."""
+    rng = np.random.default_rng(100 * n + m)
+    count = 6
+    S = sp.random(n, n, density=min(1.0, 3.0 / n), random_state=rng, format="csc")
+    S.data[:] = 1.0
+    pat_P = sp.triu(S + S.T + sp.eye(n), format="csc")
+    pat_P.data[:] = 1.0
+    pat_P.sort_indices()
+    pat_A = sp.random(m, n, density=min(1.0, 4.0 / max(n, 1)), random_state=rng, format="csc")
+    pat_A.data[:] = 1.0
+    pat_A.sort_indices()
+    Px, Ax, qs, ls, us, probs = [], [], [], [], [], []
+    for _ in range(count):
+        U = pat_P.copy()
+        U.data = 0.3 * rng.standard_normal(U.nnz)
+        full = (U + U.T).tolil()
+        row_sum = np.asarray(abs(U + U.T).sum(axis=1)).ravel()
+        full.setdiag(row_sum + 0.1 + rng.random(n))  # diagonally dominant: positive definite
+        P = sp.triu(full.tocsc(), format="csc")
+        P.sort_indices()
+        assert np.array_equal(P.indices, pat_P.indices) and np.array_equal(P.indptr, pat_P.indptr)
+        A = pat_A.copy()
+        A.data = rng.standard_normal(A.nnz)
+        x0 = rng.standard_normal(n)
+        w = rng.random(m) * rng.choice([0.0, 1.0], size=m)
+        q = rng.standard_normal(n)
+        l, u = A @ x0 - w, A @ x0 + w
+        Px.append(P.data.copy()); Ax.append(A.data.copy()); qs.append(q); ls.append(l); us.append(u)
+        probs.append((P, q, A, l, u))
+    x, y, info = batch.solve_batch(product_lib, pat_P, pat_A, np.array(Px), np.array(Ax).reshape(count, pat_A.nnz), np.array(qs),
+                                   np.array(ls).reshape(count, m), np.array(us).reshape(count, m), **OPTS)
+    ref = _oracle_solutions(oracle_lib, probs)
+    for i, r in enumerate(ref):
+        assert r.info.status == "Solved" and int(info[i, 1]) == 1, (i, r.info.status, info[i])
+        assert abs(r.info.iter - info[i, 0]) <= 50
+        assert np.max(np.abs(x[i] - r.x)) <= 2e-4 * max(1.0, np.max(np.abs(r.x)))
+        if m:
+            assert np.max(np.abs(y[i] - r.y)) <= 2e-4 * max(1.0, np.max(np.abs(r.y)))
+
+
 def test_batch_generated_matches_host_fed(product_lib, oracle_lib):
     import torch
 
