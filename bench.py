@@ -578,8 +578,8 @@ def batch_leg(ctx, want_cpu):
         dist.all_gather(allc, check)
         same = all(bool((c == allc[0]).all().item()) for c in allc)
     ms = 1e3 * elapsed / steps
-    # LDS roofline of the kernel (HBM sees each instance once): bytes read from LDS per ADMM iteration of one instance =
-    # the dense M^-1 b (8 n^2) + three sparse products over A (A'(rho z - y), A x~: value + 2 indices + operand per entry)
+    # on-chip roofline of the kernel (HBM sees each instance once): operand bytes per ADMM iteration of one instance =
+    # the dense M^-1 b (8 n^2, registers) + the sparse products over A (A'(rho z - y), A x~: value + 2 indices + operand per entry)
     n_, m_, nnzA = batch.MPC_N, batch.MPC_M, 800
     lds_per_iter = 8.0 * n_ * n_ + 2 * nnzA * (8 + 2 + 2 + 8) + 8.0 * (6 * n_ + 10 * m_)
     lds_rate = lds_per_iter * iters * steps / elapsed / 1e9
@@ -596,8 +596,10 @@ def batch_leg(ctx, want_cpu):
                      "traffic": None,
                      "lds_bytes_per_admm_iteration": lds_per_iter,
                      "hbm_GBs": round(per_inst_bytes * BATCH_TOTAL * steps / elapsed / 1e9, 3),
-                     "note": "LDS-read bound by construction (fp64 mat-vec with M^-1 from LDS: 0.25 flop per byte against 256 B/clk/CU); "
-                             "peak = 256 CUs x 256 B/clk x 2.4 GHz per GPU; what is achieved below it is barrier / LDS-latency time, not bandwidth"},
+                     "note": "on-chip operand bytes per ADMM iteration (8 n^2 of M^-1 -- held in registers since round 2 -- plus values, 16-bit "
+                             "indices and operands of the two sparse products and the vector updates from LDS) against the aggregate "
+                             "ds_read peak, 256 CUs x 256 B/clk x 2.4 GHz per GPU; HBM sees each instance once (hbm_GBs); what is achieved "
+                             "below the peak is the latency of the barrier-separated phases of an iteration, not bandwidth"},
     }
     if want_cpu:
         rec["cpu_baseline"] = batch_cpu_leg(oq, args)

@@ -26,3 +26,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf $O/prof_* $O/pmc_FETCH* $O/pmc_WRITE*  # the databases are large; the summaries stay
 ls -la $O
+# 4. standard QP classes (direct / PCG / CPU oracle) and the control class's kernel stats
+cd $GRAFT_REPO_ROOT
+timeout 1500 python tools/zoo_rates.py > $O/zoo_rates.jsonl 2>/dev/null
+cd /tmp && ZOO_LABELS=gpu_direct timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_control -o ctl -- python $GRAFT_REPO_ROOT/tools/zoo_rates.py control > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $(find $O/prof_control -name '*_results.db' | head -1) > $O/kernel_stats_control.md
+rm -rf $O/prof_control
+ls -la $O
