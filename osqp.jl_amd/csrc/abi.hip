@@ -308,6 +308,17 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
     choose_dense_top(S, 512, 2048, 1024, 32, lD, cD, kD);
     out[10] = level_solve_cost_us(S, 512, lD, kD); out[11] = supernode_solve_cost_us(T, 256);
     out[12] = supernodes_pay(S, T, 512, lD, kD, 256) ? 1.0 : 0.0;
+    if (getenv("OSQP_AMD_PROBE_VERBOSE"))
+      for (int L = 0; L < T.nlev; L++) {
+        int64_t rows = 0, pre = 0, post = 0, back = 0;
+        int smax_l = 0;
+        for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+          smax_l = std::max(smax_l, T.ptr[J + 1] - T.ptr[J]);
+          for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) { rows++; pre += T.Fsplit[q] - T.Fp[q]; post += T.Fp[q + 1] - T.Fsplit[q]; back += T.Gp[q + 1] - T.Gp[q]; }
+        }
+        fprintf(stderr, "level %d: %d supernodes, %lld rows (largest %d), per row: %.1f entries at level 0, %.1f above, %.1f backward\n", L,
+                T.lvl_ptr[L + 1] - T.lvl_ptr[L], (long long)rows, smax_l, (double)pre / rows, (double)post / rows, (double)back / rows);
+      }
     return 0;
   });
 }

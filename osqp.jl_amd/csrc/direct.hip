@@ -53,29 +53,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter_A(int64_t nnz, const int64_t
 // ------------------------------------------------------------------ K2: numeric LDL'
 // Dot-product form, two launches per level (levels ascending; every column of a level only needs columns of
 // lower levels).  On entry Lx / D hold the entries of K (lower part), on exit L and the pivots.
-//   phase 1, one wavefront per column k:   d_k = K_kk - sum_j L_kj^2 d_j              (row k of L, CSR view)
+//   phase 1, one wavefront per column k:   d_k = K_kk - sum_j L_kj^2 d_j              (row k of L, CSR view; k_ldl_diag_w)
 //   phase 2, one thread per entry (i, k):  L_ik = (K_ik - sum_j L_ij L_kj d_j) / d_k   (merge of rows i and k,
 //            both sorted by column; only j < k can match because row k ends at k)
 // All entries of a column -- and all columns of a level -- are independent, so a dense trailing block
 // exposes (N - k) lanes per column instead of one wavefront walking k updates one after the other.
-__global__ __launch_bounds__(kBlock) void k_ldl_diag(int c0, int c1, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                     const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                     double *__restrict__ D, double *__restrict__ Dinv, int *__restrict__ status) {
-  const int lane = threadIdx.x & 63;
-  const int k = c0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (k >= c1) return;
-  double acc = 0.0;
-  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) { const double l = Lx[Rmap[q]]; acc += l * l * D[Rj[q]]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) {
-    const double dk = D[k] - acc;
-    const bool bad = (dk == 0.0) || (dk != dk);
-    D[k] = dk; Dinv[k] = 1.0 / dk;
-    if (bad) atomicOr(&status[0], 1);
-    else if (dk > 0.0) atomicAdd(&status[1], 1);
-  }
-}
 __global__ __launch_bounds__(kBlock) void k_ldl_entries(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                         double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                         const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
@@ -108,6 +90,40 @@ __global__ __launch_bounds__(kBlock) void k_ldl_wrow(int c0, int c1, int N, cons
   if (k >= c1) return;
   double *w = W + (size_t)(k - c0) * N;
   for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) { const int j = Rj[q]; w[j] = fill ? Lx[Rmap[q]] * D[j] : 0.0; }
+}
+// phase 1 of a level and the work rows of its phase 2 in one launch: one wavefront per column k of [c0, c1) walks row k
+// once for d_k and (Wfill != nullptr) for w_k = L_k,: o d; the wavefronts behind them clear the work rows of the previous
+// such level [p0, p1) in the other half of W (its phase 2 has run: stream order), so a level is two launches, not four.
+__global__ __launch_bounds__(kBlock) void k_ldl_diag_w(int c0, int c1, int N, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                       const int *__restrict__ Rj, const int64_t *__restrict__ Rmap, double *__restrict__ D,
+                                                       double *__restrict__ Dinv, int *__restrict__ status, double *__restrict__ Wfill, int p0,
+                                                       int p1, double *__restrict__ Wclear) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (wv < c1 - c0) {
+    const int k = c0 + (int)wv;
+    double *w = Wfill ? Wfill + (size_t)(k - c0) * N : nullptr;
+    double acc = 0.0;
+    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) {
+      const int j = Rj[q];
+      const double l = Lx[Rmap[q]], ld = l * D[j];
+      acc += l * ld;
+      if (w) w[j] = ld;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const double dk = D[k] - acc;
+      const bool bad = (dk == 0.0) || (dk != dk);
+      D[k] = dk; Dinv[k] = 1.0 / dk;
+      if (bad) atomicOr(&status[0], 1);
+      else if (dk > 0.0) atomicAdd(&status[1], 1);
+    }
+  } else if (wv < (int64_t)(c1 - c0) + (p1 - p0)) {
+    const int k = p0 + (int)(wv - (c1 - c0));
+    double *w = Wclear + (size_t)(k - p0) * N;
+    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) w[Rj[q]] = 0.0;
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                           double *__restrict__ Lx, const int64_t *__restrict__ Rp,
@@ -735,6 +751,7 @@ __device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, in
   for (; i < i1; i += la) acc += Ex[i] * ld(Ej[i]);
   return acc;
 }
+constexpr int kSnCap = 16;  // entries per lane whose index and value are in registers before the wait
 template <bool kForward>
 __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                             const int64_t *__restrict__ Ep, const int64_t *__restrict__ Es,
@@ -743,55 +760,77 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
                                                             const int *__restrict__ up, const int *__restrict__ waits,
                                                             int *__restrict__ sync, int *__restrict__ fault, double *b) {
   __shared__ double t[kSnMax];
+  __shared__ double Wl[kSnMax * kSnMax];
   const int J = kForward ? J0 + (int)blockIdx.x : count - 1 - (int)blockIdx.x;
   const int P = up[J];
   const int q0 = ptr[J], s = ptr[J + 1] - q0;
-  const int64_t mean = (Ep[q0 + s] - Ep[q0]) / s;
-  const int la = mean <= 8 ? 4 : (mean <= 64 ? 16 : 64);  // lanes per row
-  const int lane = threadIdx.x & (la - 1);
+  // all rows of the supernode at once: 64 / 32 / 16 lanes per row
+  const int la = s <= 16 ? 64 : (s <= 32 ? 32 : 16);
+  const int lane = threadIdx.x & (la - 1), a = threadIdx.x / la;
+  const bool mine = a < s;
+  const int q = q0 + (mine ? a : 0);
   // Entries of b written inside this launch (slots of level >= 1) are stored and loaded at device scope, past the
   // per-XCD L2s, so no cache write-back / invalidate is needed around the counters; everything else (level-0 slots, L,
-  // W) was written by earlier launches and is read through the caches -- and, in the forward direction, before the
-  // wait: the part of each row that points at level 0 does not depend on anything in this launch.
-  for (int a = threadIdx.x / la; a < s; a += kSnTreeThreads / la) {
-    const int q = q0 + a;
-    double acc = kForward ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
-    for (int o = la >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
+  // W) was written by earlier launches and is read through the caches.  Everything that does not depend on the wait
+  // happens before it: the part of each forward row that points at level 0, the indices and values of the rest (into
+  // registers), the inverted block (into LDS); behind the wait there is one round of loads of b, the two small
+  // products and the store.
+  double acc0 = (kForward && mine) ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
+  const int64_t i0 = (kForward ? Es[q] : Ep[q]) + lane, i1 = mine ? Ep[q + 1] : 0;
+  int jj[kSnCap];
+  double xx[kSnCap];
+#pragma unroll
+  for (int u = 0; u < kSnCap; u++) {
+    const int64_t i = i0 + (int64_t)u * la;
+    const bool in = i < i1;
+    jj[u] = in ? Ej[i] : q;  // padding: the row's own slot (a finite number) times zero
+    xx[u] = in ? Ex[i] : 0.0;
   }
+  {
+    const double *Wj = W + woff[J];
+    for (int e = threadIdx.x; e < s * s; e += kSnTreeThreads) Wl[e] = Wj[e];
+  }
+  const double own = mine ? (kForward ? b[q] : b[q] * Dinv_s[q]) : 0.0;
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     if (kForward) {
-      while (sn_load(&sync[J]) != 0) {
+      for (unsigned spins = 1; sn_load(&sync[J]) != 0; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+        if ((spins & 255u) == 0 && wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
       }
       sync[J] = waits[J];  // resting value for the next solve (its children are all past their decrement)
     } else if (P >= 0) {
-      while (sn_load(&sync[P]) == 0) {
+      for (unsigned spins = 1; sn_load(&sync[P]) == 0; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+        if ((spins & 255u) == 0 && wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
       }
       __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  for (int a = threadIdx.x / la; a < s; a += kSnTreeThreads / la) {
-    const int q = q0 + a;
-    double acc = sn_gather<true>(kForward ? Es[q] : Ep[q], Ep[q + 1], lane, la, Ej, Ex, b);
+  {
+    double bb[kSnCap];
+#pragma unroll
+    for (int u = 0; u < kSnCap; u++) bb[u] = __hip_atomic_load(&b[jj[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kSnCap; u++) acc += xx[u] * bb[u];
+    if (i0 + (int64_t)kSnCap * la < i1) acc += sn_gather<true>(i0 - lane + (int64_t)kSnCap * la, i1, lane, la, Ej, Ex, b);
+    acc += acc0;
     for (int o = la >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) t[a] -= acc;
+    if (lane == 0 && mine) t[a] = own - acc;
   }
   __syncthreads();
-  const double *Wj = W + woff[J];
-  const int part = threadIdx.x & 15;
-  for (int a = threadIdx.x >> 4; a < s; a += kSnTreeThreads / 16) {
+  {
+    const int part = threadIdx.x & 15, r = threadIdx.x >> 4;  // 64 rows x 16 lanes
     double acc = 0.0;
-    if (kForward) { for (int j = part; j <= a; j += 16) acc += Wj[j * s + a] * t[j]; }
-    else { for (int j = a + part; j < s; j += 16) acc += Wj[j * s + a] * t[j]; }
+    if (r < s) {
+      if (kForward) { for (int j = part; j <= r; j += 16) acc += Wl[j * s + r] * t[j]; }
+      else { for (int j = r + part; j < s; j += 16) acc += Wl[j * s + r] * t[j]; }
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (part == 0) __hip_atomic_store(&b[q0 + a], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (part == 0 && r < s) __hip_atomic_store(&b[q0 + r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
   __syncthreads();
@@ -816,6 +855,7 @@ struct LdlFactor {
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
+  size_t w_half = 0;            // doubles in one half of W
   std::vector<Step> fwd, bwd;
   long long factorizations = 0;
   // supernodal solves (k_sn_*): chosen when the level schedule is deep and the supernode graph is shallow
@@ -878,7 +918,8 @@ struct LdlFactor {
         }
       }
       if (kD) wmax = std::max(wmax, (size_t)dense_batch() * (size_t)N);
-      if (wmax) { W.alloc(wmax); W.zero(s); }
+      w_half = wmax;
+      if (wmax) { W.alloc(2 * wmax); W.zero(s); }  // two halves: the work rows of a level are cleared while the next level fills its own
       if (kD) { S0a.alloc((size_t)kD * kD); S0b.alloc((size_t)kD * kD); x2.alloc(kD); }
     }
     e.sync();
@@ -1037,21 +1078,26 @@ struct LdlFactor {
                 e.Pf.val.get(), Lx.get(), D.get());
     if (e.nnzA > 0)
       OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
+    int p0 = 0, p1 = 0, half = 0;  // the previous level that went through work rows, and the half of W it used
     for (int l = 0; l < lD; l++) {
       const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
-      OQ_LAUNCH(k_ldl_diag, dim3(blocks_for((int64_t)(c1 - c0) * 64)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(),
-                Rmap.get(), D.get(), Dinv.get(), status.get());
       const int64_t entries = S.Lp[c1] - S.Lp[c0];
-      if (entries > 0 && long_rows[l]) {
-        const dim3 gw(blocks_for((int64_t)(c1 - c0) * 64));
-        OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 1);
+      const bool through_w = entries > 0 && long_rows[l];
+      double *wf = through_w ? W.get() + (size_t)(half ^ 1) * w_half : nullptr, *wc = p1 > p0 ? W.get() + (size_t)half * w_half : nullptr;
+      OQ_LAUNCH(k_ldl_diag_w, dim3(blocks_for((int64_t)(c1 - c0 + (p1 - p0)) * 64)), dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(),
+                Rmap.get(), D.get(), Dinv.get(), status.get(), wf, p0, p1, wc);
+      p0 = p1 = 0;
+      if (through_w) {
         OQ_LAUNCH(k_ldl_entries_w, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, N, Lp.get(), Li.get(), Lx.get(),
-                  Rp.get(), Rj.get(), Rmap.get(), W.get(), Dinv.get());
-        OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 0);
+                  Rp.get(), Rj.get(), Rmap.get(), wf, Dinv.get());
+        p0 = c0; p1 = c1; half ^= 1;
       } else if (entries > 0)
         OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
                   Rj.get(), Rmap.get(), D.get(), Dinv.get());
     }
+    if (p1 > p0)  // the last work rows
+      OQ_LAUNCH(k_ldl_wrow, dim3(blocks_for((int64_t)(p1 - p0) * 64)), dim3(kBlock), 0, s, p0, p1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(),
+                D.get(), W.get() + (size_t)half * w_half, 0);
     if (kD) factor_dense_block();
     if (sn) {
       const int64_t nf = T.Fp[N], big = std::max<int64_t>(N, nf);

@@ -467,15 +467,29 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
   auto big = [&](int v) { return size[v] > smax; };
   for (int v = 0; v < N; v++)
     if (parent[v] >= 0 && big(v)) big_children[parent[v]]++;
-  // roots first: a small node joins its parent's subtree supernode; a big node continues its parent's path segment
-  // when it is the only big child and the segment has room
-  std::vector<int> sn(N, -1), members;
+  // Roots first.  A small node joins its parent's subtree supernode.  The big nodes form the top of the tree; there a
+  // supernode is a connected piece of it: a node continues the path it is on (it is its parent's only big child), and the
+  // top of a path (a separator of a nested-dissection tree) joins the piece of its parent when the whole path still fits,
+  // so that a separator and the separators right below it share one inverted block and one step of the solves.
+  std::vector<int> only_big(N, -1), plen(N, 1);
+  for (int v = 0; v < N; v++)
+    if (parent[v] >= 0 && big(v)) only_big[parent[v]] = v;           // meaningful when big_children == 1
+  for (int v = 0; v < N; v++)                                         // children before parents
+    if (big(v) && big_children[v] == 1) plen[v] = 1 + plen[only_big[v]];
+  std::vector<int> sn(N, -1), members, reserved;
   for (int v = N - 1; v >= 0; v--) {
     const int p = parent[v];
     if (!big(v)) {
       if (p >= 0 && !big(p)) sn[v] = sn[p];
-    } else if (p >= 0 && big_children[p] == 1 && members[sn[p]] < smax) sn[v] = sn[p];
-    if (sn[v] < 0) { sn[v] = (int)members.size(); members.push_back(0); }
+    } else if (p >= 0) {
+      if (big_children[p] == 1 && (members[sn[p]] < reserved[sn[p]])) sn[v] = sn[p];              // the path goes on
+      else if (reserved[sn[p]] + plen[v] <= smax) { sn[v] = sn[p]; reserved[sn[p]] += plen[v]; }  // a new path joins
+    }
+    if (sn[v] < 0) {
+      sn[v] = (int)members.size();
+      members.push_back(0);
+      reserved.push_back(big(v) ? std::min(plen[v], smax) : 0);
+    }
     members[sn[v]]++;
   }
   const int count = (int)members.size();

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_batch_gpu.py -m gpu -x -q 2>&1 | tail -15
-OSQP_AMD_BATCH_MFMA=0 timeout 900 python -m pytest tests/test_batch_gpu.py -m gpu -x -q -k generic 2>&1 | tail -5
+OSQP_AMD_LIB=$GRAFT_REPO_ROOT/osqp.jl_amd/csrc/libosqp_amd_cv.so timeout 300 python bench.py --workload mpc-batch --steps 20 --warmup 3 --no-cpu --traffic off 2>/dev/null | cut -c1-260
+timeout 300 python bench.py --workload mpc-batch --steps 20 --warmup 3 --no-cpu --traffic off 2>/dev/null | cut -c1-260
