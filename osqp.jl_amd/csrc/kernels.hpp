@@ -46,6 +46,12 @@ struct SpmvExtra {
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
           const double *v, hipStream_t s, const SpmvExtra *extra = nullptr);
 
+// ya = Ma x (+ extras) and yb = Mb x + gamma_b vb in one product launch + one reduce launch (panel.hip; bit-identical to
+// the two single products); spmv_pair_ok: both matrices run the LDS-staged panel kernel with the same panel width
+bool spmv_pair_ok(const DevCsr &Ma, const DevCsr &Mb);
+void spmv_pair(const DevCsr &Ma, const DevCsr &Mb, const double *x, double *ya, const SpmvExtra *extra_a, double *yb, double gamma_b,
+               const double *vb, hipStream_t s);
+
 // LDS-staged column-panel variant (panel.hip); spmv() dispatches to it when M.panel.active
 bool panel_wanted(const DevCsr &M);
 void panel_build(DevCsr &M, hipStream_t s);                    // structure + values from the CSR arrays

@@ -247,17 +247,15 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
 // the product
 // ---------------------------------------------------------------------------------------------
 // kSquare: y = (M .* M) x -- the Jacobi diagonal of A' diag(rho) A is this product of A' with rho (compact mode)
-template <typename ColT, bool kStageX, bool kSquare = false>
-__global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
-                                                        const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
-                                                        const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
-                                                        const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
-                                                        const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
-                                                        const double *__restrict__ sval, const double *__restrict__ x,
-                                                        double *__restrict__ partial, const int *__restrict__ skip) {
+template <typename ColT, bool kStageX, bool kSquare>
+__device__ __forceinline__ void sell_tile(int t, int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
+                                          const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                          const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
+                                          const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
+                                          const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
+                                          const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (skip && *skip) return;
-  const int t = blockIdx.x, g = tile_g[t];
+  const int g = tile_g[t];
   const int W = 1 << shift;
   const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
   double *xs_lds = lds;
@@ -315,17 +313,47 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int 
   double *out = partial + (size_t)g * rows + r0;
   for (int i = threadIdx.x; i < nrows; i += kThreads) out[i] = ys[i];
 }
+template <typename ColT, bool kStageX, bool kSquare = false>
+__global__ __launch_bounds__(kThreads) void k_spmv_sell(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
+                                                        const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                                        const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
+                                                        const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
+                                                        const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
+                                                        const double *__restrict__ sval, const double *__restrict__ x,
+                                                        double *__restrict__ partial, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  sell_tile<ColT, kStageX, kSquare>(blockIdx.x, rows, cols, shift, B, Gp, tile_g, tile_r0, tile_r1, unit_s0, unit_ns, slice_base, slice_len,
+                                    slice_rows, scol, sval, x, partial);
+}
+// Two matrices against the same vector in one launch (A p and P p of a CG iteration): at mid size neither fills the
+// device on its own -- 1e7 non-zeros are 153 tiles on 256 CUs -- and the two products do not depend on each other.  Same
+// tiles, same arithmetic: the results are those of the two single launches, bit for bit.
+struct SellSide {
+  int rows, cols, B, Gp, ntiles;
+  const int *tile_g, *tile_r0, *tile_r1, *unit_s0, *unit_ns, *slice_len, *slice_rows;
+  const uint32_t *slice_base;
+  const uint16_t *scol;
+  const double *sval;
+  double *partial;
+};
+__global__ __launch_bounds__(kThreads) void k_spmv_sell_pair(SellSide a, SellSide b, int shift, const double *__restrict__ x,
+                                                             const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  const bool first = (int)blockIdx.x < a.ntiles;
+  const SellSide &m = first ? a : b;
+  sell_tile<uint16_t, true, false>(first ? (int)blockIdx.x : (int)blockIdx.x - a.ntiles, m.rows, m.cols, shift, m.B, m.Gp, m.tile_g, m.tile_r0,
+                                   m.tile_r1, m.unit_s0, m.unit_ns, m.slice_base, m.slice_len, m.slice_rows, m.scol, m.sval, x, m.partial);
+}
 
 // y[i] = (rscale ? rscale[i] : 1) * sum_g partial[g][i] + beta * y[i] + gamma * v[i]   (group order is fixed)
 // Grid of at most kReduceBlocks blocks, grid-stride over the rows -- the thread-to-row assignment of the two-stage
 // reductions (k_dot_partial), so that the optional dot product of the result with another vector lands in the same
 // partials, in the same order, as a separate reduce_dot would form (SpmvExtra).
-__global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
-                                                         const double *__restrict__ rscale, double beta, double gamma,
-                                                         const double *__restrict__ v, SpmvExtra ex, const int *__restrict__ skip) {
-  if (skip && *skip) return;
+__device__ __forceinline__ void panel_reduce_rows(int vb, int vg, int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
+                                                  const double *__restrict__ rscale, double beta, double gamma,
+                                                  const double *__restrict__ v, const SpmvExtra &ex) {
   double dot = 0.0, mx = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < rows; i += gridDim.x * kBlock) {
+  for (int i = vb * kBlock + threadIdx.x; i < rows; i += vg * kBlock) {
     double acc = 0.0;
     for (int b = 0; b < B; b++) acc += partial[(size_t)b * rows + i];
     if (ex.y2) ex.y2[i] = ex.s2[i] * acc;
@@ -338,14 +366,35 @@ __global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const 
   }
   if (ex.dot_partials) {
     dot = block_sum(dot);
-    if (threadIdx.x == 0) ex.dot_partials[blockIdx.x] = dot;
-    if (blockIdx.x == 0)  // blocks that do not exist hold zeroes, as in a kReduceBlocks-wide first stage
-      for (int t = gridDim.x + threadIdx.x; t < kReduceBlocks; t += kBlock) ex.dot_partials[t] = 0.0;
+    if (threadIdx.x == 0) ex.dot_partials[vb] = dot;
+    if (vb == 0)  // blocks that do not exist hold zeroes, as in a kReduceBlocks-wide first stage
+      for (int t = vg + threadIdx.x; t < kReduceBlocks; t += kBlock) ex.dot_partials[t] = 0.0;
   }
   if (ex.absmax_slot) {
     mx = block_max(mx);
     if (threadIdx.x == 0) atomic_max_nonneg(ex.absmax_slot, mx);
   }
+}
+__global__ __launch_bounds__(kBlock) void k_panel_reduce(int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
+                                                         const double *__restrict__ rscale, double beta, double gamma,
+                                                         const double *__restrict__ v, SpmvExtra ex, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  panel_reduce_rows(blockIdx.x, gridDim.x, rows, B, partial, y, rscale, beta, gamma, v, ex);
+}
+// the reduces of a pair launch: blocks [0, ga) are the grid of the first, the rest that of the second
+struct ReduceSide {
+  int rows, B, grid;
+  const double *partial;
+  double *y;
+  double gamma;
+  const double *v;
+  SpmvExtra ex;
+};
+__global__ __launch_bounds__(kBlock) void k_panel_reduce_pair(ReduceSide a, ReduceSide b, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  const bool first = (int)blockIdx.x < a.grid;
+  const ReduceSide &m = first ? a : b;
+  panel_reduce_rows(first ? (int)blockIdx.x : (int)blockIdx.x - a.grid, m.grid, m.rows, m.B, m.partial, m.y, nullptr, 0.0, m.gamma, m.v, m.ex);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -578,6 +627,36 @@ void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscal
               P.Gp, P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(),
               P.slice_len.get(), P.slice_rows.get(), P.scol.get(), P.sval.get(), x, P.partial.get(), g_skip);
   OQ_LAUNCH(k_panel_reduce, dim3(reduce_grid(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), y, rscale, beta, gamma, v, ex, g_skip);
+}
+
+// ya = Ma x (+ extras), yb = Mb x + gamma_b vb: one product launch and one reduce launch for the two
+bool spmv_pair_ok(const DevCsr &Ma, const DevCsr &Mb) {
+  const DevPanel &A = Ma.panel, &B = Mb.panel;
+  static const bool enabled = !(getenv("OSQP_AMD_SPMV_PAIR") && atoi(getenv("OSQP_AMD_SPMV_PAIR")) == 0);
+  // worth it while one matrix alone leaves compute units idle for a good part of its launch
+  return enabled && A.active && B.active && !A.wide && !B.wide && A.shift == B.shift && Ma.cols == Mb.cols && A.ntiles + B.ntiles <= 2048;
+}
+void spmv_pair(const DevCsr &Ma, const DevCsr &Mb, const double *x, double *ya, const SpmvExtra *extra_a, double *yb, double gamma_b,
+               const double *vb, hipStream_t s) {
+  auto side = [](const DevCsr &M) {
+    const DevPanel &P = M.panel;
+    SellSide t;
+    t.rows = M.rows; t.cols = M.cols; t.B = P.B; t.Gp = P.Gp; t.ntiles = P.ntiles;
+    t.tile_g = P.tile_g.get(); t.tile_r0 = P.tile_r0.get(); t.tile_r1 = P.tile_r1.get(); t.unit_s0 = P.unit_s0.get(); t.unit_ns = P.unit_ns.get();
+    t.slice_len = P.slice_len.get(); t.slice_rows = P.slice_rows.get(); t.slice_base = P.slice_base.get(); t.scol = P.scol.get();
+    t.sval = P.sval.get(); t.partial = P.partial.get();
+    return t;
+  };
+  const DevPanel &A = Ma.panel, &B = Mb.panel;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spmv_lds_bytes(A.shift)));
+    attr_set = true;
+  }
+  OQ_LAUNCH(k_spmv_sell_pair, dim3(A.ntiles + B.ntiles), dim3(kThreads), spmv_lds_bytes(A.shift), s, side(Ma), side(Mb), A.shift, x, g_skip);
+  ReduceSide ra{Ma.rows, A.NG, reduce_grid(Ma.rows), A.partial.get(), ya, 0.0, nullptr, extra_a ? *extra_a : SpmvExtra()};
+  ReduceSide rb{Mb.rows, B.NG, reduce_grid(Mb.rows), B.partial.get(), yb, gamma_b, vb, SpmvExtra()};
+  OQ_LAUNCH(k_panel_reduce_pair, dim3(ra.grid + rb.grid), dim3(kBlock), 0, s, ra, rb, g_skip);
 }
 
 // ---- compact mode: host side -------------------------------------------------------------------------------------------

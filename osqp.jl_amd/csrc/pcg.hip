@@ -234,6 +234,7 @@ struct Pcg : Linsys {
   bool carried_valid = false;
   int since_refresh = 0;
   bool fused_on = false;            // the fused kernels apply (single device, panel kernels on all three matrices)
+  bool pair_on = false;             // A p and P p of a CG iteration in one launch (mid-size matrices: neither fills the device alone)
   // asynchronous form
   bool async_on = false;
   DevBuf<int> ctl;
@@ -255,6 +256,7 @@ struct Pcg : Linsys {
     {
       const char *fv = getenv("OSQP_AMD_PCG_FUSED");
       fused_on = !e.comm && e.m > 0 && e.A.panel.active && e.At.panel.active && e.Pf.panel.active && !(fv && atoi(fv) == 0);
+      pair_on = fused_on && spmv_pair_ok(e.A, e.Pf);
     }
     const char *ev = getenv("OSQP_AMD_PCG_ASYNC");
     // opt-in (OSQP_AMD_PCG_ASYNC=1): measured on rand-1e5 the empty kernels of the iterations enqueued beyond convergence
@@ -432,8 +434,11 @@ struct Pcg : Linsys {
     if (fused_on) {
       SpmvExtra exA;
       exA.y2 = t.get(); exA.s2 = e.rho.get();                        // t = rho .* (A p) next to u = A p
-      spmv(e.A, p.get(), u.get(), nullptr, 0.0, 0.0, nullptr, s, &exA);
-      spmv(e.Pf, p.get(), w.get(), nullptr, 0.0, e.st.sigma, p.get(), s);
+      if (pair_on) spmv_pair(e.A, e.Pf, p.get(), u.get(), &exA, w.get(), e.st.sigma, p.get(), s);  // u = A p, w = P p + sigma p
+      else {
+        spmv(e.A, p.get(), u.get(), nullptr, 0.0, 0.0, nullptr, s, &exA);
+        spmv(e.Pf, p.get(), w.get(), nullptr, 0.0, e.st.sigma, p.get(), s);
+      }
       SpmvExtra exT;
       exT.dotv = p.get(); exT.dot_partials = part + R_DOT;            // p'w with the result of w += A' t
       spmv(e.At, t.get(), w.get(), nullptr, 1.0, 0.0, nullptr, s, &exT);
