@@ -273,40 +273,61 @@ __device__ __forceinline__ void sell_tile(int t, int rows, int cols, int shift, 
     if (kStageX) {
       if (!first) __syncthreads();   // the previous panel is no longer read
       const int wlen = cols - c0 < W ? cols - c0 : W;
-      for (int i = threadIdx.x; i < wlen; i += kThreads) xs_lds[i] = x[c0 + i];
+      double2 *xl = reinterpret_cast<double2 *>(xs_lds);
+      if (wlen == 16 * kThreads) {
+        // a full panel of the default width: 16 doubles per thread as 8 independent 16-byte loads, all in flight before the
+        // first LDS write (the plain loop below is 16 dependent round trips to L2 -- as long as streaming half the tile).
+        // (Fetching the NEXT panel into registers while this one streams was measured too: 1.90 -> 2.51 ms at nnz = 1e9.)
+        const double2 *xg = reinterpret_cast<const double2 *>(x + c0);
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = xg[threadIdx.x + k * kThreads];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xl[threadIdx.x + k * kThreads] = v[k];
+      } else {
+        for (int i = threadIdx.x; i < wlen; i += kThreads) xs_lds[i] = x[c0 + i];
+      }
       __syncthreads();
       xs = xs_lds;
     } else {
       __syncthreads();               // first pass: the zeroes of ys are in place; later: the row sums of the previous panel are
     }
     first = false;
-    for (int sl = s0 + wave; sl < s0 + ns; sl += kWaves) {
-      const size_t base = (size_t)slice_base[sl] + lane;
-      const int L = slice_len[sl];
-      const int row = slice_rows[(size_t)sl * 64 + lane];
+    // A slice is short (a row has ~16 entries per panel at 1000 per row and 61 panels), so what a wavefront pays per slice
+    // is round trips, not bytes: the descriptor of the NEXT slice is fetched while this one is worked on, and a slice's
+    // entries go out as batches of up to 16 values + 16 column ids per lane, all issued before the first is consumed --
+    // the tail of a slice is a guarded batch (the guards are wave-uniform), not one load at a time.
+    int sl = s0 + wave;
+    size_t nbase = 0;
+    int nL = 0, nrow = -1;
+    if (sl < s0 + ns) { nbase = (size_t)slice_base[sl]; nL = slice_len[sl]; nrow = slice_rows[(size_t)sl * 64 + lane]; }
+    for (; sl < s0 + ns; sl += kWaves) {
+      const size_t base = nbase + lane;
+      const int L = nL, row = nrow;
+      if (sl + kWaves < s0 + ns) {
+        nbase = (size_t)slice_base[sl + kWaves]; nL = slice_len[sl + kWaves]; nrow = slice_rows[(size_t)(sl + kWaves) * 64 + lane];
+      }
       const double *v = sval + base;
       const ColT *c = scol + base;
-      double a0 = 0.0, a1 = 0.0;
-      int k = 0;
-      for (; k + 8 <= L; k += 8) {  // 16 loads in flight per lane before the first one is consumed
-        double cv[8];
-        ColT cc[8];
+      double a0 = 0.0;
+      for (int k = 0; k < L; k += 16) {
+        double cv[16];
+        ColT cc[16];
+        if (k + 16 <= L) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
+          for (int u = 0; u < 16; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
+        } else {
 #pragma unroll
-        for (int u = 0; u < 8; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
+          for (int u = 0; u < 16; u++) {
+            const bool in = k + u < L;
+            cv[u] = in ? v[(size_t)(k + u) * 64] : 0.0;
+            cc[u] = in ? c[(size_t)(k + u) * 64] : (ColT)0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
       }
-      if (k + 4 <= L) {
-        double cv[4];
-        ColT cc[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
-        k += 4;
-      }
-      for (; k < L; k++) { const double e = v[(size_t)k * 64]; a1 += (kSquare ? e * e : e) * xs[c[(size_t)k * 64]]; }
-      if (row >= 0) ys[row - r0] += a0 + a1;  // a row appears once per panel; panels are separated by barriers
+      if (row >= 0) ys[row - r0] += a0;  // a row appears once per panel; panels are separated by barriers
     }
   }
   __syncthreads();
