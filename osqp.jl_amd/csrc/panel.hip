@@ -48,6 +48,10 @@ namespace oq {
 namespace {
 
 constexpr int kThreads = 1024;
+#ifndef OQ_SELL_BATCH
+#define OQ_SELL_BATCH 16
+#endif
+constexpr int kBatch = OQ_SELL_BATCH;  // entries of a slice per lane whose loads are issued together
 constexpr int kWaves = kThreads / 64;
 constexpr int kTileRowsMax = 3968;  // row sums of a tile are staged in LDS (31 KB next to the 128 KB x panel)
 constexpr int kSortN = 4096;        // power of two >= kTileRowsMax: per-tile ordering of the rows in LDS
@@ -295,7 +299,7 @@ __device__ __forceinline__ void sell_tile(int t, int rows, int cols, int shift, 
     first = false;
     // A slice is short (a row has ~16 entries per panel at 1000 per row and 61 panels), so what a wavefront pays per slice
     // is round trips, not bytes: the descriptor of the NEXT slice is fetched while this one is worked on, and a slice's
-    // entries go out as batches of up to 16 values + 16 column ids per lane, all issued before the first is consumed --
+    // entries go out as batches of up to kBatch values + column ids per lane, all issued before the first is consumed --
     // the tail of a slice is a guarded batch (the guards are wave-uniform), not one load at a time.
     int sl = s0 + wave;
     size_t nbase = 0;
@@ -310,22 +314,22 @@ __device__ __forceinline__ void sell_tile(int t, int rows, int cols, int shift, 
       const double *v = sval + base;
       const ColT *c = scol + base;
       double a0 = 0.0;
-      for (int k = 0; k < L; k += 16) {
-        double cv[16];
-        ColT cc[16];
-        if (k + 16 <= L) {
+      for (int k = 0; k < L; k += kBatch) {
+        double cv[kBatch];
+        ColT cc[kBatch];
+        if (k + kBatch <= L) {
 #pragma unroll
-          for (int u = 0; u < 16; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
+          for (int u = 0; u < kBatch; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = c[(size_t)(k + u) * 64]; }
         } else {
 #pragma unroll
-          for (int u = 0; u < 16; u++) {
+          for (int u = 0; u < kBatch; u++) {
             const bool in = k + u < L;
             cv[u] = in ? v[(size_t)(k + u) * 64] : 0.0;
             cc[u] = in ? c[(size_t)(k + u) * 64] : (ColT)0;
           }
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
+        for (int u = 0; u < kBatch; u++) a0 += (kSquare ? cv[u] * cv[u] : cv[u]) * xs[cc[u]];
       }
       if (row >= 0) ys[row - r0] += a0;  // a row appears once per panel; panels are separated by barriers
     }
