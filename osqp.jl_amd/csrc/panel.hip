@@ -380,7 +380,23 @@ __device__ __forceinline__ void panel_reduce_rows(int vb, int vg, int rows, int 
   double dot = 0.0, mx = 0.0;
   for (int i = vb * kBlock + threadIdx.x; i < rows; i += vg * kBlock) {
     double acc = 0.0;
-    for (int b = 0; b < B; b++) acc += partial[(size_t)b * rows + i];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {  // eight loads in flight, added in group order
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = partial[(size_t)(b + u) * rows + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += t[u];
+    }
+    if (b + 4 <= B) {
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[u] = partial[(size_t)(b + u) * rows + i];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc += t[u];
+      b += 4;
+    }
+    for (; b < B; b++) acc += partial[(size_t)b * rows + i];
     if (ex.y2) ex.y2[i] = ex.s2[i] * acc;
     if (rscale) acc *= rscale[i];
     if (beta != 0.0) acc += beta * y[i];

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for B in 24 32; do OSQP_AMD_LIB=$GRAFT_REPO_ROOT/osqp.jl_amd/csrc/libosqp_amd_b$B.so python tools/sweep_spmv.py rand-1e6 BATCH=$B 2>/dev/null; OSQP_AMD_LIB=$GRAFT_REPO_ROOT/osqp.jl_amd/csrc/libosqp_amd_b$B.so python tools/sweep_spmv.py rand-1e5 BATCH=$B 2>/dev/null; done
+python tools/sweep_spmv.py rand-1e5 2>/dev/null
 python tools/sweep_spmv.py rand-1e6 2>/dev/null
+timeout 600 python bench.py --workload rand-1e5 --steps 20 --warmup 5 --no-cpu --traffic off 2>/dev/null | cut -c1-200
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "spmv or arithmetic or panel" 2>&1 | tail -2
