@@ -773,8 +773,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __syncthreads();
   PROF(0)
   // ---- K0: Ruiz equilibration + cost scaling --------------------------------
+  // the thread's share of the entries of A, both orientations (positions and indices in registers, values from LDS): the
+  // positions do not change under scaling, so the walks of the scaling passes use them too (4 lanes per column, 2 per
+  // row: a column of 13 entries is 4 dependent LDS round trips instead of 13)
+  const bool regs = sparse_fits(P);
+  SparseRegs R;
+  if (regs) load_sparse(P, s, R);
   double c = 1.0;
   for (int it = 0; it < st.scaling; it++) {
+    if (regs) {
+      double mx = 0.0;
+#pragma unroll
+      for (int e = 0; e < KT; e++) if (e < R.ccnt) mx = fmax(mx, fabs(s.Av[opaque_word(R.ce[e]) >> 16]));
+      mx = fmax(mx, quad_xor<2>(mx));
+      mx = fmax(mx, quad_xor<1>(mx));
+      if ((tid & 3) == 0 && R.col >= 0) {
+        const int j = R.col;
+        for (int q = s.Fp[j]; q < s.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
+        s.tn[j] = 1.0 / sqrt(lim(mx));
+      }
+      double mr = 0.0;
+#pragma unroll
+      for (int e = 0; e < KR; e++) if (e < R.rcnt) mr = fmax(mr, fabs(s.Av[opaque_word(R.re[e]) >> 16]));
+      mr = fmax(mr, quad_xor<1>(mr));
+      if ((tid & 1) == 0 && R.row >= 0) s.tm[R.row] = 1.0 / sqrt(lim(mr));
+    } else {
     for (int j = tid; j < n; j += NT) {
       double mx = 0.0;
       for (int q = s.Fp[j]; q < s.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
@@ -786,6 +809,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       for (int q = s.Rp[i]; q < s.Rp[i + 1]; q++) mx = fmax(mx, fabs(s.Av[s.Rmap[q]]));
       s.tm[i] = 1.0 / sqrt(lim(mx));
     }
+    }
     __syncthreads();
     for (int r = tid; r < n; r += NT)
       for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) {
@@ -793,10 +817,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         int lo = cc < r ? cc : r, hi = cc < r ? r : cc;
         s.Pv[q] = (s.Pv[q] * s.tn[lo]) * s.tn[hi];
       }
+    if (regs) {
+      if (R.col >= 0) {
+        const double tj = s.tn[R.col];
+#pragma unroll
+        for (int e = 0; e < KT; e++) if (e < R.ccnt) {
+          const unsigned w = opaque_word(R.ce[e]);
+          s.Av[w >> 16] = (s.Av[w >> 16] * s.tm[w & 0xFFFFu]) * tj;
+        }
+      }
+      for (int j = tid; j < n; j += NT) { s.q[j] *= s.tn[j]; s.D[j] *= s.tn[j]; }
+    } else {
     for (int j = tid; j < n; j += NT) {
       for (int k = s.Ap[j]; k < s.Ap[j + 1]; k++) s.Av[k] = (s.Av[k] * s.tm[s.Ai[k]]) * s.tn[j];
       s.q[j] *= s.tn[j];
       s.D[j] *= s.tn[j];
+    }
     }
     for (int i = tid; i < m; i += NT) s.E[i] *= s.tm[i];
     __syncthreads();
@@ -807,8 +843,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       w[0] += mx;
       v[0] = fmax(v[0], fabs(s.q[j]));
     }
-    block_reduce<1>(w, 1, s.red);
-    block_reduce<2>(v, 0, s.red);
+    {  // the sum and the maximum in one exchange: wavefront reductions, one barrier, the two halves of the upper part of
+       // s.red taken in turn so that the pass after next may overwrite what this one reads
+      double sm = w[0], mq = v[0];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); mq = nmax(mq, __shfl_xor(mq, o, 64)); }
+      ldouble *rr = s.red + 8 * NW + (it & 1) * 2 * NW;
+      if ((tid & 63) == 0) { rr[2 * (tid >> 6)] = sm; rr[2 * (tid >> 6) + 1] = mq; }
+      __syncthreads();
+      sm = rr[0]; mq = rr[1];
+#pragma unroll
+      for (int wv = 1; wv < NW; wv++) { sm += rr[2 * wv]; mq = nmax(mq, rr[2 * wv + 1]); }
+      w[0] = sm; v[0] = mq;
+    }
     double c_temp = w[0] / (double)n;
     c_temp = lim(fmax(c_temp, lim(v[0])));
     c_temp = 1.0 / c_temp;
@@ -830,10 +877,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // scratch of the sweeps, n + 1 doubles each: tn runs on into ldinv (unused by this kernel), Px into Aty -- Px and Aty are
   // only live inside a residual evaluation
   ldouble *gj0 = s.tn, *gj1 = s.Px;
-  // the thread's share of the entries of A, both orientations (positions and indices in registers, values from LDS)
-  const bool regs = sparse_fits(P);
-  SparseRegs R;
-  if (regs) load_sparse(P, s, R);
   // y = A v / y = A' v through whichever walk of A applies
   auto a_rows = [&](const ldouble *v, auto finish) {
     if (regs) row_dot(R, s.Av, v, finish);

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-OSQP_AMD_LIB=$GRAFT_REPO_ROOT/osqp.jl_amd/csrc/libosqp_amd_cv.so timeout 300 python bench.py --workload mpc-batch --steps 20 --warmup 3 --no-cpu --traffic off 2>/dev/null | cut -c1-260
+timeout 900 python -m pytest tests/test_batch_gpu.py tests/test_full_size_gpu.py -m gpu -x -q -k "batch" 2>&1 | tail -3
+OSQP_AMD_LIB=$GRAFT_REPO_ROOT/osqp.jl_amd/csrc/libosqp_amd_prof.so timeout 120 python bench.py --workload mpc-batch --steps 2 --warmup 1 --no-cpu --traffic off 2>&1 | grep -v '^{' | tail -1
 timeout 300 python bench.py --workload mpc-batch --steps 20 --warmup 3 --no-cpu --traffic off 2>/dev/null | cut -c1-260
