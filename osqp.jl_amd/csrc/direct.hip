@@ -731,9 +731,11 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
 // supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
 // their resting values when the launch ends, so a captured graph can replay it.  Workgroups are dispatched in
 // blockIdx order per XCD and a workgroup only waits on lower blockIdx values, so the lowest unfinished one is always
-// resident and never waits on an unscheduled one; a wait that still exceeds one second sets *fault (mapped host memory)
+// resident and never waits on an unscheduled one; a wait that still exceeds 200 ms sets *fault (mapped host memory)
 // and carries on, so a broken assumption is a reported error, not a hang.
 constexpr int kSnTreeThreads = 1024;
+constexpr long long kSnWaitTicks = 20000000LL;  // 200 ms of the 100 MHz wall clock (a legitimate wait is microseconds; a workgroup
+                                                 // pre-empted on a shared device can look like milliseconds)
 __device__ __forceinline__ int sn_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // sum of Ex[i] * b[Ej[i]] over i = i0 + lane, i0 + lane + la, ... < i1, four gathers in flight per lane
 template <bool kCoherent>
@@ -796,13 +798,13 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
     if (kForward) {
       for (unsigned spins = 1; sn_load(&sync[J]) != 0; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0 && wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+        if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
       }
       sync[J] = waits[J];  // resting value for the next solve (its children are all past their decrement)
     } else if (P >= 0) {
       for (unsigned spins = 1; sn_load(&sync[P]) == 0; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0 && wall_clock64() - t0 > 100000000LL) { *fault = 1; break; }
+        if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
       }
       __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1320,7 +1322,15 @@ struct Direct : Linsys {
                 e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     return 0;
   }
-  int flush() override { return F->faulted() ? 6 : 0; }  // a supernode waited a second for its children: internal error
+  // a supernode waited 200 ms for its children: an internal error for the solve in progress; the factor goes back to one
+  // launch per level (no waiting inside a kernel) for everything after it
+  int flush() override {
+    if (!F->faulted()) return 0;
+    *F->sn_fault_host = 0;
+    F->sn_tree = false;
+    e.drop_chunk_graph();
+    return 6;
+  }
   int update_rho() override { return F->refactor(e.rho_inv.get()); }
   int update_matrices() override { return F->refactor(e.rho_inv.get()); }
   double nnzL() const override { return (double)F->S.nnzL; }

@@ -666,8 +666,11 @@ bool Engine::can_chunk(long long iter, long long max_iter) const {
   return true;
 }
 
-void Engine::settings_changed() {
+void Engine::drop_chunk_graph() {
   if (chunk_exec) { (void)hipGraphExecDestroy(chunk_exec); chunk_exec = nullptr; chunk_len = 0; }
+}
+void Engine::settings_changed() {
+  drop_chunk_graph();
   if (lin) { if (int rc = lin->flush()) deferred_error = rc; lin->invalidate(); }
 }
 
@@ -694,7 +697,7 @@ void Engine::run_chunk() {
 // Ax, Px, A'y at the current iterate and the 16 norms / sums of Slot order into h_slots
 void Engine::residual_evaluation() {
   if (int rc = lin->flush()) {  // the iterate must be the one the host believes it is
-    if (rc == 6) throw Error(6, "internal: a supernode of the triangular solve waited a second for its children");
+    if (rc == 6) throw Error(6, "internal: a supernode of the triangular solve waited 200 ms for its children (the solves fall back to one launch per level)");
     deferred_error = rc;
   }
   const double *xg = full_n(x.get());

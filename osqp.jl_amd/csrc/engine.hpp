@@ -160,6 +160,7 @@ struct Engine {
   // The captured chunk bakes the scalar launch arguments (alpha, sigma) and the kernel choice into its nodes:
   // whatever changes a setting, rho or the matrices drops it, and the next chunk is captured afresh.
   void settings_changed();
+  void drop_chunk_graph();
   int kkt_solve();
   void residual_evaluation();
   void update_info(long long iter, bool compute_objective);
