@@ -866,7 +866,12 @@ struct LdlFactor {
   DevBuf<int> sn_ptr, sn_piv, perm_s, pinv_s, sn_Fj, sn_Gi, sn_up, sn_waits, sn_pending, sn_ready;
   int *sn_fault = nullptr, *sn_fault_host = nullptr;  // mapped host memory: a wait inside k_sn_tree timed out
   ~LdlFactor() { if (sn_fault_host) (void)hipHostFree(sn_fault_host); }
-  bool faulted() const { return sn_fault_host && *(volatile int *)sn_fault_host != 0; }
+  bool faulted() const {
+    if (!sn_fault_host) return false;
+    if (inject_fault) { inject_fault = false; *sn_fault_host = 1; }  // OSQP_AMD_SNODE_FAULT_TEST=1: the host side of a timed-out wait
+    return *(volatile int *)sn_fault_host != 0;
+  }
+  mutable bool inject_fault = getenv("OSQP_AMD_SNODE_FAULT_TEST") && atoi(getenv("OSQP_AMD_SNODE_FAULT_TEST")) == 1;
   bool sn_tree = false;     // levels >= 1 in one launch per direction (k_sn_tree) instead of one per level
   DevBuf<int64_t> sn_woff, sn_wmap, sn_Fp, sn_Fpos, sn_Gp, sn_Gpos, sn_Fsplit;
   DevBuf<double> sn_Wc, sn_Wr, sn_Fx, sn_Gx, sn_Dinv;

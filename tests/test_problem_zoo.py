@@ -90,6 +90,32 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_a_timed_out_wait_in_the_tree_kernels_is_an_error_and_a_fallback(product_lib, oracle_lib, monkeypatch):
+    """k_sn_tree waits inside a kernel (csrc/direct.hip); a wait that times out raises a flag in mapped host memory.
+    The host side of that: the solve in progress fails with error 6, the factor goes back to one launch per level,
+    and the next solve on the same workspace is the oracle's again.  (The flag is injected: OSQP_AMD_SNODE_FAULT_TEST.)"""
+    prob = qp_zoo.control(nx=8, nu=4, T=400)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **opts, **prob)
+    ro = oq.solve(mo)
+    monkeypatch.setenv("OSQP_AMD_SNODE_FAULT_TEST", "1")
+    m = oq.Model(product_lib)
+    oq.setup(m, linsys_solver="direct", **opts, **prob)
+    monkeypatch.delenv("OSQP_AMD_SNODE_FAULT_TEST")
+    assert oq.stats(m)[19] > 2
+    # [REF src/interface.jl:170] ignores osqp_solve's return value, and so does the mirror: the failure shows as a status
+    rc = product_lib.osqp_solve(m.workspace)
+    assert rc == 6 and b"supernode" in product_lib.osqp_amd_last_error()
+    assert oq.stats(m)[19] > 2  # still a supernodal factor, now one launch per level
+    rp = oq.solve(m)  # continues from the iterate (and rho) the failed solve left: same answer, not the same path
+    assert rp.info.status == ro.info.status == "Solved"
+    assert np.max(np.abs(ro.x - rp.x)) <= 1e-4 * max(1.0, np.max(np.abs(ro.x)))
+    assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-5 * max(1.0, abs(ro.info.obj_val))
+    oq.clean(m); oq.clean(mo)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["portfolio", "svm", "huber", "lasso_data", "equality_qp", "control"])
 def test_polish_on_zoo(product_lib, oracle_lib, name):
     """Polish on the standard classes: same outcome and objective as the oracle's polish."""
