@@ -106,9 +106,9 @@ __global__ __launch_bounds__(kBlock) void k_ldl_diag_w(int c0, int c1, int N, co
     double acc = 0.0;
     for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) {
       const int j = Rj[q];
-      const double l = Lx[Rmap[q]], ld = l * D[j];
-      acc += l * ld;
-      if (w) w[j] = ld;
+      const double l = Lx[Rmap[q]], d = D[j];
+      acc += l * l * d;  // (l l) d, the order of the oracle's column update: pivots agree to the last bit on short rows
+      if (w) w[j] = l * d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_problem_zoo.py -m gpu -x -q -k "timed_out or nested" 2>&1 | tail -12
+OSQP_FUZZ_BLOCKS=40 timeout 1500 python -m pytest tests/test_fuzz_gpu.py -m gpu -q 2>&1 | grep -E "AssertionError|passed|failed" | head -10
