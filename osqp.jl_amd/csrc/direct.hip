@@ -270,6 +270,21 @@ __global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_
   if (q < nnz) Rx[q] = Lx[Rmap[q]];
 }
 
+// sum of val[q] * b[idx[q]] over q = q0, q0 + stride, ... < q1: four gathers in flight per lane, added in the order of the plain
+// loop (a plain loop is one dependent index -> value round trip per entry)
+__device__ __forceinline__ double gather_dot(int64_t q0, int64_t q1, int stride, const int *__restrict__ idx, const double *__restrict__ val,
+                                             const double *b) {
+  double acc = 0.0;
+  int64_t q = q0;
+  for (; q + 3 * (int64_t)stride < q1; q += 4 * (int64_t)stride) {
+    const int j0 = idx[q], j1 = idx[q + stride], j2 = idx[q + 2 * (int64_t)stride], j3 = idx[q + 3 * (int64_t)stride];
+    const double x0 = val[q], x1 = val[q + stride], x2 = val[q + 2 * (int64_t)stride], x3 = val[q + 3 * (int64_t)stride];
+    const double b0 = b[j0], b1 = b[j1], b2 = b[j2], b3 = b[j3];
+    acc += x0 * b0; acc += x1 * b1; acc += x2 * b2; acc += x3 * b3;
+  }
+  for (; q < q1; q += stride) acc += val[q] * b[idx[q]];
+  return acc;
+}
 // ------------------------------------------------------------------ K3 / K4: level-scheduled triangular solves
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_fwd_level(int r0, int r1, const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
@@ -277,8 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_level(int r0, int r1, const int6
   const int lane = threadIdx.x & (G - 1);
   const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
   if (row >= r1) return;
-  double acc = 0.0;
-  for (int64_t q = Rp[row] + lane; q < Rp[row + 1]; q += G) acc += Rx[q] * b[Rj[q]];
+  double acc = gather_dot(Rp[row] + lane, Rp[row + 1], G, Rj, Rx, b);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) b[row] -= acc;
@@ -290,8 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int6
   const int lane = threadIdx.x & (G - 1);
   const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
   if (row >= r1) return;
-  double acc = 0.0;
-  for (int64_t t = Lp[row] + lane; t < Lp[row + 1]; t += G) acc += Lx[t] * b[Li[t]];
+  double acc = gather_dot(Lp[row] + lane, Lp[row + 1], G, Li, Lx, b);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
@@ -309,9 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_
   __shared__ double part[kBlock / 64];
   const int lane = threadIdx.x & (T - 1);
   const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
-  double acc = 0.0;
-  if (row < r1)
-    for (int64_t q = Rp[row] + lane; q < Rsplit[row]; q += T) acc += Rx[q] * b[Rj[q]];
+  double acc = row < r1 ? gather_dot(Rp[row] + lane, Rsplit[row], T, Rj, Rx, b) : 0.0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (T == 64) {
@@ -336,9 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_far(int r0, int r1, const int64_
   __shared__ double part[kBlock / 64];
   const int lane = threadIdx.x & (T - 1);
   const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
-  double acc = 0.0;
-  if (row < r1)
-    for (int64_t t = Lsplit[row] + lane; t < Lp[row + 1]; t += T) acc += Lx[t] * b[Li[t]];
+  double acc = row < r1 ? gather_dot(Lsplit[row] + lane, Lp[row + 1], T, Li, Lx, b) : 0.0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (T == 64) {
