@@ -715,8 +715,7 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
     const int lane = threadIdx.x % LA;
     for (int a = threadIdx.x / LA; a < s; a += kSnThreads / LA) {
       const int q = q0 + a;
-      double acc = 0.0;
-      for (int64_t i = Ep[q] + lane; i < Ep[q + 1]; i += LA) acc += Ex[i] * b[Ej[i]];
+      double acc = gather_dot(Ep[q] + lane, Ep[q + 1], LA, Ej, Ex, b);
 #pragma unroll
       for (int o = LA / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
