@@ -259,7 +259,19 @@ __device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, do
   __syncthreads();
   for (int t = mytid(); t < P.npair; t += NT) {
     double acc = 0.0;
-    for (int q = P.Tp[t]; q < P.Tp[t + 1]; q++) acc += s.rho[P.Tr[q]] * s.Av[P.Ta[q]] * s.Av[P.Tb[q]];
+    const int q1 = P.Tp[t + 1];
+    int q = P.Tp[t];
+    for (; q + 4 <= q1; q += 4) {  // the index triples of four terms first (global memory), then their LDS operands, then the sum in order
+      unsigned short tr[4], ta[4], tb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { tr[u] = P.Tr[q + u]; ta[u] = P.Ta[q + u]; tb[u] = P.Tb[q + u]; }
+      double r[4], a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { r[u] = s.rho[tr[u]]; a[u] = s.Av[ta[u]]; b[u] = s.Av[tb[u]]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc += r[u] * a[u] * b[u];
+    }
+    for (; q < q1; q++) acc += s.rho[P.Tr[q]] * s.Av[P.Ta[q]] * s.Av[P.Tb[q]];
     const int i = P.Ti[t], j = P.Tj[t];
     scratch[i + j * ld] = acc;
     scratch[j + i * ld] = acc;
