@@ -313,6 +313,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 16, 17 rows of the local blocks (n, m)          18 compact mode (CSR column / value arrays released) 0 / 1
  * 19 levels of the supernode graph when the triangular solves run by supernodes (0: by the level schedule)
  * 20 high-water mark of the device bytes allocated by this process (a sharded setup stays near 1/ranks of the whole)
+ * 21 solves that were run again from a cold start because a wait inside the one-launch supernodal solve timed out
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
@@ -361,6 +362,12 @@ c_int osqp_amd_setup_generated_sharded(OSQPWorkspace **workp, c_int kind, c_int 
  * termination test inside, residuals refreshed at the end); used by bench.py
  * to time K steps.  Returns 0 on success. */
 c_int osqp_amd_iterate(OSQPWorkspace *work, c_int iters);
+
+/* The current iterate in the caller's units (x = D x_scaled, y = E y_scaled / c -- what osqp_solve would store
+ * [REF src/interface.jl:176-186]) copied to host buffers of n and m doubles, without touching the iterate: what the
+ * headline-size parity record compares after osqp_amd_iterate on the engine and on the oracle.  Either pointer
+ * may be NULL. */
+c_int osqp_amd_get_iterate(OSQPWorkspace *work, c_float *x_out, c_float *y_out);
 
 /* Element-wise kernel parity hooks (tests only): run one device kernel on
  * host-provided vectors and copy the result back.

@@ -1004,8 +1004,8 @@ c_int osqp_warm_start_y(OSQPWorkspace *w, const c_float *y) {
 c_int osqp_update_max_iter(OSQPWorkspace *w, c_int v) { if (!w) return 7; if (v <= 0) return 1; w->settings->max_iter = v; return 0; }
 c_int osqp_update_eps_abs(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_abs = v; return 0; }
 c_int osqp_update_eps_rel(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_rel = v; return 0; }
-c_int osqp_update_eps_prim_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->eps_prim_inf = v; return 0; }
-c_int osqp_update_eps_dual_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->eps_dual_inf = v; return 0; }
+c_int osqp_update_eps_prim_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_prim_inf = v; return 0; }
+c_int osqp_update_eps_dual_inf(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v < 0.) return 1; w->settings->eps_dual_inf = v; return 0; }
 c_int osqp_update_alpha(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0. || v >= 2.) return 1; w->settings->alpha = v; return 0; }
 c_int osqp_update_delta(OSQPWorkspace *w, c_float v) { if (!w) return 7; if (v <= 0.) return 1; w->settings->delta = v; return 0; }
 c_int osqp_update_polish(OSQPWorkspace *w, c_int v) { if (!w) return 7; if (v != 0 && v != 1) return 1; w->settings->polish = v; w->info->polish_time = 0.0; return 0; }
@@ -1048,6 +1048,16 @@ c_int osqp_amd_iterate(OSQPWorkspace *w, c_int iters) {
     if (w->settings->check_termination && ((it + 1) % w->settings->check_termination == 0)) update_info(w, it + 1, 0, 0);
   }
   update_info(w, iters, 1, 0);
+  return 0;
+}
+
+/* the current iterate in the caller's units (what store_solution would write), the iterate untouched */
+c_int osqp_amd_get_iterate(OSQPWorkspace *w, c_float *x_out, c_float *y_out) {
+  c_int n, m, i;
+  if (!w) return 7;
+  n = w->data->n; m = w->data->m;
+  if (x_out) for (i = 0; i < n; i++) x_out[i] = w->settings->scaling ? w->x[i] * SCAL(w)->D[i] : w->x[i];
+  if (y_out) for (i = 0; i < m; i++) y_out[i] = w->settings->scaling ? w->y[i] * (SCAL(w)->E[i] * SCAL(w)->cinv) : w->y[i];
   return 0;
 }
 

@@ -406,16 +406,20 @@ c_int osqp_update_rho(OSQPWorkspace *w, c_float rho_new) {
     if (!w) return 7;                                     \
     if (!(cond)) return 1;                                \
     OQ_ON_DEVICE(w);                                      \
-    E(w)->st.field = v;                                   \
-    E(w)->settings_changed();                             \
-    w->settings->field = v;                               \
-    return 0;                                             \
+    return guarded([&]() {                                \
+      E(w)->st.field = v;                                 \
+      E(w)->settings_changed();                           \
+      w->settings->field = v;                             \
+      return 0;                                           \
+    });                                                   \
   }
 OQ_SETTING(osqp_update_max_iter, c_int, max_iter, v > 0)
 OQ_SETTING(osqp_update_eps_abs, c_float, eps_abs, v >= 0.)
 OQ_SETTING(osqp_update_eps_rel, c_float, eps_rel, v >= 0.)
-OQ_SETTING(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v > 0.)  // as setup validation (validate_settings)
-OQ_SETTING(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v > 0.)
+// libosqp's update functions reject only negative values here (the > 0 rule is the setup validation's): a caller's
+// update_settings!(eps_prim_inf = 0) [REF src/interface.jl:506-530] stays legal
+OQ_SETTING(osqp_update_eps_prim_inf, c_float, eps_prim_inf, v >= 0.)
+OQ_SETTING(osqp_update_eps_dual_inf, c_float, eps_dual_inf, v >= 0.)
 OQ_SETTING(osqp_update_alpha, c_float, alpha, v > 0. && v < 2.)
 OQ_SETTING(osqp_update_delta, c_float, delta, v > 0.)
 OQ_SETTING(osqp_update_polish_refine_iter, c_int, polish_refine_iter, v >= 0)
@@ -429,10 +433,12 @@ c_int osqp_update_polish(OSQPWorkspace *w, c_int v) {
   if (!w) return 7;
   OQ_ON_DEVICE(w);
   if (v != 0 && v != 1) return 1;
-  E(w)->st.polish = v;
-  w->settings->polish = v;
-  w->info->polish_time = 0.0;
-  return 0;
+  return guarded([&]() {
+    E(w)->st.polish = v;
+    w->settings->polish = v;
+    w->info->polish_time = 0.0;
+    return 0;
+  });
 }
 
 c_int osqp_warm_start(OSQPWorkspace *w, const c_float *x, const c_float *y) {
@@ -477,6 +483,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[18] = e.compact ? 1.0 : 0.0;
   v[19] = e.lin->supernode_levels();
   v[20] = (c_float)g_device_peak;
+  v[21] = (c_float)e.tree_restarts;
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;
@@ -526,6 +533,12 @@ c_int osqp_amd_iterate(OSQPWorkspace *w, c_int iters) {
   if (!w) return 7;
   OQ_ON_DEVICE(w);
   return guarded([&]() { return E(w)->iterate(iters); });
+}
+
+c_int osqp_amd_get_iterate(OSQPWorkspace *w, c_float *x_out, c_float *y_out) {
+  if (!w) return 7;
+  OQ_ON_DEVICE(w);
+  return guarded([&]() { E(w)->get_iterate(x_out, y_out); return 0; });
 }
 
 c_int osqp_amd_apply(OSQPWorkspace *w, c_int op, const c_float *in, c_float *out) {

@@ -1188,7 +1188,8 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
                            const OSQPSettings *settings, c_float *x_out, c_float *y_out, OSQPInfo *info_out, c_int device) {
   try {
     // the same checks osqp_setup makes [REF src/interface.jl:47-100 + the C side's validate_data / validate_settings]
-    if (count <= 0 || n <= 0 || m < 0 || !Pp || !Pi || !Ap || !Ai || !q_all || (m > 0 && (!l_all || !u_all))) { set_last_error("invalid batch data"); return 1; }
+    if (count <= 0 || n <= 0 || m < 0 || !Pp || !Pi || !Ap || !Ai || !q_all || (m > 0 && (!l_all || !u_all)) || !settings || !x_out ||
+        !info_out || (m > 0 && !y_out)) { set_last_error("invalid batch data"); return 1; }
     if (validate_settings(settings)) { set_last_error("invalid settings"); return 2; }
     if (n > 128 || m > 65535 || Pp[0] != 0 || Ap[0] != 0 || Pp[n] < 0 || Ap[n] < 0 || Pp[n] > 65535 || Ap[n] > 65535) {
       set_last_error("the batched path supports n <= 128 and fewer than 65536 rows / non-zeros"); return 1;
@@ -1197,7 +1198,12 @@ c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const
       if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) { set_last_error("column pointers must not decrease"); return 1; }
       for (c_int k = Pp[j]; k < Pp[j + 1]; k++) if (Pi[k] < 0 || Pi[k] > j) { set_last_error("P must be upper triangular with row indices in range"); return 1; }
       for (c_int k = Ap[j]; k < Ap[j + 1]; k++) if (Ai[k] < 0 || Ai[k] >= m) { set_last_error("row index of A out of range"); return 1; }
+      // the term lists of A' rho A are built by merging sorted columns (DevicePattern::build): unsorted or repeated rows
+      // would silently drop terms
+      for (c_int k = Ap[j] + 1; k < Ap[j + 1]; k++) if (Ai[k] <= Ai[k - 1]) { set_last_error("the rows of every column of A must be sorted and unique"); return 1; }
+      for (c_int k = Pp[j] + 1; k < Pp[j + 1]; k++) if (Pi[k] <= Pi[k - 1]) { set_last_error("the rows of every column of P must be sorted and unique"); return 1; }
     }
+    if ((Pp[n] > 0 && !Px_all) || (Ap[n] > 0 && !Ax_all)) { set_last_error("invalid batch data"); return 1; }
     for (c_int i = 0; i < count * m; i++) if (l_all[i] > u_all[i]) { set_last_error("lower bound greater than upper bound"); return 1; }
     DeviceScope on_device((int)device);
     hipStream_t s = nullptr;

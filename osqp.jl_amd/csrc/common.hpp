@@ -19,6 +19,11 @@ struct Error : std::runtime_error {
   int code;
   Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
+// a wait inside k_sn_tree timed out (direct.hip): the iterations since the last residual evaluation cannot be trusted.
+// Engine::solve catches it, cold-starts and runs the solve again on the per-level form of the triangular solves.
+struct TreeFault : Error {
+  TreeFault() : Error(6, "internal: a supernode of the triangular solve waited 200 ms for its children (the solves fall back to one launch per level)") {}
+};
 void set_last_error(const std::string &m);
 
 #define HIP_CHECK(expr)                                                                             \

@@ -739,8 +739,12 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
 // supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
 // their resting values when the launch ends, so a captured graph can replay it.  Workgroups are dispatched in
 // blockIdx order per XCD and a workgroup only waits on lower blockIdx values, so the lowest unfinished one is always
-// resident and never waits on an unscheduled one; a wait that still exceeds 200 ms sets *fault (mapped host memory)
-// and carries on, so a broken assumption is a reported error, not a hang.
+// resident and never waits on an unscheduled one -- and the launch is only used when ALL its workgroups fit the device
+// at once (LdlFactor: occupancy x CUs >= grid), so on a device of its own nothing can wait on an unscheduled workgroup
+// whatever the dispatch order; a wait that still exceeds 200 ms (a shared, pre-empted device) sets *fault (mapped host
+// memory) and carries on: the host sees the flag at the next residual evaluation -- tested again once the read-back has
+// drained the stream -- and at the end of osqp_solve, switches the factor to one launch per level and runs the solve
+// again from a cold start (Engine::solve), so a broken assumption costs time, never a wrong or missing answer.
 constexpr int kSnTreeThreads = 1024;
 constexpr long long kSnWaitTicks = 20000000LL;  // 200 ms of the 100 MHz wall clock (a legitimate wait is microseconds; a workgroup
                                                  // pre-empted on a shared device can look like milliseconds)
@@ -973,6 +977,17 @@ struct LdlFactor {
     up32(sn_up, T.up); up32(sn_waits, T.waits); up32(sn_pending, T.waits);
     sn_ready.alloc(T.count); sn_ready.zero(s);
     sn_tree = T.nlev > 2 && !(getenv("OSQP_AMD_SNODE_TREE") && atoi(getenv("OSQP_AMD_SNODE_TREE")) == 0);
+    if (sn_tree) {
+      // every workgroup of the launch must be resident at once: then a waiting workgroup can never keep the one it waits
+      // for off the device, whatever order the dispatcher picks (the blockIdx-order argument in the kernel's comment is
+      // the second line of defence, the 200 ms flag the third)
+      int per_cu_f = 0, per_cu_b = 0, cus = 0, dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true>, kSnTreeThreads, 0));
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false>, kSnTreeThreads, 0));
+      if ((long long)std::min(per_cu_f, per_cu_b) * cus < (long long)(T.count - T.lvl_ptr[1])) sn_tree = false;
+    }
     if (sn_tree) {
       HIP_CHECK(hipHostMalloc((void **)&sn_fault_host, sizeof(int), hipHostMallocMapped));
       *sn_fault_host = 0;
@@ -1335,8 +1350,8 @@ struct Direct : Linsys {
                 e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     return 0;
   }
-  // a supernode waited 200 ms for its children: an internal error for the solve in progress; the factor goes back to one
-  // launch per level (no waiting inside a kernel) for everything after it
+  // a supernode waited 200 ms for its children: the factor goes back to one launch per level (no waiting inside a
+  // kernel); 6 tells the engine that the iterations since the last test cannot be trusted (TreeFault: the solve restarts)
   int flush() override {
     if (!F->faulted()) return 0;
     *F->sn_fault_host = 0;

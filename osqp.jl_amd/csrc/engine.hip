@@ -697,7 +697,7 @@ void Engine::run_chunk() {
 // Ax, Px, A'y at the current iterate and the 16 norms / sums of Slot order into h_slots
 void Engine::residual_evaluation() {
   if (int rc = lin->flush()) {  // the iterate must be the one the host believes it is
-    if (rc == 6) throw Error(6, "internal: a supernode of the triangular solve waited 200 ms for its children (the solves fall back to one launch per level)");
+    if (rc == 6) throw TreeFault();
     deferred_error = rc;
   }
   const double *xg = full_n(x.get());
@@ -707,6 +707,9 @@ void Engine::residual_evaluation() {
   residual_norms(n, m, x.get(), z.get(), Ax.get(), Px_.get(), Aty.get(), q.get(), Dinv.get(), Einv.get(), slots.get(),
                  partials.get(), stream);
   fetch_slots(0, 16, (1u << S_XPX) | (1u << S_QX));
+  // the read-back has drained the stream: a wait that timed out in the iterations that were still in flight at the
+  // test above shows now, before anything is decided from these numbers
+  if (lin->flush() == 6) throw TreeFault();
 }
 
 void Engine::update_info(long long iter, bool compute_objective) {
@@ -856,6 +859,17 @@ void Engine::download_full(const double *vn, const double *vm, double *hn, doubl
   sync();
 }
 
+// the current iterate, unscaled, to caller buffers (osqp_amd_get_iterate; the iterate itself is not touched)
+void Engine::get_iterate(double *hx, double *hy) {
+  if (st.scaling) {
+    if (hx) vec_ew_prod(tn.get(), x.get(), D.get(), n, stream);
+    if (hy) { vec_ew_prod(tm.get(), y.get(), E.get(), m, stream); vec_scale(tm.get(), cinv, m, stream); }
+    download_full(hx ? tn.get() : nullptr, hy ? tm.get() : nullptr, hx, hy);
+  } else {
+    download_full(hx ? x.get() : nullptr, hy ? y.get() : nullptr, hx, hy);
+  }
+}
+
 // A.5: host mirrors refreshed here (the Julia side reads solution->x/y, delta_x, delta_y as host pointers)
 void Engine::store_solution() {
   OSQPInfo *info = ws->info;
@@ -893,7 +907,24 @@ void Engine::store_solution() {
 // --------------------------------------------------------------------------
 // osqp_solve [REF src/interface.jl:171]
 // --------------------------------------------------------------------------
+// A timed-out wait inside k_sn_tree (direct back-end, supernodal solves in one launch per direction) leaves an iterate
+// that cannot be trusted: the factor has gone back to one launch per level (Direct::flush), the solve starts again from
+// a cold start.  A second fault cannot happen (nothing waits inside a kernel any more); if it does it is error 6.
 int Engine::solve() {
+  for (int attempt = 0;; attempt++) {
+    try {
+      int rc = solve_attempt(attempt > 0);
+      if (lin->flush() == 6) throw TreeFault();  // store_solution has synchronised: nothing is in flight
+      return rc;
+    } catch (const TreeFault &) {
+      if (attempt >= 1) throw;
+      tree_restarts++;
+      deferred_error = 0;
+    }
+  }
+}
+
+int Engine::solve_attempt(bool restarted) {
   OSQPInfo *info = ws->info;
   long long iter, max_iter = st.max_iter;
   bool can_check_termination = false, can_print = st.verbose != 0;
@@ -901,9 +932,10 @@ int Engine::solve() {
   double temp_run_time;
   if (clear_update_time) info->update_time = 0.0;
   rho_update_from_solve = true;
-  tic();
+  if (!restarted) tic();  // the time of the abandoned attempt counts
   if (st.verbose && rank() == 0) printf("iter   objective    pri res    dua res    rho\n");
-  if (!st.warm_start) cold_start();
+  if (!st.warm_start || restarted) cold_start();
+  if (restarted) update_status(info, OSQP_UNSOLVED);
   lin->set_guess(x.get());
   have_res = false; have_ref = false; lambda = lambda0; have_seed = false;
   if (lin->kind() == 2) {  // seed the PCG tolerance rule with the residuals of the start point (as oracle/osqp_oracle.c)

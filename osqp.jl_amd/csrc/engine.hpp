@@ -162,6 +162,8 @@ struct Engine {
   void settings_changed();
   void drop_chunk_graph();
   int kkt_solve();
+  int solve_attempt(bool restarted);
+  long long tree_restarts = 0;  // solves run again after a TreeFault
   void residual_evaluation();
   void update_info(long long iter, bool compute_objective);
   double obj_from_slots_fresh();
@@ -175,6 +177,7 @@ struct Engine {
   int adapt_rho();
   int update_rho(double rho_new);
   void store_solution();
+  void get_iterate(double *hx, double *hy);
   void download_full(const double *vn, const double *vm, double *hn, double *hm);
   double obj_from_slots() const;
 

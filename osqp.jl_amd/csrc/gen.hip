@@ -173,6 +173,7 @@ struct GeneratedColumns : ColumnSource {
       S.alloc((size_t)n); S.zero(s);
       OQ_LAUNCH(k_gen_U_cols, dim3(blocks_for(((long long)n + 1) * 64)), dim3(kBlock), 0, s, 0LL, (long long)n, kp, seed,
                 (int64_t *)nullptr, (int *)nullptr, (double *)nullptr, S.get());
+      HIP_CHECK(hipStreamSynchronize(s));  // S is read by launches on the engine's (non-blocking) stream later on
     } else if (kind == OSQP_AMD_GEN_LASSO) {
       m = 2 * n; nnzP = n; nnzA = 2LL * n;
     } else throw Error(1, "unknown problem kind for the device generator");

@@ -182,6 +182,7 @@ EXT_SYMBOLS = {
     "osqp_amd_get_stats": (c_int, [Workspace_p, c_float_p, c_int]),
     "osqp_amd_time_kernel": (c_float, [Workspace_p, c_int, c_int]),
     "osqp_amd_iterate": (c_int, [Workspace_p, c_int]),
+    "osqp_amd_get_iterate": (c_int, [Workspace_p, c_float_p, c_float_p]),
     "osqp_amd_apply": (c_int, [Workspace_p, c_int, c_float_p, c_float_p]),
     "osqp_amd_batch_solve": (
         c_int,

@@ -123,7 +123,7 @@ int main(int argc, char **argv) {
   check(fabs(rd_f(hop(work, 208), 56) - 100.0) < 1e-5, "G2 obj_val [REF test/basic.jl:75]");
 
   /* --- settings entry points: the validation the reference relies on [REF src/interface.jl:515-567] --- */
-  check(update_epi(work, 0.0) != 0 && update_epi(work, -1.0) != 0 && update_epi(work, 1e-4) == 0, "eps_prim_inf must be positive");
+  check(update_epi(work, -1.0) != 0 && update_epi(work, 0.0) == 0 && update_epi(work, 1e-4) == 0, "eps_prim_inf: negative values refused on update (zero only at setup)");
   check(update_alpha(work, 2.0) != 0 && update_alpha(work, 1.6) == 0, "alpha in (0, 2)");
 
   /* --- primal infeasible variant: rows 0 and 1 say x >= 0, so 2 x1 + 5 x2 <= -100 (row 3) cannot hold; the

@@ -80,8 +80,13 @@ def test_pcg_tolerance_rule_does_not_bend_the_answer(product_lib, oracle_lib, mo
 
 
 def test_mpc_batch_all_4096_instances(product_lib, oracle_lib):
-    """Config 5 at full size on one device: every instance Solved; 64 instances spread over the range compared with the
-    oracle one by one; every instance's primal residual re-evaluated on the host."""
+    """Config 5 at full size on one device, bench.py's settings (eps = 1e-4 on both sides):
+      * every one of the 4096 instances Solved, and OSQP's stopping criteria (primal and dual residual on unscaled,
+        host-regenerated data) plus the dual sign convention re-evaluated on the host for EVERY instance;
+      * 256 instances spread over the range (every 16th) compared with the oracle one by one at the tolerance of the
+        other full-size configurations: x, y within 2e-4 * scale, termination at most one check (25 iterations) apart.
+        The kernel solves the reduced system (P + sigma I + A' rho A) x~ = b with an explicit inverse where the oracle
+        factorises the quasi-definite KKT matrix: same iteration in exact arithmetic, rounding apart."""
     total, seed = 4096, 1
     opts = dict(bench.SETTINGS)
     solver = batch.device_mpc_solver(product_lib, 0, **opts)
@@ -89,20 +94,33 @@ def test_mpc_batch_all_4096_instances(product_lib, oracle_lib):
     x, y, info = x.cpu().numpy(), y.cpu().numpy(), info.cpu().numpy()
     assert np.all(info[:, 1] == 1), np.unique(info[:, 1], return_counts=True)
     assert np.all(np.isfinite(x)) and np.all(np.isfinite(y))
-    for i in range(0, total, 64):
+    eps = 1e-4
+    worst = dict(pri=0.0, dua=0.0, dx=0.0, dy=0.0, dit=0)
+    for i in range(total):
         d = oracle_lib.oracle_generate(2, 100, i, seed)
         P, q, A, l, u = _data_to_scipy(d.contents)
         oracle_lib.oracle_data_free(d)
+        Pfull = P + sp.triu(P, 1).T
+        Ax, Px, Aty = A @ x[i], Pfull @ x[i], A.T @ y[i]
+        z = np.clip(Ax, l, u)
+        pri, dua = np.max(np.abs(Ax - z)), np.max(np.abs(Px + q + Aty))
+        eps_pri = eps + eps * max(np.max(np.abs(Ax)), np.max(np.abs(z)))
+        eps_dua = eps + eps * max(np.max(np.abs(Px)), np.max(np.abs(Aty)), np.max(np.abs(q)))
+        assert pri <= 2 * eps_pri and dua <= 2 * eps_dua, (i, pri, eps_pri, dua, eps_dua)
+        worst["pri"], worst["dua"] = max(worst["pri"], pri / eps_pri), max(worst["dua"], dua / eps_dua)
+        tol = 1e-3 * max(1.0, np.max(np.abs(y[i])))
+        assert np.all((y[i] > -tol) | (Ax - l < 20 * eps_pri)) and np.all((y[i] < tol) | (u - Ax < 20 * eps_pri)), i
+        if i % 16:
+            continue
         m = oq.Model(oracle_lib)
         oq.setup(m, P=P, q=q, A=A, l=l, u=u, **opts)
         r = oq.solve(m)
+        oq.clean(m)
         assert r.info.status == "Solved"
-        assert abs(r.info.iter - info[i, 0]) <= 50, (i, r.info.iter, info[i, 0])
-        assert np.max(np.abs(x[i] - r.x)) <= 2e-3 * max(1.0, np.max(np.abs(r.x))), i   # eps = 1e-4 on both sides
-        assert np.max(np.abs(y[i] - r.y)) <= 2e-3 * max(1.0, np.max(np.abs(r.y))), i
-        Ax = A @ x[i]
-        pri = np.max(np.abs(Ax - np.clip(Ax, l, u)))
-        assert pri <= 2 * (1e-4 + 1e-4 * np.max(np.abs(Ax)))
-        Pfull = P + sp.triu(P, 1).T
-        dua = np.max(np.abs(Pfull @ x[i] + q + A.T @ y[i]))
-        assert dua <= 2 * (1e-4 + 1e-4 * max(np.max(np.abs(Pfull @ x[i])), np.max(np.abs(A.T @ y[i])), np.max(np.abs(q))))
+        dit = abs(r.info.iter - int(info[i, 0]))
+        dx = np.max(np.abs(x[i] - r.x)) / max(1.0, np.max(np.abs(r.x)))
+        dy = np.max(np.abs(y[i] - r.y)) / max(1.0, np.max(np.abs(r.y)))
+        assert dit <= 25, (i, r.info.iter, info[i, 0])
+        assert dx <= 2e-4 and dy <= 2e-4, (i, dx, dy, r.info.iter, info[i, 0])
+        worst["dx"], worst["dy"], worst["dit"] = max(worst["dx"], dx), max(worst["dy"], dy), max(worst["dit"], dit)
+    print("mpc-batch parity, worst over the batch:", worst)

@@ -90,10 +90,12 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_a_timed_out_wait_in_the_tree_kernels_is_an_error_and_a_fallback(product_lib, oracle_lib, monkeypatch):
+def test_a_timed_out_wait_in_the_tree_kernels_restarts_the_solve_on_the_level_path(product_lib, oracle_lib, monkeypatch):
     """k_sn_tree waits inside a kernel (csrc/direct.hip); a wait that times out raises a flag in mapped host memory.
-    The host side of that: the solve in progress fails with error 6, the factor goes back to one launch per level,
-    and the next solve on the same workspace is the oracle's again.  (The flag is injected: OSQP_AMD_SNODE_FAULT_TEST.)"""
+    The host side of that: the factor goes back to one launch per level and the solve in progress starts again from a
+    cold start (the iterations run since the last test cannot be trusted) -- the caller gets the oracle's answer, not an
+    error and not a damaged iterate; the next solve on the same workspace is the oracle's again.  (The flag is injected at
+    the first health check: OSQP_AMD_SNODE_FAULT_TEST.)"""
     prob = qp_zoo.control(nx=8, nu=4, T=400)
     opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
     mo = oq.Model(oracle_lib)
@@ -104,14 +106,16 @@ def test_a_timed_out_wait_in_the_tree_kernels_is_an_error_and_a_fallback(product
     oq.setup(m, linsys_solver="direct", **opts, **prob)
     monkeypatch.delenv("OSQP_AMD_SNODE_FAULT_TEST")
     assert oq.stats(m)[19] > 2
-    # [REF src/interface.jl:170] ignores osqp_solve's return value, and so does the mirror: the failure shows as a status
-    rc = product_lib.osqp_solve(m.workspace)
-    assert rc == 6 and b"supernode" in product_lib.osqp_amd_last_error()
-    assert oq.stats(m)[19] > 2  # still a supernodal factor, now one launch per level
-    rp = oq.solve(m)  # continues from the iterate (and rho) the failed solve left: same answer, not the same path
-    assert rp.info.status == ro.info.status == "Solved"
-    assert np.max(np.abs(ro.x - rp.x)) <= 1e-4 * max(1.0, np.max(np.abs(ro.x)))
-    assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-5 * max(1.0, abs(ro.info.obj_val))
+    for k in range(2):  # the solve that meets the fault and restarts, then a fresh one on the same workspace
+        rp = oq.solve(m)
+        assert rp.info.status == ro.info.status == "Solved"
+        assert np.max(np.abs(ro.x - rp.x)) <= 1e-4 * max(1.0, np.max(np.abs(ro.x)))
+        assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-5 * max(1.0, abs(ro.info.obj_val))
+        if k == 0:
+            assert abs(rp.info.iter - ro.info.iter) <= 25  # the restart is the oracle's cold-start solve
+        assert oq.stats(m)[19] > 2   # still a supernodal factor, now one launch per level
+        assert oq.stats(m)[21] == 1  # one restart, none after it
+    assert oq.stats(m)[21] == 1
     oq.clean(m); oq.clean(mo)
 
 
