@@ -57,7 +57,32 @@ SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25,
                 polish=False, max_iter=4000)
 
 BATCH_TOTAL = 4096
-CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r02_cpu_rand1e6.json")}
+CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r03_cpu_rand1e6.json")}
+CPU_RECORD_WINDOW = (5, 20)  # W, K of the committed CPU record (the driver's protocol)
+
+
+def _sha16(paths):
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def oracle_sha16():
+    """The CPU oracle's sources: a CPU record measured with other sources is stale."""
+    d = os.path.join(ROOT, "oracle")
+    return _sha16([os.path.join(d, f) for f in os.listdir(d) if f.endswith((".c", ".h")) or f == "Makefile"])
+
+
+def protocol_sha16(workload, warm, iters):
+    """What a CPU record depends on besides the oracle sources: the workload tuple, the settings, the window."""
+    import hashlib
+
+    blob = json.dumps({"workload": WORKLOADS.get(workload, workload), "settings": SETTINGS, "warm": warm, "iters": iters}, sort_keys=True)
+    return hashlib.sha256(blob.encode()).hexdigest()[:16]
 
 
 def free_port():
@@ -76,6 +101,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=os.environ.get("OSQP_AMD_BENCH_WORKLOAD", "rand-1e6"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="re-measure the CPU oracle on rand-1e6 itself at the driver's window (W = 5, K = 20) in a child process and rewrite "
+                         "the committed record (about 10 minutes and 46 GiB of host memory)")
     ap.add_argument("--mode", choices=["replicas", "sharded", "batch"], default=os.environ.get("OSQP_AMD_BENCH_MODE", "replicas"),
                     help="which multi-GPU leg is the headline value (all are measured when N > 1)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the row-sharded leg")
@@ -293,7 +321,9 @@ def replica_bench(ctx):
             "time_to_eps_s": round(solve_s, 4), "iters_to_eps": int(res.info.iter), "status": res.info.status,
             "cg_iters_to_eps": int(st2[6] - st1[6]),
             "pri_res": res.info.pri_res, "dua_res": res.info.dua_res, "rho_updates": int(res.info.rho_updates),
-            "setup_s": round(setup_s, 3), "device_gb": round(st[9] / 1e9, 2),
+            "setup_s": round(setup_s, 3), "device_gb": round(st[9] / 1e9, 2), "device_peak_gb": round(st[20] / 1e9, 2),
+            # the reference reports run_time = setup + solve [REF src/types.jl:92-96]: the same solve priced on that clock
+            "run_time_s": round(setup_s + solve_s, 4), "iterations_per_s_incl_setup": round(res.info.iter / (setup_s + solve_s), 3),
             "per_rank": summaries, "rccl_ranks_seen": rccl_ranks_seen, "launch": "self-spawned" if os.environ.get("OSQP_AMD_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
             "roofline": roofline, "cpu_baseline": None,
         }
@@ -311,6 +341,7 @@ def replica_bench(ctx):
 
     if rank == 0 and not args.no_cpu and world == 1:  # the CPU leg belongs to the 1-GPU line only
         out["cpu_baseline"] = cpu_leg(oq, args)
+        out["cpu_baseline"]["all_cores_bandwidth_bound"] = all_cores_bound(out["roofline"]["step"]["algorithmic_bytes_per_step"])
 
     if world > 1:
         legs = []
@@ -667,30 +698,85 @@ def batch_cpu_leg(oq, args):
 # ----------------------------------------------------------------------------------------------------------------
 def cpu_leg(oq, args):
     """CPU oracle (oracle/, a port of the published algorithm; libosqp itself is not available in this image), 1 thread.
-    Workloads the bounded leg can hold are timed live.  rand-1e6 (2.5e9 stored entries: minutes of setup, ~1 minute per
-    ADMM iteration) was timed ONCE on the GPU box's host by tools/cpu_rand1e6.py on the workload itself; that record
-    (profiles/r02_cpu_rand1e6.json) is `value`, and the live sample of the same family at n = 1e5 sits beside it under
-    `live_sample` -- no scaled estimates."""
+    Workloads the bounded leg can hold are timed live.  rand-1e6 (2.5e9 stored entries: 90 s of setup, ~16 s per ADMM
+    iteration) is measured on the workload itself by tools/cpu_rand1e6.py at the driver's window; its record
+    (profiles/r03_cpu_rand1e6.json) is `value`.  `--cpu-full` re-measures it in this run (a child process, ~10 minutes);
+    otherwise the committed record is read and checked against hashes of the oracle sources and of the protocol
+    (workload, settings, window) -- `"stale": true` when either no longer matches.  Beside it: the same family at
+    n = 1e5 timed live (`live_sample`), and a context figure `all_cores_bandwidth_bound` -- the rate a perfectly
+    threaded host implementation would be capped at by the host's measured memory bandwidth.  No scaled estimates."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     name = args.workload
     if name not in CPU_RECORDS:
         return cpu_live(oq, args, name)
     out = {"value": None, "unit": "iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port", "config": name, "live": False}
+    W, K = CPU_RECORD_WINDOW
+    if getattr(args, "cpu_full", False):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_rand1e6.py"), "--phases", "cpu", "--warm", str(W), "--iters", str(K),
+               "--out", os.path.join(ROOT, "gpurun_out", "cpu_full_run.json"), "--cpu-record", CPU_RECORDS[name]]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        out["live"] = p.returncode == 0
+        if p.returncode != 0:
+            out["cpu_full_error"] = (p.stderr.decode(errors="replace").strip().splitlines() or ["?"])[-1][:200]
     try:
         rec = json.load(open(CPU_RECORDS[name]))
         out["value"] = rec.get("value")
         if rec.get("value") is None:
             out["reason"] = rec.get("reason", "not run")
         else:
-            out["sample"] = (f"{name} itself: {rec['iters']} ADMM iterations of the CPU oracle (PCG back-end, 1 thread of {rec.get('host_cores')} cores, "
-                             f"{rec.get('cpu_model', 'host CPU')}) in {rec['seconds']} s after a {rec['setup_s']} s setup, "
-                             f"{rec['cg_iters_per_admm_iter']} CG iterations per ADMM iteration, peak RSS {rec['peak_rss_gib']} GiB; measured once by "
-                             f"tools/cpu_rand1e6.py on the GPU box's host, record committed as profiles/{os.path.basename(CPU_RECORDS[name])}")
+            out["sample"] = (f"{name} itself: K = {rec['iters']} ADMM iterations of the CPU oracle after W = {rec.get('warm')} (PCG back-end, 1 thread of "
+                             f"{rec.get('host_cores')} cores, {rec.get('cpu_model', 'host CPU')}) in {rec['seconds']} s after a {rec['setup_s']} s setup, "
+                             f"{rec['cg_iters_per_admm_iter']} CG iterations per ADMM iteration, peak RSS {rec['peak_rss_gib']} GiB; measured by "
+                             f"tools/cpu_rand1e6.py on the GPU box's host ({'in this run' if out['live'] else 'record committed'} as "
+                             f"profiles/{os.path.basename(CPU_RECORDS[name])})")
             out["cg_iters_per_admm_iter"] = rec["cg_iters_per_admm_iter"]
+            now = {"oracle_sha16": oracle_sha16(), "protocol_sha16": protocol_sha16(name, W, K)}
+            out["stale"] = any(rec.get(k) != v for k, v in now.items())
+            out["record_hashes"] = {k: rec.get(k) for k in now}
+            if out["stale"]:
+                out["current_hashes"] = now
     except Exception as e:
         out["reason"] = "not run: no committed record (%s)" % str(e)[:100]
     out["live_sample"] = cpu_live(oq, args, "rand-1e5")
     return out
+
+
+def _stream_worker(task):
+    """One host core: a = b + c over arrays far beyond the caches, `reps` times; returns (bytes moved, seconds)."""
+    n, reps = task
+    import numpy as np
+
+    b, c = np.ones(n), np.ones(n)
+    a = np.empty(n)
+    np.add(b, c, out=a)  # touch
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        np.add(b, c, out=a)
+    return 24.0 * n * reps, time.perf_counter() - t0
+
+
+def host_stream_gbs(cores=None, n=8_000_000, reps=12):
+    """STREAM-style add (2 reads + 1 write, 24 B per element, write-allocate not counted) on every host core at once, one
+    process per core: the memory bandwidth a perfectly threaded host implementation could draw on."""
+    import multiprocessing as mp
+
+    cores = cores or os.cpu_count() or 1
+    try:
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_stream_worker, [(n, reps)] * cores)
+        return sum(r[0] for r in res) / max(r[1] for r in res) / 1e9, cores
+    except Exception:
+        return None, cores
+
+
+def all_cores_bound(step_bytes):
+    """Context, not a measurement of any implementation: host memory bandwidth / SURVEY.md 8d bytes per ADMM iteration."""
+    gbs, cores = host_stream_gbs()
+    if not gbs:
+        return None
+    return {"host_stream_GBs": round(gbs, 1), "cores": cores, "iterations_per_s": round(gbs * 1e9 / step_bytes, 3),
+            "note": "an upper bound for ANY host implementation of this step (bandwidth-perfect, all cores): measured STREAM-add bandwidth of "
+                    "the host / algorithmic bytes of one ADMM iteration at the measured CG count; nobody's code runs at it"}
 
 
 def cpu_live(oq, args, sample):

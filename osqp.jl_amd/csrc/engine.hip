@@ -354,6 +354,18 @@ __global__ __launch_bounds__(kBlock) void k_fill_int(int64_t n, int *p, int v) {
   if (k < n) p[k] = v;
 }
 
+// OSQP_AMD_SETUP_TRACE=1: wall time and device bytes after every phase of the setup, on stderr (experiments only; each
+// mark synchronises the stream)
+void Engine::setup_mark(const char *what) {
+  static const bool on = getenv("OSQP_AMD_SETUP_TRACE") && atoi(getenv("OSQP_AMD_SETUP_TRACE")) == 1;
+  if (!on) return;
+  sync();
+  const double t = toc();
+  fprintf(stderr, "[setup] %-28s %8.1f ms (+%7.1f)  device %6.2f GB  peak %6.2f GB\n", what, 1e3 * t, 1e3 * (t - mark_prev),
+          g_device_bytes / 1e9, g_device_peak / 1e9);
+  mark_prev = t;
+}
+
 void Engine::open_device() {
   HIP_CHECK(hipGetDevice(&device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -399,6 +411,19 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     invert_map(A.nnz, src.get(), 0, nnzA, A_k2pos.get(), stream);
     sync();
   }
+  setup_mark("A = transpose(A')");
+  // A problem that is certain to run the indirect back-end at a size where the workspace goes compact: every matrix gets
+  // its sliced-ELL copy and gives up its CSR arrays NOW, one after the other (Ruiz scaling then runs over the slices:
+  // scale_data), instead of all three copies living side by side until the end of the setup.
+  const bool early = pcg_certain() && !comm && compact_wanted(nnzA + std::max<int64_t>(0, 2 * nnzPtriu - n));
+  auto early_compact = [&](int which) {
+    DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
+    if (!early || M.rows == 0 || M.nnz == 0 || !panel_wanted(M)) return;
+    try { panel_build(M, stream); }
+    catch (const Error &) { M.panel = DevPanel(); return; }  // stays on its CSR arrays
+    compact_one(which);
+  };
+  if (m > 0) { early_compact(0); setup_mark("slices of A"); early_compact(1); setup_mark("slices of A'"); }
   // ---- full symmetric P from the upper triangle ----
   {
     DevBuf<int> colid((size_t)nnzPtriu), erow((size_t)(2 * nnzPtriu)), ecol((size_t)(2 * nnzPtriu)), src;
@@ -423,6 +448,9 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   // keep the patterns reachable for the direct back-end's symbolic phase
   Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
   Px.release();
+  setup_mark("full symmetric P");
+  early_compact(2);
+  setup_mark("slices of P");
 
   if (comm) shard_rows(q_, l_, u_);  // from here on n, m are the local sizes
   finish_setup(q_, l_, u_);
@@ -445,15 +473,20 @@ void Engine::finish_setup(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double>
   sync();
   for (int i = 0; i < m; i++) if (h_l[i] > h_u[i]) throw Error(1, "lower bound greater than upper bound");
 
+  setup_mark("vectors");
   if (st.scaling) scale_data();
+  setup_mark("Ruiz scaling");
   refresh_panels();
+  setup_mark("slices (late)");
   set_rho_vec();
   h_x.assign(ng, 0.0); h_y.assign(mg, 0.0); h_dx.assign(ng, 0.0); h_dy.assign(mg, 0.0);
   lambda0 = 0.015;
   if (const char *e = getenv("OSQP_AMD_PCG_LAMBDA")) lambda0 = atof(e);
   lambda = lambda0;
   select_linsys();
+  setup_mark("back-end");
   compact_matrices();
+  setup_mark("compaction (late)");
   sync();
 }
 
@@ -495,39 +528,49 @@ void Engine::fetch_host_pattern() {
 // --------------------------------------------------------------------------
 // K0: Ruiz equilibration + cost scaling
 // --------------------------------------------------------------------------
+// Every iteration touches each matrix ONCE: the scaling pass leaves the row norms of its result behind (what the next
+// iteration starts from), and the cost scaling of P is not a pass of its own -- the scalar waits in c_pend and goes in
+// first in the next pass, ((v c) D_lo) D_hi, which is bit for bit what scaling by c in place and by D afterwards gives;
+// the column norms of c P are fl(c * norm) (x -> fl(c x) is monotone, so it commutes with the maximum).  Same values
+// as the plain statement (oracle/osqp_oracle.c scale_data) with a third of its passes; on compact matrices the passes
+// run over the sliced-ELL copies with the column factors staged through LDS (panel.hip, k_sell_scale_norm).
 void Engine::scale_data() {
   c = 1.0;
   vec_set(D.get(), 1.0, n, stream); vec_set(E.get(), 1.0, m, stream);
   double *Dt = tn.get(), *Et = tm.get();
+  double *nP = tn2.get(), *nAc = Px_.get(), *nAr = tm2.get();  // column norms of P, of A, row norms of A as they stand
+  csr_row_absmax(Pf, nP, false, stream);             // ||P[:,j]||inf (P symmetric: row = column)
+  if (m > 0) {
+    csr_row_absmax(At, nAc, false, stream);          // ||A[:,j]||inf
+    csr_row_absmax(A, nAr, false, stream);           // ||A[i,:]||inf
+  }
+  double c_pend = 1.0;  // cost scaling not yet applied to the stored values of P
   for (int it = 0; it < st.scaling; it++) {
-    csr_row_absmax(Pf, Dt, false, stream);             // ||P[:,j]||inf (P symmetric: row = column)
-    if (m > 0) csr_row_absmax(At, Dt, true, stream);   // max with ||A[:,j]||inf
-    if (m > 0) csr_row_absmax(A, Et, false, stream);   // ||A[i,:]||inf
-    vec_limit_rsqrt(Dt, n, stream);
-    vec_limit_rsqrt(Et, m, stream);
+    vec_ruiz_factor(Dt, c_pend, nP, m > 0 ? nAc : nullptr, n, stream);
+    vec_ruiz_factor(Et, 1.0, nAr, nullptr, m, stream);
     const double *Dg = full_n(Dt);  // column scalings are indexed by global ids
-    csr_scale_rows_cols(Pf, Dt, Dg, 1, 1.0, stream, n0);
+    csr_scale_rows_cols(Pf, Dt, Dg, 1, 1.0, stream, n0, c_pend, nP);
     if (m > 0) {
-      csr_scale_rows_cols(A, Et, Dg, 0, 1.0, stream);
-      csr_scale_rows_cols(At, Dt, full_m(Et), 2, 1.0, stream);
+      csr_scale_rows_cols(A, Et, Dg, 0, 1.0, stream, 0, 1.0, nAr);
+      csr_scale_rows_cols(At, Dt, full_m(Et), 2, 1.0, stream, 0, 1.0, nAc);
     }
     vec_ew_prod(q.get(), q.get(), Dt, n, stream);
     vec_ew_prod(D.get(), D.get(), Dt, n, stream);
     vec_ew_prod(E.get(), E.get(), Et, m, stream);
-    // cost scaling
-    csr_row_absmax(Pf, Dt, false, stream);
+    // cost scaling: mean column norm of D P D (nP, just computed) and ||q||inf
     HIP_CHECK(hipMemsetAsync(slots.get() + S_T0, 0, sizeof(double) * 2, stream));
-    reduce_sum(Dt, n, partials.get(), slots.get() + S_T0, stream);
+    reduce_sum(nP, n, partials.get(), slots.get() + S_T0, stream);
     reduce_absmax(q.get(), nullptr, n, slots.get() + S_T1, stream);
     fetch_slots(S_T0, 2, 1u);
     double c_temp = h_slots[S_T0] / (double)ng;
     double qn = limit_scaling(h_slots[S_T1]);
     c_temp = limit_scaling(std::max(c_temp, qn));
     c_temp = 1.0 / c_temp;
-    csr_scale_rows_cols(Pf, nullptr, nullptr, 0, c_temp, stream);
+    c_pend = c_temp;
     vec_scale(q.get(), c_temp, n, stream);
     c *= c_temp;
   }
+  if (c_pend != 1.0) csr_scale_rows_cols(Pf, nullptr, nullptr, 0, c_pend, stream);
   cinv = 1.0 / c;
   vec_ew_recip(Dinv.get(), D.get(), n, stream);
   vec_ew_recip(Einv.get(), E.get(), m, stream);
@@ -561,32 +604,50 @@ __global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const in
   const int p = k2pos ? k2pos[i] : (int)i;
   out[i] = p >= 0 ? pos2slot[p] : 0xFFFFFFFFu;
 }
-void Engine::compact_matrices() {
-  const double limit = getenv("OSQP_AMD_COMPACT_NNZ") ? atof(getenv("OSQP_AMD_COMPACT_NNZ")) : 5e7;  // stored entries of A + P (< 0: never)
-  if (compact || !lin || lin->kind() != 2) return;
-  if (limit < 0.0 || (double)nnzA + (double)Pf.nnz < limit) return;
-  if (!panel_can_compact(Pf) || (m > 0 && !(panel_can_compact(A) && panel_can_compact(At)))) return;
-  const bool maps = A_k2pos.n > 0 || nnzA == 0;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
-  auto slots = [&](const DevCsr &M, DevBuf<uint32_t> &tmp) { tmp.alloc((size_t)M.nnz); panel_slot_of_pos(M, tmp.get(), stream); };
+// which: 0 = A, 1 = A', 2 = P.  One matrix at a time, so that a setup which knows it will run the indirect back-end can
+// release each CSR copy as soon as its sliced-ELL copy exists (setup_device: the high-water mark of the device memory stays
+// near the resident size instead of CSR + slices of all three), and so that a matrix whose slices cannot be built (mostly
+// padding) simply keeps its CSR arrays: every consumer looks at the matrix's own flag.
+void Engine::compact_one(int which) {
+  DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
+  if (M.compact || !panel_can_compact(M)) return;
   auto compose = [&](int64_t k, const int *k2pos, const DevBuf<uint32_t> &p2s, DevBuf<uint32_t> &out) {
     out.alloc((size_t)k);
     if (k > 0) OQ_LAUNCH(k_compose_slot_map, dim3(blocks_for(k)), dim3(kBlock), 0, stream, k, k2pos, p2s.get(), out.get());
   };
+  const bool maps = which == 2 ? (P_k2lo.n > 0 || nnzPtriu == 0) : (A_k2pos.n > 0 || nnzA == 0);  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
   if (maps) {
-    DevBuf<uint32_t> p2s;
-    if (m > 0) {
-      slots(A, p2s); compose(nnzA, A_k2pos.get(), p2s, A_k2slot); sync(); A_k2pos.release();
-      slots(At, p2s); compose(nnzA, nullptr, p2s, At_k2slot); sync();
-    }
-    slots(Pf, p2s);
-    compose(nnzPtriu, P_k2lo.get(), p2s, P_k2slot_lo); compose(nnzPtriu, P_k2up.get(), p2s, P_k2slot_up);
-    sync();
-    P_k2lo.release(); P_k2up.release();
+    DevBuf<uint32_t> p2s((size_t)M.nnz);
+    panel_slot_of_pos(M, p2s.get(), stream);
+    if (which == 0) { compose(nnzA, A_k2pos.get(), p2s, A_k2slot); sync(); }
+    else if (which == 1) { sync(); At_k2slot = std::move(p2s); }  // position k of A' is the caller's nnz index k
+    else { compose(nnzPtriu, P_k2lo.get(), p2s, P_k2slot_lo); compose(nnzPtriu, P_k2up.get(), p2s, P_k2slot_up); sync(); }
   }
-  Pi_keep.release();  // the direct back-end's symbolic phase is out of reach at this size
-  if (m > 0) { panel_compact(A); panel_compact(At); }
-  panel_compact(Pf);
+  if (which == 0) A_k2pos.release();
+  if (which == 2) { P_k2lo.release(); P_k2up.release(); Pi_keep.release(); }  // the direct back-end's symbolic phase is out of reach at this size
+  panel_compact(M);
   compact = true;
+}
+
+bool Engine::compact_wanted(int64_t stored) const {
+  const double limit = getenv("OSQP_AMD_COMPACT_NNZ") ? atof(getenv("OSQP_AMD_COMPACT_NNZ")) : 5e7;  // stored entries of A + P (< 0: never)
+  return limit >= 0.0 && (double)stored >= limit;
+}
+
+// the indirect back-end whatever the symbolic phase would say (select_linsys below)
+bool Engine::pcg_certain() const {
+  const int want = st.linsys_solver;
+  if (comm || want == AMD_PCG_SOLVER) return true;
+  const double nnzK = (double)nnzPtriu + (double)nnzA + (double)ng + (double)mg;
+  return want != AMD_DIRECT_SOLVER && nnzK > 4e7;
+}
+
+void Engine::compact_matrices() {
+  if (!lin || lin->kind() != 2) return;
+  if (!compact_wanted(nnzA + Pf.nnz)) return;
+  if (!compact && (!panel_can_compact(Pf) || (m > 0 && !(panel_can_compact(A) && panel_can_compact(At))))) return;
+  if (m > 0) { compact_one(0); compact_one(1); }
+  compact_one(2);
 }
 
 void Engine::unscale_data() {
@@ -1139,12 +1200,21 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
               dv.get(), t1, map1, t2, map2);
     sync();
   };
-  if (compact) {
-    if (doP) scatter_slots(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.panel.sval.get(), P_k2slot_lo.get(), Pf.panel.sval.get(), P_k2slot_up.get());
-    if (doA) scatter_slots(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.panel.sval.get(), At_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
-  } else {
-    if (doP) scatter(Px_new, Pidx, Pidx ? Pn : (c_int)nnzPtriu, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
-    if (doA) scatter(Ax_new, Aidx, Aidx ? An : (c_int)nnzA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
+  // every copy through its own map: slots of the sliced-ELL copy where the CSR arrays are gone, CSR positions otherwise
+  const c_int kP = Pidx ? Pn : (c_int)nnzPtriu, kA = Aidx ? An : (c_int)nnzA;
+  if (doP) {
+    if (Pf.compact) scatter_slots(Px_new, Pidx, kP, Pf.panel.sval.get(), P_k2slot_lo.get(), Pf.panel.sval.get(), P_k2slot_up.get());
+    else scatter(Px_new, Pidx, kP, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
+  }
+  if (doA) {
+    if (At.compact && A.compact) scatter_slots(Ax_new, Aidx, kA, At.panel.sval.get(), At_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
+    else if (!At.compact && !A.compact) scatter(Ax_new, Aidx, kA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
+    else {
+      if (At.compact) scatter_slots(Ax_new, Aidx, kA, At.panel.sval.get(), At_k2slot.get(), At.panel.sval.get(), At_k2slot.get());
+      else scatter(Ax_new, Aidx, kA, At.val.get(), nullptr, nullptr, nullptr);
+      if (A.compact) scatter_slots(Ax_new, Aidx, kA, A.panel.sval.get(), A_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
+      else scatter(Ax_new, Aidx, kA, A.val.get(), A_k2pos.get(), nullptr, nullptr);
+    }
   }
   if (st.scaling) scale_data();
   refresh_panels();

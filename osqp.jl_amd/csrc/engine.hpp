@@ -149,6 +149,11 @@ struct Engine {
   void unscale_data();
   void refresh_panels();
   void compact_matrices();
+  void setup_mark(const char *what);
+  double mark_prev = 0.0;
+  void compact_one(int which);
+  bool compact_wanted(int64_t stored) const;
+  bool pcg_certain() const;
   void set_rho_vec();
   int update_rho_vec_from_bounds();
   void cold_start();

@@ -326,13 +326,15 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int64_t *__restrict__ rp, const int *__restrict__ ci,
                                                             double *__restrict__ va, const double *__restrict__ r,
                                                             const double *__restrict__ c, int symmetric_order, double scalar,
-                                                            int row0) {
+                                                            int row0, double pre, double *__restrict__ norm) {
   const int lane = threadIdx.x & (G - 1);
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
   if (row >= rows) return;
   const int64_t s = rp[row], e = rp[row + 1];
+  double mx = 0.0;
   for (int64_t k = s + lane; k < e; k += G) {
     double x = va[k];
+    if (pre != 1.0) x *= pre;
     if (r) {
       const int col = ci[k];
       double a, b;
@@ -347,17 +349,31 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows_cols(int rows, const int6
     }
     if (scalar != 1.0) x *= scalar;
     va[k] = x;
+    mx = fmax(mx, fabs(x));
+  }
+  if (norm) {  // max |row| of the result: what the next Ruiz iteration starts from
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) norm[row] = mx;
   }
 }
+// val <- ((((val * pre) * a) * b) * scalar); norm (may be null): norm[i] = max |row i| of the result
 void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int symmetric_order, double scalar, hipStream_t s,
-                         int row0) {
-  if (M.rows == 0 || M.nnz == 0) return;
-  if (M.compact) { panel_scale(M, r, c, symmetric_order, scalar, s, row0); return; }
+                         int row0, double pre, double *norm) {
+  if (M.rows == 0) return;
+  if (M.nnz == 0) { if (norm) HIP_CHECK(hipMemsetAsync(norm, 0, sizeof(double) * (size_t)M.rows, s)); return; }
+  if (M.compact) {
+    if ((pre != 1.0 || norm) && scalar == 1.0 && r && norm) { panel_scale_norm(M, r, c, symmetric_order, pre, row0, norm, s); return; }
+    if (pre != 1.0) panel_scale(M, nullptr, nullptr, 0, pre, s, row0);
+    panel_scale(M, r, c, symmetric_order, scalar, s, row0);
+    if (norm) panel_row_absmax(M, norm, false, s);
+    return;
+  }
   const int G = M.group >= 16 ? 64 : (M.group >= 4 ? 8 : 1);
   dim3 grid(blocks_for((int64_t)M.rows * G)), block(kBlock);
-  if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
-  else if (G == 8) OQ_LAUNCH(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
-  else OQ_LAUNCH(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0);
+  if (G == 64) OQ_LAUNCH(k_scale_rows_cols<64>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0, pre, norm);
+  else if (G == 8) OQ_LAUNCH(k_scale_rows_cols<8>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0, pre, norm);
+  else OQ_LAUNCH(k_scale_rows_cols<1>, grid, block, 0, s, M.rows, M.rowptr.get(), M.col.get(), M.val.get(), r, c, symmetric_order, scalar, row0, pre, norm);
 }
 
 #define MIN_SCALING 1e-4
@@ -378,6 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_vec_op(int op, double *__restrict__ 
   case 7: out[i] = (out[i] * a[i]) * sc; break;
   case 8: out[i] += sc * a[i]; break;
   case 9: out[i] = fmin(fmax(out[i], sc), sc2); break;
+  case 10: { double d = sc * a[i]; if (b) d = fmax(d, b[i]); d = d < MIN_SCALING ? 1.0 : d; d = d > MAX_SCALING ? MAX_SCALING : d; out[i] = 1.0 / sqrt(d); break; }
   }
 }
 static void vec_op(int op, double *out, const double *a, const double *b, double sc, double sc2, int n, hipStream_t s) {
@@ -385,6 +402,7 @@ static void vec_op(int op, double *out, const double *a, const double *b, double
   OQ_LAUNCH(k_vec_op, dim3(blocks_for(n)), dim3(kBlock), 0, s, op, out, a, b, sc, sc2, n, g_skip);
 }
 void vec_limit_rsqrt(double *d, int n, hipStream_t s) { vec_op(0, d, nullptr, nullptr, 0, 0, n, s); }
+void vec_ruiz_factor(double *out, double sc, const double *a, const double *b, int n, hipStream_t s) { vec_op(10, out, a, b, sc, 0, n, s); }
 void vec_limit(double *d, int n, hipStream_t s) { vec_op(1, d, nullptr, nullptr, 0, 0, n, s); }
 void vec_ew_prod(double *out, const double *a, const double *b, int n, hipStream_t s) { vec_op(2, out, a, b, 0, 0, n, s); }
 void vec_ew_recip(double *out, const double *a, int n, hipStream_t s) { vec_op(3, out, a, nullptr, 0, 0, n, s); }
@@ -654,6 +672,22 @@ __global__ __launch_bounds__(kBlock) void k_pcg_precond(int n, const int64_t *__
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) dinv[j] = 1.0 / (sigma + acc);
 }
+// one piece of the Jacobi diagonal from CSR arrays (the other matrix being compact): out = (accumulate ? out : 0) + piece
+__global__ __launch_bounds__(kBlock) void k_precond_piece(int n, const int64_t *__restrict__ atp, const int *__restrict__ ati,
+                                                          const double *__restrict__ atx, const int64_t *__restrict__ pp,
+                                                          const int *__restrict__ pi, const double *__restrict__ px,
+                                                          const double *__restrict__ rho, double *__restrict__ out, int row0, int accumulate) {
+  constexpr int G = 8;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t j = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  if (j >= n) return;
+  double acc = 0.0;
+  if (atp) for (int64_t k = atp[j] + lane; k < atp[j + 1]; k += G) { double a = atx[k]; acc += rho[ati[k]] * a * a; }
+  if (pp) for (int64_t k = pp[j] + lane; k < pp[j + 1]; k += G) if (pi[k] == (int)j + row0) acc += px[k];
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[j] = accumulate ? out[j] + acc : acc;
+}
 // compact matrices: dinv = 1 / (sigma + diag(P) + (A' .* A') rho), both pieces from the sliced-ELL copies
 __global__ __launch_bounds__(kBlock) void k_precond_finish(int n, double sigma, const double *__restrict__ acc, double *__restrict__ dinv) {
   int j = blockIdx.x * kBlock + threadIdx.x;
@@ -661,11 +695,16 @@ __global__ __launch_bounds__(kBlock) void k_precond_finish(int n, double sigma, 
 }
 void pcg_precond(const DevCsr &At, const DevCsr &Pf, const double *rho, double sigma, double *dinv, hipStream_t s, int row0) {
   int n = Pf.rows;
-  if (At.compact || Pf.compact) {
-    if (!(Pf.compact && (At.compact || At.rows == 0 || At.cols == 0)))
-      throw Error(6, "internal: P and A' must be compacted together");
-    panel_diag(Pf, dinv, row0, s);                                          // dinv <- diag(P)
-    if (At.rows > 0 && At.cols > 0) spmv_panel_squared(At, rho, dinv, 1.0, dinv, s);  // dinv <- (A' .* A') rho + diag(P)
+  if (At.compact || Pf.compact) {  // each piece from the copy its matrix still has
+    const bool hasA = At.rows > 0 && At.cols > 0;
+    if (Pf.compact) panel_diag(Pf, dinv, row0, s);                           // dinv <- diag(P)
+    else OQ_LAUNCH(k_precond_piece, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n, (const int64_t *)nullptr, (const int *)nullptr,
+                   (const double *)nullptr, Pf.rowptr.get(), Pf.col.get(), Pf.val.get(), rho, dinv, row0, 0);
+    if (hasA) {
+      if (At.compact) spmv_panel_squared(At, rho, dinv, 1.0, dinv, s);      // dinv <- (A' .* A') rho + diag(P)
+      else OQ_LAUNCH(k_precond_piece, dim3(blocks_for((int64_t)n * 8)), dim3(kBlock), 0, s, n, At.rowptr.get(), At.col.get(), At.val.get(),
+                     (const int64_t *)nullptr, (const int *)nullptr, (const double *)nullptr, rho, dinv, row0, 1);
+    }
     OQ_LAUNCH(k_precond_finish, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, sigma, dinv, dinv);
     return;
   }

@@ -65,15 +65,21 @@ void panel_slot_of_pos(const DevCsr &M, uint32_t *slot, hipStream_t s);  // befo
 void panel_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);
 void panel_scale(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0);
 void panel_diag(const DevCsr &M, double *diag, int row0, hipStream_t s);
+void panel_scale_norm(DevCsr &M, const double *r, const double *c, int order, double pre, int row0, double *norm, hipStream_t s);
 void spmv_panel_squared(const DevCsr &M, const double *x, double *y, double gamma, const double *v, hipStream_t s);
 
 // ---------------- K0: Ruiz equilibration pieces ----------------
 void csr_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t s);  // out[i] = max(|row i|) (or max with old)
 // order 0: (v*r[row])*c[col]; 1: symmetric (v*r[min])*r[max]; 2: (v*c[col])*r[row]; then *scalar
 // row0: global id of the first row when M is a row block (order 1 indexes c by global row and column)
-void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0 = 0);
+// pre: a scalar applied to the value FIRST; norm (may be null): norm[i] = max |row i| of the result (one pass: the fused
+// Ruiz iteration of Engine::scale_data)
+void csr_scale_rows_cols(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0 = 0,
+                         double pre = 1.0, double *norm = nullptr);
 void vec_limit_rsqrt(double *d, int n, hipStream_t s);  // d <- 1/sqrt(limit(d))
 void vec_limit(double *d, int n, hipStream_t s);
+// out = 1/sqrt(limit(max(sc * a, b))) (b may be null): the factor of a Ruiz iteration from the norms the last one left
+void vec_ruiz_factor(double *out, double sc, const double *a, const double *b, int n, hipStream_t s);
 void vec_ew_prod(double *out, const double *a, const double *b, int n, hipStream_t s);       // out = a.*b
 void vec_ew_recip(double *out, const double *a, int n, hipStream_t s);                       // out = 1./a
 void vec_scale(double *x, double a, int n, hipStream_t s);                                   // x *= a

@@ -500,6 +500,115 @@ __global__ __launch_bounds__(kThreads) void k_sell_visit(int rows, int shift, in
     for (int i = threadIdx.x; i < nrows; i += kThreads) o[i] = ys[i];
   }
 }
+// One pass of a Ruiz iteration over the sliced-ELL copy: val <- (((val * pre) * a) * b) with the three orders of
+// k_scale_rows_cols, written back in place, AND partial[g][row] = max |new val| -- the row norms the next iteration
+// needs, so that an iteration touches every matrix once (10 B read + 8 B written per entry) instead of once for the
+// norms, once for the scaling and, for P, twice more for the cost scaling.  The product kernel's structure: the column
+// scaling vector goes through LDS panel by panel (the gathers never leave the CU), lane = row, batches of kBatch
+// entries in flight.  pre: a scalar applied FIRST (the cost scaling of the previous iteration, deferred to here --
+// ((v c) D_lo) D_hi is exactly what scaling by c in place and by D afterwards gives).
+template <typename ColT>
+__global__ __launch_bounds__(kThreads) void k_sell_scale_norm(int rows, int cols, int shift, int B, int Gp, const int *__restrict__ tile_g,
+                                                              const int *__restrict__ tile_r0, const int *__restrict__ tile_r1,
+                                                              const int *__restrict__ unit_s0, const int *__restrict__ unit_ns,
+                                                              const uint32_t *__restrict__ slice_base, const int *__restrict__ slice_len,
+                                                              const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
+                                                              double *__restrict__ sval, const double *__restrict__ r,
+                                                              const double *__restrict__ c, int order, double pre, int row0,
+                                                              double *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int t = blockIdx.x, g = tile_g[t];
+  const int W = 1 << shift;
+  const int r0 = tile_r0[t], nrows = tile_r1[t] - r0;
+  double *cs = lds, *ys = lds + W;
+  for (int i = threadIdx.x; i < nrows; i += kThreads) ys[i] = 0.0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double *rv = order == 1 ? c + row0 : r;  // the row's own factor: c[global row] for the symmetric order
+  bool first = true;
+  for (int j = 0; j < Gp; j++) {
+    const int b = g * Gp + j;
+    if (b >= B) break;
+    const int s0 = unit_s0[(size_t)t * Gp + j], ns = unit_ns[(size_t)t * Gp + j];
+    if (ns == 0) continue;
+    const int c0 = b << shift;
+    if (!first) __syncthreads();
+    const int wlen = cols - c0 < W ? cols - c0 : W;
+    if (wlen == 16 * kThreads) {
+      const double2 *xg = reinterpret_cast<const double2 *>(c + c0);
+      double2 *xl = reinterpret_cast<double2 *>(cs);
+      double2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = xg[threadIdx.x + k * kThreads];
+#pragma unroll
+      for (int k = 0; k < 8; k++) xl[threadIdx.x + k * kThreads] = v[k];
+    } else {
+      for (int i = threadIdx.x; i < wlen; i += kThreads) cs[i] = c[c0 + i];
+    }
+    __syncthreads();
+    first = false;
+    int sl = s0 + wave;
+    size_t nbase = 0;
+    int nL = 0, nrow = -1;
+    double nrs = 1.0;
+    if (sl < s0 + ns) {
+      nbase = (size_t)slice_base[sl]; nL = slice_len[sl]; nrow = slice_rows[(size_t)sl * 64 + lane];
+      nrs = nrow >= 0 ? rv[nrow] : 1.0;
+    }
+    for (; sl < s0 + ns; sl += kWaves) {
+      const size_t base = nbase + lane;
+      const int L = nL, row = nrow;
+      const double rs = nrs;
+      if (sl + kWaves < s0 + ns) {
+        nbase = (size_t)slice_base[sl + kWaves]; nL = slice_len[sl + kWaves]; nrow = slice_rows[(size_t)(sl + kWaves) * 64 + lane];
+        nrs = nrow >= 0 ? rv[nrow] : 1.0;
+      }
+      double *v = sval + base;
+      const ColT *cc_ = scol + base;
+      const int grow = row + row0 - c0;  // the row's global id relative to the panel (symmetric order: col < grow <=> column below the diagonal)
+      double mx = 0.0;
+      for (int k = 0; k < L; k += kBatch) {
+        double cv[kBatch];
+        ColT cc[kBatch];
+        const bool full = k + kBatch <= L;
+        if (full) {
+#pragma unroll
+          for (int u = 0; u < kBatch; u++) { cv[u] = v[(size_t)(k + u) * 64]; cc[u] = cc_[(size_t)(k + u) * 64]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kBatch; u++) {
+            const bool in = k + u < L;
+            cv[u] = in ? v[(size_t)(k + u) * 64] : 0.0;
+            cc[u] = in ? cc_[(size_t)(k + u) * 64] : (ColT)0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+          double x = cv[u];
+          if (pre != 1.0) x *= pre;
+          const double cf = cs[cc[u]];
+          if (order == 1) { const bool below = (int)cc[u] < grow; x = (x * (below ? cf : rs)) * (below ? rs : cf); }
+          else if (order == 2) x = (x * cf) * rs;
+          else x = (x * rs) * cf;
+          cv[u] = x;
+          mx = fmax(mx, fabs(x));
+        }
+        if (row >= 0) {
+          if (full) {
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) v[(size_t)(k + u) * 64] = cv[u];
+          } else {
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) if (k + u < L) v[(size_t)(k + u) * 64] = cv[u];
+          }
+        }
+      }
+      if (row >= 0) ys[row - r0] = fmax(ys[row - r0], mx);  // a row appears once per panel; panels are separated by barriers
+    }
+  }
+  __syncthreads();
+  double *out = partial + (size_t)g * rows + r0;
+  for (int i = threadIdx.x; i < nrows; i += kThreads) out[i] = ys[i];
+}
 __global__ __launch_bounds__(kBlock) void k_panel_reduce_max(int rows, int NG, const double *__restrict__ partial, double *__restrict__ out,
                                                              int accumulate) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -723,6 +832,17 @@ void panel_row_absmax(const DevCsr &M, double *out, bool accumulate, hipStream_t
 void panel_scale(DevCsr &M, const double *r, const double *c, int order, double scalar, hipStream_t s, int row0) {
   const DevPanel &P = M.panel;
   OQ_SELL_VISIT(0, r, c, order, scalar, row0, (double *)nullptr);
+}
+// the fused Ruiz pass (k_sell_scale_norm): scale in place, norm[i] = max |row i| of the result
+void panel_scale_norm(DevCsr &M, const double *r, const double *c, int order, double pre, int row0, double *norm, hipStream_t s) {
+  const DevPanel &P = M.panel;
+  if (P.wide) throw Error(6, "internal: the fused scaling pass needs LDS-staged panels");
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_sell_scale_norm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)spmv_lds_bytes(P.shift)));
+  OQ_LAUNCH((k_sell_scale_norm<uint16_t>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B, P.Gp,
+            P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),
+            P.slice_rows.get(), P.scol.get(), P.sval.get(), r, c, order, pre, row0, P.partial.get());
+  OQ_LAUNCH(k_panel_reduce_max, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), norm, 0);
 }
 void panel_diag(const DevCsr &M, double *diag, int row0, hipStream_t s) {
   const DevPanel &P = M.panel;
