@@ -20,7 +20,9 @@ At N > 1 the line carries three multi-GPU legs:
     library itself (strong scaling);
   * `sharded`: the 1-GPU run's QP (seed 1) cut into row blocks over the ranks, all-gather of every sparse product's
     input vector over RCCL (SURVEY.md 8f row N4; strong scaling of one solve);
-  plus `rccl_ranks_seen` (a sum of ones over the RCCL group).  `batch` and `sharded` run after the replica leg in child
+  plus `collective_ranks_seen` (a sum of ones over the torch.distributed group) with its `collective_backend`, and in every leg
+  `comm_ranks_seen` / `transport_ranks` (distinct rank ids gathered on the library's own communicator / what the transport
+  itself reports: RCCL's ncclCommCount).  `batch` and `sharded` run after the replica leg in child
   processes of their own (their own process groups on the next ports, a time limit) so that neither an exception nor a
   hang in a transport can take the headline numbers with it.  `--mode sharded|batch` promotes a leg to the headline.
 
@@ -252,14 +254,14 @@ def replica_bench(ctx):
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = oq.stats(model)
-    rccl_ranks_seen = None
+    collective_ranks_seen = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         ones = torch.ones(1, dtype=torch.float64, device="cuda")
         dist.all_reduce(ones)  # how many ranks the collective library really connected
-        rccl_ranks_seen = int(ones.item())
+        collective_ranks_seen = int(ones.item())
     cg_per_admm = (st1[6] - st0[6]) / max(args.steps, 1)
 
     # time-to-eps: a full cold-start solve to eps_abs = eps_rel = 1e-4
@@ -324,7 +326,7 @@ def replica_bench(ctx):
             "setup_s": round(setup_s, 3), "device_gb": round(st[9] / 1e9, 2), "device_peak_gb": round(st[20] / 1e9, 2),
             # the reference reports run_time = setup + solve [REF src/types.jl:92-96]: the same solve priced on that clock
             "run_time_s": round(setup_s + solve_s, 4), "iterations_per_s_incl_setup": round(res.info.iter / (setup_s + solve_s), 3),
-            "per_rank": summaries, "rccl_ranks_seen": rccl_ranks_seen, "launch": "self-spawned" if os.environ.get("OSQP_AMD_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
+            "per_rank": summaries, "collective_ranks_seen": collective_ranks_seen, "collective_backend": ctx["backend"] if world > 1 else None, "launch": "self-spawned" if os.environ.get("OSQP_AMD_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
             "roofline": roofline, "cpu_baseline": None,
         }
 
@@ -510,6 +512,11 @@ def comm_ranks_seen(ctx, comm):
     return int(len(set(int(v) for v in buf.cpu().tolist() if v >= 0)))
 
 
+def transport_ranks(comm):
+    """What the transport itself says its communicator spans (RCCL: ncclCommCount); None without a communicator."""
+    return None if comm is None else comm.info()[2]
+
+
 def sharded_leg(ctx, kind, n, per_row, one_gpu_its):
     """One QP (seed 1, the 1-GPU run's instance) cut into row blocks over the ranks; same timing protocol."""
     args, oq, lib, torch, dist, world = (ctx[k] for k in ("args", "oq", "lib", "torch", "dist", "world"))
@@ -555,7 +562,7 @@ def sharded_leg(ctx, kind, n, per_row, one_gpu_its):
         "cg_iters_per_admm_iter": round((st1[6] - st0[6]) / max(args.steps, 1), 3),
         "exchanges_per_admm_iter": round((st1[14] - st0[14]) / max(args.steps, 1), 2),
         "exchange_bytes_per_admm_iter": round((st1[15] - st0[15]) / max(args.steps, 1), 1),
-        "setup_s": round(setup_s, 3), "device_gb_per_rank": round(st[9] / 1e9, 2), "transport": transport, "comm_ranks_seen": seen,
+        "setup_s": round(setup_s, 3), "device_gb_per_rank": round(st[9] / 1e9, 2), "transport": transport, "comm_ranks_seen": seen, "transport_ranks": transport_ranks(comm),
         "local_rows": [int(st[16]), int(st[17])],
         "spmv_local_ms": round(ms_spmv, 4),
         "spmv_local_GBs": round(st[10] / (ms_spmv * 1e-3) / 1e9, 1) if ms_spmv > 0 else None,
@@ -619,7 +626,7 @@ def batch_leg(ctx, want_cpu):
         "value": round(iters * steps / elapsed, 1), "unit": "iterations/s", "scaling": "strong", "ms_per_step": round(ms, 4),
         "instances": BATCH_TOTAL, "instances_per_rank": BATCH_TOTAL // world, "instances_per_s": round(BATCH_TOTAL * steps / elapsed, 1),
         "mean_iters_per_instance": round(iters / BATCH_TOTAL, 2), "solved": int((info[:, 1] == 1).sum()),
-        "transport": transport, "comm_ranks_seen": seen, "every_rank_holds_the_whole_batch": bool(same),
+        "transport": transport, "comm_ranks_seen": seen, "transport_ranks": transport_ranks(comm), "every_rank_holds_the_whole_batch": bool(same),
         "gather_bytes_per_rank": (BATCH_TOTAL // world) * 304 * 8 * (world - 1),
         "sharding": f"{BATCH_TOTAL // world} instances per GPU (contiguous blocks), one in-place all-gather of [x|y|info] at the end of each solve",
         "roofline": {"bound": "lds", "kernel": "k_batch_solve (one QP per workgroup, all state in LDS)",
@@ -646,7 +653,7 @@ def batch_line(args, world, rec):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "mpc-batch", "instances": BATCH_TOTAL, "n": 100, "m": 200, "eps_abs": 1e-4, "eps_rel": 1e-4,
                       "sharding": rec["sharding"]}}
-    for k in ("instances_per_s", "mean_iters_per_instance", "solved", "transport", "comm_ranks_seen", "every_rank_holds_the_whole_batch", "roofline"):
+    for k in ("instances_per_s", "mean_iters_per_instance", "solved", "transport", "comm_ranks_seen", "transport_ranks", "every_rank_holds_the_whole_batch", "roofline"):
         out[k] = rec[k]
     out["cpu_baseline"] = rec.get("cpu_baseline")
     return out

@@ -352,6 +352,9 @@ c_int osqp_amd_comm_destroy(osqp_amd_comm *comm);
 /* The communicator's one primitive, exposed: in-place all-gather of `count` doubles per rank on a DEVICE buffer of
  * world*count doubles whose chunk `rank` is filled in; blocks until done. */
 c_int osqp_amd_comm_all_gather(osqp_amd_comm *comm, c_float *dev_buf, c_int count);
+/* rank / size as the communicator was created, and the size the transport itself reports (RCCL: ncclCommCount; the
+ * host transport: the size it was created with; -1: the transport cannot say).  Any pointer may be NULL. */
+c_int osqp_amd_comm_info(const osqp_amd_comm *comm, c_int *rank, c_int *world, c_int *transport_ranks);
 /* as osqp_setup [REF src/interface.jl:147-162] / osqp_amd_setup_generated, keeping this rank's row block */
 c_int osqp_amd_setup_sharded(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings,
                              osqp_amd_comm *comm);

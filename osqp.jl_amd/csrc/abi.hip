@@ -232,15 +232,19 @@ c_int osqp_amd_comm_create_host(osqp_amd_comm **out, c_int rank, c_int world, os
   *out = nullptr;
   return guarded([&]() { *out = (osqp_amd_comm *)make_host_comm((int)rank, (int)world, (host_allgather_fn)fn, ctx); return 0; });
 }
+// OSQP_AMD_RCCL_STUB=1 (tests/test_rccl_stub_transport.py): `librccl_path` names a host-side stand-in for librccl, the
+// "device" buffers of osqp_amd_comm_all_gather are host memory and no HIP device is needed -- the RCCL transport's own logic
+// (id hand-over, rank bookkeeping, the in-place gather call) runs with several ranks on a box without GPUs
+static bool rccl_stub_mode() { const char *e = getenv("OSQP_AMD_RCCL_STUB"); return e && atoi(e) == 1; }
 c_int osqp_amd_comm_unique_id(void *out128, const char *librccl_path) {
   if (!out128) return 1;
-  return guarded([&]() { require_device(); rccl_unique_id(out128, librccl_path); return 0; });
+  return guarded([&]() { if (!rccl_stub_mode()) require_device(); rccl_unique_id(out128, librccl_path); return 0; });
 }
 c_int osqp_amd_comm_create_rccl(osqp_amd_comm **out, c_int rank, c_int world, const void *unique_id, const char *librccl_path) {
   if (!out) return 1;
   *out = nullptr;
   return guarded([&]() {
-    require_device();
+    if (!rccl_stub_mode()) require_device();
     *out = (osqp_amd_comm *)make_rccl_comm((int)rank, (int)world, unique_id, librccl_path);
     return 0;
   });
@@ -249,9 +253,17 @@ c_int osqp_amd_comm_all_gather(osqp_amd_comm *c, c_float *dev_buf, c_int count) 
   if (!c || !dev_buf || count < 0) return 1;
   return guarded([&]() {
     ((Comm *)c)->all_gather(dev_buf, (size_t)count, nullptr);
-    HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (!(rccl_stub_mode() && std::string(((Comm *)c)->kind()) == "rccl")) HIP_CHECK(hipStreamSynchronize(nullptr));
     return 0;
   });
+}
+c_int osqp_amd_comm_info(const osqp_amd_comm *c, c_int *rank, c_int *world, c_int *transport_ranks) {
+  if (!c) return 1;
+  const Comm *k = (const Comm *)c;
+  if (rank) *rank = k->rank;
+  if (world) *world = k->world;
+  if (transport_ranks) *transport_ranks = k->transport_ranks();
+  return 0;
 }
 c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_int *Ap, const c_int *Ai,
                               c_int ordering, c_int smax, c_float *out, c_int count) {

@@ -49,6 +49,7 @@ struct RcclApi {
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;  // optional
 };
 
 RcclApi &rccl_api(const char *library_path) {
@@ -72,6 +73,7 @@ RcclApi &rccl_api(const char *library_path) {
   api.comm_destroy = (decltype(api.comm_destroy))sym("ncclCommDestroy");
   api.all_gather = (decltype(api.all_gather))sym("ncclAllGather");
   api.error_string = (decltype(api.error_string))sym("ncclGetErrorString");
+  api.comm_count = (decltype(api.comm_count))dlsym(h, "ncclCommCount");
   api.handle = h;
   return api;
 }
@@ -92,6 +94,11 @@ struct RcclComm : Comm {
   }
   ~RcclComm() override { if (comm) (void)api.comm_destroy(comm); }
   const char *kind() const override { return "rccl"; }
+  int transport_ranks() const override {  // what the collective library itself says its communicator spans
+    int cnt = -1;
+    if (api.comm_count && api.comm_count(comm, &cnt) == ncclSuccess) return cnt;
+    return -1;
+  }
   void all_gather(double *buf, size_t count, hipStream_t s) override {
     // in-place form: the send buffer is this rank's chunk of the receive buffer
     rccl_check(api, api.all_gather(buf + (size_t)rank * count, buf, count, ncclDouble, comm, s), "ncclAllGather");

@@ -22,6 +22,7 @@ struct Comm {
   // Stream-ordered with respect to `s` on return (the host may or may not have blocked).
   virtual void all_gather(double *buf, size_t count, hipStream_t s) = 0;
   virtual const char *kind() const = 0;
+  virtual int transport_ranks() const { return world; }  // ranks the transport itself reports (RCCL: ncclCommCount; -1: unknown)
 };
 
 // fn(ctx, host_buf, count): host_buf holds world*count doubles, chunk `rank` filled in; fill in the others.  Returns 0.

@@ -58,6 +58,9 @@ Engine::~Engine() {
   lin.reset();
   if (chunk_exec) (void)hipGraphExecDestroy(chunk_exec);
   if (h_slots) (void)hipHostFree(h_slots);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (aux_stream) (void)hipStreamDestroy(aux_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -138,6 +141,27 @@ const double *Engine::full_m(const double *v) {
   vec_copy(gm.get() + (size_t)comm->rank * chunk_m, v, m, stream);
   comm->all_gather(gm.get(), (size_t)chunk_m, stream);
   return gm.get();
+}
+
+// The same exchange on a second stream, ordered behind everything enqueued on `stream` so far: what is enqueued on
+// `stream` between full_m_begin and full_m_end runs while the m-vector travels (the P product of a CG iteration while
+// t = rho (A p) is gathered for the A' product).  full_m_end makes `stream` wait for the gathered vector.
+const double *Engine::full_m_begin(const double *v) {
+  if (!comm) return v;
+  if (!aux_stream) {
+    HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  HIP_CHECK(hipEventRecord(ev_fork, stream));
+  HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+  vec_copy(gm.get() + (size_t)comm->rank * chunk_m, v, m, aux_stream);
+  comm->all_gather(gm.get(), (size_t)chunk_m, aux_stream);
+  HIP_CHECK(hipEventRecord(ev_join, aux_stream));
+  return gm.get();
+}
+void Engine::full_m_end() {
+  if (comm) HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
 }
 
 // The row partition of a sharded workspace: ceil-sized contiguous blocks (include/osqp_amd.h).  Returns the local ranges.
@@ -406,6 +430,8 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     DevBuf<int> colid((size_t)nnzA), src;
     expand_colptr(n, At.rowptr.get(), nnzA, colid.get(), stream);
     csr_from_coo(m, n, nnzA, At.col.get(), colid.get(), A, src, stream);
+    sync();
+    colid.release();
     gather_values(A.nnz, src.get(), At.val.get(), A.val.get(), 0, stream);
     A_k2pos.alloc((size_t)nnzA);
     invert_map(A.nnz, src.get(), 0, nnzA, A_k2pos.get(), stream);
@@ -434,9 +460,14 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     int bad = 0;
     flag.download(&bad, 1, stream);
     sync();
+    colid.release();  // every temporary goes as soon as it has been read: this block is the high-water mark of a large setup
     if (bad) throw Error(1, "P is not upper triangular");
     csr_from_coo(n, n, 2 * nnzPtriu, erow.get(), ecol.get(), Pf, src, stream);
+    sync();
+    erow.release(); ecol.release();
     gather_values(Pf.nnz, src.get(), Px.get(), Pf.val.get(), nnzPtriu, stream);
+    sync();
+    Px.release();
     P_k2lo.alloc((size_t)nnzPtriu); P_k2up.alloc((size_t)nnzPtriu);
     if (nnzPtriu > 0) {
       OQ_LAUNCH(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
@@ -597,8 +628,8 @@ void Engine::refresh_panels() {
 // inside osqp_update_P / _A, the Jacobi diagonal after a rho update, value updates by nnz index.  Those walk the slices
 // instead (panel.hip, compact mode), the nnz-index maps are rewritten as positions in the slice arrays, and the CSR
 // arrays go.  Row pointers stay (8 B per row).
-__global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const int *__restrict__ k2pos, const uint32_t *__restrict__ pos2slot,
-                                                             uint32_t *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const int *k2pos, const uint32_t *__restrict__ pos2slot,
+                                                             uint32_t *out) {  // out may alias k2pos
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= k) return;
   const int p = k2pos ? k2pos[i] : (int)i;
@@ -611,20 +642,21 @@ __global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const in
 void Engine::compact_one(int which) {
   DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
   if (M.compact || !panel_can_compact(M)) return;
-  auto compose = [&](int64_t k, const int *k2pos, const DevBuf<uint32_t> &p2s, DevBuf<uint32_t> &out) {
-    out.alloc((size_t)k);
-    if (k > 0) OQ_LAUNCH(k_compose_slot_map, dim3(blocks_for(k)), dim3(kBlock), 0, stream, k, k2pos, p2s.get(), out.get());
+  // The slot maps take the place of the position maps, entry by entry, in the same buffers (a thread reads its position and
+  // writes its slot): A_k2pos / P_k2lo / P_k2up hold CSR positions while their matrix has CSR arrays, slots of the sliced
+  // copy once it is compact (the consumers go by the matrix's flag).
+  auto compose_in_place = [&](int64_t k, DevBuf<int> &k2pos, const DevBuf<uint32_t> &p2s) {
+    if (k > 0) OQ_LAUNCH(k_compose_slot_map, dim3(blocks_for(k)), dim3(kBlock), 0, stream, k, (const int *)k2pos.get(), p2s.get(), (uint32_t *)k2pos.get());
   };
-  const bool maps = which == 2 ? (P_k2lo.n > 0 || nnzPtriu == 0) : (A_k2pos.n > 0 || nnzA == 0);  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
+  const bool maps = !comm;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
   if (maps) {
     DevBuf<uint32_t> p2s((size_t)M.nnz);
     panel_slot_of_pos(M, p2s.get(), stream);
-    if (which == 0) { compose(nnzA, A_k2pos.get(), p2s, A_k2slot); sync(); }
+    if (which == 0) { compose_in_place(nnzA, A_k2pos, p2s); sync(); }
     else if (which == 1) { sync(); At_k2slot = std::move(p2s); }  // position k of A' is the caller's nnz index k
-    else { compose(nnzPtriu, P_k2lo.get(), p2s, P_k2slot_lo); compose(nnzPtriu, P_k2up.get(), p2s, P_k2slot_up); sync(); }
+    else { compose_in_place(nnzPtriu, P_k2lo, p2s); compose_in_place(nnzPtriu, P_k2up, p2s); sync(); }
   }
-  if (which == 0) A_k2pos.release();
-  if (which == 2) { P_k2lo.release(); P_k2up.release(); Pi_keep.release(); }  // the direct back-end's symbolic phase is out of reach at this size
+  if (which == 2) Pi_keep.release();  // the direct back-end's symbolic phase is out of reach at this size
   panel_compact(M);
   compact = true;
 }
@@ -1203,16 +1235,16 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
   // every copy through its own map: slots of the sliced-ELL copy where the CSR arrays are gone, CSR positions otherwise
   const c_int kP = Pidx ? Pn : (c_int)nnzPtriu, kA = Aidx ? An : (c_int)nnzA;
   if (doP) {
-    if (Pf.compact) scatter_slots(Px_new, Pidx, kP, Pf.panel.sval.get(), P_k2slot_lo.get(), Pf.panel.sval.get(), P_k2slot_up.get());
+    if (Pf.compact) scatter_slots(Px_new, Pidx, kP, Pf.panel.sval.get(), (const uint32_t *)P_k2lo.get(), Pf.panel.sval.get(), (const uint32_t *)P_k2up.get());
     else scatter(Px_new, Pidx, kP, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
   }
   if (doA) {
-    if (At.compact && A.compact) scatter_slots(Ax_new, Aidx, kA, At.panel.sval.get(), At_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
+    if (At.compact && A.compact) scatter_slots(Ax_new, Aidx, kA, At.panel.sval.get(), At_k2slot.get(), A.panel.sval.get(), (const uint32_t *)A_k2pos.get());
     else if (!At.compact && !A.compact) scatter(Ax_new, Aidx, kA, At.val.get(), nullptr, A.val.get(), A_k2pos.get());
     else {
       if (At.compact) scatter_slots(Ax_new, Aidx, kA, At.panel.sval.get(), At_k2slot.get(), At.panel.sval.get(), At_k2slot.get());
       else scatter(Ax_new, Aidx, kA, At.val.get(), nullptr, nullptr, nullptr);
-      if (A.compact) scatter_slots(Ax_new, Aidx, kA, A.panel.sval.get(), A_k2slot.get(), A.panel.sval.get(), A_k2slot.get());
+      if (A.compact) scatter_slots(Ax_new, Aidx, kA, A.panel.sval.get(), (const uint32_t *)A_k2pos.get(), A.panel.sval.get(), (const uint32_t *)A_k2pos.get());
       else scatter(Ax_new, Aidx, kA, A.val.get(), A_k2pos.get(), nullptr, nullptr);
     }
   }

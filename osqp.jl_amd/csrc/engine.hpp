@@ -79,6 +79,8 @@ struct Engine {
   Comm *comm = nullptr;  // not owned
   int ng = 0, mg = 0, n0 = 0, m0 = 0, chunk_n = 0, chunk_m = 0;
   DevBuf<double> gn, gm, gslots;
+  hipStream_t aux_stream = nullptr;  // the m-vector exchange of a CG iteration runs here, beside the P product (full_m_begin / _end)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   OSQPSettings st;
   hipStream_t stream = nullptr;
   int device = 0;
@@ -86,7 +88,7 @@ struct Engine {
   DevCsr A, At, Pf;
   DevBuf<int> A_k2pos, P_k2lo, P_k2up;
   // compact mode (compact_matrices): the same maps as positions in the sliced-ELL value arrays (0xFFFFFFFF: none)
-  DevBuf<uint32_t> A_k2slot, At_k2slot, P_k2slot_lo, P_k2slot_up;
+  DevBuf<uint32_t> At_k2slot;  // slot of A' entry k in its sliced copy; A and P keep theirs in A_k2pos / P_k2lo / P_k2up (compact_one)
   bool compact = false;
   DevBuf<int64_t> Pp_keep;  // caller's triu(P) CSC pattern, kept for the direct back-end's symbolic phase
   DevBuf<int> Pi_keep;
@@ -208,6 +210,8 @@ struct Engine {
   double agree_max(double v);
   const double *full_n(const double *v);  // v (n local entries) as a full-length vector
   const double *full_m(const double *v);
+  const double *full_m_begin(const double *v);  // the same exchange on a second stream ...
+  void full_m_end();                            // ... joined here
   void shard_rows(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_);
   int rank() const { return comm ? comm->rank : 0; }
   void select_linsys();

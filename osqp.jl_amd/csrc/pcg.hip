@@ -287,12 +287,17 @@ struct Pcg : Linsys {
   void apply_M(const double *v, double *Av, double *out) {
     hipStream_t s = e.stream;
     const double *vg = e.full_n(v);  // sharded: the one n-vector exchange of the product ...
+    const double *tg = nullptr;
     if (e.m > 0) {
       spmv(e.A, vg, Av, nullptr, 0.0, 0.0, nullptr, s);
       vec_ew_prod(t.get(), e.rho.get(), Av, e.m, s);
+      tg = e.full_m_begin(t.get());  // ... and the one m-vector exchange, on its own stream while the P product runs
     }
     spmv(e.Pf, vg, out, nullptr, 0.0, e.st.sigma, v, s);
-    if (e.m > 0) spmv(e.At, e.full_m(t.get()), out, nullptr, 1.0, 0.0, nullptr, s);  // ... and the one m-vector exchange
+    if (e.m > 0) {
+      e.full_m_end();
+      spmv(e.At, tg, out, nullptr, 1.0, 0.0, nullptr, s);
+    }
   }
 
   int solve(double *xz, double cand) override {

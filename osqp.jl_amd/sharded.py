@@ -48,6 +48,12 @@ class _Comm:
             self.lib.osqp_amd_comm_destroy(self.handle)
             self.handle = C.c_void_p()
 
+    def info(self):
+        """(rank, world, ranks the transport itself reports: RCCL's ncclCommCount; -1 if it cannot say)."""
+        r, w, t = T.c_int(), T.c_int(), T.c_int()
+        self._check(self.lib.osqp_amd_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(t)), "osqp_amd_comm_info")
+        return int(r.value), int(w.value), int(t.value)
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self.lib.osqp_amd_last_error()

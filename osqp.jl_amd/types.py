@@ -198,6 +198,7 @@ EXT_SYMBOLS = {
     "osqp_amd_comm_create_rccl": (c_int, [C.POINTER(C.c_void_p), c_int, c_int, C.c_void_p, C.c_char_p]),
     "osqp_amd_comm_destroy": (c_int, [C.c_void_p]),
     "osqp_amd_comm_all_gather": (c_int, [C.c_void_p, C.c_void_p, c_int]),
+    "osqp_amd_comm_info": (c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
     "osqp_amd_batch_mpc_create": (c_int, [C.POINTER(C.c_void_p), c_int, C.c_ulonglong, C.POINTER(Settings), C.c_void_p, c_int]),
     "osqp_amd_batch_mpc_solve": (c_int, [C.c_void_p, C.c_void_p]),
     "osqp_amd_batch_destroy": (c_int, [C.c_void_p]),
