@@ -2,17 +2,22 @@
 // BASELINE.json config 5: 4096 independent MPC QPs, n = 100, m = 200).
 //
 // One workgroup solves one QP from start to finish out of LDS and registers:
-//   * LDS (~46 KB at n = 100, m = 200: three workgroups fit a CU): the instance's values of A (shared sparsity
-//     pattern, CSC order) and of the full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates;
-//   * REGISTERS: the inverse of the reduced KKT matrix M = P + sigma I + A' diag(rho) A -- thread (row i, column part c)
-//     of the 512 holds M^-1[i, c*n/4 .. (c+1)*n/4) (25 doubles at n = 100) -- and the thread's share of the entries of A
-//     in both orientations (value + index), so that an iteration's products are one LDS gather deep;
-//   * M is assembled from host-precomputed term lists through a per-instance scratch in global memory (L2-resident, written
-//     and read once per factorisation) and inverted by n Gauss-Jordan sweeps on the register tiles: a sweep is one LDS
-//     broadcast of the pivot column + one barrier + 25 fused multiply-adds per thread.
-// Per iteration: b = sigma x - q + A'(rho z - y); x~ = M^-1 b (registers x LDS broadcast); z~ = A x~ consumed row by
-// row by the x/z/y update; every `check_termination` iterations the same residual / infeasibility tests as the
-// large-problem path.
+//   * LDS (~75 KB at n = 100, m = 200: two workgroups fit a CU): the instance's values of A (shared sparsity
+//     pattern, CSC order) and of the full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates, and the thread's
+//     share of the pattern of A in both orientations as packed (value offset, operand offset) words;
+//   * REGISTERS: the inverse of the reduced KKT matrix M = P + sigma I + A' diag(rho) A -- thread 4 i + c of the 512
+//     holds M^-1[i, c*n/4 .. (c+1)*n/4) (25 doubles at n = 100): the four column parts of a row sit in neighbouring
+//     lanes, so the dense product ends in two DPP adds instead of a trip through LDS;
+//   * M is assembled from host-precomputed term lists straight into the accumulator layout of the fp64 matrix cores,
+//     inverted there by Gauss-Jordan block sweeps (invert_mfma) and handed to the register tiles through a 20 KB LDS
+//     window, column part by column part: nothing of a factorisation touches global memory.
+// Per iteration, three barrier-separated phases: b = sigma x - q + A'(rho z - y) (4 lanes per column of A);
+// x~ = M^-1 b (registers x LDS broadcast) with the x update; z~ = A x~ consumed row by row by the z / y update (2 lanes
+// per row); every `check_termination` iterations the same residual / infeasibility tests as the large-problem path.
+// The kernel is issue-bound, not latency-bound (round 3: 16 waves per CU, every vector instruction of a wavefront is four
+// cycles of its SIMD): the iteration is written for instruction count -- operand addresses come ready-made out of one
+// packed word (two instructions per entry), short columns / rows are padded with a zero-valued entry instead of
+// branching, nothing the loop needs lives in spilled registers.
 // Same algorithm as oracle/osqp_oracle.c with the KKT system in reduced form.
 // There is no communication between instances: the multi-GPU path shards the
 // instance range over ranks and gathers the packed results once (batch.py).
@@ -79,15 +84,11 @@ __device__ __forceinline__ T *opaque(T *p) {
   return p;
 }
 // The same for per-thread values: the thread id as a value the optimiser cannot trace (every use site gets its own copy, so
-// nothing derived from it -- row ids, LDS addresses, predicates -- is a loop invariant worth keeping), and a register word.
+// nothing derived from it -- row ids, LDS addresses, predicates -- is a loop invariant worth keeping).
 __device__ __forceinline__ int mytid() {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
   return t;
-}
-__device__ __forceinline__ unsigned opaque_word(unsigned w) {
-  asm volatile("" : "+v"(w));
-  return w;
 }
 
 // lane `lane` (a compile-time constant) of v, as a wave-uniform value: two v_readlane into scalar registers.  A vector of up
@@ -136,30 +137,38 @@ __device__ __forceinline__ void block_reduce(double *v, int op, ldouble *red) {
   }
 }
 
+typedef __attribute__((address_space(3))) unsigned luint;
+constexpr int KT = 4, KR = 6;  // entries per lane: 4 lanes per column of A (A' v), 2 lanes per row (A v)
+constexpr int KRW = 8;         // dwords per thread of the row-side words (6 used: a 16-byte and an 8-byte read)
+
 struct Lds {
   ldouble *gjc;  // 2 x (4 x 128): the four pivot rows of a block step of the MFMA inversion, double-buffered; behind them
                  // 2 x 32: the inverse of the 4 x 4 pivot block and its positive-definite flag
-  ldouble *part, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv, *nrm;
+  ldouble *bb, *Av, *Pv, *q, *l, *u, *D, *E, *rho, *rhoi, *x, *z, *y, *xp, *zp, *xt, *zt, *dx, *dy, *Ax, *Px, *Aty, *tn, *tm, *red, *ldinv, *nrm;
   lint *ctype;
   lshort *Ap, *Ai, *Rp, *Rc, *Rmap, *Fp, *Fc;  // shared pattern, staged into LDS as 16-bit indices
+  luint *cw, *rw;  // the thread's entries of A, column side (KT words per thread) and row side (KRW per thread): (byte offset of
+                   // the value in Av) << 16 | byte offset of the operand; only when the pattern fits (sparse_fits)
   int ld;
 };
+// Av carries one more double than A has entries: a zero that padded entries point at
 __host__ __device__ inline size_t lds_doubles(int n, int m, int nnzA, int nnzF) {
-  return (NT / 128) * (size_t)n + nnzA + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW + 24 + 2 * 4 * 128 + 64;
+  return (size_t)n + nnzA + 1 + nnzF + 10 * (size_t)n + 12 * (size_t)m + 16 * NW + 24 + 2 * 4 * 128 + 64 + 1;  // + 1: alignment slack
 }
 __host__ __device__ inline size_t lds_shorts(int n, int m, int nnzA, int nnzF) {
   return 2 * ((size_t)n + 1) + ((size_t)m + 1) + 3 * (size_t)nnzA + (size_t)nnzF + 8;
 }
-__host__ __device__ inline size_t lds_bytes(int n, int m, int nnzA, int nnzF) {
-  return lds_doubles(n, m, nnzA, nnzF) * 8 + (((size_t)m * 4 + 15) / 16) * 16 + lds_shorts(n, m, nnzA, nnzF) * 2 + 16;
+__host__ __device__ inline size_t lds_bytes(int n, int m, int nnzA, int nnzF, bool words) {
+  return lds_doubles(n, m, nnzA, nnzF) * 8 + (((size_t)m * 4 + 15) / 16) * 16 + (words ? (size_t)NT * (KT + KRW) * 4 : 0) +
+         lds_shorts(n, m, nnzA, nnzF) * 2 + 16;
 }
-__device__ __forceinline__ Lds carve(ldouble *base, const Pattern &P) {
+__device__ __forceinline__ Lds carve(ldouble *base, const Pattern &P, bool words) {
   Lds s;
   const int n = P.n, m = P.m;
   s.ld = n + 1;
   ldouble *p = base;
-  s.part = p; p += (NT / 128) * (size_t)n;  // the column parts of the dense product meet here
-  s.Av = p; p += P.nnzA; s.Pv = p; p += P.nnzF;
+  s.bb = p; p += n;  // the right-hand side of the reduced system
+  s.Av = p; p += P.nnzA + 1; s.Pv = p; p += P.nnzF;
   s.q = p; p += n; s.D = p; p += n; s.x = p; p += n; s.xp = p; p += n; s.xt = p; p += n; s.dx = p; p += n;
   s.Px = p; p += n; s.Aty = p; p += n; s.tn = p; p += n; s.ldinv = p; p += n;
   s.l = p; p += m; s.u = p; p += m; s.E = p; p += m; s.rho = p; p += m; s.rhoi = p; p += m; s.z = p; p += m; s.y = p; p += m;
@@ -167,8 +176,11 @@ __device__ __forceinline__ Lds carve(ldouble *base, const Pattern &P) {
   s.red = p; p += 16 * NW;  // NW * K doubles of block_reduce, K <= 14
   s.nrm = p; p += 24;
   s.gjc = p; p += 2 * 4 * 128 + 64;
+  p += (p - base) & 1;  // what follows starts on a 16-byte boundary
   s.ctype = (lint *)p;
-  lshort *h = (lshort *)((lchar *)p + (((size_t)m * 4 + 15) / 16) * 16);
+  luint *w = (luint *)((lchar *)p + (((size_t)m * 4 + 15) / 16) * 16);  // 16-byte aligned: the words are read four at a time
+  s.cw = w; s.rw = w + (words ? NT * KT : 0);
+  lshort *h = (lshort *)(w + (words ? NT * (KT + KRW) : 0));
   s.Ap = h; h += n + 1; s.Fp = h; h += n + 1; s.Rp = h; h += m + 1;
   s.Ai = h; h += P.nnzA; s.Rc = h; h += P.nnzA; s.Rmap = h; h += P.nnzA; s.Fc = h;
   return s;
@@ -213,37 +225,34 @@ __device__ __forceinline__ void set_rho(const Pattern &P, const Lds &s, double r
 // ---------------------------------------------------------------------------------------------------------
 // The reduced KKT matrix and its inverse, in registers.
 //
-// Thread t = part * 128 + lane owns row `lane` (lanes >= n idle) and the NC = ceil(n / PARTS) columns
-// [part * NC, (part + 1) * NC) of the n x n array: Mr[u] = M[row, j0 + u].  NCT is the compile-time bound of NC.
+// Thread t = 4 * row + part owns row `row` (rows >= n idle) and the NC = ceil(n / PARTS) columns
+// [part * NC, (part + 1) * NC) of the n x n array: T.v[u] = M^-1[row, j0 + u].  NCT is the compile-time bound of NC.
+// The four parts of a row are neighbouring lanes: the dense product M^-1 b ends in two quad-permute adds.
 //
 // Why an explicit inverse: it is applied to thousands of right-hand sides (one per ADMM iteration) between two rho
 // updates, and a dense product M^-1 b keeps every row independent while a triangular solve is a chain of 2n dependent
-// steps.  Why Gauss-Jordan sweeps (Goodnight's sweep operator): one sweep is a rank-1 update of the whole array --
-// every thread updates its own registers, the only shared data is the pivot column (n doubles through LDS, one barrier,
-// double-buffered) -- no serial column loop anywhere.  The pivots are the Schur complements of M, so the
+// steps.  Why Gauss-Jordan sweeps (Goodnight's sweep operator): a block sweep is a rank-4 update of the whole array on the
+// matrix cores (invert_mfma below) -- no serial column loop anywhere.  The pivots are the Schur complements of M, so the
 // positive-definiteness test of the Cholesky factorisation carries over unchanged.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int PARTS = NT / 128;
+constexpr int PARTS = 4;
+static_assert(NT == 512, "the register tiles assume 128 rows x 4 column parts");
 
 template <int NCT>
 struct MTile {
   double v[NCT];
 };
 
-// M = P + sigma I + A' diag(rho) A: the lower triangle from the host-precomputed term lists (the intersections of the
-// columns of A do not depend on the instance), both triangles into the instance's scratch (global memory, n x ld,
-// column-major), then every thread picks up its tile.
-// Addressing rule of the three routines below: ONE base register per array (array + j0, resp. scratch + row + j0 ld)
-// and compile-time offsets u / u ld -- a column test is `u == k - j0` against the constant u.  (Written with the global
-// column j = j0 + u, the 25 column ids and 25 clamped addresses are loop invariants that the compiler precomputes
+// Addressing rule of the routines below: ONE base register per array and compile-time offsets u / u ld.  (Written with the
+// global column j = j0 + u, the 25 column ids and 25 clamped addresses are loop invariants that the compiler precomputes
 // and then has to keep in -- or spill from -- registers across the whole ADMM loop.)  EXACT: PARTS * NCT == n, no
 // column of a tile lies outside the matrix; otherwise columns u >= ncv of the last part are masked.
-// the thread's tile (row = tid & 127, NCT columns of part tid >> 7) of the n x n array in the instance's scratch
+// the thread's tile (row = tid >> 2, NCT columns of part tid & 3) of the n x n array in the instance's scratch
 template <int NCT, bool EXACT>
 __device__ __forceinline__ void load_tile(int n, const double *scratch, MTile<NCT> &T) {
   scratch = opaque(scratch);
   const int ld = n;
-  const int row = mytid() & 127, part = mytid() >> 7;
+  const int row = mytid() >> 2, part = mytid() & 3;
   const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
   const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
   const bool live = row < n;
@@ -251,8 +260,10 @@ __device__ __forceinline__ void load_tile(int n, const double *scratch, MTile<NC
 #pragma unroll
   for (int u = 0; u < NCT; u++) T.v[u] = (live && (EXACT || u < ncv)) ? src[(size_t)u * ld] : 0.0;
 }
-template <int NCT, bool EXACT, bool LOAD>
-__device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, double sigma, double *__restrict__ scratch, MTile<NCT> &T) {
+// M = P + sigma I + A' diag(rho) A: the lower triangle from the host-precomputed term lists (the intersections of the
+// columns of A do not depend on the instance), both triangles into the instance's scratch (global memory, n x n,
+// column-major)
+__device__ __forceinline__ void assemble_scratch(const Pattern &P, const Lds &s, double sigma, double *__restrict__ scratch) {
   const int n = P.n, ld = n;
   scratch = opaque(scratch);
   for (int e = mytid(); e < n * ld; e += NT) scratch[e] = 0.0;
@@ -282,79 +293,6 @@ __device__ __forceinline__ void assemble_tile(const Pattern &P, const Lds &s, do
   for (int r = mytid(); r < n; r += NT)
     for (int q = s.Fp[r]; q < s.Fp[r + 1]; q++) scratch[r + s.Fc[q] * ld] += s.Pv[q];  // full symmetric P: both triangles
   __syncthreads();
-  if (LOAD) load_tile<NCT, EXACT>(n, scratch, T);
-}
-
-// T <- (the matrix it holds)^-1.  Returns false if the matrix is not positive definite.  c0, c1: two LDS vectors of n
-// doubles (scratch: the pivot column of the current and of the next sweep), followed in LDS by at least NCT more doubles.
-template <int NCT, bool EXACT>
-__device__ __forceinline__ bool invert_tile(int n, MTile<NCT> &T, ldouble *c0, ldouble *c1) {
-  const int row = mytid() & 127, part = mytid() >> 7;
-  const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
-  const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
-  const bool live = row < n;
-  const int lane = mytid() & 63;
-  bool ok = true;
-  // c0 / c1 hold n + 1 doubles each: the pivot row and, behind it, the reciprocal of the pivot (computed once by the
-  // publishing thread instead of once per wavefront)
-  for (int k = 0; k < n; k++) {
-    ldouble *c = (k & 1) ? c1 : c0;
-    // column k inside this tile (when 0 <= kl < ncv); wave-uniform, so the fix-up below is a scalar jump, not NCT compares
-    const int kl = __builtin_amdgcn_readfirstlane(k - j0);
-    // Publish the pivot column.  The array stays symmetric under the sweeps, so column k is row k: the PARTS threads of
-    // row k write their tiles with compile-time register indices (extracting register kl from the tile that holds
-    // column k is a dynamic index -- the compiler parks the whole tile in scratch memory for it, every sweep).
-    if (row == k) {
-      ldouble *cw = c + j0;
-#pragma unroll
-      for (int u = 0; u < NCT; u++) if (EXACT || u < ncv) cw[u] = T.v[u];
-      if (kl >= 0 && kl < ncv) {  // this thread holds the pivot itself
-        double piv = T.v[0];
-#pragma unroll
-        for (int u = 1; u < NCT; u++) piv = (u == kl) ? T.v[u] : piv;
-        c[n] = 1.0 / piv;
-      }
-    }
-    __syncthreads();  // (the buffer written two sweeps ago is free: every thread passed the barrier in between)
-    const double piv = c[k], ip = c[n];
-    if (!(piv > 0.0)) ok = false;
-    const double ci = live ? c[row] : 0.0;
-    const double f = ci * ip;
-    const ldouble *cb = c + j0;
-    const double mine = cb[lane < NCT ? lane : NCT - 1];  // element `lane` of this part's stretch of the pivot row
-    // the elements of the pivot row as wave-uniform values (scalar registers), all of them before the arithmetic
-    double cj[NCT];
-#pragma unroll
-    for (int u = 0; u < NCT; u++) cj[u] = lane_bcast(mine, u);
-    // the common case is one fused multiply-add per element; the pivot row (one thread per part) and the pivot column (the
-    // waves of one part) are fixed up under branches that the other wavefronts skip
-    if (row == k) {
-#pragma unroll
-      for (int u = 0; u < NCT; u++) T.v[u] = (u == kl) ? -ip : cj[u] * ip;   // row k: M_kj / p, pivot: -1 / p
-    } else {
-#pragma unroll
-      for (int u = 0; u < NCT; u++) T.v[u] = __builtin_fma(-f, cj[u], T.v[u]);  // M_ij - M_ik M_kj / p
-      if (kl >= 0 && kl < NCT) {                                                // column k: M_ik / p
-        switch (kl) {
-#define OQ_COLFIX(U) case U: if (U < NCT) T.v[U < NCT ? U : 0] = f; break;
-          OQ_COLFIX(0) OQ_COLFIX(1) OQ_COLFIX(2) OQ_COLFIX(3) OQ_COLFIX(4) OQ_COLFIX(5) OQ_COLFIX(6) OQ_COLFIX(7)
-          OQ_COLFIX(8) OQ_COLFIX(9) OQ_COLFIX(10) OQ_COLFIX(11) OQ_COLFIX(12) OQ_COLFIX(13) OQ_COLFIX(14) OQ_COLFIX(15)
-          OQ_COLFIX(16) OQ_COLFIX(17) OQ_COLFIX(18) OQ_COLFIX(19) OQ_COLFIX(20) OQ_COLFIX(21) OQ_COLFIX(22) OQ_COLFIX(23)
-          OQ_COLFIX(24) OQ_COLFIX(25) OQ_COLFIX(26) OQ_COLFIX(27) OQ_COLFIX(28) OQ_COLFIX(29) OQ_COLFIX(30) OQ_COLFIX(31)
-#undef OQ_COLFIX
-          default: break;
-        }
-      }
-    }
-    if (!EXACT) {
-#pragma unroll
-      for (int u = 0; u < NCT; u++) T.v[u] = (u < ncv) ? T.v[u] : 0.0;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < NCT; u++) T.v[u] = -T.v[u];  // the sweeps leave -M^-1
-  __syncthreads();  // c0 / c1 are scratch of the caller again
-  return ok;
 }
 
 
@@ -493,89 +431,145 @@ __device__ __forceinline__ bool invert_mfma(int n, double *scratch, ldouble *cb)
   return ok;
 }
 
-// xt <- M^-1 xt: registers x LDS broadcast, the PARTS column parts meet in LDS
+// LDS through a byte offset: with the arrays at compile-time addresses (the shape-specialised kernel) the base is an
+// immediate of the ds_read and the offset register goes in as it comes out of the packed word
+__device__ __forceinline__ double lds_at(const ldouble *base, unsigned byte_off) {
+  return *(const ldouble *)((const lchar *)base + byte_off);
+}
+
+// x~ = M^-1 b with b in s.bb: the thread's NCT entries of row `row` against its stretch of b (every lane of a quad reads
+// its own part: four addresses per wavefront, each a broadcast), then the four parts of the row add up inside the quad.
+// The lane of part 0 finishes the row on the spot: x~ to s.xt (the row-side product reads it), x and delta_x.
 template <int NCT, bool EXACT>
-__device__ __forceinline__ void apply_tile(int n, const MTile<NCT> &T, const Lds &s) {
-  const int row = mytid() & 127, part = mytid() >> 7;
+__device__ __forceinline__ void apply_tile(int n, const MTile<NCT> &T, const Lds &s, double alpha, const ldouble *xp, ldouble *x) {
+  const int row = mytid() >> 2, part = mytid() & 3;
   const int nc = EXACT ? NCT : (n + PARTS - 1) / PARTS, j0 = part * nc;
   const int ncv = EXACT ? NCT : max(0, min(nc, n - j0));
-  const ldouble *xb = s.xt + j0;
-  const int lane = mytid() & 63;
-  const double mine = xb[lane < NCT ? lane : NCT - 1];  // one LDS read per wavefront; the elements go round by lane_bcast
+  const ldouble *bp = s.bb + j0;
+  double bj[NCT];
+#pragma unroll
+  for (int u = 0; u < NCT; u++) bj[u] = (EXACT || u < ncv) ? bp[u] : 0.0;
+  const double xo = xp[row < n ? row : 0];
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll
   for (int u = 0; u < NCT; u++) {
-    const double xj = (EXACT || u < ncv) ? lane_bcast(mine, u) : 0.0;
-    if (u & 1) a1 = __builtin_fma(T.v[u], xj, a1); else a0 = __builtin_fma(T.v[u], xj, a0);
+    if (u & 1) a1 = __builtin_fma(T.v[u], bj[u], a1); else a0 = __builtin_fma(T.v[u], bj[u], a0);
   }
-  if (row < n) s.part[part * n + row] = a0 + a1;
-  __syncthreads();
-  for (int i = mytid(); i < n; i += NT) {
-    double a = s.part[i];
-#pragma unroll
-    for (int q = 1; q < PARTS; q++) a += s.part[q * n + i];
-    s.xt[i] = a;
+  double a = a0 + a1;
+  a += quad_xor<2>(a);
+  a += quad_xor<1>(a);
+  if (part == 0 && row < n) {
+    s.xt[row] = a;
+    const double xn = alpha * a + (1.0 - alpha) * xo;
+    x[row] = xn;
+    s.dx[row] = xn - xo;
   }
-  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The thread's share of the pattern of A in registers, both orientations:
+// The thread's share of the pattern of A, both orientations, as packed words in LDS (s.cw, s.rw):
 //   column side (A' v):  4 lanes per column, lane l of column c walks entries Ap[c] + l, + 4, ...   (KT per lane)
 //   row side    (A v):   2 lanes per row,    lane l of row r    walks entries Rp[r] + l, + 2, ...   (KR per lane)
-// A register holds (position of the value, index of the operand): both LDS reads of an entry are independent, where the
-// walk through the pattern arrays is a chain of three dependent ones.
-// Same lane-strided order and the same xor-shuffle reduction as rows_dot<4> / rows_dot<2>: bit-identical sums.  Used
-// when the pattern fits (at most 4 KT per column, 2 KR per row, 4 n and 2 m threads); rows_dot on the LDS copy otherwise.
+// A word holds (byte offset of the value inside Av) << 16 | (byte offset of the operand inside its vector): both LDS reads
+// of an entry take their address from one shift / one mask, where the walk through the pattern arrays is a chain of three
+// dependent reads.  A lane with fewer entries than KT / KR is padded with words that point at the zero behind the values
+// of A (and at operand 0): the loops have no tails and no predicates, the padded terms add +0.0 and change nothing.
+// The words live in LDS, not in registers: the hot loop fetches them with one 16-byte read (two on the row side) -- held
+// in registers across the ADMM loop they were the first thing the allocator spilled, and a spilled word came back from
+// scratch memory once per entry and iteration (round 2: ~10 dependent round trips to memory per iteration).
+// Same lane-strided order and the same quad reduction as rows_dot<4> / rows_dot<2>: bit-identical sums.  Used when the
+// pattern fits (at most 4 KT per column, 2 KR per row, 4 n and 2 m threads); rows_dot on the LDS copy otherwise.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int KT = 4, KR = 6;
-struct SparseRegs {
-  unsigned ce[KT], re[KR];  // (position in the value array) << 16 | (row resp. column index)
-  int ccnt, rcnt, col, row;  // col / row = -1: no work on that side
-};
-__device__ __forceinline__ bool sparse_fits(const Pattern &P) {
-  return 4 * P.n <= NT && 2 * P.m <= NT && P.max_col <= 4 * KT && P.max_row <= 2 * KR;
+__host__ __device__ inline bool sparse_fits(const Pattern &P) {
+  return 4 * P.n <= NT && 2 * P.m <= NT && P.max_col <= 4 * KT && P.max_row <= 2 * KR && (size_t)(P.nnzA + 1) * 8 < 65536;
 }
-__device__ __forceinline__ void load_sparse(const Pattern &P, const Lds &s, SparseRegs &R) {
+__device__ __forceinline__ void store_sparse(const Pattern &P, const Lds &s) {
   const int t = mytid();
-  R.col = (t >> 2) < P.n ? (t >> 2) : -1;
-  R.row = (t >> 1) < P.m ? (t >> 1) : -1;
-  R.ccnt = R.rcnt = 0;
+  const unsigned pad = (unsigned)(P.nnzA * 8) << 16;  // the zero behind the values, operand 0
+  const int col = (t >> 2) < P.n ? (t >> 2) : -1, row = (t >> 1) < P.m ? (t >> 1) : -1;
 #pragma unroll
   for (int e = 0; e < KT; e++) {
-    R.ce[e] = 0;
-    if (R.col >= 0) {
-      const int k = s.Ap[R.col] + (t & 3) + 4 * e;
-      if (k < s.Ap[R.col + 1]) { R.ce[e] = ((unsigned)k << 16) | s.Ai[k]; R.ccnt = e + 1; }
+    unsigned w = pad;
+    if (col >= 0) {
+      const int k = s.Ap[col] + (t & 3) + 4 * e;
+      if (k < s.Ap[col + 1]) w = ((unsigned)(k * 8) << 16) | (unsigned)(s.Ai[k] * 8);
     }
+    s.cw[t * KT + e] = w;
   }
 #pragma unroll
-  for (int e = 0; e < KR; e++) {
-    R.re[e] = 0;
-    if (R.row >= 0) {
-      const int q = s.Rp[R.row] + (t & 1) + 2 * e;
-      if (q < s.Rp[R.row + 1]) { R.re[e] = ((unsigned)s.Rmap[q] << 16) | s.Rc[q]; R.rcnt = e + 1; }
+  for (int e = 0; e < KRW; e++) {
+    unsigned w = pad;
+    if (row >= 0 && e < KR) {
+      const int q = s.Rp[row] + (t & 1) + 2 * e;
+      if (q < s.Rp[row + 1]) w = ((unsigned)(s.Rmap[q] * 8) << 16) | (unsigned)(s.Rc[q] * 8);
     }
+    s.rw[t * KRW + e] = w;
   }
 }
-// finish(col, sum over the column of A of value * v[row]) on one lane per column; every thread reaches the shuffles
-template <typename G>
-__device__ __forceinline__ void col_dot(const SparseRegs &R, const ldouble *Av, const ldouble *v, G finish) {
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint4_t luint4;
+typedef __attribute__((address_space(3))) uint2_t luint2;
+struct ColWords { unsigned w[KT]; };
+struct RowWords { unsigned w[KR]; };
+__device__ __forceinline__ ColWords col_words(const Lds &s) {
+  const uint4_t v = *(const luint4 *)(s.cw + mytid() * KT);
+  ColWords c;
+  c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+  return c;
+}
+__device__ __forceinline__ RowWords row_words(const Lds &s) {
+  const luint *p = s.rw + mytid() * KRW;
+  const uint4_t v = *(const luint4 *)p;
+  const uint2_t v2 = *(const luint2 *)(p + 4);
+  RowWords r;
+  r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; r.w[4] = v2.x; r.w[5] = v2.y;
+  return r;
+}
+// sum over the lane's entries of value * v[operand]; the value is read through `val(byte offset)` so that the scaling
+// passes can look at |value| with the same walk
+// finish(col, sum over the column of A of value * v[row]) on one lane per column
+// All LDS reads of a phase are issued before the first one is consumed (values and operands into arrays first, the
+// arithmetic in a second loop, in entry order): one round trip to LDS per phase instead of one per entry.
+// pre(index) reads what finish() will need about the column / row (every lane: the reads join the batch above, clamped
+// index for lanes without one); finish(index, sum, what pre returned) runs on one lane per column / row.
+template <typename PRE, typename G>
+__device__ __forceinline__ void col_dot(const Lds &s, const ldouble *v, int n, PRE pre, G finish) {
+  const ColWords c = col_words(s);
+  const int t = mytid(), j = t >> 2;
+  double av[KT], ov[KT];
+#pragma unroll
+  for (int e = 0; e < KT; e++) { av[e] = lds_at(s.Av, c.w[e] >> 16); ov[e] = lds_at(v, c.w[e] & 0xFFFFu); }
+  const auto ops = pre(j < n ? j : 0);
   double a = 0.0;
 #pragma unroll
-  for (int e = 0; e < KT; e++) if (e < R.ccnt) { const unsigned w = opaque_word(R.ce[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
+  for (int e = 0; e < KT; e++) a += av[e] * ov[e];
   a += quad_xor<2>(a);
   a += quad_xor<1>(a);
-  if ((mytid() & 3) == 0 && R.col >= 0) finish(R.col, a);
+  if ((t & 3) == 0 && j < n) finish(j, a, ops);
 }
-template <typename G>
-__device__ __forceinline__ void row_dot(const SparseRegs &R, const ldouble *Av, const ldouble *v, G finish) {
+template <typename PRE, typename G>
+__device__ __forceinline__ void row_dot(const Lds &s, const ldouble *v, int m, PRE pre, G finish) {
+  const RowWords r = row_words(s);
+  const int t = mytid(), i = t >> 1;
+  double av[KR], ov[KR];
+#pragma unroll
+  for (int e = 0; e < KR; e++) { av[e] = lds_at(s.Av, r.w[e] >> 16); ov[e] = lds_at(v, r.w[e] & 0xFFFFu); }
+  const auto ops = pre(i < m ? i : 0);
   double a = 0.0;
 #pragma unroll
-  for (int e = 0; e < KR; e++) if (e < R.rcnt) { const unsigned w = opaque_word(R.re[e]); a += Av[w >> 16] * v[w & 0xFFFFu]; }
+  for (int e = 0; e < KR; e++) a += av[e] * ov[e];
   a += quad_xor<1>(a);
-  if ((mytid() & 1) == 0 && R.row >= 0) finish(R.row, a);
+  if ((t & 1) == 0 && i < m) finish(i, a, ops);
 }
+// a wave-uniform double the optimiser cannot see through: what is derived from it (1 - alpha ...) is recomputed where it is
+// used instead of being kept in -- or spilled from -- a register across the ADMM loop
+__device__ __forceinline__ double opaque_s(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+struct Ops2 { double a, b; };
+struct Ops6 { double a, b, c, d, e, f; };
 
 #ifdef OQ_BATCH_PROFILE
 #define PROF_DECL long long pt0 = clock64(), pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -597,7 +591,7 @@ __device__ __forceinline__ void row_dot(const SparseRegs &R, const ldouble *Av, 
 // ---------------------------------------------------------------------------------------------------------
 enum { N_PRI = 14, N_DUA = 15, N_OBJ = 16, N_STATUS = 17, N_COUNT = 24 };
 struct CheckArgs {
-  int n, m, nnzA, nnzF, swapped, uns, passes, last;
+  int n, m, nnzA, nnzF, swapped, uns, passes, last, words;
   double ea, er, epi, edi, c, cinv;
 };
 extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -632,7 +626,7 @@ template <int CN, int CM, int CA, int CF>
 __device__ __noinline__ void residual_phase(CheckArgs a) {
   Pattern P;
   P.n = CN ? CN : a.n; P.m = CN ? CM : a.m; P.nnzA = CN ? CA : a.nnzA; P.nnzF = CN ? CF : a.nnzF;
-  const Lds s = carve((ldouble *)lds_raw, P);
+  const Lds s = carve((ldouble *)lds_raw, P, a.words != 0);
   const int n = P.n, m = P.m, tid = mytid();
   ldouble *x = a.swapped ? s.xp : s.x, *z = a.swapped ? s.zp : s.z;
   ldouble *nrm = s.nrm, *tmp = s.nrm + 18;  // tmp: 6 scratch results of the small reductions
@@ -754,7 +748,7 @@ __device__ __noinline__ void residual_phase(CheckArgs a) {
 // CN > 0: the instance shape (n, m, nnz(A), nnz(P full)) = (CN, CM, CA, CF) is known at compile time -- every LDS address
 // becomes an immediate and every vector loop a fixed trip count (the registers otherwise spent on ~35 LDS pointers are
 // what the inverse needs); CN = 0: the same source with the shape read from the pattern at run time.
-template <int NCT, int CN, int CM, int CA, int CF, bool MFMA>
+template <int NCT, int CN, int CM, int CA, int CF>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_batch_solve(Pattern Pin, OSQPSettings st, int count, double *__restrict__ scratch_all,
                                                     const double *__restrict__ Px_all,
                                                     const double *__restrict__ Ax_all, const double *__restrict__ q_all,
@@ -768,7 +762,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (CN > 0) { P.n = CN; P.m = CM; P.nnzA = CA; P.nnzF = CF; }
   constexpr bool EXACT = CN > 0 && PARTS * NCT == CN;
   const int n = P.n, m = P.m, tid = mytid();
-  Lds s = carve((ldouble *)lds_raw, P);
+  // the thread's share of the entries of A as packed words in LDS (both orientations; the positions do not change under
+  // scaling, so the walks of the scaling passes use them too: 4 lanes per column, 2 per row)
+  const bool regs = sparse_fits(P);
+  Lds s = carve((ldouble *)lds_raw, P, regs);
   PROF_DECL
   // ---- stage the shared pattern (16-bit) and load the instance -----------------
   for (int k = tid; k <= n; k += NT) { s.Ap[k] = (unsigned short)P.Ap[k]; s.Fp[k] = (unsigned short)P.Fp[k]; }
@@ -776,6 +773,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   for (int k = tid; k < P.nnzA; k += NT) { s.Ai[k] = (unsigned short)P.Ai[k]; s.Rc[k] = (unsigned short)P.Rc[k]; s.Rmap[k] = (unsigned short)P.Rmap[k]; }
   for (int k = tid; k < P.nnzF; k += NT) s.Fc[k] = (unsigned short)P.Fc[k];
   for (int k = tid; k < P.nnzA; k += NT) s.Av[k] = Ax_all[(size_t)inst * P.nnzA + k];
+  if (tid == 0) s.Av[P.nnzA] = 0.0;  // what padded entries of the packed words point at
   for (int k = tid; k < P.nnzF; k += NT) s.Pv[k] = Px_all[(size_t)inst * P.nnzP + P.Fmap[k]];
   for (int j = tid; j < n; j += NT) { s.q[j] = q_all[(size_t)inst * n + j]; s.D[j] = 1.0; s.x[j] = 0.0; s.xp[j] = 0.0; s.dx[j] = 0.0; }
   for (int i = tid; i < m; i += NT) {
@@ -785,30 +783,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __syncthreads();
   PROF(0)
   // ---- K0: Ruiz equilibration + cost scaling --------------------------------
-  // the thread's share of the entries of A, both orientations (positions and indices in registers, values from LDS): the
-  // positions do not change under scaling, so the walks of the scaling passes use them too (4 lanes per column, 2 per
-  // row: a column of 13 entries is 4 dependent LDS round trips instead of 13)
-  const bool regs = sparse_fits(P);
-  SparseRegs R;
-  if (regs) load_sparse(P, s, R);
+  if (regs) store_sparse(P, s);
+  __syncthreads();
   double c = 1.0;
   for (int it = 0; it < st.scaling; it++) {
     if (regs) {
+      const ColWords cwd = col_words(s);
       double mx = 0.0;
 #pragma unroll
-      for (int e = 0; e < KT; e++) if (e < R.ccnt) mx = fmax(mx, fabs(s.Av[opaque_word(R.ce[e]) >> 16]));
+      for (int e = 0; e < KT; e++) mx = fmax(mx, fabs(lds_at(s.Av, cwd.w[e] >> 16)));  // padded entries: |0|
       mx = fmax(mx, quad_xor<2>(mx));
       mx = fmax(mx, quad_xor<1>(mx));
-      if ((tid & 3) == 0 && R.col >= 0) {
-        const int j = R.col;
+      if ((tid & 3) == 0 && (tid >> 2) < n) {
+        const int j = tid >> 2;
         for (int q = s.Fp[j]; q < s.Fp[j + 1]; q++) mx = fmax(mx, fabs(s.Pv[q]));
         s.tn[j] = 1.0 / sqrt(lim(mx));
       }
+      const RowWords rwd = row_words(s);
       double mr = 0.0;
 #pragma unroll
-      for (int e = 0; e < KR; e++) if (e < R.rcnt) mr = fmax(mr, fabs(s.Av[opaque_word(R.re[e]) >> 16]));
+      for (int e = 0; e < KR; e++) mr = fmax(mr, fabs(lds_at(s.Av, rwd.w[e] >> 16)));
       mr = fmax(mr, quad_xor<1>(mr));
-      if ((tid & 1) == 0 && R.row >= 0) s.tm[R.row] = 1.0 / sqrt(lim(mr));
+      if ((tid & 1) == 0 && (tid >> 1) < m) s.tm[tid >> 1] = 1.0 / sqrt(lim(mr));
     } else {
     for (int j = tid; j < n; j += NT) {
       double mx = 0.0;
@@ -830,12 +826,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         s.Pv[q] = (s.Pv[q] * s.tn[lo]) * s.tn[hi];
       }
     if (regs) {
-      if (R.col >= 0) {
-        const double tj = s.tn[R.col];
+      if ((tid >> 2) < n) {
+        const double tj = s.tn[tid >> 2];
+        const ColWords cwd = col_words(s);
+        const unsigned padw = (unsigned)(P.nnzA * 8);
 #pragma unroll
-        for (int e = 0; e < KT; e++) if (e < R.ccnt) {
-          const unsigned w = opaque_word(R.ce[e]);
-          s.Av[w >> 16] = (s.Av[w >> 16] * s.tm[w & 0xFFFFu]) * tj;
+        for (int e = 0; e < KT; e++) {
+          const unsigned vo = cwd.w[e] >> 16;
+          if (vo != padw) *(ldouble *)((lchar *)s.Av + vo) = (lds_at(s.Av, vo) * lds_at(s.tm, cwd.w[e] & 0xFFFFu)) * tj;
         }
       }
       for (int j = tid; j < n; j += NT) { s.q[j] *= s.tn[j]; s.D[j] *= s.tn[j]; }
@@ -886,17 +884,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   int status = OSQP_UNSOLVED;
   double *scratch = scratch_all + (size_t)inst * n * n;
   MTile<NCT> Minv;
-  // scratch of the sweeps, n + 1 doubles each: tn runs on into ldinv (unused by this kernel), Px into Aty -- Px and Aty are
-  // only live inside a residual evaluation
-  ldouble *gj0 = s.tn, *gj1 = s.Px;
   // y = A v / y = A' v through whichever walk of A applies
-  auto a_rows = [&](const ldouble *v, auto finish) {
-    if (regs) row_dot(R, s.Av, v, finish);
-    else rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * v[s.Rc[q]]; }, finish);
+  auto a_rows = [&](const ldouble *v, auto pre, auto finish) {
+    if (regs) row_dot(s, v, m, pre, finish);
+    else rows_dot<2>(m, s.Rp, [&](int q) { return s.Av[s.Rmap[q]] * v[s.Rc[q]]; }, [&](int r, double a) { finish(r, a, pre(r)); });
   };
-  auto a_cols = [&](const ldouble *v, auto finish) {
-    if (regs) col_dot(R, s.Av, v, finish);
-    else rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * v[s.Ai[k]]; }, finish);
+  auto a_cols = [&](const ldouble *v, auto pre, auto finish) {
+    if (regs) col_dot(s, v, n, pre, finish);
+    else rows_dot<4>(n, s.Ap, [&](int k) { return s.Av[k] * v[s.Ai[k]]; }, [&](int r, double a) { finish(r, a, pre(r)); });
   };
   PROF(2)
   const bool uns = st.scaling && !st.scaled_termination;
@@ -916,39 +911,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];
   __syncthreads();
   for (iter = 1; iter <= max_iter; iter++) {
-    const int tid = mytid();  // shadows the outer one: nothing derived from the thread id outlives an iteration
     if (need_factor) {  // first iteration and after every rho update
-      assemble_tile<NCT, EXACT, !MFMA>(P, s, st.sigma, scratch, Minv);
+      assemble_scratch(P, s, st.sigma, scratch);
       PROF(8)
-      bool pd;
-      if (MFMA) {
-        pd = invert_mfma<(NCT <= 16 ? 2 : (NCT <= 25 ? 4 : 5))>(n, scratch, s.gjc);
-        load_tile<NCT, EXACT>(n, scratch, Minv);
-      } else pd = invert_tile<NCT, EXACT>(n, Minv, gj0, gj1);
+      const bool pd = invert_mfma<(NCT <= 16 ? 2 : (NCT <= 25 ? 4 : 5))>(n, scratch, s.gjc);
+      load_tile<NCT, EXACT>(n, scratch, Minv);
       if (!pd) { status = OSQP_NON_CVX; iter--; break; }
       need_factor = false;
       PROF(2)
     }
     { ldouble *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
     // b = sigma x_prev - q + A'(rho z_prev - y); s.zt = rho z_prev - y was left behind by the previous z / y update
-    a_cols(s.zt, [&](int j, double a) { s.xt[j] = sigma * xp[j] - s.q[j] + a; });
+    a_cols(s.zt, [&](int j) { return Ops2{xp[j], s.q[j]}; }, [&](int j, double a, const Ops2 &o) { s.bb[j] = sigma * o.a - o.b + a; });
     __syncthreads();
     PROF(3)
-    // x~ = M^-1 b: the thread's tile of the inverse against b from LDS (every lane of a wavefront reads the same word:
-    // a broadcast), the column parts meet in LDS
-    apply_tile<NCT, EXACT>(n, Minv, s);
+    // x~ = M^-1 b: the thread's tile of the inverse against its stretch of b, the four parts of a row add up inside a
+    // quad of lanes; the lane that ends up with the row writes x~, x and delta_x
+    apply_tile<NCT, EXACT>(n, Minv, s, opaque_s(alpha), xp, x);
+    __syncthreads();
     PROF(4)
     // z~ = A x~ row by row, each row finished on the spot: z, y, delta_y and s.zt = rho z - y for the next right-hand side
-    a_rows(s.xt, [&](int i, double zt) {
-      const double zh = alpha * zt + (1.0 - alpha) * zp[i];
-      const double yo = s.y[i];
-      const double zn = fmin(fmax(zh + s.rhoi[i] * yo, s.l[i]), s.u[i]);
+    a_rows(s.xt, [&](int i) { return Ops6{zp[i], s.y[i], s.rhoi[i], s.l[i], s.u[i], s.rho[i]}; },
+           [&](int i, double zt, const Ops6 &o) {
+      const double al = opaque_s(alpha);
+      const double zh = al * zt + (1.0 - al) * o.a;
+      const double yo = o.b;
+      const double zn = fmin(fmax(zh + o.c * yo, o.d), o.e);
       z[i] = zn;
-      const double d = s.rho[i] * (zh - zn);
+      const double d = o.f * (zh - zn);
       s.dy[i] = d; s.y[i] = yo + d;
-      s.zt[i] = s.rho[i] * zn - (yo + d);
+      s.zt[i] = o.f * zn - (yo + d);
     });
-    for (int j = tid; j < n; j += NT) { double xn = alpha * s.xt[j] + (1.0 - alpha) * xp[j]; x[j] = xn; s.dx[j] = xn - xp[j]; }
     __syncthreads();
     PROF(5)
     const bool last = iter == max_iter;
@@ -960,7 +953,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     {
       CheckArgs ca;
       ca.n = n; ca.m = m; ca.nnzA = P.nnzA; ca.nnzF = P.nnzF;
-      ca.swapped = (x != s.x); ca.uns = uns; ca.passes = (due || last) ? (last ? 2 : 1) : 0; ca.last = last;
+      ca.swapped = (x != s.x); ca.uns = uns; ca.words = regs; ca.passes = (due || last) ? (last ? 2 : 1) : 0; ca.last = last;
       ca.ea = st.eps_abs; ca.er = st.eps_rel; ca.epi = st.eps_prim_inf; ca.edi = st.eps_dual_inf; ca.c = c; ca.cinv = cinv;
       residual_phase<CN, CM, CA, CF>(ca);
     }
@@ -980,7 +973,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
         rho = est; rho_updates++;
         set_rho(P, s, rho, false);
-        for (int i = tid; i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];  // the carried vector follows rho
+        for (int i = mytid(); i < m; i += NT) s.zt[i] = s.rho[i] * z[i] - s.y[i];  // the carried vector follows rho
         __syncthreads();
         need_factor = true;  // picked up at the top of the next iteration
       }
@@ -1133,7 +1126,7 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
                   const double *l, const double *u, double *x, double *y, double *info, int x_stride, int y_stride, int info_stride,
                   int info_cols, hipStream_t s) {
   const Pattern &P = dp.P;
-  size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF);
+  size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF, sparse_fits(P));
   if (P.n > 128 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 128 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
   const size_t need = (size_t)count * P.n * P.n;
@@ -1146,20 +1139,11 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
               x_stride, y_stride, info_stride, info_cols);                                                                             \
   } while (0)
   // shapes compiled in (same source, constants folded): the MPC family of BASELINE.json config 5
-  // OSQP_AMD_BATCH_MFMA=0: the inverse by rank-1 sweeps on the vector units (invert_tile) instead of the matrix cores
-  const bool mfma = !(getenv("OSQP_AMD_BATCH_MFMA") && atoi(getenv("OSQP_AMD_BATCH_MFMA")) == 0);
   const bool mpc = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N;
-  if (mfma) {
-    if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N, true);
-    else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0, true);
-    else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0, true);
-    else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0, true);
-  } else {
-    if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N, false);
-    else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0, false);
-    else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0, false);
-    else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0, false);
-  }
+  if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N);
+  else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0);
+  else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0);
+  else OQ_BATCH_LAUNCH(32, 0, 0, 0, 0);
 #undef OQ_BATCH_LAUNCH
 }
 
