@@ -14,3 +14,19 @@ def test_moi_face_on_oracle(oracle_lib, case):
 @pytest.mark.parametrize("case", moi_cases.ALL, ids=lambda f: f.__name__)
 def test_moi_face_on_product(product_lib, case):
     case(product_lib)
+
+
+import moi_conformance
+
+
+@pytest.mark.parametrize("case", moi_conformance.ALL, ids=lambda f: f.__name__)
+def test_moi_conformance_subset_on_oracle(oracle_lib, case):
+    """The known-answer problems of MathOptInterface's generic suite that the reference runs through `MOI.Test.runtests`
+    [REF test/MOI_wrapper.jl:59-93], restated by name (tests/moi_conformance.py)."""
+    case(oracle_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", moi_conformance.ALL, ids=lambda f: f.__name__)
+def test_moi_conformance_subset_on_product(product_lib, case):
+    case(product_lib)
