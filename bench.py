@@ -688,12 +688,13 @@ def batch_cpu_leg(oq, args):
     out = {"value": round(its / spent, 2), "unit": "iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
            "sample": f"{k} instances of the batch solved one after another by the CPU oracle (setup + solve) in {spent:.1f} s",
            "instances_per_s": round(k / spent, 2)}
-    cores = os.cpu_count() or 1
+    cores = usable_cores()[0]
     try:
         with mp.get_context("fork").Pool(cores) as pool:
             res = pool.map(_batch_cpu_worker, [(r, cores, args.cpu_seconds / 2.0, opts) for r in range(cores)])
         kk, ii, tmax = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
-        out["all_cores"] = {"cores": cores, "value": round(ii / tmax, 1), "instances_per_s": round(kk / tmax, 1),
+        out["all_cores"] = {"cores": cores, "host_cores": os.cpu_count(), "cgroup_cpu_quota": usable_cores()[1],
+                            "value": round(ii / tmax, 1), "instances_per_s": round(kk / tmax, 1),
                             "sample": f"{kk} instances over {cores} processes (one per host core) in {tmax:.1f} s"}
     except Exception as e:  # the single-thread figure stands on its own
         out["all_cores"] = {"error": str(e)[:200]}
@@ -762,12 +763,37 @@ def _stream_worker(task):
     return 24.0 * n * reps, time.perf_counter() - t0
 
 
+def usable_cores():
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup's CPU quota (a container on a
+    256-core host is often allowed a fraction of it -- the all-cores figures below are within that allowance and say so)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def host_stream_gbs(cores=None, n=8_000_000, reps=12):
     """STREAM-style add (2 reads + 1 write, 24 B per element, write-allocate not counted) on every host core at once, one
     process per core: the memory bandwidth a perfectly threaded host implementation could draw on."""
     import multiprocessing as mp
 
-    cores = cores or os.cpu_count() or 1
+    cores = cores or usable_cores()[0]
     try:
         with mp.get_context("fork").Pool(cores) as pool:
             res = pool.map(_stream_worker, [(n, reps)] * cores)
@@ -781,7 +807,8 @@ def all_cores_bound(step_bytes):
     gbs, cores = host_stream_gbs()
     if not gbs:
         return None
-    return {"host_stream_GBs": round(gbs, 1), "cores": cores, "iterations_per_s": round(gbs * 1e9 / step_bytes, 3),
+    return {"host_stream_GBs": round(gbs, 1), "cores": cores, "host_cores": os.cpu_count(), "cgroup_cpu_quota": usable_cores()[1],
+            "iterations_per_s": round(gbs * 1e9 / step_bytes, 3),
             "note": "an upper bound for ANY host implementation of this step (bandwidth-perfect, all cores): measured STREAM-add bandwidth of "
                     "the host / algorithmic bytes of one ADMM iteration at the measured CG count; nobody's code runs at it"}
 
