@@ -605,11 +605,10 @@ def batch_leg(ctx, want_cpu):
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    x, y, info = batch.split_packed(packed)
-    info = info.cpu().numpy()
+    x, y, info = batch.split_packed(packed.numpy())  # the packed array is the library's own allocation (no torch on this path)
     iters = float(info[:, 0].sum())
     # every rank must hold the whole batch after the gather: a checksum of checksums over the ranks
-    check = torch.stack([x.sum(), y.sum(), torch.as_tensor(float(iters), device=x.device)])
+    check = torch.tensor([float(x.sum()), float(y.sum()), float(iters)], dtype=torch.float64, device="cuda")
     same = True
     if world > 1:
         allc = [torch.zeros_like(check) for _ in range(world)]

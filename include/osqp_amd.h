@@ -413,6 +413,12 @@ c_int osqp_amd_batch_mpc_create(osqp_amd_batch **out, c_int total, unsigned long
 c_int osqp_amd_batch_mpc_solve(osqp_amd_batch *batch, c_float *packed_dev);
 c_int osqp_amd_batch_destroy(osqp_amd_batch *batch);
 
+/* Device memory for callers without an allocator of their own (the packed result array above): plain hipMalloc / hipFree /
+ * hipMemcpy on `device`.  copy kind: 0 device -> host, 1 host -> device, 2 device -> device; blocking. */
+void *osqp_amd_device_alloc(c_int bytes, c_int device);
+c_int osqp_amd_device_free(void *ptr, c_int device);
+c_int osqp_amd_device_copy(void *dst, const void *src, c_int bytes, c_int kind, c_int device);
+
 /* Differences between the batched path and osqp_setup / osqp_solve: instances share one sparsity pattern, n <= 128,
  * fewer than 65536 rows and non-zeros, everything must fit 160 KB of LDS; `adaptive_rho_interval` = 0 (automatic) means
  * every 100 iterations (there is no per-instance clock); `polish`, `time_limit`, `warm_start`, `verbose` and

@@ -7,7 +7,7 @@ communication during the solve.  The only collective is the final gather of
 the packed per-rank results [x | y | info]: an in-place all-gather on the
 library's own communicator (`sharded.RcclComm`: ncclAllGather over xGMI issued by
 libosqp_amd.so itself; `sharded.HostComm`: pinned-host staging + a caller callback)
--- `MpcBatch` below.  torch is only the allocator of the device array here.
+-- `MpcBatch` below, which needs no torch at all: its packed result array is a `DeviceArray` allocated through the library.
 """
 import ctypes as C
 
@@ -99,6 +99,44 @@ def solve_mpc_sharded(solver, count, seed, rank=0, world=1, gather=None):
     return split_packed(full)
 
 
+class DeviceArray:
+    """A [rows x cols] fp64 array in HBM allocated through the library (osqp_amd_device_alloc): what `MpcBatch.solve` writes
+    into.  `numpy()` downloads it; `clone()` copies it on the device."""
+
+    def __init__(self, lib, rows, cols, device=0):
+        self.lib, self.shape, self.device = lib, (int(rows), int(cols)), int(device)
+        self.nbytes = 8 * self.shape[0] * self.shape[1]
+        self.ptr = lib.osqp_amd_device_alloc(self.nbytes, self.device)
+        if not self.ptr:
+            raise OSQPError("device allocation failed: " + lib.osqp_amd_last_error().decode())
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numpy(self):
+        out = np.empty(self.shape)
+        if self.lib.osqp_amd_device_copy(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes, 0, self.device) != 0:
+            raise OSQPError("device copy failed: " + self.lib.osqp_amd_last_error().decode())
+        return out
+
+    def clone(self):
+        other = DeviceArray(self.lib, self.shape[0], self.shape[1], self.device)
+        if self.lib.osqp_amd_device_copy(other.ptr, self.ptr, self.nbytes, 2, self.device) != 0:
+            raise OSQPError("device copy failed: " + self.lib.osqp_amd_last_error().decode())
+        return other
+
+    def free(self):
+        if self.ptr:
+            self.lib.osqp_amd_device_free(self.ptr, self.device)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class MpcBatch:
     """`total` MPC instances cut over the ranks of `comm` (None: one rank), resident in HBM; `solve()` = rows K11 + K12
     in one library call (osqp_amd_batch_mpc_solve): this rank's block, one workgroup per instance, written in place into
@@ -117,9 +155,7 @@ class MpcBatch:
             raise OSQPError("Error in batched setup: " + lib.osqp_amd_last_error().decode())
 
     def alloc(self):
-        import torch
-
-        return torch.empty((self.total, MPC_N + MPC_M + INFO_COLS), dtype=torch.float64, device=f"cuda:{self.device}")
+        return DeviceArray(self.lib, self.total, MPC_N + MPC_M + INFO_COLS, self.device)
 
     def solve(self, out=None):
         packed = self.alloc() if out is None else out

@@ -265,6 +265,31 @@ c_int osqp_amd_comm_info(const osqp_amd_comm *c, c_int *rank, c_int *world, c_in
   if (transport_ranks) *transport_ranks = k->transport_ranks();
   return 0;
 }
+// Device memory for callers that have no allocator of their own (the packed result array of the batched path: the Python
+// mirror and bench.py hand these to osqp_amd_batch_mpc_solve -- torch is not needed for a buffer)
+void *osqp_amd_device_alloc(c_int bytes, c_int device) {
+  if (bytes <= 0) return nullptr;
+  void *p = nullptr;
+  c_int rc = guarded([&]() {
+    require_device();
+    DeviceScope on_device((int)device);
+    HIP_CHECK(hipMalloc(&p, (size_t)bytes));
+    return 0;
+  });
+  return rc == 0 ? p : nullptr;
+}
+c_int osqp_amd_device_free(void *p, c_int device) {
+  if (!p) return 0;
+  return guarded([&]() { DeviceScope on_device((int)device); HIP_CHECK(hipFree(p)); return 0; });
+}
+c_int osqp_amd_device_copy(void *dst, const void *src, c_int bytes, c_int kind, c_int device) {  // kind 0: device -> host, 1: host -> device, 2: device -> device
+  if (!dst || !src || bytes < 0 || kind < 0 || kind > 2) return 1;
+  return guarded([&]() {
+    DeviceScope on_device((int)device);
+    HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, kind == 0 ? hipMemcpyDeviceToHost : (kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice)));
+    return 0;
+  });
+}
 c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_int *Ap, const c_int *Ai,
                               c_int ordering, c_int smax, c_float *out, c_int count) {
   if (n <= 0 || m < 0 || !Pp || !Ap || !out || count < 13 || smax < 1) return 1;

@@ -445,9 +445,11 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   auto early_compact = [&](int which) {
     DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
     if (!early || M.rows == 0 || M.nnz == 0 || !panel_wanted(M)) return;
-    try { panel_build(M, stream); }
+    DevBuf<uint32_t> p2s;
+    if (!comm) p2s.alloc((size_t)M.nnz);  // the slot of every entry, recorded while the slices are filled
+    try { panel_build(M, stream, p2s.get()); }
     catch (const Error &) { M.panel = DevPanel(); return; }  // stays on its CSR arrays
-    compact_one(which);
+    compact_one(which, &p2s);
   };
   if (m > 0) { early_compact(0); setup_mark("slices of A"); early_compact(1); setup_mark("slices of A'"); }
   // ---- full symmetric P from the upper triangle ----
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const in
 // release each CSR copy as soon as its sliced-ELL copy exists (setup_device: the high-water mark of the device memory stays
 // near the resident size instead of CSR + slices of all three), and so that a matrix whose slices cannot be built (mostly
 // padding) simply keeps its CSR arrays: every consumer looks at the matrix's own flag.
-void Engine::compact_one(int which) {
+void Engine::compact_one(int which, DevBuf<uint32_t> *known_slots) {
   DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
   if (M.compact || !panel_can_compact(M)) return;
   // The slot maps take the place of the position maps, entry by entry, in the same buffers (a thread reads its position and
@@ -650,8 +652,9 @@ void Engine::compact_one(int which) {
   };
   const bool maps = !comm;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
   if (maps) {
-    DevBuf<uint32_t> p2s((size_t)M.nnz);
-    panel_slot_of_pos(M, p2s.get(), stream);
+    DevBuf<uint32_t> own;
+    if (!(known_slots && known_slots->n > 0)) { own.alloc((size_t)M.nnz); panel_slot_of_pos(M, own.get(), stream); }
+    DevBuf<uint32_t> &p2s = (known_slots && known_slots->n > 0) ? *known_slots : own;
     if (which == 0) { compose_in_place(nnzA, A_k2pos, p2s); sync(); }
     else if (which == 1) { sync(); At_k2slot = std::move(p2s); }  // position k of A' is the caller's nnz index k
     else { compose_in_place(nnzPtriu, P_k2lo, p2s); compose_in_place(nnzPtriu, P_k2up, p2s); sync(); }

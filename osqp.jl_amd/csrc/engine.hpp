@@ -153,7 +153,7 @@ struct Engine {
   void compact_matrices();
   void setup_mark(const char *what);
   double mark_prev = 0.0;
-  void compact_one(int which);
+  void compact_one(int which, DevBuf<uint32_t> *known_slots = nullptr);
   bool compact_wanted(int64_t stored) const;
   bool pcg_certain() const;
   void set_rho_vec();

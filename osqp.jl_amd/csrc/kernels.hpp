@@ -54,8 +54,9 @@ void spmv_pair(const DevCsr &Ma, const DevCsr &Mb, const double *x, double *ya, 
 
 // LDS-staged column-panel variant (panel.hip); spmv() dispatches to it when M.panel.active
 bool panel_wanted(const DevCsr &M);
-void panel_build(DevCsr &M, hipStream_t s);                    // structure + values from the CSR arrays
-void panel_fill(DevCsr &M, bool with_cols, hipStream_t s);     // refresh the values after the CSR values changed
+// slot (may be null): slot[k] = position of CSR entry k inside the sliced copy, recorded while the entries are placed
+void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot = nullptr);                 // structure + values from the CSR arrays
+void panel_fill(DevCsr &M, bool with_cols, hipStream_t s, uint32_t *slot = nullptr);  // refresh the values after the CSR values changed
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
                 const double *v, hipStream_t s, const SpmvExtra *extra = nullptr);
 // compact mode: the CSR column / value arrays released, every maintenance pass on the sliced-ELL copy (panel.hip)
