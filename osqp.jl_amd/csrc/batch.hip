@@ -481,7 +481,8 @@ __device__ __forceinline__ void apply_tile(int n, const MTile<NCT> &T, const Lds
 // pattern fits (at most 4 KT per column, 2 KR per row, 4 n and 2 m threads); rows_dot on the LDS copy otherwise.
 // ---------------------------------------------------------------------------------------------------------
 __host__ __device__ inline bool sparse_fits(const Pattern &P) {
-  return 4 * P.n <= NT && 2 * P.m <= NT && P.max_col <= 4 * KT && P.max_row <= 2 * KR && (size_t)(P.nnzA + 1) * 8 < 65536;
+  // m > 0: a padded entry reads operand 0 of the vector it is multiplied into -- there has to be one (0 x garbage is not 0)
+  return P.m > 0 && P.nnzA > 0 && 4 * P.n <= NT && 2 * P.m <= NT && P.max_col <= 4 * KT && P.max_row <= 2 * KR && (size_t)(P.nnzA + 1) * 8 < 65536;
 }
 __device__ __forceinline__ void store_sparse(const Pattern &P, const Lds &s) {
   const int t = mytid();
