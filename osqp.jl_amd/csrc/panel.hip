@@ -737,7 +737,19 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot) {
   DevBuf<int64_t> gcnt((size_t)gcells + 1), tid((size_t)gcells + 1);
   OQ_LAUNCH(k_group_count, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, P.B, P.Gp, gcells, cnt.get(), gcnt.get());
   cnt.release();
-  const int64_t budget = std::max<int64_t>((int64_t)panel_tile_nnz() * P.Gp, kTileRowsMax);
+  // Mid-size matrices (fewer tiles than twice the compute units): a 65536-entry budget leaves a matrix of 1e7 entries with 153
+  // tiles on 256 CUs, and the paired A p / P p launch with one full round and a fifth of one.  A budget that gives the single
+  // matrix ~0.85 tiles per CU (rand-1e5: 46000 -> 217 tiles, the pair 437 = two rounds, the second 70 % full) measured +4 % on
+  // the rand-1e5 step; below ~42000 the single product falls into a second round and loses more than the pair gains
+  // (profiles/r03_rand1e5_tile_sweep.txt).
+  int64_t tile_nnz = panel_tile_nnz();
+  if (!getenv("OSQP_AMD_PANEL_TILE_NNZ") && P.Gp == 1) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if ((double)M.nnz / (double)tile_nnz < (double)cus)
+      tile_nnz = std::max<int64_t>(32768, std::min<int64_t>(tile_nnz, (int64_t)((double)M.nnz / (0.85 * (double)cus))));
+  }
+  const int64_t budget = std::max<int64_t>(tile_nnz * P.Gp, kTileRowsMax);
   const int64_t cmin = (budget + kTileRowsMax - 1) / kTileRowsMax;
   OQ_LAUNCH(k_tile_cost, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, gcells, cmin, gcnt.get());
   exclusive_scan(gcnt.get(), tid.get(), gcells, s);
