@@ -169,8 +169,12 @@ static c_int setup_from_host(OSQPWorkspace **workp, const OSQPData *data, const 
     Engine &e = *E(w);
     e.comm = comm;
     e.tic();
-    if (comm) { auto src = host_columns(data); e.setup_sharded(*src, *settings); }
-    else e.setup_host(data, *settings);
+    {
+      DevCacheScope pooled;  // one stream throughout; what is pooled goes back to the driver inside setup_time
+      if (comm) { auto src = host_columns(data); e.setup_sharded(*src, *settings); }
+      else e.setup_host(data, *settings);
+      dev_cache_trim();
+    }
     finish_setup(w);
     w->info->setup_time = e.toc();
     return 0;
@@ -192,10 +196,12 @@ static c_int setup_from_generator(OSQPWorkspace **workp, c_int kind, c_int n, c_
     w = new_workspace();
     Engine &e = *E(w);
     e.comm = comm;
+    DevCacheScope pooled;  // the generator's stream and the engine's are separated by a synchronisation
     if (comm) {  // only this rank's row blocks are ever resident
       e.tic();
       auto src = generated_columns((int)kind, (int)n, (int)per_row, seed, nullptr);
       e.setup_sharded(*src, *settings);
+      dev_cache_trim();
       finish_setup(w);
       w->info->setup_time = e.toc();
       return 0;
@@ -208,6 +214,7 @@ static c_int setup_from_generator(OSQPWorkspace **workp, c_int kind, c_int n, c_
     HIP_CHECK(hipDeviceSynchronize());
     e.tic();  // setup_time covers setup only; generation stands in for the caller's own data
     e.setup_device(nn, mm, Pp, Pi, Px, Ap, Ai, Ax, q, l, u, *settings);
+    dev_cache_trim();  // inside setup_time: pooled chunks are this process's memory until they are returned
     finish_setup(w);
     w->info->setup_time = e.toc();
     return 0;

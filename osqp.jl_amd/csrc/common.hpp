@@ -1,6 +1,7 @@
 // common.hpp -- shared declarations of the HIP engine (libosqp_amd.so).
 // MI355X / gfx950 only: 64-lane wavefronts, 256 CUs in 8 XCDs, HBM3E.
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -58,35 +59,53 @@ inline void post_launch(const char *name, hipStream_t s) {
 // ---- device buffers -------------------------------------------------------
 extern size_t g_device_bytes;  // bytes currently allocated through DevBuf
 extern size_t g_device_peak;   // high-water mark of the above since the process started
+extern double g_alloc_s, g_free_s;  // wall time spent inside hipMalloc / hipFree by DevBuf (OSQP_AMD_SETUP_TRACE prints them)
+extern size_t g_cache_bytes;  // blocks parked by dev_free inside a DevCacheScope (counted in the peak: they are still this process's)
+inline double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Device blocks of a setup.  A setup allocates and releases ~150 GB of temporaries for a 62 GB peak (rand-1e6); on the
+// MI355X boxes of this pool a hipFree of a multi-GB block costs ~8 ms/GB and one hipMalloc in a few stalls for 1-5 s behind
+// the driver's deferred release of earlier frees (profiles/r03_setup_alloc_stalls.txt).  Inside a DevCacheScope released
+// blocks of >= 1 MiB are parked by size class (64 classes per octave, <= 1.6 % padding) and handed to the next request of
+// the class; the scope's end (or dev_cache_trim) returns what is parked to the driver.  All work of a scope is on one
+// stream (or separated by a device synchronisation), so a parked block is reused in stream order.
+size_t dev_size_class(size_t bytes);
+void *dev_alloc(size_t bytes, size_t &granted);
+void dev_free(void *p, size_t granted);
+void dev_cache_trim();
+struct DevCacheScope {
+  DevCacheScope();
+  ~DevCacheScope();
+  DevCacheScope(const DevCacheScope &) = delete;
+  DevCacheScope &operator=(const DevCacheScope &) = delete;
+};
 
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  size_t cap = 0;  // bytes granted by dev_alloc (the size class of the request)
   DevBuf() = default;
   explicit DevBuf(size_t count) { alloc(count); }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = 0; o.cap = 0; }
   DevBuf &operator=(DevBuf &&o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = 0; o.cap = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
   void alloc(size_t count) {
     release();
     n = count;
-    size_t bytes = (count ? count : 1) * sizeof(T);
-    HIP_CHECK(hipMalloc((void **)&p, bytes));
-    g_device_bytes += bytes;
-    if (g_device_bytes > g_device_peak) g_device_peak = g_device_bytes;
+    p = (T *)dev_alloc((count ? count : 1) * sizeof(T), cap);
   }
   void release() {
     if (p) {
-      (void)hipFree(p);
-      g_device_bytes -= (n ? n : 1) * sizeof(T);
+      dev_free(p, cap);
       p = nullptr;
       n = 0;
+      cap = 0;
     }
   }
   void zero(hipStream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), s)); }

@@ -385,9 +385,11 @@ void Engine::setup_mark(const char *what) {
   if (!on) return;
   sync();
   const double t = toc();
-  fprintf(stderr, "[setup] %-28s %8.1f ms (+%7.1f)  device %6.2f GB  peak %6.2f GB\n", what, 1e3 * t, 1e3 * (t - mark_prev),
-          g_device_bytes / 1e9, g_device_peak / 1e9);
-  mark_prev = t;
+  static double alloc_prev = 0., free_prev = 0.;
+  fprintf(stderr, "[setup] %-28s %8.1f ms (+%7.1f; hipMalloc %6.1f, hipFree %6.1f)  device %6.2f GB + %5.2f parked  peak %6.2f GB\n", what,
+          1e3 * t, 1e3 * (t - mark_prev), 1e3 * (g_alloc_s - alloc_prev), 1e3 * (g_free_s - free_prev), g_device_bytes / 1e9,
+          g_cache_bytes / 1e9, g_device_peak / 1e9);
+  mark_prev = t; alloc_prev = g_alloc_s; free_prev = g_free_s;
 }
 
 void Engine::open_device() {

@@ -12,8 +12,6 @@
 
 namespace oq {
 
-size_t g_device_bytes = 0;
-size_t g_device_peak = 0;
 thread_local const int *g_skip = nullptr;
 int g_debug_sync = getenv("OSQP_AMD_DEBUG") ? atoi(getenv("OSQP_AMD_DEBUG")) : 0;
 
