@@ -528,6 +528,45 @@ void admm_update(int n, int m, double alpha, const double *xz, const double *rho
   OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xz, xz + n, rho, rho_inv, l, u, x, z, y,
             delta_x, delta_y, g_skip);
 }
+// the update, and in the same pass what the NEXT iteration's right-hand side starts from (pcg.hip, k_pcg_rhs: the same
+// expressions on the values just written): xz_x = sigma x - q, t = rho (z - rho^-1 y), the six scratch slots cleared
+__global__ __launch_bounds__(kBlock) void k_admm_update_rhs(int n, int m, double alpha, const double *__restrict__ xt, const double *__restrict__ ztv,
+                                                            const double *__restrict__ rho, const double *__restrict__ rho_inv,
+                                                            const double *__restrict__ l, const double *__restrict__ u,
+                                                            double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
+                                                            double *__restrict__ delta_x, double *__restrict__ delta_y, double sigma,
+                                                            const double *__restrict__ q, double *__restrict__ xz_x, double *__restrict__ t,
+                                                            double *__restrict__ slots, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < 6) slots[S_T0 + i] = 0.0;
+  if (i < n) {
+    double xp = x[i];
+    double xn = alpha * xt[i] + (1.0 - alpha) * xp;
+    x[i] = xn;
+    delta_x[i] = xn - xp;
+    xz_x[i] = sigma * xn - q[i];
+  } else if (i < n + m) {
+    int j = i - n;
+    double zt = ztv[j], zp = z[j], yj = y[j];
+    double zh = alpha * zt + (1.0 - alpha) * zp;
+    double zn = zh + rho_inv[j] * yj;
+    zn = fmin(fmax(zn, l[j]), u[j]);
+    z[j] = zn;
+    double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    const double yn = yj + dy;
+    y[j] = yn;
+    const double rz = zn - rho_inv[j] * yn;
+    t[j] = rho[j] * rz;
+  }
+}
+void admm_update2_rhs(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv, const double *l,
+                      const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, double sigma, const double *q,
+                      double *xz_x, double *t, double *slots, hipStream_t s) {
+  OQ_LAUNCH(k_admm_update_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xt, zt, rho, rho_inv, l, u, x, z, y,
+            delta_x, delta_y, sigma, q, xz_x, t, slots, g_skip);
+}
 void admm_update2(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv, const double *l,
                   const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s) {
   OQ_LAUNCH(k_admm_update, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, alpha, xt, zt, rho, rho_inv, l, u, x, z, y,

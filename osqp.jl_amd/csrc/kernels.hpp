@@ -41,6 +41,10 @@ struct SpmvExtra {
   const double *dotv = nullptr;       // dot_partials[block] = sum over the block's rows of dotv[i] * y[i] (the layout and
   double *dot_partials = nullptr;     //   order of reduce_dot's first stage: kReduceBlocks entries, unused ones zeroed)
   double *absmax_slot = nullptr;      // *absmax_slot = max(*absmax_slot, |y[i]|)  (zero it first)
+  // first stage of the two sums behind the CG start vector (pcg.hip, k_extrap_partials), y being the right-hand side:
+  // e2_partials[block] = sum (x1 - x0) (y - m1),  e2_partials[kReduceBlocks + block] = sum (x1 - x0) (m1 - m0); same blocks, same order
+  const double *e2_x1 = nullptr, *e2_x0 = nullptr, *e2_m1 = nullptr, *e2_m0 = nullptr;
+  double *e2_partials = nullptr;
 };
 // y[i] = (rscale ? rscale[i] : 1) * sum_k val[k] x[col[k]] + beta * y[i] + gamma * v[i]
 void spmv(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
@@ -112,6 +116,9 @@ void admm_update(int n, int m, double alpha, const double *xz, const double *rho
 // the same with x~ and z~ in two separate arrays
 void admm_update2(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv,
                   const double *l, const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, hipStream_t s);
+void admm_update2_rhs(int n, int m, double alpha, const double *xt, const double *zt, const double *rho, const double *rho_inv, const double *l,
+                      const double *u, double *x, double *z, double *y, double *delta_x, double *delta_y, double sigma, const double *q,
+                      double *xz_x, double *t, double *slots, hipStream_t s);
 
 // ---------------- K8: residual norms + objective pieces ----------------
 void residual_norms(int n, int m, const double *x, const double *z, const double *Ax, const double *Px,

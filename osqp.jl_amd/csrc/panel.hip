@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv_sell_pair(SellSide a, SellSid
 __device__ __forceinline__ void panel_reduce_rows(int vb, int vg, int rows, int B, const double *__restrict__ partial, double *__restrict__ y,
                                                   const double *__restrict__ rscale, double beta, double gamma,
                                                   const double *__restrict__ v, const SpmvExtra &ex) {
-  double dot = 0.0, mx = 0.0;
+  double dot = 0.0, mx = 0.0, num = 0.0, den = 0.0;
   for (int i = vb * kBlock + threadIdx.x; i < rows; i += vg * kBlock) {
     double acc = 0.0;
     int b = 0;
@@ -424,6 +424,18 @@ __device__ __forceinline__ void panel_reduce_rows(int vb, int vg, int rows, int 
     y[i] = acc;
     if (ex.dotv) dot += ex.dotv[i] * acc;
     if (ex.absmax_slot) mx = nanmax(mx, fabs(acc));
+    if (ex.e2_partials) {
+      const double d = ex.e2_x1[i] - ex.e2_x0[i], m1 = ex.e2_m1[i];
+      num += d * (acc - m1);
+      den += d * (m1 - ex.e2_m0[i]);
+    }
+  }
+  if (ex.e2_partials) {
+    num = block_sum(num);
+    den = block_sum(den);
+    if (threadIdx.x == 0) { ex.e2_partials[vb] = num; ex.e2_partials[kReduceBlocks + vb] = den; }
+    if (vb == 0)
+      for (int t = vg + threadIdx.x; t < kReduceBlocks; t += kBlock) { ex.e2_partials[t] = 0.0; ex.e2_partials[kReduceBlocks + t] = 0.0; }
   }
   if (ex.dot_partials) {
     dot = block_sum(dot);

@@ -132,14 +132,30 @@ __global__ __launch_bounds__(kBlock) void k_pcg_start(int n, int m, int have_pre
   if (threadIdx.x == 0) { partials[R_RZ + blockIdx.x] = rz; partials[R_RN + blockIdx.x] = mx; }
 }
 // r'z and ||r||inf of the start vector into their slots; asynchronous form: also the tolerance and the first flag
+// spec_done (host loop with a speculative first iteration): the verdict on the start vector, taken here with the host's
+// arithmetic (tolerance from cand_v) and handed to both sides -- the flag the kernels of the iteration enqueued behind this
+// kernel look at, and word S_COUNT + 1 of the published slots, which the host follows instead of deciding again.
 __global__ __launch_bounds__(kBlock) void k_pcg_finish_start(const double *__restrict__ partials, double *__restrict__ slots, int *ctl,
-                                                             const double *cand_p, double *tol_p, Publish pub, const int *__restrict__ skip) {
+                                                             const double *cand_p, double *tol_p, Publish pub, int *spec_done, double cand_v,
+                                                             const int *__restrict__ skip) {
   if (skip && *skip) { if (ctl && threadIdx.x == 0) ctl[C_DONE0] = 1; return; }
   const double rz = sum_partials(partials + R_RZ), rn = max_partials(partials + R_RN);
   if (threadIdx.x != 0) return;
   slots[S_T0] = rz; slots[S_T1] = rn;
-  if (pub.host_slots) {  // the host loop waits for exactly these three
+  int done = 0;
+  if (spec_done) {
+    const double bnorm = slots[S_T5];
+    const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
+    double tol = hi;
+    if (cand_v >= 0.0) tol = cand_v;
+    if (!(tol < hi)) tol = hi;
+    if (tol < lo) tol = lo;
+    done = (rn != rn || rn <= tol) ? 1 : 0;
+    *spec_done = done;
+  }
+  if (pub.host_slots) {  // the host loop waits for exactly these three (and the verdict, when it launched ahead)
     pub.host_slots[S_T0] = rz; pub.host_slots[S_T1] = rn; pub.host_slots[S_T5] = slots[S_T5];
+    pub.host_slots[S_COUNT + 1] = (double)done;
     __threadfence_system();
     *pub.host_seq = pub.seq;
     __threadfence_system();
@@ -277,7 +293,7 @@ struct Pcg : Linsys {
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
   }
-  void invalidate() override { drop_graphs(); }
+  void invalidate() override { drop_graphs(); rhs_ready = false; }
   int kind() const override { return 2; }
   double cg_iters() const override { return (double)total_iters; }
 
@@ -370,28 +386,40 @@ struct Pcg : Linsys {
     vec_copy2(xz, xs.get(), n, xz + n, Axs.get(), m, s);  // x~ and z~ = A x~
     return status;
   }
-  int update_rho() override { int rc = flush(); precond(); carried_valid = false; have_prev = false; return rc; }
-  int update_matrices() override { int rc = flush(); precond(); carried_valid = false; have_prev = false; return rc; }
-  void set_guess(const double *x) override { (void)flush(); vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; have_prev = false; }
+  int update_rho() override { int rc = flush(); precond(); carried_valid = false; have_prev = false; rhs_ready = false; return rc; }
+  int update_matrices() override { int rc = flush(); precond(); carried_valid = false; have_prev = false; rhs_ready = false; return rc; }
+  void set_guess(const double *x) override { (void)flush(); vec_copy(xs.get(), x, e.n, e.stream); carried_valid = false; have_prev = false; rhs_ready = false; }
 
   // ---------------------------------------------------------------- asynchronous form
   // ---- the pieces of a step, fused kernels where they apply (fused_on), the launches of solve() otherwise -------------
   // right-hand side b1, its norm, the carried products, the start vector, the initial residual; r'z -> S_T0, ||r||inf -> S_T1
   Publish pub_next;  // set by the host loop before a launch whose kernel publishes its scalars itself
+  // host loop, first CG iteration launched ahead of the verdict on the start vector (step_sync)
+  DevBuf<int> spec_flag;
+  bool spec_now = false;     // this start_solve hands its verdict to spec_flag
+  double spec_cand = -1.0;
+  double need_one = 1.0;     // running share of the steps that needed at least one CG iteration
   void start_solve(bool hp, bool refresh, bool async) {
     hipStream_t s = e.stream;
     const int n = e.n, m = e.m;
     double *slots = e.slots.get(), *xz = e.xz.get(), *part = e.partials.get();
     int *flags = async ? ctl.get() : nullptr;
     if (fused_on) {
-      OQ_LAUNCH(k_pcg_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(),
-                e.rho.get(), e.rho_inv.get(), e.y.get(), xz, t.get(), slots, g_skip);
+      if (!(rhs_ready && !async))
+        OQ_LAUNCH(k_pcg_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(),
+                  e.rho.get(), e.rho_inv.get(), e.y.get(), xz, t.get(), slots, g_skip);
+      rhs_ready = false;
       SpmvExtra ex;
       ex.absmax_slot = slots + S_T5;
+      const bool ext = extrapolate && hp;
+      // the two sums of the extrapolation ride on the reduce of the right-hand side (same blocks, same order as
+      // k_extrap_partials) unless the carried products are about to be refreshed
+      static const bool fuse_e2 = !(getenv("OSQP_AMD_PCG_FUSE_EXTRAP") && atoi(getenv("OSQP_AMD_PCG_FUSE_EXTRAP")) == 0);
+      const bool e2 = ext && !refresh && fuse_e2;
+      if (e2) { ex.e2_x1 = xs.get(); ex.e2_x0 = xs0.get(); ex.e2_m1 = Mxs.get(); ex.e2_m0 = Mxs0.get(); ex.e2_partials = part + R_DOT; }
       spmv(e.At, t.get(), b1.get(), nullptr, 0.0, 1.0, xz, s, &ex);
       if (refresh) apply_M(xs.get(), Axs.get(), Mxs.get());
-      const bool ext = extrapolate && hp;
-      if (ext) OQ_LAUNCH(k_extrap_partials, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), part, g_skip);
+      if (ext && !e2) OQ_LAUNCH(k_extrap_partials, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), b1.get(), part, g_skip);
       if (extrapolate)
         OQ_LAUNCH(k_pcg_start, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, ext ? 1 : 0, xs.get(), xs0.get(), Mxs.get(), Mxs0.get(), Axs.get(),
                   Axs0.get(), b1.get(), dinv.get(), r.get(), zz.get(), p.get(), part, g_skip);
@@ -399,7 +427,7 @@ struct Pcg : Linsys {
         pcg_init_residual(n, b1.get(), Mxs.get(), dinv.get(), r.get(), zz.get(), p.get(), part + R_RZ, slots + S_T0, slots + S_T1, s);
       if (extrapolate)
         OQ_LAUNCH(k_pcg_finish_start, dim3(1), dim3(kBlock), 0, s, (const double *)part, slots, flags, (const double *)dctl.get(), dctl.get() + 1,
-                  async ? Publish() : pub_next, g_skip);
+                  async ? Publish() : pub_next, (!async && spec_now) ? spec_flag.get() : (int *)nullptr, spec_cand, g_skip);
       else if (async)
         OQ_LAUNCH(k_pcg_begin, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)dctl.get(), dctl.get() + 1);
       return;
@@ -464,8 +492,19 @@ struct Pcg : Linsys {
       OQ_LAUNCH(k_pcg_decide, dim3(1), dim3(1), 0, s, flags, (const double *)slots, (const double *)(dctl.get() + 1), cur);
     }
   }
-  void finish_step() {  // x~ = xs, z~ = A xs carried along: the ADMM update of (x, z, y)
+  // host loop: the update of step k leaves the vector part of step k + 1's right-hand side behind (k_admm_update_rhs), and
+  // k_pcg_rhs is skipped -- as long as nothing looks at or changes the iterate in between: flush() (before every residual
+  // evaluation), update_rho / update_matrices / set_guess (start of every solve) clear the mark
+  bool rhs_ready = false;
+  void finish_step(bool leave_rhs = false) {  // x~ = xs, z~ = A xs carried along: the ADMM update of (x, z, y)
     hipStream_t s = e.stream;
+    if (leave_rhs) {
+      admm_update2_rhs(e.n, e.m, e.st.alpha, xs.get(), Axs.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(),
+                       e.y.get(), e.dx.get(), e.dy.get(), e.st.sigma, e.q.get(), e.xz.get(), t.get(), e.slots.get(), s);
+      rhs_ready = true;
+      return;
+    }
+    rhs_ready = false;
     admm_update2(e.n, e.m, e.st.alpha, xs.get(), Axs.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(),
                  e.dx.get(), e.dy.get(), s);
   }
@@ -497,10 +536,26 @@ struct Pcg : Linsys {
     const bool refresh = !carried_valid || since_refresh + 1 >= kRefresh;
     const bool self_publish = fused_on && extrapolate;  // k_pcg_finish_start / k_pcg_next hand their scalars to the host themselves
     pub_next = self_publish ? e.begin_publish() : Publish();
+    // Most steps need at least one CG iteration, and the verdict on the start vector costs the device ~12 us of idling while
+    // the host reads it and launches: the first iteration goes in behind the start kernels at once, its kernels looking at
+    // the verdict k_pcg_finish_start leaves on the device (they fall through when the start vector already passes).  The
+    // host follows the device's verdict, so both sides always agree; the arithmetic is that of the plain loop.
+    static const bool spec_allowed = !(getenv("OSQP_AMD_PCG_SPEC") && atoi(getenv("OSQP_AMD_PCG_SPEC")) == 0);
+    const bool spec = spec_allowed && self_publish && pub_next.host_slots && max_iter > 0 && need_one >= 0.5;
+    if (spec && spec_flag.n == 0) spec_flag.alloc(1);
+    spec_now = spec; spec_cand = cand;
     start_solve(have_prev, refresh, false);
+    spec_now = false;
+    const Publish pub_start = pub_next;
+    Publish pub_first;
+    if (spec) {
+      pub_first = pub_next = e.begin_publish();
+      SkipScope on_verdict(spec_flag.get());
+      cg_iteration(0, false);
+    }
     if (refresh) { carried_valid = true; since_refresh = 0; } else since_refresh++;
     if (extrapolate) have_prev = true;
-    if (pub_next.host_slots) e.wait_publish(pub_next); else e.read_slots(S_T0, 6);
+    if (pub_start.host_slots) e.wait_publish(pub_start); else e.read_slots(S_T0, 6);
     const double bnorm = e.h_slots[S_T5];
     const double hi = 1e-2 * bnorm, lo = 1e-13 * bnorm + 1e-300;
     double tol = hi;
@@ -509,19 +564,28 @@ struct Pcg : Linsys {
     if (tol < lo) tol = lo;
     double rn = e.h_slots[S_T1];
     int it = 0, cur = 0, status = 0;
+    bool ahead = spec;  // the iteration about to be looked at is already enqueued
     while (it < max_iter) {
-      if (rn <= tol) break;
-      if (rn != rn) { status = 5; break; }
-      pub_next = fused_on ? e.begin_publish() : Publish();
-      cg_iteration(cur, false);
-      if (pub_next.host_slots) e.wait_publish(pub_next); else e.read_slots(S_T0, 5);
+      if (ahead) {
+        if (e.h_slots[S_COUNT + 1] != 0.0) { if (rn != rn) status = 5; break; }  // the device's verdict: its kernels fell through
+      } else {
+        if (rn <= tol) break;
+        if (rn != rn) { status = 5; break; }
+        pub_next = fused_on ? e.begin_publish() : Publish();
+        cg_iteration(cur, false);
+      }
+      const Publish &pub_it = ahead ? pub_first : pub_next;
+      ahead = false;
+      if (pub_it.host_slots) e.wait_publish(pub_it); else e.read_slots(S_T0, 5);
       if (!(e.h_slots[S_T4] > 0.0)) { status = 5; carried_valid = false; break; }
       rn = e.h_slots[S_T1 + 2 * (1 - cur)];
       cur = 1 - cur;
       it++;
     }
+    need_one = 0.9 * need_one + (it > 0 ? 0.1 : 0.0);
     total_iters += it;
-    finish_step();
+    static const bool fuse_rhs = !(getenv("OSQP_AMD_PCG_FUSE_RHS") && atoi(getenv("OSQP_AMD_PCG_FUSE_RHS")) == 0);
+    finish_step(fuse_rhs && fused_on && status == 0);
     return status;
   }
 
@@ -571,6 +635,7 @@ struct Pcg : Linsys {
 
   // Wait for what was enqueued; finish a stalled solve on the host loop and re-issue the steps behind it.
   int flush() override {
+    rhs_ready = false;
     if (!async_on) return 0;
     if (deferred) { int rc = deferred; deferred = 0; issued = 0; return rc; }
     hipStream_t s = e.stream;
