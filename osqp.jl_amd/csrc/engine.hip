@@ -428,18 +428,6 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   At.rows = n; At.cols = m; At.nnz = nnzA;
   At.rowptr = std::move(Ap); At.col = std::move(Ai); At.val = std::move(Ax_in);
   At.group = pick_group(n, nnzA);
-  {
-    DevBuf<int> colid((size_t)nnzA), src;
-    expand_colptr(n, At.rowptr.get(), nnzA, colid.get(), stream);
-    csr_from_coo(m, n, nnzA, At.col.get(), colid.get(), A, src, stream);
-    sync();
-    colid.release();
-    gather_values(A.nnz, src.get(), At.val.get(), A.val.get(), 0, stream);
-    A_k2pos.alloc((size_t)nnzA);
-    invert_map(A.nnz, src.get(), 0, nnzA, A_k2pos.get(), stream);
-    sync();
-  }
-  setup_mark("A = transpose(A')");
   // A problem that is certain to run the indirect back-end at a size where the workspace goes compact: every matrix gets
   // its sliced-ELL copy and gives up its CSR arrays NOW, one after the other (Ruiz scaling then runs over the slices:
   // scale_data), instead of all three copies living side by side until the end of the setup.
@@ -453,39 +441,66 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     catch (const Error &) { M.panel = DevPanel(); return; }  // stays on its CSR arrays
     compact_one(which, &p2s);
   };
-  if (m > 0) { early_compact(0); setup_mark("slices of A"); early_compact(1); setup_mark("slices of A'"); }
-  // ---- full symmetric P from the upper triangle ----
-  {
-    DevBuf<int> colid((size_t)nnzPtriu), erow((size_t)(2 * nnzPtriu)), ecol((size_t)(2 * nnzPtriu)), src;
-    expand_colptr(n, Pp.get(), nnzPtriu, colid.get(), stream);
-    if (nnzPtriu > 0)
-      OQ_LAUNCH(k_sym_coo, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, Pi.get(), colid.get(),
-                         erow.get(), ecol.get(), flag.get());
-    int bad = 0;
-    flag.download(&bad, 1, stream);
-    sync();
-    colid.release();  // every temporary goes as soon as it has been read: this block is the high-water mark of a large setup
-    if (bad) throw Error(1, "P is not upper triangular");
-    csr_from_coo(n, n, 2 * nnzPtriu, erow.get(), ecol.get(), Pf, src, stream);
-    sync();
-    erow.release(); ecol.release();
-    gather_values(Pf.nnz, src.get(), Px.get(), Pf.val.get(), nnzPtriu, stream);
-    sync();
-    Px.release();
-    P_k2lo.alloc((size_t)nnzPtriu); P_k2up.alloc((size_t)nnzPtriu);
-    if (nnzPtriu > 0) {
-      OQ_LAUNCH(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
-      invert_map(Pf.nnz, src.get(), 0, nnzPtriu, P_k2lo.get(), stream);
-      invert_map(Pf.nnz, src.get(), nnzPtriu, 2 * nnzPtriu, P_k2up.get(), stream);
+  auto transpose_A = [&]() {
+    {
+      DevBuf<int> colid((size_t)nnzA), src;
+      expand_colptr(n, At.rowptr.get(), nnzA, colid.get(), stream);
+      csr_from_coo(m, n, nnzA, At.col.get(), colid.get(), A, src, stream);
+      sync();
+      colid.release();
+      gather_values(A.nnz, src.get(), At.val.get(), A.val.get(), 0, stream);
+      A_k2pos.alloc((size_t)nnzA);
+      invert_map(A.nnz, src.get(), 0, nnzA, A_k2pos.get(), stream);
+      sync();
     }
-    sync();
+  };
+  auto symmetric_P = [&]() {  // full symmetric P from the upper triangle
+    {
+      DevBuf<int> colid((size_t)nnzPtriu), erow((size_t)(2 * nnzPtriu)), ecol((size_t)(2 * nnzPtriu)), src;
+      expand_colptr(n, Pp.get(), nnzPtriu, colid.get(), stream);
+      if (nnzPtriu > 0)
+        OQ_LAUNCH(k_sym_coo, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, Pi.get(), colid.get(),
+                           erow.get(), ecol.get(), flag.get());
+      int bad = 0;
+      flag.download(&bad, 1, stream);
+      sync();
+      colid.release();  // every temporary goes as soon as it has been read: this block is the high-water mark of a large setup
+      if (bad) throw Error(1, "P is not upper triangular");
+      csr_from_coo(n, n, 2 * nnzPtriu, erow.get(), ecol.get(), Pf, src, stream);
+      sync();
+      erow.release(); ecol.release();
+      gather_values(Pf.nnz, src.get(), Px.get(), Pf.val.get(), nnzPtriu, stream);
+      sync();
+      Px.release();
+      P_k2lo.alloc((size_t)nnzPtriu); P_k2up.alloc((size_t)nnzPtriu);
+      if (nnzPtriu > 0) {
+        OQ_LAUNCH(k_fill_int, dim3(blocks_for(nnzPtriu)), dim3(kBlock), 0, stream, nnzPtriu, P_k2up.get(), -1);
+        invert_map(Pf.nnz, src.get(), 0, nnzPtriu, P_k2lo.get(), stream);
+        invert_map(Pf.nnz, src.get(), nnzPtriu, 2 * nnzPtriu, P_k2up.get(), stream);
+      }
+      sync();
+    }
+  };
+  // Early compaction: P first -- while it is built and sliced only the caller's arrays are there, and the high-water mark of
+  // the setup moves from "slices of P on top of both compact copies of A" to "slices of A' next to compact P and A".
+  if (early) {
+    symmetric_P();
+    Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
+    Px.release();
+    setup_mark("full symmetric P");
+    early_compact(2);
+    setup_mark("slices of P");
+    transpose_A();
+    setup_mark("A = transpose(A')");
+    if (m > 0) { early_compact(0); setup_mark("slices of A"); early_compact(1); setup_mark("slices of A'"); }
+  } else {
+    transpose_A();
+    setup_mark("A = transpose(A')");
+    symmetric_P();
+    Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
+    Px.release();
+    setup_mark("full symmetric P");
   }
-  // keep the patterns reachable for the direct back-end's symbolic phase
-  Pp_keep = std::move(Pp); Pi_keep = std::move(Pi);
-  Px.release();
-  setup_mark("full symmetric P");
-  early_compact(2);
-  setup_mark("slices of P");
 
   if (comm) shard_rows(q_, l_, u_);  // from here on n, m are the local sizes
   finish_setup(q_, l_, u_);
