@@ -7,6 +7,8 @@ echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)  nproc: $(nproc)
 # 0. the gpu suite and smoke
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# 0b. rand-1e6 parity record of the END state (engine iterate vs CPU oracle after W + K iterations, host KKT; ~12 minutes, mostly the oracle)
+timeout 2400 python tools/cpu_rand1e6.py --phases gpu,kkt,cpu --out $O/rand1e6_parity.json --cpu-record $O/cpu_rand1e6_from_parity_run.json > $O/rand1e6_parity.log 2>&1; echo "parity rc=$?"; tail -2 $O/rand1e6_parity.log | cut -c1-400
 # 1. bench lines (the driver's K/W first, then bench.py's defaults); --cpu-full re-measures the CPU record of rand-1e6 in this run
 timeout 1800 python bench.py --steps 20 --warmup 5 --cpu-full > $O/bench_rand1e6_k20w5.json 2> $O/bench_rand1e6_k20w5.err; echo "rand-1e6 k20w5 rc=$?"
 timeout 900 python bench.py > $O/bench_rand1e6_default.json 2> $O/bench_rand1e6_default.err
