@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void k_sell_scale_norm(int rows, int cols
                                                               const int *__restrict__ slice_rows, const ColT *__restrict__ scol,
                                                               double *__restrict__ sval, const double *__restrict__ r,
                                                               const double *__restrict__ c, int order, double pre, int row0,
-                                                              double *__restrict__ partial, int nt) {
+                                                              double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int t = blockIdx.x, g = tile_g[t];
   const int W = 1 << shift;
@@ -625,10 +625,7 @@ __global__ __launch_bounds__(kThreads) void k_sell_scale_norm(int rows, int cols
           mx = fmax(mx, fabs(x));
         }
         if (row >= 0) {
-          if (full && nt) {
-#pragma unroll
-            for (int u = 0; u < kBatch; u++) __builtin_nontemporal_store(cv[u], &v[(size_t)(k + u) * 64]);
-          } else if (full) {
+          if (full) {
 #pragma unroll
             for (int u = 0; u < kBatch; u++) v[(size_t)(k + u) * 64] = cv[u];
           } else {
@@ -884,12 +881,11 @@ void panel_scale(DevCsr &M, const double *r, const double *c, int order, double 
 void panel_scale_norm(DevCsr &M, const double *r, const double *c, int order, double pre, int row0, double *norm, hipStream_t s) {
   const DevPanel &P = M.panel;
   if (P.wide) throw Error(6, "internal: the fused scaling pass needs LDS-staged panels");
-  static const int scale_nt = getenv("OSQP_AMD_SCALE_NT") ? atoi(getenv("OSQP_AMD_SCALE_NT")) : 0;
   HIP_CHECK(hipFuncSetAttribute((const void *)k_sell_scale_norm<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)spmv_lds_bytes(P.shift)));
   OQ_LAUNCH((k_sell_scale_norm<uint16_t>), dim3(P.ntiles), dim3(kThreads), spmv_lds_bytes(P.shift), s, M.rows, M.cols, P.shift, P.B, P.Gp,
             P.tile_g.get(), P.tile_r0.get(), P.tile_r1.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(),
-            P.slice_rows.get(), P.scol.get(), P.sval.get(), r, c, order, pre, row0, P.partial.get(), scale_nt);
+            P.slice_rows.get(), P.scol.get(), P.sval.get(), r, c, order, pre, row0, P.partial.get());
   OQ_LAUNCH(k_panel_reduce_max, dim3(blocks_for(M.rows)), dim3(kBlock), 0, s, M.rows, P.NG, P.partial.get(), norm, 0);
 }
 void panel_diag(const DevCsr &M, double *diag, int row0, hipStream_t s) {
