@@ -107,6 +107,13 @@ void *vm_alloc(size_t bytes, size_t &granted, int dev) {
       g_cache_bytes -= kChunk;
     } else {
       hipError_t e = hipMemCreate(&h, kChunk, &prop, 0);
+      if (e != hipSuccess && !g_parked.empty()) {  // what this thread has parked may be what is missing
+        (void)hipGetLastError();
+        for (auto &kv : g_parked)
+          for (void *q : kv.second) { (void)hipFree(q); g_cache_bytes -= kv.first.second; }
+        g_parked.clear();
+        e = hipMemCreate(&h, kChunk, &prop, 0);
+      }
       if (e != hipSuccess) {
         (void)hipGetLastError();
         vm_drop(va, i * kChunk, b);
@@ -144,9 +151,13 @@ bool vm_free(void *p) {
   auto it = g_vm.find(p);
   if (it == g_vm.end()) return false;
   VmBlock &b = it->second;
-  // the range disappears at once: everything queued on the device that may touch it has to be through (hipFree waits too)
+  // the range disappears at once: everything queued on ITS device that may touch it has to be through (hipFree waits too)
+  int cur = b.dev;
+  (void)hipGetDevice(&cur);
+  if (cur != b.dev) (void)hipSetDevice(b.dev);
   (void)hipDeviceSynchronize();
   hipError_t e1 = hipMemUnmap(p, b.size);
+  if (cur != b.dev) (void)hipSetDevice(cur);
   if (e1 != hipSuccess) fprintf(stderr, "[osqp-amd] hipMemUnmap: %s\n", hipGetErrorString(e1));
   va_retire(p, b.size);
   g_device_bytes -= b.size;
