@@ -65,3 +65,36 @@ def test_mapped_chunk_blocks_give_the_results_of_plain_hipmalloc():
     assert plain[0].endswith("Solved") and plain[3].endswith("Solved"), plain  # the updated problems may stop at max_iter: equal iterates are the point
     assert mapped == plain
     assert default == plain
+
+
+CYCLES = r"""
+import sys, os, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import osqp_jl_amd as oq
+lib = oq.load_library()
+def digest(r):
+    return hashlib.sha256(np.ascontiguousarray(r.x).tobytes() + np.ascontiguousarray(r.y).tobytes()).hexdigest()[:16] + ":%d:%s" % (r.info.iter, r.info.status)
+seen = []
+keep = []   # two workspaces of three stay alive until the process ends
+for cycle in range(10):
+    m = oq.Model(lib)
+    oq.setup_generated(m, 0, 30000, 64, 9, verbose=False, linsys_solver="pcg", eps_abs=1e-4, eps_rel=1e-4, max_iter=300)
+    a = digest(oq.solve(m))
+    oq.update(m, q=np.full(30000, 0.25))
+    b = digest(oq.solve(m))
+    seen.append(a + "|" + b)
+    if cycle % 3 == 2: oq.clean(m)
+    else: keep.append(m)
+print(len(set(seen)), seen[0])
+"""
+
+
+def test_setup_cleanup_cycles_on_mapped_blocks_repeat_exactly():
+    env = dict(os.environ)
+    env.update({"OSQP_AMD_VMM_MIN_MB": "1", "OSQP_AMD_POISON": "1"})
+    r = subprocess.run([sys.executable, "-c", CYCLES, ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "1", r.stdout  # ten cycles, one distinct pair of digests
+    assert last[1].count("Solved") == 2, r.stdout
