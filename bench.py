@@ -286,6 +286,7 @@ def replica_bench(ctx):
     else:            # direct back-end: the kernels of one iteration (right-hand side | triangular solves | update, fused as the factor allows)
         kname, which = "direct ADMM iteration: rhs + forward | backward + update around the LDL' factor (k_direct2_fwd + k_direct2_bwd_update on a two-level factor)", 5
         abytes = st[11] + 8.0 * (6 * n + 12 * int(oq.dimensions(model)[1]))  # trisolve bytes + the vector updates
+        pmc_names = ["k_direct2_fwd", "k_direct2_bwd_update"]  # the two-launch iteration; another factor shape: no live traffic (None)
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -391,10 +392,21 @@ def step_algorithmic_bytes(st, n, m, cg_per_admm, k=25):
 def pmc_child(ctx):
     """Under rocprofv3 --pmc: build the workload and launch its dominant kernel a few times, nothing else."""
     args, oq, lib = ctx["args"], ctx["oq"], ctx["lib"]
+    if args.workload == "mpc-batch":
+        from osqp_jl_amd import batch
+        b = batch.MpcBatch(lib, BATCH_TOTAL, 1, device=ctx["local_rank"], comm=None, **SETTINGS)
+        packed = b.alloc()
+        for _ in range(4):
+            b.solve(packed)
+        ctx["torch"].cuda.synchronize()
+        print("PMC_CHILD_OK 0")
+        b.close()
+        return
     kind, n, per_row, linsys = WORKLOADS[args.workload]
     model = oq.Model(lib)
     oq.setup_generated(model, kind, n, per_row, 1, linsys_solver=linsys, **SETTINGS)
-    ms = float(lib.osqp_amd_time_kernel(model.workspace, 0, 6))
+    which = 0 if oq.stats(model)[0] == 2 else 5  # the product of the indirect back-end / the iteration kernels of the direct one
+    ms = float(lib.osqp_amd_time_kernel(model.workspace, which, 6))
     print("PMC_CHILD_OK %.4f" % ms)
     oq.clean(model)
 
@@ -641,6 +653,9 @@ def batch_leg(ctx, want_cpu):
     if want_cpu:
         rec["cpu_baseline"] = batch_cpu_leg(oq, args)
     b.close()
+    if rank == 0 and world == 1 and args.child is None and args.traffic == "live":  # HBM bytes of one launch, two --pmc passes over a child
+        tr, src = live_traffic(args, ["k_batch_solve"])
+        rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr, src
     if comm is not None:
         comm.close()
     return rec
