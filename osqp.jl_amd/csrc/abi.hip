@@ -46,9 +46,10 @@ int validate_data(const OSQPData *d) {
   if (d->n <= 0 || d->m < 0) return 1;
   if (d->n >= 2147483647LL || d->m >= 2147483647LL) return 1;
   if (d->P->m != d->n || d->P->n != d->n) return 1;
-  for (c_int j = 0; j < d->n; j++)
-    for (c_int k = d->P->p[j]; k < d->P->p[j + 1]; k++)
-      if (d->P->i[k] > j || d->P->i[k] < 0) return 1;  // P must be upper triangular
+  if (d->P->p[d->n] <= 10000000)  // larger ones: the device checks the same while it builds the full symmetric P (engine.hip: k_narrow_indices, k_sym_coo)
+    for (c_int j = 0; j < d->n; j++)
+      for (c_int k = d->P->p[j]; k < d->P->p[j + 1]; k++)
+        if (d->P->i[k] > j || d->P->i[k] < 0) return 1;  // P must be upper triangular
   if (d->A->m != d->m || d->A->n != d->n) return 1;
   for (c_int j = 0; j < d->m; j++)
     if (d->l[j] > d->u[j]) return 1;

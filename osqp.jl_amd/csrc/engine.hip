@@ -540,26 +540,64 @@ void Engine::finish_setup(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double>
   sync();
 }
 
+// 64-bit indices of the caller, as they arrive in a staging buffer, to the 32-bit arrays of the engine; an index outside
+// [0, limit) raises the flag (the host loop this replaces checked A only)
+__global__ __launch_bounds__(kBlock) void k_narrow_indices(int64_t cnt, const long long *__restrict__ in, int *__restrict__ out, long long limit,
+                                                           int *__restrict__ flag) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= cnt) return;
+  const long long v = in[k];
+  if (v < 0 || v >= limit) { *flag = 1; out[k] = 0; return; }
+  out[k] = (int)v;
+}
+
 void Engine::setup_host(const OSQPData *d, const OSQPSettings &s) {
   const int n_ = (int)d->n, m_ = (int)d->m;
   hipStream_t s0 = nullptr;  // uploads on the null stream, synchronous
   const int64_t nzP = d->P->p[n_], nzA = d->A->p[n_];
   if (nzA >= 2147483647LL || 2 * nzP >= 2147483647LL) throw Error(6, "matrix too large: more than 2^31-1 non-zeros");
-  // host patterns (32-bit row indices) are kept for the direct back-end
-  hP.rows = n_; hP.cols = n_; hP.p.assign(d->P->p, d->P->p + n_ + 1); hP.i.resize(nzP);
-  for (int64_t k = 0; k < nzP; k++) hP.i[k] = (int)d->P->i[k];
-  hA.rows = m_; hA.cols = n_; hA.p.assign(d->A->p, d->A->p + n_ + 1); hA.i.resize(nzA);
-  for (int64_t k = 0; k < nzA; k++) hA.i[k] = (int)d->A->i[k];
-  for (int64_t k = 0; k < nzA; k++) if (hA.i[k] < 0 || hA.i[k] >= m_) throw Error(1, "row index of A out of range");
-  have_host_pattern = true;
+  // A problem that is certain to run the indirect back-end never looks at the host copies of the patterns (they feed the
+  // direct back-end's symbolic phase): at rand-1e6 they are 6 GB of host memory and 1.5e9 single-threaded conversions.  Its
+  // 64-bit index arrays go to the device as they are, in pieces, and are narrowed (and range-checked) there.
+  const double nnzK = (double)nzP + (double)nzA + (double)n_ + (double)m_;
+  const bool indirect_for_sure = s.linsys_solver == AMD_PCG_SOLVER || (s.linsys_solver != AMD_DIRECT_SOLVER && nnzK > 4e7);
   DevBuf<int64_t> Pp((size_t)n_ + 1), Ap((size_t)n_ + 1);
   DevBuf<int> Pi((size_t)nzP), Ai((size_t)nzA);
   DevBuf<double> Px((size_t)nzP), Ax_((size_t)nzA), q_((size_t)n_), l_((size_t)m_), u_((size_t)m_);
-  Pp.upload((const int64_t *)hP.p.data(), (size_t)n_ + 1, s0); Ap.upload((const int64_t *)hA.p.data(), (size_t)n_ + 1, s0);
-  Pi.upload(hP.i.data(), nzP, s0); Ai.upload(hA.i.data(), nzA, s0);
+  DevBuf<int> range_flag(1);
+  range_flag.zero(s0);
+  if (indirect_for_sure) {
+    have_host_pattern = false;
+    const int64_t piece = (int64_t)1 << 25;  // 256 MB of indices per copy
+    DevBuf<long long> stage((size_t)std::min<int64_t>(piece, std::max<int64_t>(1, std::max(nzP, nzA))));
+    auto narrow = [&](const c_int *src, int64_t cnt, int *dst, long long limit) {
+      for (int64_t o = 0; o < cnt; o += piece) {
+        const int64_t c = std::min(piece, cnt - o);
+        HIP_CHECK(hipMemcpyAsync(stage.get(), src + o, sizeof(long long) * (size_t)c, hipMemcpyHostToDevice, s0));
+        OQ_LAUNCH(k_narrow_indices, dim3(blocks_for(c)), dim3(kBlock), 0, s0, c, (const long long *)stage.get(), dst + o, limit, range_flag.get());
+      }
+    };
+    narrow(d->P->i, nzP, Pi.get(), (long long)n_);
+    narrow(d->A->i, nzA, Ai.get(), (long long)m_);
+    Pp.upload((const int64_t *)d->P->p, (size_t)n_ + 1, s0); Ap.upload((const int64_t *)d->A->p, (size_t)n_ + 1, s0);
+  } else {
+    // host patterns (32-bit row indices) are kept for the direct back-end
+    hP.rows = n_; hP.cols = n_; hP.p.assign(d->P->p, d->P->p + n_ + 1); hP.i.resize(nzP);
+    for (int64_t k = 0; k < nzP; k++) hP.i[k] = (int)d->P->i[k];
+    hA.rows = m_; hA.cols = n_; hA.p.assign(d->A->p, d->A->p + n_ + 1); hA.i.resize(nzA);
+    for (int64_t k = 0; k < nzA; k++) hA.i[k] = (int)d->A->i[k];
+    for (int64_t k = 0; k < nzA; k++) if (hA.i[k] < 0 || hA.i[k] >= m_) throw Error(1, "row index of A out of range");
+    for (int64_t k = 0; k < nzP; k++) if (hP.i[k] < 0 || hP.i[k] >= n_) throw Error(1, "row index of P out of range");
+    have_host_pattern = true;
+    Pp.upload((const int64_t *)hP.p.data(), (size_t)n_ + 1, s0); Ap.upload((const int64_t *)hA.p.data(), (size_t)n_ + 1, s0);
+    Pi.upload(hP.i.data(), nzP, s0); Ai.upload(hA.i.data(), nzA, s0);
+  }
   Px.upload(d->P->x, nzP, s0); Ax_.upload(d->A->x, nzA, s0);
   q_.upload(d->q, n_, s0); l_.upload(d->l, m_, s0); u_.upload(d->u, m_, s0);
+  int bad = 0;
+  range_flag.download(&bad, 1, s0);
   HIP_CHECK(hipDeviceSynchronize());
+  if (bad) throw Error(1, "row index of P or A out of range");
   setup_device(n_, m_, Pp, Pi, Px, Ap, Ai, Ax_, q_, l_, u_, s);
 }
 

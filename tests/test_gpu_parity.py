@@ -393,3 +393,29 @@ def test_cleanup_releases_device_memory(product_lib):
         if base is None:
             base = after
         assert after == base
+
+
+def test_host_arrays_of_an_indirect_setup_are_narrowed_and_checked_on_the_device(product_lib, oracle_lib):
+    """A setup that is certain to run the indirect back-end sends the caller's 64-bit index arrays to the device as they
+    are and narrows them there (engine.hip, setup_host): the same solution as through the host-side conversion (the
+    direct back-end's path, here forced by linsys_solver), and a row index outside the matrix is refused with error 1 as
+    libosqp's validate_data does [REF src/interface.jl:147-153: a non-zero exit flag is an error]."""
+    d = oracle_lib.oracle_generate(0, 3000, 30, 3)
+    P, q, A, l, u = _data_to_scipy(d.contents)
+    oracle_lib.oracle_data_free(d)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25)
+    xs = {}
+    for solver in ("pcg", "qdldl"):
+        m = oq.Model(product_lib)
+        oq.setup(m, P=P, q=q, A=A, l=l, u=u, linsys_solver=solver, **opts)
+        r = oq.solve(m)
+        assert r.info.status == "Solved"
+        xs[solver] = r.x.copy()
+        oq.clean(m)
+    assert np.max(np.abs(xs["pcg"] - xs["qdldl"])) <= 1e-4 * max(1.0, np.max(np.abs(xs["qdldl"])))
+    A2 = A.copy()
+    A2.indices = A2.indices.copy()
+    A2.indices[5] = A.shape[0] + 7
+    m = oq.Model(product_lib)
+    with pytest.raises(oq.OSQPError):
+        oq.setup(m, P=P, q=q, A=A2, l=l, u=u, linsys_solver="pcg", **opts)
