@@ -71,8 +71,10 @@ __device__ __forceinline__ int64_t lower_bound_col(const int *__restrict__ col, 
 // planning
 // ---------------------------------------------------------------------------------------------
 // cnt[b * rows + i] = entries of row i inside panel b   (one wavefront per row, lane = panel)
+// cellsrc[b * rows + i] = CSR position of the first of them (what the first fill of the slices reads from)
 __global__ __launch_bounds__(kBlock) void k_panel_count(int rows, int B, int shift, const int64_t *__restrict__ rp,
-                                                        const int *__restrict__ col, int64_t *__restrict__ cnt) {
+                                                        const int *__restrict__ col, int64_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ cellsrc) {
   const int lane = threadIdx.x & 63;
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (row >= rows) return;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(kBlock) void k_panel_count(int rows, int B, int shi
     int64_t lo = lower_bound_col(col, s, e, b << shift);
     int64_t hi = (b + 1 == B) ? e : lower_bound_col(col, s, e, (b + 1) << shift);
     cnt[(size_t)b * rows + row] = hi - lo;
+    cellsrc[(size_t)b * rows + row] = (uint32_t)lo;
   }
 }
 
@@ -264,6 +267,89 @@ __global__ __launch_bounds__(kBlock) void k_sell_scatter(int rows, int shift, co
     // carry: the state at lane 63 (a full chunk, or the row ends here)
     carry_b = __shfl(b, 63, 64);
     carry_seg = __shfl(seg, 63, 64);
+  }
+}
+
+// The FIRST fill of the slices (panel_build), through LDS: one wavefront per slice.  The entries of the slice's 64 (row, panel)
+// cells are read in CSR order -- each cell is a contiguous run of ~16 entries, so the loads are whole lines -- sixteen
+// positions of every row at a time, put down transposed in LDS and written out position by position as 512-byte pieces
+// (values, local column ids, padding included); the slot of every entry goes out in read order.  k_sell_scatter, which
+// writes the 8-byte values of a row 512 bytes apart and leaves the merging to the L2, stays for the refresh of values; a
+// plain gather (lane = row, no LDS) was 17 ms SLOWER than the scatter: 64 lanes on 64 different lines per instruction.
+constexpr int kFillK = 16;            // positions per pass
+constexpr int kFillStride = 65;       // LDS row stride (64 rows + 1: the transposed writes spread over the banks)
+constexpr int kFillWaves = 4;
+template <typename ColT>
+__global__ __launch_bounds__(kFillWaves * 64) void k_sell_fill_lds(int rows, int shift, const int *__restrict__ ub, const int *__restrict__ unit_s0,
+                                                                 const int *__restrict__ unit_ns, const uint32_t *__restrict__ slice_base,
+                                                                 const int *__restrict__ slice_len, const int *__restrict__ slice_rows,
+                                                                 const uint32_t *__restrict__ cellsrc, const int64_t *__restrict__ off,
+                                                                 const int *__restrict__ col, const double *__restrict__ val,
+                                                                 ColT *__restrict__ scol, double *__restrict__ sval, uint32_t *__restrict__ slot) {
+  __shared__ double tv[kFillWaves][kFillK * kFillStride];
+  __shared__ uint32_t tc[kFillWaves][kFillK * kFillStride];
+  __shared__ int start[kFillWaves][65];
+  const int u = blockIdx.x, b = ub[u];
+  const int s0 = unit_s0[u], ns = unit_ns[u];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mask = (1 << shift) - 1;
+  double *mv = tv[wave];
+  uint32_t *mc = tc[wave];
+  int *st = start[wave];
+  for (int sl = s0 + wave; sl < s0 + ns; sl += kFillWaves) {
+    const uint32_t base = slice_base[sl];
+    const int L = slice_len[sl];
+    const int row = slice_rows[(size_t)sl * 64 + lane];
+    uint32_t src = 0;
+    int len = 0;
+    if (row >= 0) {
+      const size_t c = (size_t)b * rows + row;
+      src = cellsrc[c];
+      len = (int)(off[c + 1] - off[c]);
+    }
+    for (int k0 = 0; k0 < L; k0 += kFillK) {
+      int mine = len - k0;
+      mine = mine < 0 ? 0 : (mine > kFillK ? kFillK : mine);
+      int incl = mine;  // inclusive scan over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const int total = __shfl(incl, 63, 64);
+      st[lane] = incl - mine;
+      if (lane == 63) st[64] = total;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int f = lane; f < ((total + 63) & ~63); f += 64) {
+        const bool in = f < total;
+        int r = 0;
+        if (in) {  // the row whose run holds f: the last r with st[r] <= f
+          int lo = 0, hi = 64;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (st[mid] <= f) lo = mid; else hi = mid; }
+          r = lo;
+          // rows with an empty share have st[r] == st[r + 1]: step to the last of the equal ones (it is the one with entries)
+        }
+        const uint32_t rsrc = (uint32_t)__shfl((int)src, r, 64);
+        if (in) {
+          const int k = f - st[r];
+          const size_t g = (size_t)rsrc + (size_t)(k0 + k);
+          mv[k * kFillStride + r] = val[g];
+          mc[k * kFillStride + r] = (uint32_t)(col[g] & mask);
+          if (slot) slot[g] = base + (uint32_t)((k0 + k) * 64 + r);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int kend = L - k0 < kFillK ? L - k0 : kFillK;
+      for (int k = 0; k < kend; k++) {
+        const size_t at = (size_t)base + (size_t)(k0 + k) * 64 + lane;
+        const bool in = k < mine;
+        sval[at] = in ? mv[k * kFillStride + lane] : 0.0;
+        scol[at] = in ? (ColT)mc[k * kFillStride + lane] : (ColT)0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -739,8 +825,9 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot) {
   const int64_t cells = (int64_t)P.B * M.rows;
   // per-(panel, row) counts and their offsets
   DevBuf<int64_t> cnt((size_t)cells + 1), off((size_t)cells + 1);
+  DevBuf<uint32_t> cellsrc((size_t)cells);
   OQ_LAUNCH(k_panel_count, dim3(blocks_for((int64_t)M.rows * 64)), dim3(kBlock), 0, s, M.rows, P.B, P.shift, M.rowptr.get(),
-            M.col.get(), cnt.get());
+            M.col.get(), cnt.get(), cellsrc.get());
   exclusive_scan(cnt.get(), off.get(), cells, s);
   P.Gp = panel_group_size(M, P.B);
   P.NG = (P.B + P.Gp - 1) / P.Gp;
@@ -802,7 +889,16 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot) {
   else { P.scol.alloc((size_t)padded); P.scol.zero(s); }
   P.partial.alloc((size_t)gcells);
   P.partial.zero(s);  // every (group, row) cell is rewritten by each product: the zeroes only matter before the first one
-  panel_fill(M, true, s, slot);
+  static const bool lds_fill = !(getenv("OSQP_AMD_SELL_FILL") && atoi(getenv("OSQP_AMD_SELL_FILL")) == 0);
+  if (!lds_fill) panel_fill(M, true, s, slot);
+  else if (P.wide)
+    OQ_LAUNCH(k_sell_fill_lds<uint32_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
+              P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
+              P.scol32.get(), P.sval.get(), slot);
+  else
+    OQ_LAUNCH(k_sell_fill_lds<uint16_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
+              P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
+              P.scol.get(), P.sval.get(), slot);
   HIP_CHECK(hipStreamSynchronize(s));
   if (!P.wide)
     HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
