@@ -182,6 +182,19 @@ def make_settings(lib, settings):
     return s
 
 
+def _istriu(P):
+    """istriu(P) of [REF src/interface.jl:88-90] on a CSC matrix, without building its lower triangle."""
+    if P.nnz == 0:
+        return True
+    first = P.indptr[:-1]
+    nonempty = P.indptr[1:] > first
+    if P.has_sorted_indices:  # the last stored row of every column decides
+        last = P.indices[P.indptr[1:][nonempty] - 1]
+        return not np.any(last > np.nonzero(nonempty)[0])
+    cols = np.repeat(np.arange(P.shape[1], dtype=P.indices.dtype), np.diff(P.indptr))
+    return not np.any(P.indices > cols)
+
+
 def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, **settings):
     """[REF src/interface.jl:35-162].  Extension: `comm` (sharded.HostComm / sharded.RcclComm) makes this rank keep
     its row block of one QP shared by all ranks of the communicator (osqp_amd_setup_sharded)."""
@@ -217,7 +230,7 @@ def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, **settings):
     if len(u) != m:
         raise OSQPError("Incorrect dimensions of u")
     P = sp.csc_matrix(P)
-    if sp.tril(P, -1).nnz != 0:  # !istriu(P)
+    if not _istriu(P):
         P = sp.triu(P, format="csc")
     u = np.minimum(u, OSQP_INFTY)
     l = np.maximum(l, -OSQP_INFTY)
