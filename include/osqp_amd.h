@@ -231,7 +231,11 @@ OSQP_AMD_OFFSET(OSQPWorkspace, impl, 240); /* past everything the reference mirr
 void osqp_set_default_settings(OSQPSettings *settings);
 
 /* [REF src/interface.jl:147]  0 on success; non-zero (1 data, 2 settings,
- * 4 linsys init, 5 non-convex, 6 alloc) makes setup! throw. */
+ * 4 linsys init, 5 non-convex, 6 alloc) makes setup! throw.
+ * data->A: the row indices inside every column must ascend without repeats -- what Julia's SparseMatrixCSC guarantees
+ * and ManagedCcsc copies verbatim [REF src/types.jl:21-47]; the arrays serve as the CSR arrays of A' as they are.  A
+ * caller that hands over unsorted columns gets exit flag 1, not a wrong answer.  data->P (upper triangle) may come in
+ * any order inside its columns. */
 c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings);
 
 /* [REF src/interface.jl:171]  return value ignored by the caller; the outcome

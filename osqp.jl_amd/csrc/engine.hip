@@ -411,6 +411,19 @@ void Engine::open_device() {
   flag.alloc(4); flag.zero(stream);
 }
 
+// the caller's CSC arrays of A serve as the CSR arrays of A' as they come: the row indices of every column have to ascend (what
+// Julia's SparseMatrixCSC guarantees [REF src/types.jl:21-47 copies it verbatim]); the panel layout bisects them
+__global__ __launch_bounds__(kBlock) void k_csr_cols_descend(int64_t nnz, int rows, const int64_t *__restrict__ rp, const int *__restrict__ col,
+                                                             int *__restrict__ flag) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < 1 || k >= nnz) return;
+  if (col[k - 1] < col[k]) return;
+  // not ascending across k-1 -> k: fine only if k starts a row
+  int lo = 0, hi = rows;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rp[mid] <= k) lo = mid; else hi = mid; }
+  if (rp[lo] != k) *flag = 1;
+}
+
 void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, DevBuf<double> &Px, DevBuf<int64_t> &Ap,
                           DevBuf<int> &Ai, DevBuf<double> &Ax_in, DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double> &u_,
                           const OSQPSettings &s) {
@@ -428,6 +441,15 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
   At.rows = n; At.cols = m; At.nnz = nnzA;
   At.rowptr = std::move(Ap); At.col = std::move(Ai); At.val = std::move(Ax_in);
   At.group = pick_group(n, nnzA);
+  if (nnzA > 1) {
+    flag.zero(stream);
+    OQ_LAUNCH(k_csr_cols_descend, dim3(blocks_for(nnzA)), dim3(kBlock), 0, stream, nnzA, n, At.rowptr.get(), At.col.get(), flag.get());
+    int bad = 0;
+    flag.download(&bad, 1, stream);
+    sync();
+    flag.zero(stream);
+    if (bad) throw Error(1, "the row indices inside a column of A must ascend (and not repeat)");
+  }
   // A problem that is certain to run the indirect back-end at a size where the workspace goes compact: every matrix gets
   // its sliced-ELL copy and gives up its CSR arrays NOW, one after the other (Ruiz scaling then runs over the slices:
   // scale_data), instead of all three copies living side by side until the end of the setup.

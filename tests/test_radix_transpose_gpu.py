@@ -2,8 +2,8 @@
 csr_from_coo): counting sort with row counters and a per-row sort, and -- for large matrices -- the stable radix sort
 that needs neither device-scope atomics nor the per-row sort when the rows arrive column-ascending.  Forced on for every
 size (OSQP_AMD_RADIX_MIN=1) it has to give bit for bit what the counting path gives (OSQP_AMD_RADIX_MIN=-1): on generated
-problems (sorted input: no fallback), on a caller's CSC arrays with unsorted row indices inside the columns (the check
-finds unsorted rows and the per-row sort runs on top), with empty rows and columns, and through value updates by index
+problems (sorted input: no fallback), on a caller's upper triangle of P with unsorted row indices inside the columns (handed to the C ABI as they are: the check
+finds unsorted rows of the full matrix and the per-row sort runs on top; unsorted columns of A are refused), with empty rows and columns, and through value updates by index
 (the nnz-index maps come from the same permutation).  The switch is read when the library loads: child processes."""
 import os
 import subprocess
@@ -20,7 +20,16 @@ import sys, os, hashlib
 sys.path.insert(0, sys.argv[1])
 import numpy as np, scipy.sparse as sp
 import osqp_jl_amd as oq
+from osqp_jl_amd import types as T
 lib = oq.load_library()
+class RawCcsc:  # the mirror's ManagedCcsc sorts the row indices of every column (Julia's SparseMatrixCSC is always sorted); a C caller need not
+    def __init__(self, M):
+        M = sp.csc_matrix(M)
+        self.m, self.n = M.shape
+        self.x = np.ascontiguousarray(M.data, dtype=np.float64)
+        self.i = np.ascontiguousarray(M.indices, dtype=np.int64)
+        self.p = np.ascontiguousarray(M.indptr, dtype=np.int64)
+        self.ccsc = T.Ccsc(len(self.x), self.m, self.n, oq.interface._iptr(self.p), oq.interface._iptr(self.i), oq.interface._fptr(self.x), -1)
 out = []
 def digest(r):
     return hashlib.sha256(np.ascontiguousarray(r.x).tobytes() + np.ascontiguousarray(r.y).tobytes()).hexdigest()[:16] + ":%d:%s" % (r.info.iter, r.info.status)
@@ -46,15 +55,29 @@ def shuffle_columns(M):
 Au = shuffle_columns(A)
 Ps = shuffle_columns(P)  # rows of the full symmetric P then arrive out of order: the check has to send them through the per-row sort
 q = rng.standard_normal(n); l = -rng.random(mm); u = rng.random(mm)
-for solver in ("pcg", "qdldl"):
-    m = oq.Model(lib); oq.setup(m, P=Ps, q=q, A=Au, l=l, u=u, linsys_solver=solver, **opts)
-    out.append(digest(oq.solve(m)))
-    idx = np.arange(0, Au.nnz, 7)
-    oq.update(m, Ax=Au.data[idx] * 0.5, Ax_idx=idx)
+ref = None
+for solver in ("sorted", "pcg"):
+    if solver == "pcg": oq.interface.ManagedCcsc = RawCcsc   # from here on the arrays reach the C ABI unsorted
+    m = oq.Model(lib); oq.setup(m, P=(P if solver == "sorted" else Ps), q=q, A=A, l=l, u=u, linsys_solver="pcg", **opts)
+    r0 = oq.solve(m)
+    out.append(digest(r0))
+    if ref is None: ref = r0.x.copy()
+    else: assert np.max(np.abs(r0.x - ref)) <= 1e-3 * max(1.0, np.max(np.abs(ref))), "unsorted columns changed the solution"
+    if solver == "sorted":
+        out.append("skip:0:Solved"); oq.clean(m); continue
+    idx = np.arange(0, A.nnz, 7)
+    oq.update(m, Ax=A.data[idx] * 0.5, Ax_idx=idx)
     pidx = np.arange(0, Ps.nnz, 3)
     oq.update(m, Px=Ps.data[pidx] * 0.9, Px_idx=pidx)
     out.append(digest(oq.solve(m)))
     oq.clean(m)
+# 3. the columns of A themselves have to come sorted (the arrays are used as they are): refused, not mangled
+m = oq.Model(lib)
+try:
+    oq.setup(m, P=P, q=q, A=Au, l=l, u=u, linsys_solver="pcg", **opts)
+    out.append("unsorted-A:0:accepted")
+except oq.OSQPError:
+    out.append("unsorted-A:0:refused")
 print("\n".join(out))
 """
 
@@ -66,7 +89,7 @@ def _run(extra_env):
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ":" in ln]
-    assert len(lines) == 6, r.stdout
+    assert len(lines) == 7, r.stdout
     return lines
 
 
@@ -75,3 +98,4 @@ def test_radix_path_equals_counting_path():
     radix = _run({"OSQP_AMD_RADIX_MIN": "1"})
     assert counting[0].endswith("Solved") and counting[2].endswith("Solved"), counting
     assert radix == counting
+    assert counting[6].endswith("refused")
