@@ -1,4 +1,5 @@
 #!/bin/bash
+# (A/B of the host-loop switches on rand-1e5: profiles/r03_rand1e5_hostloop_ab.txt)
 # host CG loop: speculative first iteration, extrapolation sums in the reduce, rhs left behind by the update -- A/B on rand-1e5, suite
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (dispatch timelines of rand-1e5: profiles/r03_rand1e5_timeline.md)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3ae; mkdir -p $O
