@@ -322,12 +322,9 @@ static bool csr_from_coo_radix(int rows, int cols, int64_t E, const int *erow, c
   const unsigned mask = (unsigned)nb - 1u;
   const int64_t nchunks = (E + kSortChunk - 1) / kSortChunk;
   if (nchunks > 2147483647LL) return false;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_radix_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SortLds)));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_radix_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SortLds)));
-    attr_set = true;
-  }
+  // per call: the attribute belongs to the current device's copy of the kernel
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_radix_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SortLds)));
+  HIP_CHECK(hipFuncSetAttribute((const void *)k_radix_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SortLds)));
   out.rows = rows; out.cols = cols;
   DevBuf<unsigned long long> ping((size_t)E), pong((size_t)E);
   DevBuf<int64_t> H((size_t)nb * nchunks), offs((size_t)nb * nchunks + 1);
