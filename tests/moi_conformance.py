@@ -529,4 +529,116 @@ def case_model_supports_and_unsupported_constraint(lib):
         pass
 
 
+
+# ---- the one-constraint problems of MathOptInterface's test_constraint_* / test_variable_* / test_solve_* families ----------
+def _one_constraint(lib, sense, obj_coef, coefs, cset, obj, xval, dual):
+    m = MOI.Model()
+    x = m.add_variable()
+    c = m.add_constraint(saf(coefs, [x] * len(coefs)), cset)
+    m.set_objective_function(saf([obj_coef], [x]))
+    m.set_objective_sense(sense)
+    a = float(sum(coefs))
+    lo = cset.lower if hasattr(cset, "lower") else (cset.value if isinstance(cset, MOI.EqualTo) else -np.inf)
+    hi = cset.upper if hasattr(cset, "upper") else (cset.value if isinstance(cset, MOI.EqualTo) else np.inf)
+    if isinstance(cset, MOI.GreaterThan):
+        lo, hi = cset.lower, np.inf
+    if isinstance(cset, MOI.LessThan):
+        lo, hi = -np.inf, cset.upper
+    bnds = sorted([lo / a, hi / a])
+    ref, xr = lp_reference([obj_coef], bounds=[(None if not np.isfinite(bnds[0]) else bnds[0], None if not np.isfinite(bnds[1]) else bnds[1])],
+                           maximize=(sense == MOI.MAX_SENSE))
+    assert approx(ref, obj) and approx(xr, [xval])
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, obj, [xval], [x], [(c, dual)])
+    return opt, idx, m, x, c
+
+
+def case_constraint_ScalarAffineFunction_LessThan(lib):
+    """max x  s.t.  2x <= 1   ->  0.5 at x = 0.5, dual -0.5."""
+    _one_constraint(lib, MOI.MAX_SENSE, 1.0, [2.0], MOI.LessThan(1.0), 0.5, 0.5, -0.5)
+
+
+def case_constraint_ScalarAffineFunction_GreaterThan(lib):
+    """min x  s.t.  2x >= 1   ->  0.5 at x = 0.5, dual 0.5."""
+    _one_constraint(lib, MOI.MIN_SENSE, 1.0, [2.0], MOI.GreaterThan(1.0), 0.5, 0.5, 0.5)
+
+
+def case_constraint_ScalarAffineFunction_EqualTo(lib):
+    """min x  s.t.  2x == 1   ->  0.5 at x = 0.5, dual 0.5."""
+    _one_constraint(lib, MOI.MIN_SENSE, 1.0, [2.0], MOI.EqualTo(1.0), 0.5, 0.5, 0.5)
+
+
+def case_constraint_ScalarAffineFunction_Interval(lib):
+    """min 3x  s.t.  2x in [1, 4]   ->  1.5 at x = 0.5, dual 1.5."""
+    _one_constraint(lib, MOI.MIN_SENSE, 3.0, [2.0], MOI.Interval(1.0, 4.0), 1.5, 0.5, 1.5)
+
+
+def case_constraint_ScalarAffineFunction_duplicate(lib):
+    """min x  s.t.  x + x >= 1 (the same variable twice in one function)   ->  0.5 at x = 0.5, dual 0.5."""
+    _one_constraint(lib, MOI.MIN_SENSE, 1.0, [1.0, 1.0], MOI.GreaterThan(1.0), 0.5, 0.5, 0.5)
+
+
+def case_variable_solve_with_lowerbound(lib):
+    """min 2x  s.t.  x >= 1, x <= 2   ->  2 at x = 1; the lower bound's dual is 2, the upper bound's 0."""
+    m = MOI.Model()
+    x = m.add_variable()
+    lb = m.add_constraint(saf([1], [x]), MOI.GreaterThan(1.0))
+    ub = m.add_constraint(saf([1], [x]), MOI.LessThan(2.0))
+    m.set_objective_function(saf([2.0], [x]))
+    m.set_objective_sense(MOI.MIN_SENSE)
+    ref, xr = lp_reference([2], bounds=[(1, 2)])
+    assert approx(ref, 2) and approx(xr, [1])
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, 2, [1], [x], [(lb, 2), (ub, 0)])
+
+
+def case_variable_solve_with_upperbound(lib):
+    """max 2x  s.t.  x <= 1, x >= 0   ->  2 at x = 1; the upper bound's dual is -2, the lower bound's 0."""
+    m = MOI.Model()
+    x = m.add_variable()
+    ub = m.add_constraint(saf([1], [x]), MOI.LessThan(1.0))
+    lb = m.add_constraint(saf([1], [x]), MOI.GreaterThan(0.0))
+    m.set_objective_function(saf([2.0], [x]))
+    m.set_objective_sense(MOI.MAX_SENSE)
+    ref, xr = lp_reference([2], bounds=[(0, 1)], maximize=True)
+    assert approx(ref, 2) and approx(xr, [1])
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, 2, [1], [x], [(ub, -2), (lb, 0)])
+
+
+def case_solve_VariableIndex_ConstraintDual_MIN_SENSE(lib):
+    """min x  s.t.  x >= 1   ->  x = 1, dual 1."""
+    _one_constraint(lib, MOI.MIN_SENSE, 1.0, [1.0], MOI.GreaterThan(1.0), 1.0, 1.0, 1.0)
+
+
+def case_solve_VariableIndex_ConstraintDual_MAX_SENSE(lib):
+    """max x  s.t.  x <= 1   ->  x = 1, dual -1."""
+    _one_constraint(lib, MOI.MAX_SENSE, 1.0, [1.0], MOI.LessThan(1.0), 1.0, 1.0, -1.0)
+
+
+def case_solve_optimize_twice(lib):
+    """min x  s.t.  x >= 1, optimised twice in a row: the second call returns the same point (and, warm-started at the
+    optimum, needs no more iterations than the first)."""
+    opt, idx, m, x, c = _one_constraint(lib, MOI.MIN_SENSE, 1.0, [1.0], MOI.GreaterThan(1.0), 1.0, 1.0, 1.0)
+    first = opt.variable_primal([idx[x]])
+    opt.optimize()
+    assert opt.termination_status() == MOI.OPTIMAL
+    assert approx(opt.variable_primal([idx[x]]), first) and approx(opt.objective_value(), 1.0)
+
+
+def case_objective_ObjectiveSense_MAX_and_MIN(lib):
+    """The same feasible set [0, 1] x [0, 2] under max x + y (-> 3) and min x + y (-> 0); the wrapper takes the sense at copy_to
+    [REF src/MOI_wrapper.jl:232, 497, 589: get and supports, no set], so the second sense is a second copy."""
+    m = MOI.Model()
+    x, y = m.add_variables(2)
+    m.add_constraint(saf([1], [x]), MOI.Interval(0.0, 1.0))
+    m.add_constraint(saf([1], [y]), MOI.Interval(0.0, 2.0))
+    m.set_objective_function(saf([1.0, 1.0], [x, y]))
+    m.set_objective_sense(MOI.MAX_SENSE)
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, 3, [1, 2], [x, y])
+    m.set_objective_sense(MOI.MIN_SENSE)
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, 0, [0, 0], [x, y])
+
 ALL = [f for name, f in sorted(globals().items()) if name.startswith("case_") and callable(f)]
