@@ -98,3 +98,41 @@ def test_setup_cleanup_cycles_on_mapped_blocks_repeat_exactly():
     last = r.stdout.strip().splitlines()[-1].split()
     assert last[0] == "1", r.stdout  # ten cycles, one distinct pair of digests
     assert last[1].count("Solved") == 2, r.stdout
+
+
+THREADS = r"""
+import sys, os, hashlib, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import osqp_jl_amd as oq
+lib = oq.load_library()
+def digest(r):
+    return hashlib.sha256(np.ascontiguousarray(r.x).tobytes() + np.ascontiguousarray(r.y).tobytes()).hexdigest()[:16] + ":%d:%s" % (r.info.iter, r.info.status)
+def work(seed, out):
+    res = []
+    for rep in range(4):
+        m = oq.Model(lib)
+        oq.setup_generated(m, 0, 20000 + 1000 * seed, 48, seed, verbose=False, linsys_solver="pcg", eps_abs=1e-4, eps_rel=1e-4, max_iter=300)
+        res.append(digest(oq.solve(m)))
+        oq.clean(m)
+    out[seed] = res
+alone = {}
+for seed in (1, 2, 3):
+    work(seed, alone)
+together = {}
+ths = [threading.Thread(target=work, args=(seed, together)) for seed in (1, 2, 3)]
+for t in ths: t.start()
+for t in ths: t.join()
+print("same" if together == alone and all(len(set(v)) == 1 for v in alone.values()) else "DIFFERENT", alone[1][0])
+"""
+
+
+def test_concurrent_setups_in_three_threads_share_the_chunk_pool():
+    """Three threads set up, solve and clean different problems at the same time on one device (ctypes releases the GIL inside the
+    library): the allocator's pool, the address-range bookkeeping and the per-thread parking of small blocks are shared state."""
+    env = dict(os.environ)
+    env.update({"OSQP_AMD_VMM_MIN_MB": "1", "OSQP_AMD_POISON": "1"})
+    r = subprocess.run([sys.executable, "-c", THREADS, ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "same" and last[1].endswith("Solved"), r.stdout
