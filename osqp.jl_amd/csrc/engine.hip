@@ -459,9 +459,13 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     if (!early || M.rows == 0 || M.nnz == 0 || !panel_wanted(M)) return;
     DevBuf<uint32_t> p2s;
     if (!comm) p2s.alloc((size_t)M.nnz);  // the slot of every entry, recorded while the slices are filled
-    try { panel_build(M, stream, p2s.get()); }
+    bool maps_done = false;
+    // as soon as the column pass of the fill has recorded every slot the nnz-index maps are rewritten and the 4 B per entry of
+    // the slot array go, BEFORE the slice values are allocated (the high-water mark of the setup is in here)
+    auto fold = [&]() { if (!comm) { fold_slot_maps(which, p2s); maps_done = true; } };
+    try { panel_build(M, stream, p2s.get(), true, fold); }
     catch (const Error &) { M.panel = DevPanel(); return; }  // stays on its CSR arrays
-    compact_one(which, &p2s);
+    compact_one(which, &p2s, maps_done);
   };
   auto transpose_A = [&]() {
     {
@@ -718,23 +722,27 @@ __global__ __launch_bounds__(kBlock) void k_compose_slot_map(int64_t k, const in
 // release each CSR copy as soon as its sliced-ELL copy exists (setup_device: the high-water mark of the device memory stays
 // near the resident size instead of CSR + slices of all three), and so that a matrix whose slices cannot be built (mostly
 // padding) simply keeps its CSR arrays: every consumer looks at the matrix's own flag.
-void Engine::compact_one(int which, DevBuf<uint32_t> *known_slots) {
-  DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
-  if (M.compact || !panel_can_compact(M)) return;
-  // The slot maps take the place of the position maps, entry by entry, in the same buffers (a thread reads its position and
-  // writes its slot): A_k2pos / P_k2lo / P_k2up hold CSR positions while their matrix has CSR arrays, slots of the sliced
-  // copy once it is compact (the consumers go by the matrix's flag).
-  auto compose_in_place = [&](int64_t k, DevBuf<int> &k2pos, const DevBuf<uint32_t> &p2s) {
+// The slot maps take the place of the position maps, entry by entry, in the same buffers (a thread reads its position and
+// writes its slot): A_k2pos / P_k2lo / P_k2up hold CSR positions while their matrix has CSR arrays, slots of the sliced
+// copy once it is compact (the consumers go by the matrix's flag).  p2s: slot of every CSR position; given up here
+// (A, P) or kept as the map itself (A': position k of A' is the caller's nnz index k).
+void Engine::fold_slot_maps(int which, DevBuf<uint32_t> &p2s) {
+  auto compose_in_place = [&](int64_t k, DevBuf<int> &k2pos) {
     if (k > 0) OQ_LAUNCH(k_compose_slot_map, dim3(blocks_for(k)), dim3(kBlock), 0, stream, k, (const int *)k2pos.get(), p2s.get(), (uint32_t *)k2pos.get());
   };
-  const bool maps = !comm;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
+  if (which == 0) { compose_in_place(nnzA, A_k2pos); sync(); p2s.release(); }
+  else if (which == 1) { sync(); At_k2slot = std::move(p2s); }
+  else { compose_in_place(nnzPtriu, P_k2lo); compose_in_place(nnzPtriu, P_k2up); sync(); p2s.release(); }
+}
+
+void Engine::compact_one(int which, DevBuf<uint32_t> *known_slots, bool maps_done) {
+  DevCsr &M = which == 0 ? A : (which == 1 ? At : Pf);
+  if (M.compact || !panel_can_compact(M)) return;
+  const bool maps = !comm && !maps_done;  // a row block (sharded) has no nnz-index maps: value updates are refused there anyway
   if (maps) {
     DevBuf<uint32_t> own;
     if (!(known_slots && known_slots->n > 0)) { own.alloc((size_t)M.nnz); panel_slot_of_pos(M, own.get(), stream); }
-    DevBuf<uint32_t> &p2s = (known_slots && known_slots->n > 0) ? *known_slots : own;
-    if (which == 0) { compose_in_place(nnzA, A_k2pos, p2s); sync(); }
-    else if (which == 1) { sync(); At_k2slot = std::move(p2s); }  // position k of A' is the caller's nnz index k
-    else { compose_in_place(nnzPtriu, P_k2lo, p2s); compose_in_place(nnzPtriu, P_k2up, p2s); sync(); }
+    fold_slot_maps(which, (known_slots && known_slots->n > 0) ? *known_slots : own);
   }
   if (which == 2) Pi_keep.release();  // the direct back-end's symbolic phase is out of reach at this size
   panel_compact(M);

@@ -153,7 +153,8 @@ struct Engine {
   void compact_matrices();
   void setup_mark(const char *what);
   double mark_prev = 0.0;
-  void compact_one(int which, DevBuf<uint32_t> *known_slots = nullptr);
+  void compact_one(int which, DevBuf<uint32_t> *known_slots = nullptr, bool maps_done = false);
+  void fold_slot_maps(int which, DevBuf<uint32_t> &p2s);
   bool compact_wanted(int64_t stored) const;
   bool pcg_certain() const;
   void set_rho_vec();

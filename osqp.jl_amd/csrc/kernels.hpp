@@ -1,6 +1,7 @@
 // kernels.hpp -- launchers of the hand-written gfx950 kernels (kernels.hip).
 // Rows K0-K10 of SURVEY.md section 8a; each launcher names its row.
 #pragma once
+#include <functional>
 #include "common.hpp"
 
 namespace oq {
@@ -59,7 +60,8 @@ void spmv_pair(const DevCsr &Ma, const DevCsr &Mb, const double *x, double *ya, 
 // LDS-staged column-panel variant (panel.hip); spmv() dispatches to it when M.panel.active
 bool panel_wanted(const DevCsr &M);
 // slot (may be null): slot[k] = position of CSR entry k inside the sliced copy, recorded while the entries are placed
-void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot = nullptr);                 // structure + values from the CSR arrays
+void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot = nullptr, bool will_compact = false,
+                 const std::function<void()> &after_cols = std::function<void()>());                 // structure + values from the CSR arrays
 void panel_fill(DevCsr &M, bool with_cols, hipStream_t s, uint32_t *slot = nullptr);  // refresh the values after the CSR values changed
 void spmv_panel(const DevCsr &M, const double *x, double *y, const double *rscale, double beta, double gamma,
                 const double *v, hipStream_t s, const SpmvExtra *extra = nullptr);

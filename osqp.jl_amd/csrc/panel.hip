@@ -41,6 +41,7 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include <functional>
 #include "devutil.hpp"
 
 namespace oq {
@@ -285,7 +286,9 @@ __global__ __launch_bounds__(kFillWaves * 64) void k_sell_fill_lds(int rows, int
                                                                  const int *__restrict__ slice_len, const int *__restrict__ slice_rows,
                                                                  const uint32_t *__restrict__ cellsrc, const int64_t *__restrict__ off,
                                                                  const int *__restrict__ col, const double *__restrict__ val,
-                                                                 ColT *__restrict__ scol, double *__restrict__ sval, uint32_t *__restrict__ slot) {
+                                                                 ColT *__restrict__ scol, double *__restrict__ sval, uint32_t *__restrict__ slot,
+                                                                 int what) {  // bit 0: column ids (+ slots), bit 1: values
+  const bool do_cols = what & 1, do_vals = what & 2;
   __shared__ double tv[kFillWaves][kFillK * kFillStride];
   __shared__ uint32_t tc[kFillWaves][kFillK * kFillStride];
   __shared__ int start[kFillWaves][65];
@@ -332,9 +335,11 @@ __global__ __launch_bounds__(kFillWaves * 64) void k_sell_fill_lds(int rows, int
         if (in) {
           const int k = f - st[r];
           const size_t g = (size_t)rsrc + (size_t)(k0 + k);
-          mv[k * kFillStride + r] = val[g];
-          mc[k * kFillStride + r] = (uint32_t)(col[g] & mask);
-          if (slot) slot[g] = base + (uint32_t)((k0 + k) * 64 + r);
+          if (do_vals) mv[k * kFillStride + r] = val[g];
+          if (do_cols) {
+            mc[k * kFillStride + r] = (uint32_t)(col[g] & mask);
+            if (slot) slot[g] = base + (uint32_t)((k0 + k) * 64 + r);
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(kFillWaves * 64) void k_sell_fill_lds(int rows, int
       for (int k = 0; k < kend; k++) {
         const size_t at = (size_t)base + (size_t)(k0 + k) * 64 + lane;
         const bool in = k < mine;
-        sval[at] = in ? mv[k * kFillStride + lane] : 0.0;
-        scol[at] = in ? (ColT)mc[k * kFillStride + lane] : (ColT)0;
+        if (do_vals) sval[at] = in ? mv[k * kFillStride + lane] : 0.0;
+        if (do_cols) scol[at] = in ? (ColT)mc[k * kFillStride + lane] : (ColT)0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -816,7 +821,7 @@ void panel_fill(DevCsr &M, bool with_cols, hipStream_t s, uint32_t *slot) {
               M.col.get(), M.val.get(), P.cellbase.get(), P.scol.get(), P.sval.get(), with_cols ? 1 : 0, slot);
 }
 
-void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot) {
+void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot, bool will_compact, const std::function<void()> &after_cols) {
   DevPanel &P = M.panel;
   P.wide = panel_mode(M) == 2;
   P.shift = P.wide ? (wide_shift(M) ? wide_shift(M) : 18) : panel_shift(); P.W = 1 << P.shift;
@@ -883,22 +888,41 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot) {
   P.cellbase.alloc((size_t)cells); P.cellbase.zero(s);
   OQ_LAUNCH(k_tile_layout, dim3((unsigned)nunits), dim3(kThreads), 0, s, M.rows, ub.get(), u0.get(), u1.get(), off.get(), slice0.get(),
             padded0.get(), P.unit_s0.get(), P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), P.cellbase.get());
-  P.sval.alloc((size_t)padded);
-  P.sval.zero(s);  // padding slots: value 0 times x[panel column 0]
-  if (P.wide) { P.scol32.alloc((size_t)padded); P.scol32.zero(s); }
-  else { P.scol.alloc((size_t)padded); P.scol.zero(s); }
   P.partial.alloc((size_t)gcells);
   P.partial.zero(s);  // every (group, row) cell is rewritten by each product: the zeroes only matter before the first one
   static const bool lds_fill = !(getenv("OSQP_AMD_SELL_FILL") && atoi(getenv("OSQP_AMD_SELL_FILL")) == 0);
-  if (!lds_fill) panel_fill(M, true, s, slot);
-  else if (P.wide)
-    OQ_LAUNCH(k_sell_fill_lds<uint32_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
-              P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
-              P.scol32.get(), P.sval.get(), slot);
-  else
-    OQ_LAUNCH(k_sell_fill_lds<uint16_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
-              P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
-              P.scol.get(), P.sval.get(), slot);
+  auto fill = [&](int what) {
+    if (P.wide)
+      OQ_LAUNCH(k_sell_fill_lds<uint32_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
+                P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
+                P.scol32.get(), P.sval.get(), slot, what);
+    else
+      OQ_LAUNCH(k_sell_fill_lds<uint16_t>, dim3((unsigned)nunits), dim3(kFillWaves * 64), 0, s, M.rows, P.shift, ub.get(), P.unit_s0.get(),
+                P.unit_ns.get(), P.slice_base.get(), P.slice_len.get(), P.slice_rows.get(), cellsrc.get(), off.get(), M.col.get(), M.val.get(),
+                P.scol.get(), P.sval.get(), slot, what);
+  };
+  if (!lds_fill) {
+    P.sval.alloc((size_t)padded);
+    P.sval.zero(s);  // padding slots: value 0 times x[panel column 0]
+    if (P.wide) { P.scol32.alloc((size_t)padded); P.scol32.zero(s); }
+    else { P.scol.alloc((size_t)padded); P.scol.zero(s); }
+    panel_fill(M, true, s, slot);
+  } else if (will_compact && !P.wide) {
+    // The matrix gives up its CSR arrays right after this: column ids (and slots) first, then the CSR column array goes BEFORE the
+    // slice values are allocated -- 4 B per entry less at the high-water mark of a large setup (rand-1e6: 59.75 -> 54.5 GB) for
+    // a second walk over the slice structure.  The fill writes every position of every slice, padding included: no memset.
+    P.scol.alloc((size_t)padded);
+    fill(1);
+    HIP_CHECK(hipStreamSynchronize(s));
+    M.col.release();
+    if (after_cols) after_cols();  // the slots are all known now: the caller folds them into its maps and lets the temporary go
+    P.sval.alloc((size_t)padded);
+    fill(2);
+  } else {
+    P.sval.alloc((size_t)padded);
+    if (P.wide) P.scol32.alloc((size_t)padded); else P.scol.alloc((size_t)padded);
+    fill(3);
+  }
   HIP_CHECK(hipStreamSynchronize(s));
   if (!P.wide)
     HIP_CHECK(hipFuncSetAttribute((const void *)k_spmv_sell<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
