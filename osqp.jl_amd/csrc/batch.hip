@@ -34,6 +34,10 @@ namespace {
 #define OQ_BATCH_NT 512
 #endif
 constexpr int NT = OQ_BATCH_NT;  // threads per workgroup = per QP
+inline bool batch_quad_enabled() {  // OSQP_AMD_BATCH_QUAD=0: the MPC family on the 512-thread kernel (A/B runs, tests)
+  const char *e = getenv("OSQP_AMD_BATCH_QUAD");
+  return !e || atoi(e) != 0;
+}
 constexpr int NW = NT / 64;
 #define B_RHO_MIN 1e-6
 #define B_RHO_MAX 1e6
@@ -746,6 +750,8 @@ __device__ __noinline__ void residual_phase(CheckArgs a) {
 }
 
 
+#include "batch_quad.hpp"
+
 // CN > 0: the instance shape (n, m, nnz(A), nnz(P full)) = (CN, CM, CA, CF) is known at compile time -- every LDS address
 // becomes an immediate and every vector loop a fixed trip count (the registers otherwise spent on ~35 LDS pointers are
 // what the inverse needs); CN = 0: the same source with the shape read from the pattern at run time.
@@ -1071,6 +1077,12 @@ struct DevicePattern {
   DevBuf<int> Ap, Ai, Rp, Rc, Rmap, Fp, Fc, Fmap, Tp;
   DevBuf<unsigned short> Ti, Tj, Tr, Ta, Tb;
   mutable DevBuf<double> scratch;  // [instances x n x n]: where a workgroup assembles its reduced KKT matrix (launch_batch sizes it)
+  // schedule of the four-wavefront kernel (batch_quad.hpp); quad_ok: the pattern fits its compile-time bounds
+  bool quad_ok = false;
+  quad::Sched QS;
+  DevBuf<unsigned short> qs_colstart, qs_collist;
+  DevBuf<unsigned> qs_roww, qs_meta;
+  DevBuf<unsigned long long> qs_stream;
   void build(int n, int m, const std::vector<int> &hPp, const std::vector<int> &hPi, const std::vector<int> &hAp,
              const std::vector<int> &hAi, hipStream_t s) {
     const int nnzA = hAp[n], nnzP = hPp[n];
@@ -1119,6 +1131,118 @@ struct DevicePattern {
     for (int i = 0; i < m; i++) max_row = std::max(max_row, rp[i + 1] - rp[i]);
     P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get(),
                 (int)ti.size(), Tp.get(), Ti.get(), Tj.get(), Tr.get(), Ta.get(), Tb.get(), max_col, max_row};
+    build_quad(n, m, hAp, hAi, rp, rc, rmap, fp, fc, tp, ti, tj, tr, ta, tb, s);
+  }
+
+  // ---- schedule of the four-wavefront kernel ------------------------------------------------------------------------
+  // Compile-time bounds of the one instantiation (the MPC family of BASELINE.json config 5; see launch_batch)
+  static constexpr int kNH = 50, kKC = 9, kKE = 11, kCH = 8;
+  void build_quad(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
+                  const std::vector<int> &rc, const std::vector<int> &rmap, const std::vector<int> &fp, const std::vector<int> &fc,
+                  const std::vector<int> &tp, const std::vector<unsigned short> &ti, const std::vector<unsigned short> &tj,
+                  const std::vector<unsigned short> &tr, const std::vector<unsigned short> &ta, const std::vector<unsigned short> &tb,
+                  hipStream_t s) {
+    using namespace quad;
+    quad_ok = false;
+    const int nnzA = hAp[n], nnzF = (int)fc.size();
+    if (n > 2 * kNH || m > QT || m == 0 || nnzA == 0) return;
+    int kc = 0;
+    for (int j = 0; j < n; j++) kc = std::max(kc, hAp[j + 1] - hAp[j]);
+    // rows by length, longest first (stable): lane L holds row order[L], so the long rows share wavefronts
+    std::vector<int> order(m);
+    for (int i = 0; i < m; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rp[a + 1] - rp[a] > rp[b + 1] - rp[b]; });
+    const int ke = rp[order[0] + 1] - rp[order[0]];
+    if (kc > kKC || ke > kKE) return;
+    const Layout L = make_layout(n, m, nnzA, nnzF, kNH, kKC, kKE, kCH);
+    if (L.total > 65535 || (size_t)(nnzA + 1) * 8 > 65535) return;
+    const int kch = L.kch, kep = L.kep;
+    std::vector<unsigned short> colstart(QT), collist((size_t)QT * kch);
+    for (int t = 0; t < QT; t++) {
+      const int wv = t >> 6, cbk = wv & 1, hb = wv >> 1, cl = t & 63, j = cbk * kNH + cl;
+      const bool col = cl < kNH && j < n;
+      colstart[t] = (unsigned short)(col ? hAp[j] : nnzA);
+      for (int e = 0; e < kch; e++) {
+        const bool real = col && hAp[j] + 2 * e + hb < hAp[j + 1];
+        collist[(size_t)t * kch + e] = (unsigned short)((real ? hAi[hAp[j] + 2 * e + hb] : m) * RECB);
+      }
+    }
+    std::vector<unsigned> roww((size_t)QT * kep, (unsigned)(nnzA * 8) << 16), meta((size_t)QT, 0xFFFFFFFFu);
+    int kew[4] = {0, 0, 0, 0};
+    for (int k = 0; k < m; k++) {
+      const int row = order[k];
+      meta[k] = (unsigned)row * RECB;
+      kew[k >> 6] = std::max(kew[k >> 6], rp[row + 1] - rp[row]);
+      for (int q = rp[row], e = 0; q < rp[row + 1]; q++, e++) roww[(size_t)k * kep + e] = ((unsigned)(rmap[q] * 8) << 16) | (unsigned)(rc[q] * 8);
+    }
+    // terms of M, grouped by position (i, j) of a window of kCH rows (windows do not straddle the two row halves), the
+    // groups of a window dealt to the threads (longest first)
+    const int nchh = (kNH + kCH - 1) / kCH, nwin = 2 * nchh;
+    struct Term { unsigned short r, a, b; };
+    std::vector<std::vector<std::vector<Term>>> groups(nwin);
+    std::vector<std::vector<unsigned short>> targets(nwin);
+    {
+      std::vector<std::vector<int>> pair_of(n, std::vector<int>(n, -1));
+      for (size_t t = 0; t < ti.size(); t++) { pair_of[ti[t]][tj[t]] = (int)t; pair_of[tj[t]][ti[t]] = (int)t; }
+      std::vector<std::vector<int>> pent(n, std::vector<int>(n, -1));
+      for (int r = 0; r < n; r++) for (int q = fp[r]; q < fp[r + 1]; q++) pent[r][fc[q]] = q;
+      for (int i = 0; i < n; i++) {
+        const int wh = i / kNH, wk = (i - wh * kNH) / kCH, cw = wh * nchh + wk, c0 = wh * kNH + wk * kCH;
+        for (int j = 0; j < n; j++) {
+          std::vector<Term> g;
+          if (pair_of[i][j] >= 0) {
+            const int t = pair_of[i][j];
+            for (int q = tp[t]; q < tp[t + 1]; q++)
+              g.push_back(Term{(unsigned short)(L.rec + tr[q] * RECB + F_RHO), (unsigned short)(L.Av + 8 * ta[q]), (unsigned short)(L.Av + 8 * tb[q])});
+          }
+          if (pent[i][j] >= 0) g.push_back(Term{(unsigned short)L.cst, (unsigned short)L.cst, (unsigned short)(L.Pv + 8 * pent[i][j])});
+          if (i == j) g.push_back(Term{(unsigned short)L.cst, (unsigned short)L.cst, (unsigned short)(L.cst + 8)});
+          if (g.empty()) continue;
+          groups[cw].push_back(g);
+          targets[cw].push_back((unsigned short)((i - c0) * n + j));
+        }
+      }
+    }
+    std::vector<std::vector<std::vector<int>>> deal(nwin, std::vector<std::vector<int>>(QT));
+    int ns = 0;
+    for (int cw = 0; cw < nwin; cw++) {
+      std::vector<int> idx(groups[cw].size());
+      for (size_t g = 0; g < idx.size(); g++) idx[g] = (int)g;
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return groups[cw][a].size() > groups[cw][b].size(); });
+      std::vector<int> load(QT, 0);
+      for (int g : idx) {
+        int best = 0;
+        for (int t = 1; t < QT; t++) if (load[t] < load[best]) best = t;
+        deal[cw][best].push_back(g);
+        load[best] += (int)groups[cw][g].size();
+      }
+      for (int t = 0; t < QT; t++) ns = std::max(ns, load[t]);
+    }
+    ns = std::max(4, (ns + 3) & ~3);
+    const unsigned long long pad = (unsigned long long)(kCH * n) | 0x8000ull | ((unsigned long long)(L.rec + m * RECB + F_RHO) << 16) |
+                                   ((unsigned long long)L.cst << 32) | ((unsigned long long)L.cst << 48);  // 0 * 1 * 1 into the spare position
+    std::vector<unsigned long long> stream((size_t)nwin * ns * QT, pad);
+    for (int cw = 0; cw < nwin; cw++)
+      for (int t = 0; t < QT; t++) {
+        int slot = 0;
+        for (int g : deal[cw][t]) {
+          const auto &G = groups[cw][g];
+          for (size_t k = 0; k < G.size(); k++, slot++) {
+            unsigned long long w = (unsigned long long)targets[cw][g] | ((unsigned long long)G[k].r << 16) | ((unsigned long long)G[k].a << 32) |
+                                   ((unsigned long long)G[k].b << 48);
+            if (k + 1 == G.size()) w |= 0x8000ull;
+            stream[((size_t)cw * ns + slot) * QT + t] = w;
+          }
+        }
+      }
+    auto up16 = [&](DevBuf<unsigned short> &d, const std::vector<unsigned short> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    auto up32 = [&](DevBuf<unsigned> &d, const std::vector<unsigned> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    up16(qs_colstart, colstart); up16(qs_collist, collist); up32(qs_roww, roww); up32(qs_meta, meta);
+    qs_stream.alloc(stream.size()); qs_stream.upload(stream.data(), stream.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    QS = Sched{n, m, nnzA, P.nnzP, nnzF, {kew[0], kew[1], kew[2], kew[3]}, ns, qs_colstart.get(), qs_collist.get(), qs_roww.get(),
+               qs_meta.get(), qs_stream.get(), Fp.get(), Fc.get(), Fmap.get()};
+    quad_ok = true;
   }
 };
 
@@ -1130,7 +1254,8 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
   size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF, sparse_fits(P));
   if (P.n > 128 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 128 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
-  const size_t need = (size_t)count * P.n * P.n;
+  const bool quad_path = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N && dp.quad_ok && batch_quad_enabled();
+  const size_t need = quad_path ? 0 : (size_t)count * P.n * P.n;  // the four-wavefront kernel has no global scratch
   if (dp.scratch.n < need) { HIP_CHECK(hipStreamSynchronize(s)); dp.scratch.alloc(need); }
   const int nc = (P.n + PARTS - 1) / PARTS;  // columns of the inverse per thread: the register tile is sized at compile time
 #define OQ_BATCH_LAUNCH(...)                                                                                                          \
@@ -1141,6 +1266,16 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
   } while (0)
   // shapes compiled in (same source, constants folded): the MPC family of BASELINE.json config 5
   const bool mpc = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N;
+  const bool use_quad = batch_quad_enabled();
+  if (mpc && dp.quad_ok && use_quad) {
+    // one QP per four wavefronts, three QPs per compute unit, the factorisation on chip (batch_quad.hpp)
+    auto kern = quad::k_batch_quad<DevicePattern::kNH, DevicePattern::kKC, DevicePattern::kKE, DevicePattern::kCH, MPC_N, MPC_M, kMpcNnzA, MPC_N>;
+    const quad::Layout L = quad::make_layout(P.n, P.m, P.nnzA, P.nnzF, DevicePattern::kNH, DevicePattern::kKC, DevicePattern::kKE, DevicePattern::kCH);
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    OQ_LAUNCH(kern, dim3(count), dim3(quad::QT), (size_t)L.total, s, dp.QS, st, count, Px, Ax, q, l, u, x, y, info, x_stride, y_stride,
+              info_stride, info_cols);
+    return;
+  }
   if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N);
   else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0);
   else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0);

@@ -1,0 +1,779 @@
+// batch_quad.hpp -- the batched small-QP kernel, round 4: ONE QP PER FOUR WAVEFRONTS, THE INVERSE IN REGISTERS AS FOUR
+// QUADRANTS (row K11 of SURVEY.md section 8a).  Included by batch.hip inside namespace oq::{anonymous} (it uses the LDS
+// pointer types and the small helpers defined there).
+//
+// Why a second decomposition (the 512-thread kernel in batch.hip stays for the patterns this one does not take): with one
+// QP per 512 threads every phase of an ADMM iteration gives a wavefront ~20 useful multiply-adds between two
+// eight-wavefront barriers, two QPs fit a compute unit, and the factorisation goes through an n x n scratch in global
+// memory (5.5 GB of HBM / L2 traffic per 4096 QPs).  Here a QP is a 256-thread workgroup, THREE are resident per compute
+// unit (<= 53 KB of LDS, 168 vector registers: three wavefronts per SIMD), nothing of a factorisation leaves the chip.
+//
+//   * wavefront w = 2 hb + cb holds the quadrant (row half hb, column half cb) of the inverse of the reduced KKT matrix
+//     M = P + sigma I + A' diag(rho) A: lane c owns column j = cb NH + c, register r of the lane is row hb NH + r (U[0..NH),
+//     2 NH vector registers; NH = 50 for n = 100);
+//   * x~ = M^-1 b: NH `v_fmac_f64_dpp ... row_newbcast` instructions per lane -- b sits in NH / 16 registers, lane l holding
+//     b[hb NH + 16 k + (l & 15)], and the DPP control broadcasts element i & 15 of the sixteen-lane row to the row: no LDS
+//     and no scalar-register traffic per multiply-add (the DPP form issues at the rate of the plain v_fma_f64; a
+//     ds_read_b128 broadcast per two multiply-adds measures 6x slower: tools/micro/dpp_probe.hip); the two row halves of a
+//     column leave two partial sums, added by whoever reads x~;
+//   * the inverse is formed IN THE REGISTERS by symmetric Gauss-Jordan sweeps (Goodnight's sweep operator), one pivot per
+//     step: the wavefronts of the pivot's row half publish, per lane, ONE number -- their column's element of the pivot row, a
+//     register picked by a branch tree on the wave-uniform pivot index -- the pivot column is the pivot row by symmetry and
+//     comes back through the same DPP broadcast, the rank-1 update is NH multiply-adds per lane; the scaling of the pivot's
+//     own column is deferred as a per-column factor (the update is linear in a column, the factor carries through);
+//   * M is assembled from a host-precomputed stream of terms through an LDS window of a few rows at a time (it aliases
+//     the row-side pattern words, which are re-staged from L2 afterwards);
+//   * the constraint rows live in LDS as 64-byte records {z, y | l, u | rho, 1 / rho | rho z - y, E}: the row finish of an
+//     iteration is three 16-byte reads and two writes; lane L owns row order[L] (longest rows first, so that the lockstep
+//     length of a wavefront is the longest row IT holds: 11 entries for the first wavefront of the MPC pattern, 2 for the
+//     others); a column of A is walked by the two lanes of its variable, one parity each.
+// Per iteration three four-wavefront barriers: partial b | partial x~ | z, y.  Same algorithm and the same arithmetic per
+// element as the 512-thread kernel except for the order of the sums inside a sparse row / column and the route to the
+// inverse.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+namespace quad {
+
+constexpr int QT = 256;    // threads per QP
+constexpr int RECB = 64;   // bytes of a row record
+enum { F_Z = 0, F_Y = 8, F_L = 16, F_U = 24, F_RHO = 32, F_RHOI = 40, F_ZT = 48, F_E = 56 };
+
+struct Sched {  // device pointers, shared by all instances (built on the host from the shared pattern)
+  int n, m, nnzA, nnzP, nnzF;
+  int kew[4];                       // longest row held by each wavefront
+  int ns;                           // term slots per thread and window (a multiple of 4)
+  const unsigned short *colstart;   // [QT]: first value of the lane's column (lanes without a column: nnzA)
+  const unsigned short *collist;    // [QT][kch]: byte offset of the row record of entries hb, hb + 2, ... of the lane's column;
+                                    // padding: the zero record (m)
+  const unsigned *roww;             // [QT][kep]: (byte offset of the value) << 16 | 8 * column, entries of the lane's row
+  const unsigned *meta;             // [QT]: byte offset of the record of the lane's row, 0xFFFFFFFF: none
+  // the terms of M, window by window: stream[(window * ns + slot) * QT + thread] = target | last << 15 | r << 16 | a << 32 |
+  // b << 48: acc += lds[r] * lds[a] * lds[b] (absolute LDS byte offsets: rho of a row record and two values of A -- or the
+  // constant one twice and a value of P / sigma); `last` closes the sum of a position: window[target] = acc, acc = 0.
+  // All terms of a position belong to one thread, in the order of the sparse dot product of the two columns.
+  const unsigned long long *stream;
+  const int *Fp, *Fc, *Fmap;        // full symmetric P, CSR; Fmap -> position in the caller's triu(P) values
+};
+
+struct Layout {  // byte offsets into the workgroup's LDS
+  int Av, Pv, cst, vec, bp, xp, xs, tmp, rec, dy, ax, red, nrm, ctype, Fp, Fc, colstart, collist, meta, roww, total;
+  int nh2, kch, kep, pbstride;
+};
+// NH: rows / columns per quadrant; KC: longest column (entries), KE: longest row; CH: rows per assembly window
+__host__ __device__ inline Layout make_layout(int n, int m, int nnzA, int nnzF, int NH, int KC, int KE, int CH) {
+  Layout L;
+  L.nh2 = 2 * ((NH + 15) & ~15);  // the broadcast registers of a row half cover 16 ceil(NH / 16) indices: both halves padded
+  L.kch = (((KC + 1) / 2) + 3) & ~3;
+  L.kep = (KE + 3) & ~3;
+  L.pbstride = L.nh2 + 2;
+  int o = 0;
+  L.Av = o; o += (nnzA + KC + 2) * 8;   // + the zero that padded row words point at, + what a padded column walk reads
+  L.Pv = o; o += nnzF * 8;
+  L.cst = o; o += 16;                   // the constants 1.0 and sigma (operands of the P / sigma terms of the assembly)
+  o = (o + 15) & ~15;
+  // two partial b (nh2 each, indexed hb NHP + r), two partial x~ (n each), a copy of x / delta_x (n), a column temporary (n);
+  // the same stretch holds the pivot-row buffers of the inversion: 2 x (scaled, unscaled) x (nh2 + 2)
+  const int vecd = (2 * L.nh2 + 4 * n) > 4 * L.pbstride ? (2 * L.nh2 + 4 * n) : 4 * L.pbstride;
+  L.vec = o; L.bp = o; L.xp = o + 2 * L.nh2 * 8; L.xs = L.xp + 2 * n * 8; L.tmp = L.xs + n * 8; o += vecd * 8;
+  o = (o + 15) & ~15;
+  L.rec = o; o += (m + 1) * RECB;       // + the zero record
+  L.dy = o; o += m * 8;
+  L.ax = o; o += m * 8;
+  L.red = o; o += 2 * 4 * 8 * 8;        // two halves x four wavefronts x up to eight values
+  L.nrm = o; o += 24 * 8;
+  L.ctype = o; o += ((m + 3) & ~3);
+  L.Fp = o; o += ((n + 1) * 2 + 3) & ~3;
+  L.Fc = o; o += (nnzF * 2 + 3) & ~3;
+  L.colstart = o; o += QT * 2;
+  o = (o + 7) & ~7;
+  L.collist = o; o += QT * L.kch * 2;
+  L.meta = o; o += QT * 4;
+  o = (o + 15) & ~15;
+  const int words = QT * L.kep * 4, window = (CH * n + 1) * 8;  // + the position padded terms are written to
+  L.roww = o; o += words > window ? words : window;
+  L.total = o;
+  return L;
+}
+
+// ---- small device helpers --------------------------------------------------------------------------------------
+template <int LN>
+__device__ __forceinline__ void fmac_bc(double &acc, double b, double m) {
+  // acc += (b of lane LN of the sixteen-lane row) * m
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(m), "n"(LN));
+}
+__device__ __forceinline__ double ld(const lchar *base, unsigned off) { return *(const ldouble *)(base + off); }
+__device__ __forceinline__ void sd(lchar *base, unsigned off, double v) { *(ldouble *)(base + off) = v; }
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d2_t ld2;
+__device__ __forceinline__ d2_t ld2at(const lchar *base, unsigned off) { return *(const ld2 *)(base + off); }
+__device__ __forceinline__ void st2at(lchar *base, unsigned off, double a, double b) { d2_t v; v.x = a; v.y = b; *(ld2 *)(base + off) = v; }
+
+template <int OP>  // 0: max (NaN-propagating as nmax), 1: sum; result in every lane
+__device__ __forceinline__ double wave_red(double a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double b = __shfl_xor(a, o, 64); a = OP ? a + b : nmax(a, b); }
+  return a;
+}
+// K per-thread values -> K workgroup results (wavefront 0's part first ... wavefront 3's last: a fixed order) in every
+// thread; one barrier.  Consecutive calls alternate halves of `red` so that a fast wavefront cannot overwrite what a slow
+// one still reads.
+template <int K, int OP>
+__device__ __forceinline__ void quad_reduce(double *v, lchar *lds, int redoff, int &flip) {
+  const int t = threadIdx.x;
+  const int base = redoff + flip * 4 * 8 * 8;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const double r = wave_red<OP>(v[k]);
+    if ((t & 63) == 0) sd(lds, base + ((t >> 6) * 8 + k) * 8, r);
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = ld(lds, base + k * 8);
+#pragma unroll
+    for (int w = 1; w < 4; w++) { const double b = ld(lds, base + (w * 8 + k) * 8); a = OP ? a + b : nmax(a, b); }
+    v[k] = a;
+  }
+  flip ^= 1;
+}
+
+#define OQ_FENCE() asm volatile("" ::: "memory")
+
+// register file of the lane's column: U[p] for a wave-uniform p, through a tree of scalar branches (a select chain would be
+// two v_cndmask per register and access).  The asm at the END of a leaf keeps the optimiser from sinking the leaves' loads /
+// stores into one access through a phi of addresses -- a dynamically indexed array lives in scratch memory.
+template <int LO, int HI, int NR>
+__device__ __forceinline__ double reg_get(const double (&U)[NR], int p) {
+  if constexpr (HI - LO == 1) {
+    double v = U[LO];
+    asm volatile("" : "+v"(v));
+    return v;
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (p < MID) return reg_get<LO, MID, NR>(U, p);
+    return reg_get<MID, HI, NR>(U, p);
+  }
+}
+template <int LO, int HI, int NR>
+__device__ __forceinline__ void reg_put(double (&U)[NR], int p, double v) {
+  if constexpr (HI - LO == 1) {
+    U[LO] = v;
+    asm volatile("" : "+v"(U[LO]));
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (p < MID) reg_put<LO, MID, NR>(U, p, v);
+    else reg_put<MID, HI, NR>(U, p, v);
+  }
+}
+// U[k * CH + r] = w[r] for a wave-uniform window index k
+template <int LO, int HI, int NR, int CH>
+__device__ __forceinline__ void chunk_store(double (&U)[NR], int k, const double (&w)[CH]) {
+  if constexpr (HI - LO == 1) {
+#pragma unroll
+    for (int r = 0; r < CH; r++) {
+      if constexpr (LO * CH + CH <= NR) U[LO * CH + r] = w[r];
+      else if (LO * CH + r < NR) U[(LO * CH + r) < NR ? (LO * CH + r) : 0] = w[r];
+    }
+    asm volatile("" : "+v"(U[LO * CH]));
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (k < MID) chunk_store<LO, MID, NR, CH>(U, k, w);
+    else chunk_store<MID, HI, NR, CH>(U, k, w);
+  }
+}
+
+// U[i] += b(i) * g over i in [I0, I1), b(i) = element i & 15 of the sixteen-lane row of bk
+template <int I0, int I1, int NR>
+__device__ __forceinline__ void rank1_16(double (&U)[NR], double bk, double g) {
+  if constexpr (I0 < I1) {
+    fmac_bc<I0 & 15>(U[I0], bk, g);
+    rank1_16<I0 + 1, I1, NR>(U, bk, g);
+  }
+}
+template <int I0, int I1, int NR, int NACC>
+__device__ __forceinline__ void dot_16(const double (&U)[NR], double bk, double (&acc)[NACC]) {
+  if constexpr (I0 < I1) {
+    fmac_bc<I0 & 15>(acc[I0 % NACC], bk, U[I0]);
+    dot_16<I0 + 1, I1, NR, NACC>(U, bk, acc);
+  }
+}
+template <int K, int NB, int NR>
+__device__ __forceinline__ void rank1_all(double (&U)[NR], const double (&B)[NB], double g) {
+  if constexpr (K < NB) {
+    rank1_16<K * 16, (K * 16 + 16 < NR ? K * 16 + 16 : NR), NR>(U, B[K], g);
+    rank1_all<K + 1, NB, NR>(U, B, g);
+  }
+}
+template <int K, int NB, int NR, int NACC>
+__device__ __forceinline__ void dot_all(const double (&U)[NR], const double (&B)[NB], double (&acc)[NACC]) {
+  if constexpr (K < NB) {
+    dot_16<K * 16, (K * 16 + 16 < NR ? K * 16 + 16 : NR), NR, NACC>(U, B[K], acc);
+    dot_all<K + 1, NB, NR, NACC>(U, B, acc);
+  }
+}
+
+// One QP per 256-thread workgroup.  NH: rows / columns per quadrant (n <= 2 NH); KC, KE: compile-time bounds of the longest
+// column / row of A; CH: rows per assembly window; CN > 0: the shape is compiled in (the MPC family), every LDS offset an
+// immediate.
+template <int NH, int KC, int KE, int CH, int CN, int CM, int CA, int CF>
+__global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batch_quad(
+    Sched S, OSQPSettings st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
+    const double *__restrict__ q_all, const double *__restrict__ l_all, const double *__restrict__ u_all,
+    double *__restrict__ x_out, double *__restrict__ y_out, double *__restrict__ info_out, int x_stride, int y_stride,
+    int info_stride, int info_cols) {
+  const int inst = blockIdx.x;
+  if (inst >= count) return;
+  const int n = CN ? CN : S.n, m = CN ? CM : S.m, nnzA = CN ? CA : S.nnzA, nnzF = CN ? CF : S.nnzF;
+  const Layout L = make_layout(n, m, nnzA, nnzF, NH, KC, KE, CH);
+  constexpr int NB = (NH + 15) / 16;       // broadcast registers of a row half
+  constexpr int NHP = NB * 16;             // a row half, padded
+  constexpr int KCH = (((KC + 1) / 2) + 3) & ~3;
+  constexpr int KEP = (KE + 3) & ~3;
+  constexpr int NCH = (NH + CH - 1) / CH;  // assembly windows per row half
+  lchar *lds = (lchar *)lds_raw;
+  // Everything derived from the thread id is a macro over mytid(): a copy of the id the optimiser cannot trace, so that
+  // lane ids, LDS addresses and predicates are recomputed where they are used (a few scalar / vector instructions)
+  // instead of living in -- or being spilled from -- registers across the ADMM loop, next to the inverse.
+#define t (mytid())
+#define lane16 (mytid() & 15)
+#define wv (uni(mytid() >> 6))
+#define cb (wv & 1)
+#define hb (wv >> 1)
+#define cl (mytid() & 63)                      /* lane = column inside the quadrant */
+#define j (cb * NH + cl)                       /* the lane's column */
+#define col (cl < NH && j < n)                 /* the lane holds a column */
+#define owner (col && hb == 0)                 /* ... and does the per-column work (x, q, D) */
+#define jp (col ? j : -1)                      /* the column as a pivot index (lanes without a column never match) */
+#define cstart ((unsigned)*(const lshort *)(lds + L.colstart + 2 * t))
+#define myrec (*(const luint *)(lds + L.meta + t * 4))
+#define hasrow (myrec != 0xFFFFFFFFu)
+#define kew (uni(S.kew[wv]))
+  const unsigned ZREC = (unsigned)m * RECB;    // the zero record
+  int flip = 0;
+
+  // ---- stage the schedule and load the instance -------------------------------------------------------------
+  for (int k = t; k <= n; k += QT) *(lshort *)(lds + L.Fp + 2 * k) = (unsigned short)S.Fp[k];
+  for (int k = t; k < nnzF; k += QT) *(lshort *)(lds + L.Fc + 2 * k) = (unsigned short)S.Fc[k];
+  *(lshort *)(lds + L.colstart + 2 * t) = S.colstart[t];
+#pragma unroll
+  for (int e = 0; e < KCH; e++) *(lshort *)(lds + L.collist + (t * KCH + e) * 2) = S.collist[t * KCH + e];
+  *(luint *)(lds + L.meta + t * 4) = S.meta[t];
+  auto stage_words = [&]() {
+#pragma unroll
+    for (int e = 0; e < KEP; e++) *(luint *)(lds + L.roww + (t * KEP + e) * 4) = S.roww[t * KEP + e];
+  };
+  stage_words();
+  for (int k = t; k < nnzA; k += QT) sd(lds, L.Av + k * 8, Ax_all[(size_t)inst * nnzA + k]);
+  for (int k = nnzA + t; k < nnzA + KC + 2; k += QT) sd(lds, L.Av + k * 8, 0.0);
+  for (int k = t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, Px_all[(size_t)inst * S.nnzP + S.Fmap[k]]);
+  for (int k = t; k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
+  for (int i = t; i <= m; i += QT) {
+    const unsigned r = (unsigned)i * RECB;
+    const bool real = i < m;
+    st2at(lds, L.rec + r + F_Z, 0.0, 0.0);
+    st2at(lds, L.rec + r + F_L, real ? fmax(l_all[(size_t)inst * m + i], -OSQP_INFTY) : 0.0, real ? fmin(u_all[(size_t)inst * m + i], OSQP_INFTY) : 0.0);
+    st2at(lds, L.rec + r + F_RHO, 0.0, 0.0);
+    st2at(lds, L.rec + r + F_ZT, 0.0, real ? 1.0 : 0.0);
+    if (real) { sd(lds, L.dy + i * 8, 0.0); sd(lds, L.ax + i * 8, 0.0); }
+  }
+  double xj = 0.0, qj = owner ? q_all[(size_t)inst * n + j] : 0.0, Dj = 1.0, dxj = 0.0;
+  __syncthreads();
+
+  // ---- walks of the pattern -----------------------------------------------------------------------------------
+  // the lane's half of column j of A (entries hb, hb + 2, ...): f(e, LDS offset of the value, record offset of its row)
+  auto col_walk = [&](auto f) {
+    unsigned short ro[KCH];
+#pragma unroll
+    for (int e4 = 0; e4 < KCH; e4 += 4) {
+      const uint2_t w = *(const luint2 *)(lds + L.collist + (t * KCH + e4) * 2);
+      ro[e4] = (unsigned short)(w.x & 0xFFFFu); ro[e4 + 1] = (unsigned short)(w.x >> 16);
+      ro[e4 + 2] = (unsigned short)(w.y & 0xFFFFu); ro[e4 + 3] = (unsigned short)(w.y >> 16);
+    }
+#pragma unroll
+    for (int e = 0; e < (KC + 1) / 2; e++) f(e, (unsigned)(L.Av + (cstart + 2 * e + hb) * 8), (unsigned)ro[e]);
+  };
+  // partial sum over the lane's half of column j of value * (field FIELD of the entry's row record)
+  auto col_dot = [&](int field) -> double {
+    constexpr int EN = (KC + 1) / 2;
+    double av[EN], ov[EN];
+    col_walk([&](int e, unsigned voff, unsigned ro) { av[e] = ld(lds, voff); ov[e] = ld(lds, L.rec + ro + field); });
+    double a = 0.0;
+#pragma unroll
+    for (int e = 0; e < EN; e++) a += av[e] * ov[e];
+    return a;
+  };
+  // the lane's row: sum over its entries of value * v[col], v = the array at vecoff (TWO: + the array n doubles behind it);
+  // four entries at a time up to the longest row of the wavefront; words padded with (zero value, operand 0)
+  auto row_dot = [&](auto two_tag, int vecoff) -> double {
+    constexpr bool TWO = decltype(two_tag)::value;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int e0 = 0; e0 < KEP; e0 += 4) {
+      if (e0 < kew) {
+        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (t * KEP + e0) * 4);
+        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+        double av[4], ov[4], ow[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          av[e] = ld(lds, L.Av + (w[e] >> 16)); ov[e] = ld(lds, vecoff + (w[e] & 0xFFFFu));
+          if (TWO) ow[e] = ld(lds, vecoff + n * 8 + (w[e] & 0xFFFFu));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double o = TWO ? ov[e] + ow[e] : ov[e];
+          if (e & 1) a1 += av[e] * o; else a0 += av[e] * o;
+        }
+      }
+    }
+    return a0 + a1;
+  };
+  auto row_absmax = [&]() -> double {
+    double mx = 0.0;
+#pragma unroll
+    for (int e0 = 0; e0 < KEP; e0 += 4) {
+      if (e0 < kew) {
+        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (t * KEP + e0) * 4);
+        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) mx = fmax(mx, fabs(ld(lds, L.Av + (w[e] >> 16))));
+      }
+    }
+    return mx;
+  };
+  std::integral_constant<bool, false> one_vec;
+  std::integral_constant<bool, true> two_vec;
+  // row j of the full symmetric P times a vector in LDS (owner lanes)
+  auto p_row_dot = [&](int vecoff) -> double {
+    double a = 0.0;
+    if (owner) {
+      const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
+      for (int q = q0; q < q1; q++) a += ld(lds, L.Pv + q * 8) * ld(lds, vecoff + 8 * *(const lshort *)(lds + L.Fc + 2 * q));
+    }
+    return a;
+  };
+  auto p_col_absmax = [&]() -> double {
+    double mx = 0.0;
+    if (owner) {
+      const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
+      for (int q = q0; q < q1; q++) mx = fmax(mx, fabs(ld(lds, L.Pv + q * 8)));
+    }
+    return mx;
+  };
+
+  // ---- K0: Ruiz equilibration + cost scaling (the arithmetic of batch.hip / oracle scale_data, element for element) ----
+  double c = 1.0;
+  for (int it = 0; it < st.scaling; it++) {
+    {  // column maxima: the two halves of a column meet in tmp
+      double mx = 0.0;
+      col_walk([&](int e, unsigned voff, unsigned ro) { const double v = fabs(ld(lds, voff)); mx = fmax(mx, ro != ZREC ? v : 0.0); });
+      if (col && hb == 1) sd(lds, L.tmp + j * 8, mx);
+      if (hasrow) sd(lds, L.ax + (myrec / RECB) * 8, 1.0 / sqrt(lim(row_absmax())));  // row factors into ax (free outside an evaluation)
+      __syncthreads();
+      if (owner) {
+        mx = fmax(fmax(mx, ld(lds, L.tmp + j * 8)), p_col_absmax());
+        sd(lds, L.xs + j * 8, 1.0 / sqrt(lim(mx)));
+      }
+    }
+    __syncthreads();
+    const double tnj = col ? ld(lds, L.xs + j * 8) : 1.0;
+    if (owner) {
+      const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
+      for (int q = q0; q < q1; q++) {
+        const int cc = *(const lshort *)(lds + L.Fc + 2 * q);
+        const int lo = cc < j ? cc : j, hi = cc < j ? j : cc;
+        sd(lds, L.Pv + q * 8, (ld(lds, L.Pv + q * 8) * ld(lds, L.xs + lo * 8)) * ld(lds, L.xs + hi * 8));
+      }
+      qj *= tnj; Dj *= tnj;
+    }
+    if (col)
+      col_walk([&](int e, unsigned voff, unsigned ro) {
+        if (ro != ZREC) sd(lds, voff, (ld(lds, voff) * ld(lds, L.ax + (ro / RECB) * 8)) * tnj);
+      });
+    if (hasrow) sd(lds, L.rec + myrec + F_E, ld(lds, L.rec + myrec + F_E) * ld(lds, L.ax + (myrec / RECB) * 8));
+    __syncthreads();
+    double sm[1] = {p_col_absmax()}, mq[1] = {owner ? fabs(qj) : 0.0};  // sum of the column maxima of P, max |q|
+    quad_reduce<1, 1>(sm, lds, L.red, flip);
+    quad_reduce<1, 0>(mq, lds, L.red, flip);
+    double c_temp = sm[0] / (double)n;
+    c_temp = lim(fmax(c_temp, lim(mq[0])));
+    c_temp = uni(1.0 / c_temp);
+    for (int k = t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, ld(lds, L.Pv + k * 8) * c_temp);
+    qj *= c_temp;
+    c = uni(c * c_temp);
+    __syncthreads();
+  }
+  const double cinv = uni(1.0 / c);
+  // ---- scaled bounds, K1: classes and rho ------------------------------------------------------------------------
+  double rho = uni(fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX));
+  auto set_rho = [&](bool classify) {
+    for (int i = t; i < m; i += QT) {
+      const unsigned r = (unsigned)i * RECB;
+      int ty;
+      if (classify) {
+        const double e = ld(lds, L.rec + r + F_E);
+        const double lo = ld(lds, L.rec + r + F_L) * e, up = ld(lds, L.rec + r + F_U) * e;
+        st2at(lds, L.rec + r + F_L, lo, up);
+        if (lo < -B_INF && up > B_INF) ty = -1;
+        else if (up - lo < 1e-4) ty = 1;
+        else ty = 0;
+        *(lchar *)(lds + L.ctype + i) = (char)ty;
+      } else ty = *(const lchar *)(lds + L.ctype + i);
+      const double rr = ty == -1 ? B_RHO_MIN : (ty == 1 ? 1e3 * rho : rho);
+      st2at(lds, L.rec + r + F_RHO, rr, 1.0 / rr);
+      sd(lds, L.rec + r + F_ZT, rr * ld(lds, L.rec + r + F_Z) - ld(lds, L.rec + r + F_Y));  // the carried vector follows rho
+    }
+    __syncthreads();
+  };
+  set_rho(true);
+
+  const bool uns = st.scaling && !st.scaled_termination;
+  const int check = (int)st.check_termination;
+  const int rho_interval = st.adaptive_rho ? (st.adaptive_rho_interval ? (int)st.adaptive_rho_interval : 100) : 0;
+  const double sigma = st.sigma;
+  const int max_iter = (int)st.max_iter;
+  double pri_res = 0.0, dua_res = 0.0, obj = 0.0;
+  int status = OSQP_UNSOLVED, iter = 0, rho_updates = 0;
+  bool need_factor = true;
+  double U[NH];
+
+  for (iter = 1; iter <= max_iter; iter++) {
+    if (need_factor) {
+      // ---- K2: M = P + sigma I + A' diag(rho) A, CH rows at a time through the LDS window, into the registers ----------
+      // (window rows i, all columns: the lane of the rows' half reads -- and clears -- its own column; the window aliases
+      // the row words)
+#pragma unroll
+      for (int u = 0; u < NH; u++) U[u] = 0.0;
+      for (int e = t; e < CH * n + 1; e += QT) sd(lds, L.roww + e * 8, 0.0);
+      if (t == 0) st2at(lds, L.cst, 1.0, sigma);
+      __syncthreads();
+      const int NS = S.ns;
+#pragma unroll 1
+      for (int cw = 0; cw < 2 * NCH; cw++) {
+        const int wh = cw >= NCH, wk = cw - wh * NCH;  // row half and window inside it
+        const int c0 = wh * NH + wk * CH;
+        if (c0 >= n) continue;
+        {
+          const unsigned long long *sp = S.stream + (size_t)cw * NS * QT + t;
+          double acc = 0.0;
+#pragma unroll 1
+          for (int sl = 0; sl < NS; sl += 4) {
+            unsigned long long w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = sp[(size_t)(sl + k) * QT];
+            double r[4], a[4], bq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              r[k] = ld(lds, (unsigned)(w[k] >> 16) & 0xFFFFu); a[k] = ld(lds, (unsigned)(w[k] >> 32) & 0xFFFFu); bq[k] = ld(lds, (unsigned)(w[k] >> 48));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              acc += r[k] * a[k] * bq[k];
+              if (w[k] & 0x8000u) { sd(lds, L.roww + 8 * ((unsigned)w[k] & 0x7FFFu), acc); acc = 0.0; }
+            }
+          }
+        }
+        __syncthreads();
+        if (wh == hb) {  // rows c0 .. c0 + CH of column j: registers wk CH + r -- compile-time indices per window, hence the tree
+          double w[CH];
+#pragma unroll
+          for (int r = 0; r < CH; r++) {
+            const bool live = col && wk * CH + r < NH && c0 + r < n;
+            w[r] = live ? ld(lds, L.roww + (r * n + j) * 8) : 0.0;
+            if (live) sd(lds, L.roww + (r * n + j) * 8, 0.0);
+          }
+          chunk_store<0, NCH, NH, CH>(U, wk, w);
+        }
+        __syncthreads();
+      }
+      stage_words();
+      // ---- the inverse by symmetric sweeps, in the registers ---------------------------------------------------------
+      // sc * U[r] = element (hb NH + r, j) of the swept array; result -M^-1.  Buffers of a step: scaled pivot row, then the
+      // unscaled one (n entries each at the positions hp NHP + r of the padded halves), d and the pivot behind them.
+      double sc = 1.0;
+      bool pd = true;
+      auto sweep16 = [&](auto ph_tag, auto pb_tag) {
+        constexpr int PH = decltype(ph_tag)::value, PB = decltype(pb_tag)::value;
+        constexpr int P1 = (PB + 1) * 16 < NH ? (PB + 1) * 16 : NH;
+#pragma unroll 1
+        for (int pr = PB * 16; pr < P1 && PH * NH + pr < n; pr++) {
+          const int p = PH * NH + pr;
+          const int pb = L.vec + (p & 1) * 2 * L.pbstride * 8;
+          const int slot = cb * NHP + cl;  // position of column j in a padded buffer (column halves padded like row halves)
+          if (hb == PH) {                 // the wavefronts that hold row p publish it
+            const double up = (cl < NHP) ? reg_get<PB * 16, P1, NH>(U, pr) : 0.0;
+            const double pv = sc * up;
+            if (cl < NHP) { sd(lds, pb + slot * 8, pv); sd(lds, pb + (L.pbstride + slot) * 8, up); }
+            if (jp == p) {
+              double d = __builtin_amdgcn_rcp(pv);
+              d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+              d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+              st2at(lds, pb + L.nh2 * 8, d, pv);
+            }
+          }
+          __syncthreads();
+          double B[NB];
+#pragma unroll
+          for (int k = 0; k < NB; k++) B[k] = ld(lds, pb + (hb * NHP + 16 * k + lane16) * 8);
+          const double up = (cl < NHP) ? ld(lds, pb + (L.pbstride + slot) * 8) : 0.0;
+          const d2_t dp = ld2at(lds, pb + L.nh2 * 8);
+          const double d = dp.x;
+          if (!(dp.y > 0.0)) pd = false;
+          const double g = (jp == p) ? 0.0 : -d * up;
+          rank1_all<0, NB, NH>(U, B, g);
+          if (hb == PH) reg_put<PB * 16, P1, NH>(U, pr, (jp == p) ? -1.0 : -g);
+          sc = (jp == p) ? d : sc;
+        }
+      };
+      [&]<int... IS>(std::integer_sequence<int, IS...>) {
+        (sweep16(std::integral_constant<int, IS / NB>{}, std::integral_constant<int, IS % NB>{}), ...);
+      }(std::make_integer_sequence<int, 2 * NB>{});
+      {
+        const double f = -sc;
+#pragma unroll
+        for (int u = 0; u < NH; u++) U[u] *= f;
+      }
+      __syncthreads();  // the pivot buffers are the partial b / x~ and the copy of x again
+      for (int k = t; k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
+      __syncthreads();
+      if (!uni((int)pd)) { status = OSQP_NON_CVX; iter--; break; }
+      need_factor = false;
+    }
+    // ---- K5 (a): b_j = sigma x_j - q_j + (A'(rho z - y))_j, in two parts (the entries of either parity) -------------
+    {
+      double a = col_dot(F_ZT);
+      if (owner) a += sigma * xj - qj;
+      if (col) sd(lds, L.bp + (hb * L.nh2 + cb * NHP + cl) * 8, a);
+    }
+    __syncthreads();
+    // ---- K3/K4 as one dense product: the part of x~_j over the rows of this half ----------------------------------------
+    {
+      double B[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const unsigned o = (hb * NHP + 16 * k + lane16) * 8;
+        B[k] = ld(lds, L.bp + o) + ld(lds, L.bp + L.nh2 * 8 + o);
+      }
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dot_all<0, NB, NH, 4>(U, B, acc);
+      if (col) sd(lds, L.xp + (hb * n + j) * 8, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+    }
+    __syncthreads();
+    // ---- K5 (b): x, delta_x by the column's owner; z~ = A x~ row by row, each row finished by its lane ------------------
+    const double alpha = opaque_s(st.alpha);
+    const bool last = iter == max_iter;
+    const bool due = check && (iter % check == 0);
+    const bool rho_due = rho_interval && (iter % rho_interval == 0);
+    const bool evaluate = due || rho_due || last;
+    if (owner) {
+      const double a = ld(lds, L.xp + j * 8) + ld(lds, L.xp + (n + j) * 8);
+      const double xn = alpha * a + (1.0 - alpha) * xj;
+      dxj = xn - xj;
+      xj = xn;
+    }
+    {
+      const double zt = row_dot(two_vec, L.xp);
+      if (hasrow) {
+        const unsigned r = myrec;
+        const d2_t zy = ld2at(lds, L.rec + r + F_Z), lu = ld2at(lds, L.rec + r + F_L), rr = ld2at(lds, L.rec + r + F_RHO);
+        const double zh = alpha * zt + (1.0 - alpha) * zy.x;
+        const double zn = fmin(fmax(zh + rr.y * zy.y, lu.x), lu.y);
+        const double d = rr.x * (zh - zn);
+        const double yn = zy.y + d;
+        st2at(lds, L.rec + r + F_Z, zn, yn);
+        sd(lds, L.rec + r + F_ZT, rr.x * zn - yn);
+        if (evaluate) sd(lds, L.dy + (r / RECB) * 8, d);
+      }
+    }
+    __syncthreads();
+    if (!evaluate) continue;
+
+    // ---- K8: residual evaluation; termination tests ----------------------------------------------------
+    lchar *nrm = lds + L.nrm;
+    auto NRM = [&](int k) -> double { return *(const ldouble *)(nrm + 8 * k); };
+    // full column sums of A' v (v a field of the row records): the odd half through tmp; one barrier
+    auto col_full = [&](int field) -> double {
+      double a = col_dot(field);
+      if (col && hb == 1) sd(lds, L.tmp + j * 8, a);
+      __syncthreads();
+      if (owner) a += ld(lds, L.tmp + j * 8);
+      return a;
+    };
+    {
+      // every group of norms goes through its reduction and into nrm[] before the next is formed: the evaluation runs next
+      // to the inverse (2 NH registers), its own working set has to stay small
+      if (owner) sd(lds, L.xs + j * 8, xj);
+      __syncthreads();
+      {
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        const double ax = row_dot(one_vec, L.xs);
+        if (hasrow) {
+          const double zi = ld(lds, L.rec + myrec + F_Z), e = 1.0 / ld(lds, L.rec + myrec + F_E), rs = ax - zi;
+          v[0] = fabs(rs); v[1] = fabs(e * rs); v[2] = fabs(zi); v[3] = fabs(ax); v[4] = fabs(e * zi); v[5] = fabs(e * ax);
+        }
+        quad_reduce<6, 0>(v, lds, L.red, flip);
+        if (t == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) *(ldouble *)(nrm + 8 * k) = v[k];
+          *(ldouble *)(nrm + 8 * N_PRI) = m == 0 ? 0.0 : (uns ? v[1] : v[0]);
+        }
+      }
+      OQ_FENCE();
+      const double at = col_full(F_Y);
+      OQ_FENCE();
+      const double px = p_row_dot(L.xs);
+      {
+        double w[4] = {0, 0, 0, 0};
+        if (owner) { const double d = 1.0 / Dj, r = (qj + px) + at; w[0] = fabs(r); w[1] = fabs(d * r); w[2] = fabs(qj); w[3] = fabs(at); }
+        quad_reduce<4, 0>(w, lds, L.red, flip);
+        if (t == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) *(ldouble *)(nrm + 8 * (6 + k)) = w[k];
+          *(ldouble *)(nrm + 8 * N_DUA) = uns ? cinv * w[1] : w[0];
+        }
+      }
+      OQ_FENCE();
+      {
+        double w[4] = {0, 0, 0, 0};
+        if (owner) { const double d = 1.0 / Dj; w[0] = fabs(px); w[1] = fabs(d * qj); w[2] = fabs(d * at); w[3] = fabs(d * px); }
+        quad_reduce<4, 0>(w, lds, L.red, flip);
+        if (t == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) *(ldouble *)(nrm + 8 * (10 + k)) = w[k];
+        }
+      }
+      OQ_FENCE();
+      {
+        double sm[2] = {owner ? xj * px : 0.0, owner ? qj * xj : 0.0};
+        quad_reduce<2, 1>(sm, lds, L.red, flip);
+        if (t == 0) *(ldouble *)(nrm + 8 * N_OBJ) = cinv * (0.5 * sm[0] + sm[1]);
+      }
+      __syncthreads();
+    }
+    pri_res = uni(NRM(N_PRI)); dua_res = uni(NRM(N_DUA)); obj = uni(NRM(N_OBJ));
+    int code = 0;
+    const int passes = (due || last) ? (last ? 2 : 1) : 0;
+    for (int pass = 0; pass < passes && code == 0; pass++) {
+      const bool approx = pass == 1;
+      double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
+      if (!(pri_res <= OSQP_INFTY) || !(dua_res <= OSQP_INFTY)) { code = OSQP_NON_CVX; break; }
+      if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+      bool pc = false, dc = false, pinf = false, dinf = false;
+      if (m == 0) pc = true;
+      else {
+        const double eps_p = ea + er * (uns ? nmax(NRM(4), NRM(5)) : nmax(NRM(2), NRM(3)));
+        if (uni((int)(pri_res < eps_p))) pc = true;
+        else {  // primal infeasibility on delta_y
+          double v1[1] = {0.0}, s1[1] = {0.0};
+          for (int i = t; i < m; i += QT) {
+            const unsigned r = (unsigned)i * RECB;
+            const double lo = ld(lds, L.rec + r + F_L), hi = ld(lds, L.rec + r + F_U), e = ld(lds, L.rec + r + F_E);
+            double d = ld(lds, L.dy + i * 8);
+            if (hi > B_INF) { if (lo < -B_INF) d = 0.0; else d = fmin(d, 0.0); }
+            else if (lo < -B_INF) d = fmax(d, 0.0);
+            sd(lds, L.dy + i * 8, d);
+            v1[0] = nmax(v1[0], fabs(uns ? e * d : d));
+            s1[0] += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
+          }
+          quad_reduce<1, 0>(v1, lds, L.red, flip);
+          quad_reduce<1, 1>(s1, lds, L.red, flip);
+          const double nv = v1[0], lhs = s1[0];
+          if (uni((int)(nv > epi && lhs < -epi * nv))) {
+            // A' delta_y: the column walk reads its operand from a row record -- lend the ZT field of every record to delta_y
+            for (int i = t; i < m; i += QT) {
+              const unsigned r = (unsigned)i * RECB;
+              sd(lds, L.ax + i * 8, ld(lds, L.rec + r + F_ZT));
+              sd(lds, L.rec + r + F_ZT, ld(lds, L.dy + i * 8));
+            }
+            __syncthreads();
+            const double tn = col_full(F_ZT);
+            __syncthreads();
+            for (int i = t; i < m; i += QT) sd(lds, L.rec + (unsigned)i * RECB + F_ZT, ld(lds, L.ax + i * 8));
+            double w1[1] = {owner ? fabs(uns ? tn / Dj : tn) : 0.0};
+            quad_reduce<1, 0>(w1, lds, L.red, flip);
+            pinf = w1[0] < epi * nv;
+            __syncthreads();
+          }
+        }
+      }
+      const double eps_d = ea + er * (uns ? cinv * nmax(NRM(11), nmax(NRM(12), NRM(13))) : nmax(NRM(8), nmax(NRM(9), NRM(10))));
+      if (uni((int)(dua_res < eps_d))) dc = true;
+      else {  // dual infeasibility on delta_x
+        double v1[1] = {owner ? fabs(uns ? Dj * dxj : dxj) : 0.0}, s1[1] = {owner ? qj * dxj : 0.0};
+        quad_reduce<1, 0>(v1, lds, L.red, flip);
+        quad_reduce<1, 1>(s1, lds, L.red, flip);
+        const double nv = v1[0], qdx = s1[0];
+        const double cs = uns ? c : 1.0;
+        if (uni((int)(nv > edi && qdx < -cs * edi * nv))) {
+          __syncthreads();
+          if (owner) sd(lds, L.xs + j * 8, dxj);
+          __syncthreads();
+          const double pdx = p_row_dot(L.xs);
+          double w1[1] = {owner ? fabs(uns ? pdx / Dj : pdx) : 0.0};
+          quad_reduce<1, 0>(w1, lds, L.red, flip);
+          if (uni((int)(w1[0] < cs * edi * nv))) {
+            double bad[1] = {0.0};
+            const double adx = row_dot(one_vec, L.xs);
+            if (hasrow) {
+              const double tt = uns ? adx / ld(lds, L.rec + myrec + F_E) : adx;
+              const double lo = ld(lds, L.rec + myrec + F_L), hi = ld(lds, L.rec + myrec + F_U);
+              if ((hi < B_INF && tt > edi * nv) || (lo > -B_INF && tt < -edi * nv) || tt != tt) bad[0] = 1.0;
+            }
+            quad_reduce<1, 0>(bad, lds, L.red, flip);
+            dinf = bad[0] == 0.0;
+          }
+          __syncthreads();
+        }
+      }
+      if (pc && dc) code = approx ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED;
+      else if (pinf) code = approx ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE;
+      else if (dinf) code = approx ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE;
+    }
+    if (last && passes && code == 0) code = OSQP_MAX_ITER_REACHED;
+    code = uni(code);
+    if (code != 0) { status = code; break; }
+    // ---- adaptive rho ----
+    if (rho_due) {
+      const double pr = m == 0 ? 0.0 : NRM(0) / (nmax(NRM(2), NRM(3)) + 1e-10);
+      const double du = NRM(6) / (nmax(nmax(NRM(8), NRM(9)), NRM(10)) + 1e-10);
+      const double est = uni(fmin(fmax(rho * sqrt(pr / (du + 1e-10)), B_RHO_MIN), B_RHO_MAX));
+      if (est > rho * st.adaptive_rho_tolerance || est < rho / st.adaptive_rho_tolerance) {
+        rho = est; rho_updates++;
+        __syncthreads();
+        set_rho(false);
+        need_factor = true;
+      }
+    }
+  }
+  if (iter > max_iter) iter = max_iter;
+  // ---- store -----------------------------------------------------
+  const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
+  if (owner) x_out[(size_t)inst * x_stride + j] = has_sol ? Dj * xj : NAN;
+  for (int i = t; i < m; i += QT) {
+    const unsigned r = (unsigned)i * RECB;
+    y_out[(size_t)inst * y_stride + i] = has_sol ? cinv * ld(lds, L.rec + r + F_E) * ld(lds, L.rec + r + F_Y) : NAN;
+  }
+  if (t == 0) {
+    double *o = info_out + (size_t)inst * info_stride;
+    o[0] = (double)iter; o[1] = (double)status; o[2] = pri_res; o[3] = dua_res;
+    if (info_cols > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
+  }
+#undef t
+#undef lane16
+#undef wv
+#undef cb
+#undef hb
+#undef cl
+#undef j
+#undef col
+#undef owner
+#undef jp
+#undef cstart
+#undef myrec
+#undef hasrow
+#undef kew
+}
+
+}  // namespace quad
