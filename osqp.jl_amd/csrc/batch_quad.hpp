@@ -36,6 +36,16 @@
 
 namespace quad {
 
+#ifdef OQ_BATCH_PROFILE  // experiment build (make prof): clock64() stamps per phase, printed by instance 0
+#define QPROF_DECL long long qt0 = clock64(), qacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define QPROF(k) { long long qt1 = clock64(); qacc[k] += qt1 - qt0; qt0 = qt1; }
+#define QPROF_PRINT if (inst == 0 && threadIdx.x == 0) printf("quad cycles: load %lld scale %lld assemble %lld invert %lld rhs %lld dense %lld rows %lld check %lld rho %lld iters %d\n", qacc[0], qacc[1], qacc[2], qacc[3], qacc[4], qacc[5], qacc[6], qacc[7], qacc[8], iter);
+#else
+#define QPROF_DECL
+#define QPROF(k)
+#define QPROF_PRINT
+#endif
+
 constexpr int QT = 256;    // threads per QP
 constexpr int RECB = 64;   // bytes of a row record
 enum { F_Z = 0, F_Y = 8, F_L = 16, F_U = 24, F_RHO = 32, F_RHOI = 40, F_ZT = 48, F_E = 56 };
@@ -58,7 +68,7 @@ struct Sched {  // device pointers, shared by all instances (built on the host f
 };
 
 struct Layout {  // byte offsets into the workgroup's LDS
-  int Av, Pv, cst, vec, bp, xp, xs, tmp, rec, dy, ax, red, nrm, ctype, Fp, Fc, colstart, collist, meta, roww, total;
+  int Av, Pv, cst, vec, bp, xp, xs, tmp, cx, cq, cD, cdx, rec, dy, ax, red, nrm, ctype, Fp, Fc, colstart, collist, meta, roww, total;
   int nh2, kch, kep, pbstride;
 };
 // NH: rows / columns per quadrant; KC: longest column (entries), KE: longest row; CH: rows per assembly window
@@ -77,6 +87,7 @@ __host__ __device__ inline Layout make_layout(int n, int m, int nnzA, int nnzF, 
   // the same stretch holds the pivot-row buffers of the inversion: 2 x (scaled, unscaled) x (nh2 + 2)
   const int vecd = (2 * L.nh2 + 4 * n) > 4 * L.pbstride ? (2 * L.nh2 + 4 * n) : 4 * L.pbstride;
   L.vec = o; L.bp = o; L.xp = o + 2 * L.nh2 * 8; L.xs = L.xp + 2 * n * 8; L.tmp = L.xs + n * 8; o += vecd * 8;
+  L.cx = o; L.cq = o + n * 8; L.cD = o + 2 * n * 8; L.cdx = o + 3 * n * 8; o += 4 * n * 8;  // x, q, D, delta_x of the columns
   o = (o + 15) & ~15;
   L.rec = o; o += (m + 1) * RECB;       // + the zero record
   L.dy = o; o += m * 8;
@@ -218,6 +229,30 @@ __device__ __forceinline__ void dot_all(const double (&U)[NR], const double (&B)
 // One QP per 256-thread workgroup.  NH: rows / columns per quadrant (n <= 2 NH); KC, KE: compile-time bounds of the longest
 // column / row of A; CH: rows per assembly window; CN > 0: the shape is compiled in (the MPC family), every LDS offset an
 // immediate.
+struct Me {  // what a lane is, recomputed at the head of every phase from an untraceable copy of the thread id (mytid()):
+             // lane ids, LDS addresses and predicates cost a few instructions per phase instead of registers -- or spills --
+             // across the ADMM loop, next to the inverse
+  int t, lane16, wv, cb, hb, cl, j, jp;
+  bool col, owner;
+};
+// lane id without a register that holds it: two mbcnt instructions wherever it is needed (the thread id the hardware leaves in
+// v0 is otherwise a cold value the allocator spills -- and reloads from scratch memory once per phase)
+__device__ __forceinline__ int lane_now() {
+  int l;  // volatile asm: neither hoisted out of the ADMM loop nor merged across phases
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+template <int NH, bool FULL>
+__device__ __forceinline__ Me make_me(int n, int wvs) {  // wvs: the wavefront's index in the workgroup (a scalar register)
+  Me me;
+  me.cl = lane_now(); me.wv = wvs; me.t = (wvs << 6) | me.cl; me.lane16 = me.cl & 15; me.cb = me.wv & 1; me.hb = me.wv >> 1;
+  me.j = me.cb * NH + me.cl;                                      // the lane's column
+  me.col = FULL ? me.cl < NH : (me.cl < NH && me.j < n);          // the lane holds a column
+  me.owner = me.col && me.hb == 0;                                // ... and does the per-column work (x, q, D)
+  me.jp = me.col ? me.j : -1;                                     // the column as a pivot index
+  return me;
+}
+
 template <int NH, int KC, int KE, int CH, int CN, int CM, int CA, int CF>
 __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batch_quad(
     Sched S, OSQPSettings st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
@@ -230,90 +265,87 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   const Layout L = make_layout(n, m, nnzA, nnzF, NH, KC, KE, CH);
   constexpr int NB = (NH + 15) / 16;       // broadcast registers of a row half
   constexpr int NHP = NB * 16;             // a row half, padded
-  constexpr int KCH = (((KC + 1) / 2) + 3) & ~3;
+  constexpr int KCE = (KC + 1) / 2;        // entries of a column per lane (one parity)
+  constexpr int KCH = (KCE + 3) & ~3;
   constexpr int KEP = (KE + 3) & ~3;
   constexpr int NCH = (NH + CH - 1) / CH;  // assembly windows per row half
+  constexpr bool FULL = CN == 2 * NH;      // every lane below NH of a quadrant has a column
   lchar *lds = (lchar *)lds_raw;
-  // Everything derived from the thread id is a macro over mytid(): a copy of the id the optimiser cannot trace, so that
-  // lane ids, LDS addresses and predicates are recomputed where they are used (a few scalar / vector instructions)
-  // instead of living in -- or being spilled from -- registers across the ADMM loop, next to the inverse.
-#define t (mytid())
-#define lane16 (mytid() & 15)
-#define wv (uni(mytid() >> 6))
-#define cb (wv & 1)
-#define hb (wv >> 1)
-#define cl (mytid() & 63)                      /* lane = column inside the quadrant */
-#define j (cb * NH + cl)                       /* the lane's column */
-#define col (cl < NH && j < n)                 /* the lane holds a column */
-#define owner (col && hb == 0)                 /* ... and does the per-column work (x, q, D) */
-#define jp (col ? j : -1)                      /* the column as a pivot index (lanes without a column never match) */
-#define cstart ((unsigned)*(const lshort *)(lds + L.colstart + 2 * t))
-#define myrec (*(const luint *)(lds + L.meta + t * 4))
-#define hasrow (myrec != 0xFFFFFFFFu)
-#define kew (uni(S.kew[wv]))
-  const unsigned ZREC = (unsigned)m * RECB;    // the zero record
+  const int wvs = uni((int)threadIdx.x >> 6);
+  auto tid = [&]() { return (wvs << 6) | lane_now(); };
+#define ME const Me me = make_me<NH, FULL>(n, wvs)
+  const unsigned ZREC = (unsigned)m * RECB;  // the zero record
   int flip = 0;
+  QPROF_DECL
 
   // ---- stage the schedule and load the instance -------------------------------------------------------------
-  for (int k = t; k <= n; k += QT) *(lshort *)(lds + L.Fp + 2 * k) = (unsigned short)S.Fp[k];
-  for (int k = t; k < nnzF; k += QT) *(lshort *)(lds + L.Fc + 2 * k) = (unsigned short)S.Fc[k];
-  *(lshort *)(lds + L.colstart + 2 * t) = S.colstart[t];
+  {
+    ME;
+    const int t = me.t;
+    for (int k = t; k <= n; k += QT) *(lshort *)(lds + L.Fp + 2 * k) = (unsigned short)S.Fp[k];
+    for (int k = t; k < nnzF; k += QT) *(lshort *)(lds + L.Fc + 2 * k) = (unsigned short)S.Fc[k];
+    *(lshort *)(lds + L.colstart + 2 * t) = S.colstart[t];
 #pragma unroll
-  for (int e = 0; e < KCH; e++) *(lshort *)(lds + L.collist + (t * KCH + e) * 2) = S.collist[t * KCH + e];
-  *(luint *)(lds + L.meta + t * 4) = S.meta[t];
+    for (int e = 0; e < KCH; e++) *(lshort *)(lds + L.collist + (t * KCH + e) * 2) = S.collist[t * KCH + e];
+    *(luint *)(lds + L.meta + t * 4) = S.meta[t];
+    for (int k = t; k < nnzA; k += QT) sd(lds, L.Av + k * 8, Ax_all[(size_t)inst * nnzA + k]);
+    for (int k = nnzA + t; k < nnzA + KC + 2; k += QT) sd(lds, L.Av + k * 8, 0.0);
+    for (int k = t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, Px_all[(size_t)inst * S.nnzP + S.Fmap[k]]);
+    for (int k = t; k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
+    for (int i = t; i <= m; i += QT) {
+      const unsigned r = (unsigned)i * RECB;
+      const bool real = i < m;
+      st2at(lds, L.rec + r + F_Z, 0.0, 0.0);
+      st2at(lds, L.rec + r + F_L, real ? fmax(l_all[(size_t)inst * m + i], -OSQP_INFTY) : 0.0, real ? fmin(u_all[(size_t)inst * m + i], OSQP_INFTY) : 0.0);
+      st2at(lds, L.rec + r + F_RHO, 0.0, 0.0);
+      st2at(lds, L.rec + r + F_ZT, 0.0, real ? 1.0 : 0.0);
+      if (real) { sd(lds, L.dy + i * 8, 0.0); sd(lds, L.ax + i * 8, 0.0); }
+    }
+    // x_j, q_j, D_j, delta_x_j live in LDS, not in registers of the column's owner: they are touched once or twice per
+    // iteration, and every register next to the inverse counts
+    if (me.owner) { sd(lds, L.cx + me.j * 8, 0.0); sd(lds, L.cq + me.j * 8, q_all[(size_t)inst * n + me.j]); sd(lds, L.cD + me.j * 8, 1.0); sd(lds, L.cdx + me.j * 8, 0.0); }
+  }
   auto stage_words = [&]() {
+    const int t = tid();
 #pragma unroll
     for (int e = 0; e < KEP; e++) *(luint *)(lds + L.roww + (t * KEP + e) * 4) = S.roww[t * KEP + e];
   };
   stage_words();
-  for (int k = t; k < nnzA; k += QT) sd(lds, L.Av + k * 8, Ax_all[(size_t)inst * nnzA + k]);
-  for (int k = nnzA + t; k < nnzA + KC + 2; k += QT) sd(lds, L.Av + k * 8, 0.0);
-  for (int k = t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, Px_all[(size_t)inst * S.nnzP + S.Fmap[k]]);
-  for (int k = t; k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
-  for (int i = t; i <= m; i += QT) {
-    const unsigned r = (unsigned)i * RECB;
-    const bool real = i < m;
-    st2at(lds, L.rec + r + F_Z, 0.0, 0.0);
-    st2at(lds, L.rec + r + F_L, real ? fmax(l_all[(size_t)inst * m + i], -OSQP_INFTY) : 0.0, real ? fmin(u_all[(size_t)inst * m + i], OSQP_INFTY) : 0.0);
-    st2at(lds, L.rec + r + F_RHO, 0.0, 0.0);
-    st2at(lds, L.rec + r + F_ZT, 0.0, real ? 1.0 : 0.0);
-    if (real) { sd(lds, L.dy + i * 8, 0.0); sd(lds, L.ax + i * 8, 0.0); }
-  }
-  double xj = 0.0, qj = owner ? q_all[(size_t)inst * n + j] : 0.0, Dj = 1.0, dxj = 0.0;
   __syncthreads();
 
   // ---- walks of the pattern -----------------------------------------------------------------------------------
   // the lane's half of column j of A (entries hb, hb + 2, ...): f(e, LDS offset of the value, record offset of its row)
-  auto col_walk = [&](auto f) {
+  auto col_walk = [&](const Me &me, auto f) {
     unsigned short ro[KCH];
 #pragma unroll
     for (int e4 = 0; e4 < KCH; e4 += 4) {
-      const uint2_t w = *(const luint2 *)(lds + L.collist + (t * KCH + e4) * 2);
+      const uint2_t w = *(const luint2 *)(lds + L.collist + (me.t * KCH + e4) * 2);
       ro[e4] = (unsigned short)(w.x & 0xFFFFu); ro[e4 + 1] = (unsigned short)(w.x >> 16);
       ro[e4 + 2] = (unsigned short)(w.y & 0xFFFFu); ro[e4 + 3] = (unsigned short)(w.y >> 16);
     }
+    const unsigned vbase = L.Av + ((unsigned)*(const lshort *)(lds + L.colstart + 2 * me.t) + me.hb) * 8;
 #pragma unroll
-    for (int e = 0; e < (KC + 1) / 2; e++) f(e, (unsigned)(L.Av + (cstart + 2 * e + hb) * 8), (unsigned)ro[e]);
+    for (int e = 0; e < KCE; e++) f(e, vbase + 16 * e, (unsigned)ro[e]);
   };
   // partial sum over the lane's half of column j of value * (field FIELD of the entry's row record)
-  auto col_dot = [&](int field) -> double {
-    constexpr int EN = (KC + 1) / 2;
-    double av[EN], ov[EN];
-    col_walk([&](int e, unsigned voff, unsigned ro) { av[e] = ld(lds, voff); ov[e] = ld(lds, L.rec + ro + field); });
-    double a = 0.0;
+  auto col_dot = [&](const Me &me, int field) -> double {
+    double av[KCE], ov[KCE];
+    col_walk(me, [&](int e, unsigned voff, unsigned ro) { av[e] = ld(lds, voff); ov[e] = ld(lds, L.rec + field + ro); });
+    double a = av[0] * ov[0];
 #pragma unroll
-    for (int e = 0; e < EN; e++) a += av[e] * ov[e];
+    for (int e = 1; e < KCE; e++) a = __builtin_fma(av[e], ov[e], a);
     return a;
   };
   // the lane's row: sum over its entries of value * v[col], v = the array at vecoff (TWO: + the array n doubles behind it);
   // four entries at a time up to the longest row of the wavefront; words padded with (zero value, operand 0)
-  auto row_dot = [&](auto two_tag, int vecoff) -> double {
+  auto row_dot = [&](const Me &me, auto two_tag, int vecoff) -> double {
     constexpr bool TWO = decltype(two_tag)::value;
+    const int kew = uni(S.kew[me.wv]);
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int e0 = 0; e0 < KEP; e0 += 4) {
       if (e0 < kew) {
-        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (t * KEP + e0) * 4);
+        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP + e0) * 4);
         const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
         double av[4], ov[4], ow[4];
 #pragma unroll
@@ -324,18 +356,19 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const double o = TWO ? ov[e] + ow[e] : ov[e];
-          if (e & 1) a1 += av[e] * o; else a0 += av[e] * o;
+          if (e & 1) a1 = __builtin_fma(av[e], o, a1); else a0 = __builtin_fma(av[e], o, a0);
         }
       }
     }
     return a0 + a1;
   };
-  auto row_absmax = [&]() -> double {
+  auto row_absmax = [&](const Me &me) -> double {
+    const int kew = uni(S.kew[me.wv]);
     double mx = 0.0;
 #pragma unroll
     for (int e0 = 0; e0 < KEP; e0 += 4) {
       if (e0 < kew) {
-        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (t * KEP + e0) * 4);
+        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP + e0) * 4);
         const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) mx = fmax(mx, fabs(ld(lds, L.Av + (w[e] >> 16))));
@@ -343,65 +376,71 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     return mx;
   };
+  auto my_rec = [&](const Me &me) -> unsigned { return *(const luint *)(lds + L.meta + me.t * 4); };  // 0xFFFFFFFF: no row
   std::integral_constant<bool, false> one_vec;
   std::integral_constant<bool, true> two_vec;
   // row j of the full symmetric P times a vector in LDS (owner lanes)
-  auto p_row_dot = [&](int vecoff) -> double {
+  auto p_row_dot = [&](const Me &me, int vecoff) -> double {
     double a = 0.0;
-    if (owner) {
-      const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
+    if (me.owner) {
+      const int q0 = *(const lshort *)(lds + L.Fp + 2 * me.j), q1 = *(const lshort *)(lds + L.Fp + 2 * me.j + 2);
       for (int q = q0; q < q1; q++) a += ld(lds, L.Pv + q * 8) * ld(lds, vecoff + 8 * *(const lshort *)(lds + L.Fc + 2 * q));
     }
     return a;
   };
-  auto p_col_absmax = [&]() -> double {
+  auto p_col_absmax = [&](const Me &me) -> double {
     double mx = 0.0;
-    if (owner) {
-      const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
+    if (me.owner) {
+      const int q0 = *(const lshort *)(lds + L.Fp + 2 * me.j), q1 = *(const lshort *)(lds + L.Fp + 2 * me.j + 2);
       for (int q = q0; q < q1; q++) mx = fmax(mx, fabs(ld(lds, L.Pv + q * 8)));
     }
     return mx;
   };
 
+  QPROF(0)
   // ---- K0: Ruiz equilibration + cost scaling (the arithmetic of batch.hip / oracle scale_data, element for element) ----
   double c = 1.0;
   for (int it = 0; it < st.scaling; it++) {
+    ME;
+    const unsigned myrec = my_rec(me);
+    const bool hasrow = myrec != 0xFFFFFFFFu;
+    const int j = me.j;
     {  // column maxima: the two halves of a column meet in tmp
       double mx = 0.0;
-      col_walk([&](int e, unsigned voff, unsigned ro) { const double v = fabs(ld(lds, voff)); mx = fmax(mx, ro != ZREC ? v : 0.0); });
-      if (col && hb == 1) sd(lds, L.tmp + j * 8, mx);
-      if (hasrow) sd(lds, L.ax + (myrec / RECB) * 8, 1.0 / sqrt(lim(row_absmax())));  // row factors into ax (free outside an evaluation)
+      col_walk(me, [&](int e, unsigned voff, unsigned ro) { const double v = fabs(ld(lds, voff)); mx = fmax(mx, ro != ZREC ? v : 0.0); });
+      if (me.col && me.hb == 1) sd(lds, L.tmp + j * 8, mx);
+      if (hasrow) sd(lds, L.ax + (myrec / RECB) * 8, 1.0 / sqrt(lim(row_absmax(me))));  // row factors into ax (free outside an evaluation)
       __syncthreads();
-      if (owner) {
-        mx = fmax(fmax(mx, ld(lds, L.tmp + j * 8)), p_col_absmax());
+      if (me.owner) {
+        mx = fmax(fmax(mx, ld(lds, L.tmp + j * 8)), p_col_absmax(me));
         sd(lds, L.xs + j * 8, 1.0 / sqrt(lim(mx)));
       }
     }
     __syncthreads();
-    const double tnj = col ? ld(lds, L.xs + j * 8) : 1.0;
-    if (owner) {
+    const double tnj = me.col ? ld(lds, L.xs + j * 8) : 1.0;
+    if (me.owner) {
       const int q0 = *(const lshort *)(lds + L.Fp + 2 * j), q1 = *(const lshort *)(lds + L.Fp + 2 * j + 2);
       for (int q = q0; q < q1; q++) {
         const int cc = *(const lshort *)(lds + L.Fc + 2 * q);
         const int lo = cc < j ? cc : j, hi = cc < j ? j : cc;
         sd(lds, L.Pv + q * 8, (ld(lds, L.Pv + q * 8) * ld(lds, L.xs + lo * 8)) * ld(lds, L.xs + hi * 8));
       }
-      qj *= tnj; Dj *= tnj;
+      sd(lds, L.cq + j * 8, ld(lds, L.cq + j * 8) * tnj); sd(lds, L.cD + j * 8, ld(lds, L.cD + j * 8) * tnj);
     }
-    if (col)
-      col_walk([&](int e, unsigned voff, unsigned ro) {
+    if (me.col)
+      col_walk(me, [&](int e, unsigned voff, unsigned ro) {
         if (ro != ZREC) sd(lds, voff, (ld(lds, voff) * ld(lds, L.ax + (ro / RECB) * 8)) * tnj);
       });
     if (hasrow) sd(lds, L.rec + myrec + F_E, ld(lds, L.rec + myrec + F_E) * ld(lds, L.ax + (myrec / RECB) * 8));
     __syncthreads();
-    double sm[1] = {p_col_absmax()}, mq[1] = {owner ? fabs(qj) : 0.0};  // sum of the column maxima of P, max |q|
+    double sm[1] = {p_col_absmax(me)}, mq[1] = {me.owner ? fabs(ld(lds, L.cq + j * 8)) : 0.0};  // sum of the column maxima of P, max |q|
     quad_reduce<1, 1>(sm, lds, L.red, flip);
     quad_reduce<1, 0>(mq, lds, L.red, flip);
     double c_temp = sm[0] / (double)n;
     c_temp = lim(fmax(c_temp, lim(mq[0])));
     c_temp = uni(1.0 / c_temp);
-    for (int k = t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, ld(lds, L.Pv + k * 8) * c_temp);
-    qj *= c_temp;
+    for (int k = me.t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, ld(lds, L.Pv + k * 8) * c_temp);
+    if (me.owner) sd(lds, L.cq + j * 8, ld(lds, L.cq + j * 8) * c_temp);
     c = uni(c * c_temp);
     __syncthreads();
   }
@@ -409,7 +448,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // ---- scaled bounds, K1: classes and rho ------------------------------------------------------------------------
   double rho = uni(fmin(fmax(st.rho, B_RHO_MIN), B_RHO_MAX));
   auto set_rho = [&](bool classify) {
-    for (int i = t; i < m; i += QT) {
+    for (int i = tid(); i < m; i += QT) {
       const unsigned r = (unsigned)i * RECB;
       int ty;
       if (classify) {
@@ -429,6 +468,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   };
   set_rho(true);
 
+  QPROF(1)
   const bool uns = st.scaling && !st.scaled_termination;
   const int check = (int)st.check_termination;
   const int rho_interval = st.adaptive_rho ? (st.adaptive_rho_interval ? (int)st.adaptive_rho_interval : 100) : 0;
@@ -446,8 +486,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       // the row words)
 #pragma unroll
       for (int u = 0; u < NH; u++) U[u] = 0.0;
-      for (int e = t; e < CH * n + 1; e += QT) sd(lds, L.roww + e * 8, 0.0);
-      if (t == 0) st2at(lds, L.cst, 1.0, sigma);
+      for (int e = tid(); e < CH * n + 1; e += QT) sd(lds, L.roww + e * 8, 0.0);
+      if (tid() == 0) st2at(lds, L.cst, 1.0, sigma);
       __syncthreads();
       const int NS = S.ns;
 #pragma unroll 1
@@ -455,8 +495,9 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int wh = cw >= NCH, wk = cw - wh * NCH;  // row half and window inside it
         const int c0 = wh * NH + wk * CH;
         if (c0 >= n) continue;
+        ME;
         {
-          const unsigned long long *sp = S.stream + (size_t)cw * NS * QT + t;
+          const unsigned long long *sp = S.stream + (size_t)cw * NS * QT + me.t;
           double acc = 0.0;
 #pragma unroll 1
           for (int sl = 0; sl < NS; sl += 4) {
@@ -476,37 +517,41 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           }
         }
         __syncthreads();
-        if (wh == hb) {  // rows c0 .. c0 + CH of column j: registers wk CH + r -- compile-time indices per window, hence the tree
+        if (wh == me.hb) {  // rows c0 .. c0 + CH of column j: registers wk CH + r -- compile-time indices per window, hence the tree
           double w[CH];
 #pragma unroll
           for (int r = 0; r < CH; r++) {
-            const bool live = col && wk * CH + r < NH && c0 + r < n;
-            w[r] = live ? ld(lds, L.roww + (r * n + j) * 8) : 0.0;
-            if (live) sd(lds, L.roww + (r * n + j) * 8, 0.0);
+            const bool live = me.col && wk * CH + r < NH && c0 + r < n;
+            w[r] = live ? ld(lds, L.roww + (r * n + me.j) * 8) : 0.0;
+            if (live) sd(lds, L.roww + (r * n + me.j) * 8, 0.0);
           }
           chunk_store<0, NCH, NH, CH>(U, wk, w);
         }
         __syncthreads();
       }
       stage_words();
+      QPROF(2)
       // ---- the inverse by symmetric sweeps, in the registers ---------------------------------------------------------
       // sc * U[r] = element (hb NH + r, j) of the swept array; result -M^-1.  Buffers of a step: scaled pivot row, then the
-      // unscaled one (n entries each at the positions hp NHP + r of the padded halves), d and the pivot behind them.
+      // unscaled one (entries at the positions cb NHP + c of the padded halves), d and the pivot behind them.
       double sc = 1.0;
       bool pd = true;
       auto sweep16 = [&](auto ph_tag, auto pb_tag) {
         constexpr int PH = decltype(ph_tag)::value, PB = decltype(pb_tag)::value;
         constexpr int P1 = (PB + 1) * 16 < NH ? (PB + 1) * 16 : NH;
+        ME;
+        const unsigned slot8 = (me.cb * NHP + me.cl) * 8;       // column j in a padded buffer (column halves padded like row halves)
+        const unsigned brow8 = (me.hb * NHP + me.lane16) * 8;   // the lane's element of the row half's broadcast registers
+        const bool inpad = NHP == 64 || me.cl < NHP;
 #pragma unroll 1
         for (int pr = PB * 16; pr < P1 && PH * NH + pr < n; pr++) {
           const int p = PH * NH + pr;
-          const int pb = L.vec + (p & 1) * 2 * L.pbstride * 8;
-          const int slot = cb * NHP + cl;  // position of column j in a padded buffer (column halves padded like row halves)
-          if (hb == PH) {                 // the wavefronts that hold row p publish it
-            const double up = (cl < NHP) ? reg_get<PB * 16, P1, NH>(U, pr) : 0.0;
+          const unsigned pb = L.vec + (p & 1) * 2 * L.pbstride * 8;
+          if (me.hb == PH) {  // the wavefronts that hold row p publish it
+            const double up = reg_get<PB * 16, P1, NH>(U, pr);  // lanes without a column hold zeros
             const double pv = sc * up;
-            if (cl < NHP) { sd(lds, pb + slot * 8, pv); sd(lds, pb + (L.pbstride + slot) * 8, up); }
-            if (jp == p) {
+            if (inpad) { sd(lds, pb + slot8, pv); sd(lds, pb + L.pbstride * 8 + slot8, up); }
+            if (me.jp == p) {
               double d = __builtin_amdgcn_rcp(pv);
               d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
               d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
@@ -516,15 +561,15 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           __syncthreads();
           double B[NB];
 #pragma unroll
-          for (int k = 0; k < NB; k++) B[k] = ld(lds, pb + (hb * NHP + 16 * k + lane16) * 8);
-          const double up = (cl < NHP) ? ld(lds, pb + (L.pbstride + slot) * 8) : 0.0;
+          for (int k = 0; k < NB; k++) B[k] = ld(lds, pb + brow8 + 128 * k);
+          const double up = inpad ? ld(lds, pb + L.pbstride * 8 + slot8) : 0.0;
           const d2_t dp = ld2at(lds, pb + L.nh2 * 8);
           const double d = dp.x;
           if (!(dp.y > 0.0)) pd = false;
-          const double g = (jp == p) ? 0.0 : -d * up;
+          const double g = (me.jp == p) ? 0.0 : -d * up;
           rank1_all<0, NB, NH>(U, B, g);
-          if (hb == PH) reg_put<PB * 16, P1, NH>(U, pr, (jp == p) ? -1.0 : -g);
-          sc = (jp == p) ? d : sc;
+          if (me.hb == PH) reg_put<PB * 16, P1, NH>(U, pr, (me.jp == p) ? -1.0 : -g);
+          sc = (me.jp == p) ? d : sc;
         }
       };
       [&]<int... IS>(std::integer_sequence<int, IS...>) {
@@ -536,47 +581,51 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (int u = 0; u < NH; u++) U[u] *= f;
       }
       __syncthreads();  // the pivot buffers are the partial b / x~ and the copy of x again
-      for (int k = t; k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
+      for (int k = tid(); k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
       __syncthreads();
       if (!uni((int)pd)) { status = OSQP_NON_CVX; iter--; break; }
       need_factor = false;
+      QPROF(3)
     }
     // ---- K5 (a): b_j = sigma x_j - q_j + (A'(rho z - y))_j, in two parts (the entries of either parity) -------------
     {
-      double a = col_dot(F_ZT);
-      if (owner) a += sigma * xj - qj;
-      if (col) sd(lds, L.bp + (hb * L.nh2 + cb * NHP + cl) * 8, a);
+      ME;
+      double a = col_dot(me, F_ZT);
+      if (me.owner) a += sigma * ld(lds, L.cx + me.j * 8) - ld(lds, L.cq + me.j * 8);
+      if (me.col) sd(lds, L.bp + (me.hb * L.nh2 + me.cb * NHP + me.cl) * 8, a);
     }
     __syncthreads();
+    QPROF(4)
     // ---- K3/K4 as one dense product: the part of x~_j over the rows of this half ----------------------------------------
     {
+      ME;
+      const unsigned b8 = L.bp + (me.hb * NHP + me.lane16) * 8;
       double B[NB];
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        const unsigned o = (hb * NHP + 16 * k + lane16) * 8;
-        B[k] = ld(lds, L.bp + o) + ld(lds, L.bp + L.nh2 * 8 + o);
-      }
+      for (int k = 0; k < NB; k++) B[k] = ld(lds, b8 + 128 * k) + ld(lds, b8 + L.nh2 * 8 + 128 * k);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       dot_all<0, NB, NH, 4>(U, B, acc);
-      if (col) sd(lds, L.xp + (hb * n + j) * 8, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if (me.col) sd(lds, L.xp + (me.hb * n + me.j) * 8, (acc[0] + acc[1]) + (acc[2] + acc[3]));
     }
     __syncthreads();
+    QPROF(5)
     // ---- K5 (b): x, delta_x by the column's owner; z~ = A x~ row by row, each row finished by its lane ------------------
     const double alpha = opaque_s(st.alpha);
     const bool last = iter == max_iter;
     const bool due = check && (iter % check == 0);
     const bool rho_due = rho_interval && (iter % rho_interval == 0);
     const bool evaluate = due || rho_due || last;
-    if (owner) {
-      const double a = ld(lds, L.xp + j * 8) + ld(lds, L.xp + (n + j) * 8);
-      const double xn = alpha * a + (1.0 - alpha) * xj;
-      dxj = xn - xj;
-      xj = xn;
-    }
     {
-      const double zt = row_dot(two_vec, L.xp);
-      if (hasrow) {
-        const unsigned r = myrec;
+      ME;
+      if (me.owner) {
+        const double a = ld(lds, L.xp + me.j * 8) + ld(lds, L.xp + (n + me.j) * 8);
+        const double xo = ld(lds, L.cx + me.j * 8), xn = alpha * a + (1.0 - alpha) * xo;
+        sd(lds, L.cx + me.j * 8, xn);
+        if (evaluate) sd(lds, L.cdx + me.j * 8, xn - xo);
+      }
+      const double zt = row_dot(me, two_vec, L.xp);
+      const unsigned r = my_rec(me);
+      if (r != 0xFFFFFFFFu) {
         const d2_t zy = ld2at(lds, L.rec + r + F_Z), lu = ld2at(lds, L.rec + r + F_L), rr = ld2at(lds, L.rec + r + F_RHO);
         const double zh = alpha * zt + (1.0 - alpha) * zy.x;
         const double zn = fmin(fmax(zh + rr.y * zy.y, lu.x), lu.y);
@@ -588,27 +637,32 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
     }
     __syncthreads();
+    QPROF(6)
     if (!evaluate) continue;
 
     // ---- K8: residual evaluation; termination tests ----------------------------------------------------
     lchar *nrm = lds + L.nrm;
     auto NRM = [&](int k) -> double { return *(const ldouble *)(nrm + 8 * k); };
     // full column sums of A' v (v a field of the row records): the odd half through tmp; one barrier
-    auto col_full = [&](int field) -> double {
-      double a = col_dot(field);
-      if (col && hb == 1) sd(lds, L.tmp + j * 8, a);
+    auto col_full = [&](const Me &me, int field) -> double {
+      double a = col_dot(me, field);
+      if (me.col && me.hb == 1) sd(lds, L.tmp + me.j * 8, a);
       __syncthreads();
-      if (owner) a += ld(lds, L.tmp + j * 8);
+      if (me.owner) a += ld(lds, L.tmp + me.j * 8);
       return a;
     };
     {
       // every group of norms goes through its reduction and into nrm[] before the next is formed: the evaluation runs next
       // to the inverse (2 NH registers), its own working set has to stay small
-      if (owner) sd(lds, L.xs + j * 8, xj);
+      ME;
+      const int t = me.t, j = me.j;
+      const unsigned myrec = my_rec(me);
+      const bool hasrow = myrec != 0xFFFFFFFFu, owner = me.owner;
+      if (owner) sd(lds, L.xs + j * 8, ld(lds, L.cx + j * 8));
       __syncthreads();
       {
         double v[6] = {0, 0, 0, 0, 0, 0};
-        const double ax = row_dot(one_vec, L.xs);
+        const double ax = row_dot(me, one_vec, L.xs);
         if (hasrow) {
           const double zi = ld(lds, L.rec + myrec + F_Z), e = 1.0 / ld(lds, L.rec + myrec + F_E), rs = ax - zi;
           v[0] = fabs(rs); v[1] = fabs(e * rs); v[2] = fabs(zi); v[3] = fabs(ax); v[4] = fabs(e * zi); v[5] = fabs(e * ax);
@@ -621,12 +675,13 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
       }
       OQ_FENCE();
-      const double at = col_full(F_Y);
+      const double at = col_full(me, F_Y);
       OQ_FENCE();
-      const double px = p_row_dot(L.xs);
+      const double px = p_row_dot(me, L.xs);
+      const double qj = owner ? ld(lds, L.cq + j * 8) : 0.0, dinv = owner ? 1.0 / ld(lds, L.cD + j * 8) : 0.0;
       {
         double w[4] = {0, 0, 0, 0};
-        if (owner) { const double d = 1.0 / Dj, r = (qj + px) + at; w[0] = fabs(r); w[1] = fabs(d * r); w[2] = fabs(qj); w[3] = fabs(at); }
+        if (owner) { const double r = (qj + px) + at; w[0] = fabs(r); w[1] = fabs(dinv * r); w[2] = fabs(qj); w[3] = fabs(at); }
         quad_reduce<4, 0>(w, lds, L.red, flip);
         if (t == 0) {
 #pragma unroll
@@ -637,7 +692,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       OQ_FENCE();
       {
         double w[4] = {0, 0, 0, 0};
-        if (owner) { const double d = 1.0 / Dj; w[0] = fabs(px); w[1] = fabs(d * qj); w[2] = fabs(d * at); w[3] = fabs(d * px); }
+        if (owner) { w[0] = fabs(px); w[1] = fabs(dinv * qj); w[2] = fabs(dinv * at); w[3] = fabs(dinv * px); }
         quad_reduce<4, 0>(w, lds, L.red, flip);
         if (t == 0) {
 #pragma unroll
@@ -646,7 +701,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
       OQ_FENCE();
       {
-        double sm[2] = {owner ? xj * px : 0.0, owner ? qj * xj : 0.0};
+        const double xj = owner ? ld(lds, L.cx + j * 8) : 0.0;
+        double sm[2] = {xj * px, qj * xj};
         quad_reduce<2, 1>(sm, lds, L.red, flip);
         if (t == 0) *(ldouble *)(nrm + 8 * N_OBJ) = cinv * (0.5 * sm[0] + sm[1]);
       }
@@ -656,6 +712,9 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int code = 0;
     const int passes = (due || last) ? (last ? 2 : 1) : 0;
     for (int pass = 0; pass < passes && code == 0; pass++) {
+      ME;
+      const int t = me.t, j = me.j;
+      const bool owner = me.owner;
       const bool approx = pass == 1;
       double ea = st.eps_abs, er = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
       if (!(pri_res <= OSQP_INFTY) || !(dua_res <= OSQP_INFTY)) { code = OSQP_NON_CVX; break; }
@@ -688,10 +747,10 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
               sd(lds, L.rec + r + F_ZT, ld(lds, L.dy + i * 8));
             }
             __syncthreads();
-            const double tn = col_full(F_ZT);
+            const double tn = col_full(me, F_ZT);
             __syncthreads();
             for (int i = t; i < m; i += QT) sd(lds, L.rec + (unsigned)i * RECB + F_ZT, ld(lds, L.ax + i * 8));
-            double w1[1] = {owner ? fabs(uns ? tn / Dj : tn) : 0.0};
+            double w1[1] = {owner ? fabs(uns ? tn / ld(lds, L.cD + j * 8) : tn) : 0.0};
             quad_reduce<1, 0>(w1, lds, L.red, flip);
             pinf = w1[0] < epi * nv;
             __syncthreads();
@@ -701,7 +760,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const double eps_d = ea + er * (uns ? cinv * nmax(NRM(11), nmax(NRM(12), NRM(13))) : nmax(NRM(8), nmax(NRM(9), NRM(10))));
       if (uni((int)(dua_res < eps_d))) dc = true;
       else {  // dual infeasibility on delta_x
-        double v1[1] = {owner ? fabs(uns ? Dj * dxj : dxj) : 0.0}, s1[1] = {owner ? qj * dxj : 0.0};
+        const double dxj = owner ? ld(lds, L.cdx + j * 8) : 0.0, Dj = owner ? ld(lds, L.cD + j * 8) : 1.0;
+        double v1[1] = {fabs(uns ? Dj * dxj : dxj)}, s1[1] = {owner ? ld(lds, L.cq + j * 8) * dxj : 0.0};
         quad_reduce<1, 0>(v1, lds, L.red, flip);
         quad_reduce<1, 1>(s1, lds, L.red, flip);
         const double nv = v1[0], qdx = s1[0];
@@ -710,13 +770,14 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
           __syncthreads();
           if (owner) sd(lds, L.xs + j * 8, dxj);
           __syncthreads();
-          const double pdx = p_row_dot(L.xs);
+          const double pdx = p_row_dot(me, L.xs);
           double w1[1] = {owner ? fabs(uns ? pdx / Dj : pdx) : 0.0};
           quad_reduce<1, 0>(w1, lds, L.red, flip);
           if (uni((int)(w1[0] < cs * edi * nv))) {
             double bad[1] = {0.0};
-            const double adx = row_dot(one_vec, L.xs);
-            if (hasrow) {
+            const double adx = row_dot(me, one_vec, L.xs);
+            const unsigned myrec = my_rec(me);
+            if (myrec != 0xFFFFFFFFu) {
               const double tt = uns ? adx / ld(lds, L.rec + myrec + F_E) : adx;
               const double lo = ld(lds, L.rec + myrec + F_L), hi = ld(lds, L.rec + myrec + F_U);
               if ((hi < B_INF && tt > edi * nv) || (lo > -B_INF && tt < -edi * nv) || tt != tt) bad[0] = 1.0;
@@ -733,6 +794,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     if (last && passes && code == 0) code = OSQP_MAX_ITER_REACHED;
     code = uni(code);
+    QPROF(7)
     if (code != 0) { status = code; break; }
     // ---- adaptive rho ----
     if (rho_due) {
@@ -746,34 +808,26 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         need_factor = true;
       }
     }
+    QPROF(8)
   }
   if (iter > max_iter) iter = max_iter;
+  QPROF_PRINT
   // ---- store -----------------------------------------------------
-  const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
-  if (owner) x_out[(size_t)inst * x_stride + j] = has_sol ? Dj * xj : NAN;
-  for (int i = t; i < m; i += QT) {
-    const unsigned r = (unsigned)i * RECB;
-    y_out[(size_t)inst * y_stride + i] = has_sol ? cinv * ld(lds, L.rec + r + F_E) * ld(lds, L.rec + r + F_Y) : NAN;
+  {
+    ME;
+    const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
+    if (me.owner) x_out[(size_t)inst * x_stride + me.j] = has_sol ? ld(lds, L.cD + me.j * 8) * ld(lds, L.cx + me.j * 8) : NAN;
+    for (int i = me.t; i < m; i += QT) {
+      const unsigned r = (unsigned)i * RECB;
+      y_out[(size_t)inst * y_stride + i] = has_sol ? cinv * ld(lds, L.rec + r + F_E) * ld(lds, L.rec + r + F_Y) : NAN;
+    }
+    if (me.t == 0) {
+      double *o = info_out + (size_t)inst * info_stride;
+      o[0] = (double)iter; o[1] = (double)status; o[2] = pri_res; o[3] = dua_res;
+      if (info_cols > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
+    }
   }
-  if (t == 0) {
-    double *o = info_out + (size_t)inst * info_stride;
-    o[0] = (double)iter; o[1] = (double)status; o[2] = pri_res; o[3] = dua_res;
-    if (info_cols > 4) { o[4] = status == OSQP_NON_CVX ? NAN : obj; o[5] = (double)rho_updates; }
-  }
-#undef t
-#undef lane16
-#undef wv
-#undef cb
-#undef hb
-#undef cl
-#undef j
-#undef col
-#undef owner
-#undef jp
-#undef cstart
-#undef myrec
-#undef hasrow
-#undef kew
+#undef ME
 }
 
 }  // namespace quad
