@@ -1136,7 +1136,7 @@ struct DevicePattern {
 
   // ---- schedule of the four-wavefront kernel ------------------------------------------------------------------------
   // Compile-time bounds of the one instantiation (the MPC family of BASELINE.json config 5; see launch_batch)
-  static constexpr int kNH = 50, kKC = 9, kKE = 11, kCH = 8;
+  static constexpr int kNH = 50, kKC = 9, kKE = 11, kCH = 16;
   void build_quad(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
                   const std::vector<int> &rc, const std::vector<int> &rmap, const std::vector<int> &fp, const std::vector<int> &fc,
                   const std::vector<int> &tp, const std::vector<unsigned short> &ti, const std::vector<unsigned short> &tj,
@@ -1166,6 +1166,7 @@ struct DevicePattern {
         const bool real = col && hAp[j] + 2 * e + hb < hAp[j + 1];
         collist[(size_t)t * kch + e] = (unsigned short)((real ? hAi[hAp[j] + 2 * e + hb] : m) * RECB);
       }
+      collist[(size_t)t * kch + kch - 1] = colstart[t];  // the first value of the column rides in the last slot
     }
     std::vector<unsigned> roww((size_t)QT * kep, (unsigned)(nnzA * 8) << 16), meta((size_t)QT, 0xFFFFFFFFu);
     int kew[4] = {0, 0, 0, 0};
@@ -1173,11 +1174,11 @@ struct DevicePattern {
       const int row = order[k];
       meta[k] = (unsigned)row * RECB;
       kew[k >> 6] = std::max(kew[k >> 6], rp[row + 1] - rp[row]);
-      for (int q = rp[row], e = 0; q < rp[row + 1]; q++, e++) roww[(size_t)k * kep + e] = ((unsigned)(rmap[q] * 8) << 16) | (unsigned)(rc[q] * 8);
+      for (int q = rp[row], e = 0; q < rp[row + 1]; q++, e++) roww[(size_t)k * kep + e] = ((unsigned)(rmap[q] * 8) << 16) | (unsigned)(rc[q] * 16);  // operands: 16 bytes per column
     }
-    // terms of M, grouped by position (i, j) of a window of kCH rows (windows do not straddle the two row halves), the
-    // groups of a window dealt to the threads (longest first)
-    const int nchh = (kNH + kCH - 1) / kCH, nwin = 2 * nchh;
+    // terms of M, grouped by position (i, j) of a window (rows k kCH / 2 + r of either row half), the groups of a window
+    // dealt to the threads (longest first)
+    const int ch2 = kCH / 2, nwin = (kNH + ch2 - 1) / ch2;
     struct Term { unsigned short r, a, b; };
     std::vector<std::vector<std::vector<Term>>> groups(nwin);
     std::vector<std::vector<unsigned short>> targets(nwin);
@@ -1187,7 +1188,7 @@ struct DevicePattern {
       std::vector<std::vector<int>> pent(n, std::vector<int>(n, -1));
       for (int r = 0; r < n; r++) for (int q = fp[r]; q < fp[r + 1]; q++) pent[r][fc[q]] = q;
       for (int i = 0; i < n; i++) {
-        const int wh = i / kNH, wk = (i - wh * kNH) / kCH, cw = wh * nchh + wk, c0 = wh * kNH + wk * kCH;
+        const int wh = i / kNH, il = i - wh * kNH, cw = il / ch2, wrow = wh * ch2 + il % ch2;
         for (int j = 0; j < n; j++) {
           std::vector<Term> g;
           if (pair_of[i][j] >= 0) {
@@ -1199,7 +1200,7 @@ struct DevicePattern {
           if (i == j) g.push_back(Term{(unsigned short)L.cst, (unsigned short)L.cst, (unsigned short)(L.cst + 8)});
           if (g.empty()) continue;
           groups[cw].push_back(g);
-          targets[cw].push_back((unsigned short)((i - c0) * n + j));
+          targets[cw].push_back((unsigned short)(wrow * n + j));
         }
       }
     }
@@ -1219,6 +1220,7 @@ struct DevicePattern {
       for (int t = 0; t < QT; t++) ns = std::max(ns, load[t]);
     }
     ns = std::max(4, (ns + 3) & ~3);
+    if (ns > 12) return;  // NSM of k_batch_quad
     const unsigned long long pad = (unsigned long long)(kCH * n) | 0x8000ull | ((unsigned long long)(L.rec + m * RECB + F_RHO) << 16) |
                                    ((unsigned long long)L.cst << 32) | ((unsigned long long)L.cst << 48);  // 0 * 1 * 1 into the spare position
     std::vector<unsigned long long> stream((size_t)nwin * ns * QT, pad);

@@ -75,7 +75,7 @@ struct Layout {  // byte offsets into the workgroup's LDS
 __host__ __device__ inline Layout make_layout(int n, int m, int nnzA, int nnzF, int NH, int KC, int KE, int CH) {
   Layout L;
   L.nh2 = 2 * ((NH + 15) & ~15);  // the broadcast registers of a row half cover 16 ceil(NH / 16) indices: both halves padded
-  L.kch = (((KC + 1) / 2) + 3) & ~3;
+  L.kch = (((KC + 1) / 2) + 1 + 3) & ~3;  // + the slot that carries the first value of the column
   L.kep = (KE + 3) & ~3;
   L.pbstride = L.nh2 + 2;
   int o = 0;
@@ -121,23 +121,45 @@ typedef __attribute__((address_space(3))) d2_t ld2;
 __device__ __forceinline__ d2_t ld2at(const lchar *base, unsigned off) { return *(const ld2 *)(base + off); }
 __device__ __forceinline__ void st2at(lchar *base, unsigned off, double a, double b) { d2_t v; v.x = a; v.y = b; *(ld2 *)(base + off) = v; }
 
-template <int OP>  // 0: max (NaN-propagating as nmax), 1: sum; result in every lane
+// Wavefront reduction of a non-negative double (max: OP 0, NaN-propagating as nmax; sum: OP 1; the identity of both is 0,
+// which is what a lane outside a DPP shift reads): row shifts by 1, 2, 4, 8 inside the sixteen-lane rows, then the row
+// totals across rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- plain VALU moves, where __shfl_xor
+// goes through the LDS crossbar and its queue six times.  The total arrives in lane 63 and is returned as a wave-uniform
+// value (v_readlane).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROWMASK, 0xF, true);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROWMASK, 0xF, true);
+  return r.d;
+}
+template <int OP>
+__device__ __forceinline__ double red_op(double a, double b) { return OP ? a + b : nmax(a, b); }
+template <int OP>
 __device__ __forceinline__ double wave_red(double a) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const double b = __shfl_xor(a, o, 64); a = OP ? a + b : nmax(a, b); }
-  return a;
+  a = red_op<OP>(a, dpp_get<0x111, 0xF>(a));  // row_shr:1
+  a = red_op<OP>(a, dpp_get<0x112, 0xF>(a));  // row_shr:2
+  a = red_op<OP>(a, dpp_get<0x114, 0xF>(a));  // row_shr:4
+  a = red_op<OP>(a, dpp_get<0x118, 0xF>(a));  // row_shr:8
+  a = red_op<OP>(a, dpp_get<0x142, 0xA>(a));  // row_bcast:15 into rows 1, 3
+  a = red_op<OP>(a, dpp_get<0x143, 0xC>(a));  // row_bcast:31 into rows 2, 3
+  union { double d; int i[2]; } u;
+  u.d = a;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+  return u.d;
 }
 // K per-thread values -> K workgroup results (wavefront 0's part first ... wavefront 3's last: a fixed order) in every
 // thread; one barrier.  Consecutive calls alternate halves of `red` so that a fast wavefront cannot overwrite what a slow
-// one still reads.
+// one still reads.  wvs: the wavefront's index (scalar).
 template <int K, int OP>
-__device__ __forceinline__ void quad_reduce(double *v, lchar *lds, int redoff, int &flip) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void quad_reduce(double *v, lchar *lds, int redoff, int &flip, int wvs) {
   const int base = redoff + flip * 4 * 8 * 8;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const double r = wave_red<OP>(v[k]);
-    if ((t & 63) == 0) sd(lds, base + ((t >> 6) * 8 + k) * 8, r);
+    sd(lds, base + (wvs * 8 + k) * 8, r);  // every lane the same value to the same address
     asm volatile("" ::: "memory");
   }
   __syncthreads();
@@ -266,9 +288,9 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   constexpr int NB = (NH + 15) / 16;       // broadcast registers of a row half
   constexpr int NHP = NB * 16;             // a row half, padded
   constexpr int KCE = (KC + 1) / 2;        // entries of a column per lane (one parity)
-  constexpr int KCH = (KCE + 3) & ~3;
+  constexpr int KCH = (KCE + 1 + 3) & ~3;  // the last slot of a lane's list carries the first value of its column
   constexpr int KEP = (KE + 3) & ~3;
-  constexpr int NCH = (NH + CH - 1) / CH;  // assembly windows per row half
+  constexpr int NCH = (NH + CH / 2 - 1) / (CH / 2);  // assembly windows: CH / 2 rows of either row half each
   constexpr bool FULL = CN == 2 * NH;      // every lane below NH of a quadrant has a column
   lchar *lds = (lchar *)lds_raw;
   const int wvs = uni((int)threadIdx.x >> 6);
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       ro[e4] = (unsigned short)(w.x & 0xFFFFu); ro[e4 + 1] = (unsigned short)(w.x >> 16);
       ro[e4 + 2] = (unsigned short)(w.y & 0xFFFFu); ro[e4 + 3] = (unsigned short)(w.y >> 16);
     }
-    const unsigned vbase = L.Av + ((unsigned)*(const lshort *)(lds + L.colstart + 2 * me.t) + me.hb) * 8;
+    const unsigned vbase = L.Av + ((unsigned)ro[KCH - 1] + me.hb) * 8;
 #pragma unroll
     for (int e = 0; e < KCE; e++) f(e, vbase + 16 * e, (unsigned)ro[e]);
   };
@@ -336,32 +358,47 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     for (int e = 1; e < KCE; e++) a = __builtin_fma(av[e], ov[e], a);
     return a;
   };
-  // the lane's row: sum over its entries of value * v[col], v = the array at vecoff (TWO: + the array n doubles behind it);
-  // four entries at a time up to the longest row of the wavefront; words padded with (zero value, operand 0)
-  auto row_dot = [&](const Me &me, auto two_tag, int vecoff) -> double {
-    constexpr bool TWO = decltype(two_tag)::value;
+  // the lane's row: sum over its entries of value * (v0[col] + v1[col]), the two operands interleaved at xp (16 bytes per
+  // column: the two partial sums of x~, or a vector and a zero); words padded with (zero value, operand 0).  All words
+  // first, then the values and operands of four entries at a time: a wavefront of short rows (<= 4 entries) makes one
+  // trip to LDS, the wavefront of the long rows three.
+  auto row_batch = [&](const unsigned *w, auto nb_tag, double &a0, double &a1) {
+    constexpr int NBE = decltype(nb_tag)::value;
+    double av[NBE];
+    d2_t op[NBE];
+#pragma unroll
+    for (int e = 0; e < NBE; e++) { av[e] = ld(lds, L.Av + (w[e] >> 16)); op[e] = ld2at(lds, L.xp + (w[e] & 0xFFFFu)); }
+#pragma unroll
+    for (int e = 0; e < NBE; e++) {
+      const double o = op[e].x + op[e].y;
+      if (e & 1) a1 = __builtin_fma(av[e], o, a1); else a0 = __builtin_fma(av[e], o, a0);
+    }
+  };
+  // hook(): called once, before the loads of the last batch are issued -- where the caller's own LDS reads (the row record of
+  // the finish) join the queue without adding to the registers the first batch holds
+  auto row_dot_h = [&](const Me &me, auto hook) -> double {
     const int kew = uni(S.kew[me.wv]);
     double a0 = 0.0, a1 = 0.0;
+    unsigned w[KEP];
+    if (kew <= 4) {
+      const uint4_t w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP) * 4);
+      w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+      hook();
+      row_batch(w, std::integral_constant<int, 4>{}, a0, a1);
+    } else {
+      constexpr int NBT = KEP / 4;
+      uint4_t w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP) * 4);
 #pragma unroll
-    for (int e0 = 0; e0 < KEP; e0 += 4) {
-      if (e0 < kew) {
-        const uint4_t w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP + e0) * 4);
-        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-        double av[4], ov[4], ow[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          av[e] = ld(lds, L.Av + (w[e] >> 16)); ov[e] = ld(lds, vecoff + (w[e] & 0xFFFFu));
-          if (TWO) ow[e] = ld(lds, vecoff + n * 8 + (w[e] & 0xFFFFu));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const double o = TWO ? ov[e] + ow[e] : ov[e];
-          if (e & 1) a1 = __builtin_fma(av[e], o, a1); else a0 = __builtin_fma(av[e], o, a0);
-        }
+      for (int bt = 0; bt < NBT; bt++) {
+        const unsigned wb[4] = {w4.x, w4.y, w4.z, w4.w};
+        if (bt + 1 < NBT) w4 = *(const luint4 *)(lds + L.roww + (me.t * KEP + 4 * bt + 4) * 4);  // the next batch's words ride along
+        if (bt == NBT - 1) hook();
+        if (bt * 4 < kew) row_batch(wb, std::integral_constant<int, 4>{}, a0, a1);
       }
     }
     return a0 + a1;
   };
+  auto row_dot = [&](const Me &me) -> double { return row_dot_h(me, [] {}); };
   auto row_absmax = [&](const Me &me) -> double {
     const int kew = uni(S.kew[me.wv]);
     double mx = 0.0;
@@ -377,8 +414,6 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     return mx;
   };
   auto my_rec = [&](const Me &me) -> unsigned { return *(const luint *)(lds + L.meta + me.t * 4); };  // 0xFFFFFFFF: no row
-  std::integral_constant<bool, false> one_vec;
-  std::integral_constant<bool, true> two_vec;
   // row j of the full symmetric P times a vector in LDS (owner lanes)
   auto p_row_dot = [&](const Me &me, int vecoff) -> double {
     double a = 0.0;
@@ -434,8 +469,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (hasrow) sd(lds, L.rec + myrec + F_E, ld(lds, L.rec + myrec + F_E) * ld(lds, L.ax + (myrec / RECB) * 8));
     __syncthreads();
     double sm[1] = {p_col_absmax(me)}, mq[1] = {me.owner ? fabs(ld(lds, L.cq + j * 8)) : 0.0};  // sum of the column maxima of P, max |q|
-    quad_reduce<1, 1>(sm, lds, L.red, flip);
-    quad_reduce<1, 0>(mq, lds, L.red, flip);
+    quad_reduce<1, 1>(sm, lds, L.red, flip, wvs);
+    quad_reduce<1, 0>(mq, lds, L.red, flip, wvs);
     double c_temp = sm[0] / (double)n;
     c_temp = lim(fmax(c_temp, lim(mq[0])));
     c_temp = uni(1.0 / c_temp);
@@ -477,58 +512,68 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   double pri_res = 0.0, dua_res = 0.0, obj = 0.0;
   int status = OSQP_UNSOLVED, iter = 0, rho_updates = 0;
   bool need_factor = true;
-  double U[NH];
+  double U[NH], nsc = 0.0;
 
   for (iter = 1; iter <= max_iter; iter++) {
     if (need_factor) {
-      // ---- K2: M = P + sigma I + A' diag(rho) A, CH rows at a time through the LDS window, into the registers ----------
-      // (window rows i, all columns: the lane of the rows' half reads -- and clears -- its own column; the window aliases
-      // the row words)
-#pragma unroll
-      for (int u = 0; u < NH; u++) U[u] = 0.0;
+      // ---- K2: M = P + sigma I + A' diag(rho) A through an LDS window, into the registers ------------------------------------
+      // A window holds CH / 2 rows of EITHER row half (rows k CH/2 + r of half 0 and of half 1; all columns): every lane
+      // reads -- and clears -- its own column of the rows of its half, registers k CH/2 + r.  The windows are unrolled:
+      // compile-time register indices, every register assigned exactly once.  The window aliases the row words.
       for (int e = tid(); e < CH * n + 1; e += QT) sd(lds, L.roww + e * 8, 0.0);
       if (tid() == 0) st2at(lds, L.cst, 1.0, sigma);
       __syncthreads();
+      // the term words of a window are fetched (L2) behind the terms of the window before, so that their latency runs under
+      // the two barriers and the read-out of that window; NSM: compile-time bound of the slots per thread
+      constexpr int NSM = 12, CH2 = CH / 2;
       const int NS = S.ns;
-#pragma unroll 1
-      for (int cw = 0; cw < 2 * NCH; cw++) {
-        const int wh = cw >= NCH, wk = cw - wh * NCH;  // row half and window inside it
-        const int c0 = wh * NH + wk * CH;
-        if (c0 >= n) continue;
-        ME;
+      unsigned long long tw[NSM];
+      auto fetch_words = [&](int cw) {
+        const unsigned long long *sp = S.stream + (size_t)cw * NS * QT + tid();
+#pragma unroll
+        for (int k = 0; k < NSM; k++) tw[k] = k < NS ? sp[(size_t)k * QT] : 0ull;
+      };
+      fetch_words(0);
+      auto window = [&](auto k_tag) {
+        constexpr int K = decltype(k_tag)::value;
         {
-          const unsigned long long *sp = S.stream + (size_t)cw * NS * QT + me.t;
           double acc = 0.0;
-#pragma unroll 1
-          for (int sl = 0; sl < NS; sl += 4) {
-            unsigned long long w[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) w[k] = sp[(size_t)(sl + k) * QT];
-            double r[4], a[4], bq[4];
+          for (int sl = 0; sl < NSM; sl += 4) {
+            if (sl < NS) {
+              double r[4], a[4], bq[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              r[k] = ld(lds, (unsigned)(w[k] >> 16) & 0xFFFFu); a[k] = ld(lds, (unsigned)(w[k] >> 32) & 0xFFFFu); bq[k] = ld(lds, (unsigned)(w[k] >> 48));
-            }
+              for (int k = 0; k < 4; k++) {
+                const unsigned long long w = tw[sl + k];
+                r[k] = ld(lds, (unsigned)(w >> 16) & 0xFFFFu); a[k] = ld(lds, (unsigned)(w >> 32) & 0xFFFFu); bq[k] = ld(lds, (unsigned)(w >> 48));
+              }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              acc += r[k] * a[k] * bq[k];
-              if (w[k] & 0x8000u) { sd(lds, L.roww + 8 * ((unsigned)w[k] & 0x7FFFu), acc); acc = 0.0; }
+              for (int k = 0; k < 4; k++) {
+                const unsigned long long w = tw[sl + k];
+                acc += r[k] * a[k] * bq[k];
+                if (w & 0x8000u) { sd(lds, L.roww + 8 * ((unsigned)w & 0x7FFFu), acc); acc = 0.0; }
+              }
             }
           }
         }
+        if constexpr (K + 1 < NCH) fetch_words(K + 1);
         __syncthreads();
-        if (wh == me.hb) {  // rows c0 .. c0 + CH of column j: registers wk CH + r -- compile-time indices per window, hence the tree
-          double w[CH];
-#pragma unroll
-          for (int r = 0; r < CH; r++) {
-            const bool live = me.col && wk * CH + r < NH && c0 + r < n;
-            w[r] = live ? ld(lds, L.roww + (r * n + me.j) * 8) : 0.0;
-            if (live) sd(lds, L.roww + (r * n + me.j) * 8, 0.0);
-          }
-          chunk_store<0, NCH, NH, CH>(U, wk, w);
+        {
+          ME;
+          [&]<int... RS>(std::integer_sequence<int, RS...>) {
+            ([&] {
+              if constexpr (K * CH2 + RS < NH) {
+                const bool live = me.col && (FULL || me.hb * NH + K * CH2 + RS < n);
+                const unsigned pos = L.roww + ((me.hb * CH2 + RS) * n + me.j) * 8;
+                U[K * CH2 + RS] = live ? ld(lds, pos) : 0.0;
+                if (live) sd(lds, pos, 0.0);
+              }
+            }(), ...);
+          }(std::make_integer_sequence<int, CH2>{});
         }
         __syncthreads();
-      }
+      };
+      [&]<int... KS>(std::integer_sequence<int, KS...>) { (window(std::integral_constant<int, KS>{}), ...); }(std::make_integer_sequence<int, NCH>{});
       stage_words();
       QPROF(2)
       // ---- the inverse by symmetric sweeps, in the registers ---------------------------------------------------------
@@ -575,11 +620,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       [&]<int... IS>(std::integer_sequence<int, IS...>) {
         (sweep16(std::integral_constant<int, IS / NB>{}, std::integral_constant<int, IS % NB>{}), ...);
       }(std::make_integer_sequence<int, 2 * NB>{});
-      {
-        const double f = -sc;
-#pragma unroll
-        for (int u = 0; u < NH; u++) U[u] *= f;
-      }
+      nsc = -sc;  // the registers stay as the sweeps left them: column j of M^-1 is nsc U, applied to the sum of the product
       __syncthreads();  // the pivot buffers are the partial b / x~ and the copy of x again
       for (int k = tid(); k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
       __syncthreads();
@@ -590,8 +631,10 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // ---- K5 (a): b_j = sigma x_j - q_j + (A'(rho z - y))_j, in two parts (the entries of either parity) -------------
     {
       ME;
+      double xo = 0.0, qo = 0.0;
+      if (me.owner) { xo = ld(lds, L.cx + me.j * 8); qo = ld(lds, L.cq + me.j * 8); }
       double a = col_dot(me, F_ZT);
-      if (me.owner) a += sigma * ld(lds, L.cx + me.j * 8) - ld(lds, L.cq + me.j * 8);
+      if (me.owner) a += sigma * xo - qo;
       if (me.col) sd(lds, L.bp + (me.hb * L.nh2 + me.cb * NHP + me.cl) * 8, a);
     }
     __syncthreads();
@@ -605,7 +648,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       for (int k = 0; k < NB; k++) B[k] = ld(lds, b8 + 128 * k) + ld(lds, b8 + L.nh2 * 8 + 128 * k);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       dot_all<0, NB, NH, 4>(U, B, acc);
-      if (me.col) sd(lds, L.xp + (me.hb * n + me.j) * 8, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if (me.col) sd(lds, L.xp + (me.j * 2 + me.hb) * 8, nsc * ((acc[0] + acc[1]) + (acc[2] + acc[3])));
     }
     __syncthreads();
     QPROF(5)
@@ -617,14 +660,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const bool evaluate = due || rho_due || last;
     {
       ME;
-      if (me.owner) {
-        const double a = ld(lds, L.xp + me.j * 8) + ld(lds, L.xp + (n + me.j) * 8);
-        const double xo = ld(lds, L.cx + me.j * 8), xn = alpha * a + (1.0 - alpha) * xo;
-        sd(lds, L.cx + me.j * 8, xn);
-        if (evaluate) sd(lds, L.cdx + me.j * 8, xn - xo);
-      }
-      const double zt = row_dot(me, two_vec, L.xp);
       const unsigned r = my_rec(me);
+      const double zt = row_dot(me);
       if (r != 0xFFFFFFFFu) {
         const d2_t zy = ld2at(lds, L.rec + r + F_Z), lu = ld2at(lds, L.rec + r + F_L), rr = ld2at(lds, L.rec + r + F_RHO);
         const double zh = alpha * zt + (1.0 - alpha) * zy.x;
@@ -634,6 +671,13 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         st2at(lds, L.rec + r + F_Z, zn, yn);
         sd(lds, L.rec + r + F_ZT, rr.x * zn - yn);
         if (evaluate) sd(lds, L.dy + (r / RECB) * 8, d);
+      }
+      if (me.owner) {  // last: its operands would otherwise sit in registers through the row products
+        const d2_t xa = ld2at(lds, L.xp + me.j * 16);
+        const double xo = ld(lds, L.cx + me.j * 8);
+        const double xn = alpha * (xa.x + xa.y) + (1.0 - alpha) * xo;
+        sd(lds, L.cx + me.j * 8, xn);
+        if (evaluate) sd(lds, L.cdx + me.j * 8, xn - xo);
       }
     }
     __syncthreads();
@@ -658,16 +702,16 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const int t = me.t, j = me.j;
       const unsigned myrec = my_rec(me);
       const bool hasrow = myrec != 0xFFFFFFFFu, owner = me.owner;
-      if (owner) sd(lds, L.xs + j * 8, ld(lds, L.cx + j * 8));
+      if (owner) { const double xv = ld(lds, L.cx + j * 8); sd(lds, L.xs + j * 8, xv); st2at(lds, L.xp + j * 16, xv, 0.0); }
       __syncthreads();
       {
         double v[6] = {0, 0, 0, 0, 0, 0};
-        const double ax = row_dot(me, one_vec, L.xs);
+        const double ax = row_dot(me);
         if (hasrow) {
           const double zi = ld(lds, L.rec + myrec + F_Z), e = 1.0 / ld(lds, L.rec + myrec + F_E), rs = ax - zi;
           v[0] = fabs(rs); v[1] = fabs(e * rs); v[2] = fabs(zi); v[3] = fabs(ax); v[4] = fabs(e * zi); v[5] = fabs(e * ax);
         }
-        quad_reduce<6, 0>(v, lds, L.red, flip);
+        quad_reduce<6, 0>(v, lds, L.red, flip, wvs);
         if (t == 0) {
 #pragma unroll
           for (int k = 0; k < 6; k++) *(ldouble *)(nrm + 8 * k) = v[k];
@@ -682,7 +726,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       {
         double w[4] = {0, 0, 0, 0};
         if (owner) { const double r = (qj + px) + at; w[0] = fabs(r); w[1] = fabs(dinv * r); w[2] = fabs(qj); w[3] = fabs(at); }
-        quad_reduce<4, 0>(w, lds, L.red, flip);
+        quad_reduce<4, 0>(w, lds, L.red, flip, wvs);
         if (t == 0) {
 #pragma unroll
           for (int k = 0; k < 4; k++) *(ldouble *)(nrm + 8 * (6 + k)) = w[k];
@@ -693,7 +737,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       {
         double w[4] = {0, 0, 0, 0};
         if (owner) { w[0] = fabs(px); w[1] = fabs(dinv * qj); w[2] = fabs(dinv * at); w[3] = fabs(dinv * px); }
-        quad_reduce<4, 0>(w, lds, L.red, flip);
+        quad_reduce<4, 0>(w, lds, L.red, flip, wvs);
         if (t == 0) {
 #pragma unroll
           for (int k = 0; k < 4; k++) *(ldouble *)(nrm + 8 * (10 + k)) = w[k];
@@ -703,7 +747,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       {
         const double xj = owner ? ld(lds, L.cx + j * 8) : 0.0;
         double sm[2] = {xj * px, qj * xj};
-        quad_reduce<2, 1>(sm, lds, L.red, flip);
+        quad_reduce<2, 1>(sm, lds, L.red, flip, wvs);
         if (t == 0) *(ldouble *)(nrm + 8 * N_OBJ) = cinv * (0.5 * sm[0] + sm[1]);
       }
       __syncthreads();
@@ -736,8 +780,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             v1[0] = nmax(v1[0], fabs(uns ? e * d : d));
             s1[0] += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
           }
-          quad_reduce<1, 0>(v1, lds, L.red, flip);
-          quad_reduce<1, 1>(s1, lds, L.red, flip);
+          quad_reduce<1, 0>(v1, lds, L.red, flip, wvs);
+          quad_reduce<1, 1>(s1, lds, L.red, flip, wvs);
           const double nv = v1[0], lhs = s1[0];
           if (uni((int)(nv > epi && lhs < -epi * nv))) {
             // A' delta_y: the column walk reads its operand from a row record -- lend the ZT field of every record to delta_y
@@ -751,7 +795,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             __syncthreads();
             for (int i = t; i < m; i += QT) sd(lds, L.rec + (unsigned)i * RECB + F_ZT, ld(lds, L.ax + i * 8));
             double w1[1] = {owner ? fabs(uns ? tn / ld(lds, L.cD + j * 8) : tn) : 0.0};
-            quad_reduce<1, 0>(w1, lds, L.red, flip);
+            quad_reduce<1, 0>(w1, lds, L.red, flip, wvs);
             pinf = w1[0] < epi * nv;
             __syncthreads();
           }
@@ -762,27 +806,27 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       else {  // dual infeasibility on delta_x
         const double dxj = owner ? ld(lds, L.cdx + j * 8) : 0.0, Dj = owner ? ld(lds, L.cD + j * 8) : 1.0;
         double v1[1] = {fabs(uns ? Dj * dxj : dxj)}, s1[1] = {owner ? ld(lds, L.cq + j * 8) * dxj : 0.0};
-        quad_reduce<1, 0>(v1, lds, L.red, flip);
-        quad_reduce<1, 1>(s1, lds, L.red, flip);
+        quad_reduce<1, 0>(v1, lds, L.red, flip, wvs);
+        quad_reduce<1, 1>(s1, lds, L.red, flip, wvs);
         const double nv = v1[0], qdx = s1[0];
         const double cs = uns ? c : 1.0;
         if (uni((int)(nv > edi && qdx < -cs * edi * nv))) {
           __syncthreads();
-          if (owner) sd(lds, L.xs + j * 8, dxj);
+          if (owner) { sd(lds, L.xs + j * 8, dxj); st2at(lds, L.xp + j * 16, dxj, 0.0); }
           __syncthreads();
           const double pdx = p_row_dot(me, L.xs);
           double w1[1] = {owner ? fabs(uns ? pdx / Dj : pdx) : 0.0};
-          quad_reduce<1, 0>(w1, lds, L.red, flip);
+          quad_reduce<1, 0>(w1, lds, L.red, flip, wvs);
           if (uni((int)(w1[0] < cs * edi * nv))) {
             double bad[1] = {0.0};
-            const double adx = row_dot(me, one_vec, L.xs);
+            const double adx = row_dot(me);
             const unsigned myrec = my_rec(me);
             if (myrec != 0xFFFFFFFFu) {
               const double tt = uns ? adx / ld(lds, L.rec + myrec + F_E) : adx;
               const double lo = ld(lds, L.rec + myrec + F_L), hi = ld(lds, L.rec + myrec + F_U);
               if ((hi < B_INF && tt > edi * nv) || (lo > -B_INF && tt < -edi * nv) || tt != tt) bad[0] = 1.0;
             }
-            quad_reduce<1, 0>(bad, lds, L.red, flip);
+            quad_reduce<1, 0>(bad, lds, L.red, flip, wvs);
             dinf = bad[0] == 0.0;
           }
           __syncthreads();
