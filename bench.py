@@ -640,11 +640,17 @@ def batch_leg(ctx, want_cpu):
         "transport": transport, "comm_ranks_seen": seen, "transport_ranks": transport_ranks(comm), "every_rank_holds_the_whole_batch": bool(same),
         "gather_bytes_per_rank": (BATCH_TOTAL // world) * 304 * 8 * (world - 1),
         "sharding": f"{BATCH_TOTAL // world} instances per GPU (contiguous blocks), one in-place all-gather of [x|y|info] at the end of each solve",
-        "roofline": {"bound": "lds", "kernel": "k_batch_solve (one QP per workgroup, all state in LDS)",
+        "roofline": {"bound": "lds", "kernel": "k_batch_quad (one QP per four wavefronts, three per compute unit; the inverse in registers, "
+                                                "everything else in LDS; OSQP_AMD_BATCH_QUAD=0: k_batch_solve, one QP per 512 threads)",
                      "achieved": round(lds_rate, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds_rate / LDS_PEAK_GBS / world, 5),
                      "traffic": None,
                      "lds_bytes_per_admm_iteration": lds_per_iter,
                      "hbm_GBs": round(per_inst_bytes * BATCH_TOTAL * steps / elapsed / 1e9, 3),
+                     # the kernel is bound by fp64 instruction issue, so the same work as a fraction of the vector fp64 peak: per QP
+                     # 2 n^2 + 4 nnz(A) + 20 (n + m) flops per ADMM iteration and 2 n^3 per Gauss-Jordan inversion
+                     "fp64": {"achieved_tflops": round((iters * steps * (2.0 * n_ * n_ + 4.0 * nnzA + 20.0 * (n_ + m_)) +
+                                                        float(info[:, 5].sum() + BATCH_TOTAL if info.shape[1] > 5 else 2 * BATCH_TOTAL) * steps * 2.0 * n_ ** 3) / elapsed / 1e12, 3),
+                              "peak_tflops": 78.6, "note": "vector fp64 peak of MI355X; inversions counted as rho updates + 1 per instance (2 when the packed rows carry no count)"},
                      "note": "on-chip operand bytes per ADMM iteration (8 n^2 of M^-1 -- held in registers since round 2 -- plus values, 16-bit "
                              "indices and operands of the two sparse products and the vector updates from LDS) against the aggregate "
                              "ds_read peak, 256 CUs x 256 B/clk x 2.4 GHz per GPU; HBM sees each instance once (hbm_GBs); what is achieved "
@@ -654,7 +660,7 @@ def batch_leg(ctx, want_cpu):
         rec["cpu_baseline"] = batch_cpu_leg(oq, args)
     b.close()
     if rank == 0 and world == 1 and args.child is None and args.traffic == "live":  # HBM bytes of one launch, two --pmc passes over a child
-        tr, src = live_traffic(args, ["k_batch_solve"])
+        tr, src = live_traffic(args, ["k_batch_quad", "k_batch_solve"])
         rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr, src
     if comm is not None:
         comm.close()

@@ -1,20 +1,27 @@
 // batch.hip -- batched small-QP path (rows K11/K12 of SURVEY.md section 8a,
 // BASELINE.json config 5: 4096 independent MPC QPs, n = 100, m = 200).
 //
-// One workgroup solves one QP from start to finish out of LDS and registers:
-//   * LDS (~75 KB at n = 100, m = 200: two workgroups fit a CU): the instance's values of A (shared sparsity
-//     pattern, CSC order) and of the full symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates, and the thread's
-//     share of the pattern of A in both orientations as packed (value offset, operand offset) words;
-//   * REGISTERS: the inverse of the reduced KKT matrix M = P + sigma I + A' diag(rho) A -- thread 4 i + c of the 512
-//     holds M^-1[i, c*n/4 .. (c+1)*n/4) (25 doubles at n = 100): the four column parts of a row sit in neighbouring
-//     lanes, so the dense product ends in two DPP adds instead of a trip through LDS;
-//   * M is assembled from host-precomputed term lists straight into the accumulator layout of the fp64 matrix cores,
-//     inverted there by Gauss-Jordan block sweeps (invert_mfma) and handed to the register tiles through a 20 KB LDS
-//     window, column part by column part: nothing of a factorisation touches global memory.
+// Two kernels behind one launcher (launch_batch):
+//   * k_batch_quad (batch_quad.hpp, round 4) -- one QP per FOUR wavefronts, three QPs per compute unit, the inverse of the
+//     reduced KKT matrix in registers as four quadrants, formed there by Gauss-Jordan sweeps, applied with
+//     v_fmac_f64_dpp row_newbcast; nothing of a factorisation touches global memory.  Takes the patterns that fit its
+//     compile-time bounds -- the MPC family of the benchmark;
+//   * k_batch_solve (this file, rounds 1-3) -- one QP per 512-thread workgroup, two per compute unit, for every other
+//     pattern with n <= 128 (run-time shapes, dense P, long rows):
+//       - LDS (~75 KB at n = 100, m = 200): the instance's values of A (shared sparsity pattern, CSC order) and of the full
+//         symmetric P, q, l, u, the Ruiz scalings, all ADMM iterates, and the thread's share of the pattern of A in both
+//         orientations as packed (value offset, operand offset) words;
+//       - REGISTERS: the inverse of the reduced KKT matrix M = P + sigma I + A' diag(rho) A -- thread 4 i + c of the 512
+//         holds M^-1[i, c*n/4 .. (c+1)*n/4) (25 doubles at n = 100): the four column parts of a row sit in neighbouring
+//         lanes, so the dense product ends in two DPP adds instead of a trip through LDS;
+//       - M is assembled from host-precomputed term lists in a per-instance n x n scratch in GLOBAL memory (L2-resident) and
+//         inverted there by Gauss-Jordan block sweeps on the fp64 matrix cores (invert_mfma), then loaded into the register
+//         tiles.  (The on-chip variant of this factorisation was built in round 3 and measured slower for this
+//         decomposition: profiles/r03_batch_experiments.md.)
 // Per iteration, three barrier-separated phases: b = sigma x - q + A'(rho z - y) (4 lanes per column of A);
 // x~ = M^-1 b (registers x LDS broadcast) with the x update; z~ = A x~ consumed row by row by the z / y update (2 lanes
 // per row); every `check_termination` iterations the same residual / infeasibility tests as the large-problem path.
-// The kernel is issue-bound, not latency-bound (round 3: 16 waves per CU, every vector instruction of a wavefront is four
+// The 512-thread kernel is issue-bound, not latency-bound (round 3: 16 waves per CU, every vector instruction of a wavefront is four
 // cycles of its SIMD): the iteration is written for instruction count -- operand addresses come ready-made out of one
 // packed word (two instructions per entry), short columns / rows are padded with a zero-valued entry instead of
 // branching, nothing the loop needs lives in spilled registers.

@@ -173,6 +173,19 @@ __device__ __forceinline__ void quad_reduce(double *v, lchar *lds, int redoff, i
   flip ^= 1;
 }
 
+// the same for one sum (v[0]) and one maximum (v[1]) in one exchange
+__device__ __forceinline__ void quad_reduce2(double *v, lchar *lds, int redoff, int &flip, int wvs) {
+  const int base = redoff + flip * 4 * 8 * 8;
+  const double r0 = wave_red<1>(v[0]), r1 = wave_red<0>(v[1]);
+  st2at(lds, base + wvs * 64, r0, r1);
+  __syncthreads();
+  d2_t a = ld2at(lds, base);
+#pragma unroll
+  for (int w = 1; w < 4; w++) { const d2_t b = ld2at(lds, base + w * 64); a.x += b.x; a.y = nmax(a.y, b.y); }
+  v[0] = a.x; v[1] = a.y;
+  flip ^= 1;
+}
+
 #define OQ_FENCE() asm volatile("" ::: "memory")
 
 // register file of the lane's column: U[p] for a wave-uniform p, through a tree of scalar branches (a select chain would be
@@ -468,11 +481,10 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       });
     if (hasrow) sd(lds, L.rec + myrec + F_E, ld(lds, L.rec + myrec + F_E) * ld(lds, L.ax + (myrec / RECB) * 8));
     __syncthreads();
-    double sm[1] = {p_col_absmax(me)}, mq[1] = {me.owner ? fabs(ld(lds, L.cq + j * 8)) : 0.0};  // sum of the column maxima of P, max |q|
-    quad_reduce<1, 1>(sm, lds, L.red, flip, wvs);
-    quad_reduce<1, 0>(mq, lds, L.red, flip, wvs);
-    double c_temp = sm[0] / (double)n;
-    c_temp = lim(fmax(c_temp, lim(mq[0])));
+    double sq[2] = {p_col_absmax(me), me.owner ? fabs(ld(lds, L.cq + j * 8)) : 0.0};  // sum of the column maxima of P, max |q|
+    quad_reduce2(sq, lds, L.red, flip, wvs);
+    double c_temp = sq[0] / (double)n;
+    c_temp = lim(fmax(c_temp, lim(sq[1])));
     c_temp = uni(1.0 / c_temp);
     for (int k = me.t; k < nnzF; k += QT) sd(lds, L.Pv + k * 8, ld(lds, L.Pv + k * 8) * c_temp);
     if (me.owner) sd(lds, L.cq + j * 8, ld(lds, L.cq + j * 8) * c_temp);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N,
 // are the same Schur complements LDL' would meet, so the inertia count is unchanged), and a solve replaces both
 // chains by one dense product x2 = S0^-1 (b2 - L21 y1).
 // wave per entry (i, k) of columns [b0, b1) of L's pattern inside the block; the work rows w_k hold L_kj d_j (k_ldl_wrow)
-__global__ __launch_bounds__(kBlock) void k_dense_entries(int b0, int b1, int cD, int kD, int N, const int64_t *__restrict__ Lp,
+__global__ __launch_bounds__(kBlock) void k_dense_entries(int b0, int b1, int cD, int kD, int ld, int N, const int64_t *__restrict__ Lp,
                                                           const int *__restrict__ Li, const double *__restrict__ Lx,
                                                           const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
                                                           const int64_t *__restrict__ Rmap, const double *__restrict__ W,
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_entries(int b0, int b1, int cD
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) {
     const double v = Lx[e] - acc;
-    S0[(size_t)(i - cD) + (size_t)(k - cD) * kD] = v;
-    S0[(size_t)(k - cD) + (size_t)(i - cD) * kD] = v;
+    S0[(size_t)(i - cD) + (size_t)(k - cD) * ld] = v;
+    S0[(size_t)(k - cD) + (size_t)(i - cD) * ld] = v;
   }
 }
 // wave per column k of [b0, b1): diagonal of the Schur complement
-__global__ __launch_bounds__(kBlock) void k_dense_diag(int b0, int b1, int cD, int kD, int N, const double *__restrict__ Lx,
+__global__ __launch_bounds__(kBlock) void k_dense_diag(int b0, int b1, int cD, int kD, int ld, int N, const double *__restrict__ Lx,
                                                        const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
                                                        const int64_t *__restrict__ Rmap, const double *__restrict__ D,
                                                        const double *__restrict__ W, double *__restrict__ S0) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_diag(int b0, int b1, int cD, i
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) S0[(size_t)(k - cD) * (kD + 1)] = D[k] - acc;
+  if (lane == 0) S0[(size_t)(k - cD) * (ld + 1)] = D[k] - acc;
 }
 // one Gauss-Jordan sweep on pivot p, out of place (no ordering between the threads of a launch is needed)
 __global__ __launch_bounds__(kBlock) void k_dense_sweep(int kD, int p, const double *__restrict__ Sold, double *__restrict__ Snew,
@@ -252,17 +252,128 @@ __global__ __launch_bounds__(kBlock) void k_dense_sweep2(int kD, int p, const do
   }
 }
 // x2 = -(S v) with S = -S0^-1 as the sweeps leave it (symmetric: row a is read as column a, contiguous); wave per row
-__global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, const double *__restrict__ S, const double *__restrict__ v,
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, int ld, const double *__restrict__ S, const double *__restrict__ v,
                                                         double *__restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int a = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
   if (a >= kD) return;
-  const double *col = S + (size_t)a * kD;
-  double acc = 0.0;
-  for (int b = lane; b < kD; b += 64) acc += col[b] * v[b];
+  const double *col = S + (size_t)a * ld;
+  double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;  // four loads in flight per lane (a 6000-row block: 94 rounds of one)
+  int b = lane;
+  for (; b + 192 < kD; b += 256) { acc += col[b] * v[b]; acc1 += col[b + 64] * v[b + 64]; acc2 += col[b + 128] * v[b + 128]; acc3 += col[b + 192] * v[b + 192]; }
+  for (; b < kD; b += 64) acc += col[b] * v[b];
+  acc = (acc + acc1) + (acc2 + acc3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) out[a] = -acc;
+}
+// ---- the same inverse by BLOCK sweeps on the fp64 matrix cores (blocks of kGjK pivots; large dense blocks) -----------
+// With B the pivot indices of a step, G = S_BB^-1, the kGjK single sweeps of the block amount to
+//   S_RR <- S_RR - S_RB G S_BR,   S_BR <- G S_BR (and its mirror),   S_BB <- -G
+// i.e. one rank-kGjK update of the whole array -- v_mfma_f64_16x16x4_f64 -- instead of kGjK passes over it: the array
+// (288 MB at 6000 pivots) is read and written once per 32 pivots, n^3 multiply-adds at matrix-core rate.  Three launches
+// per step: (1) one workgroup sweeps the pivot block by itself, pivot by pivot (the pivots are the ones the single sweeps
+// and LDL' would meet: inertia and zero-pivot checks unchanged), leaving T = -G; (2) the row panel W = G S_B: (kGjK x ld)
+// and a copy C of S_B: as it was; (3) the update of the tiles on and below the diagonal, each written to both triangles
+// through an LDS transposition, so that the array stays bit-symmetric.  The array is padded to a multiple of 64 (identity
+// on the padding: its sweeps change nothing).
+constexpr int kGjK = 32;
+__global__ __launch_bounds__(256) void k_gj_pivot(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
+                                                  int *__restrict__ status) {
+  __shared__ double buf[2][kGjK][kGjK + 1];
+  const int t = threadIdx.x;
+  for (int e = t; e < kGjK * kGjK; e += 256) { const int i = e % kGjK, j = e / kGjK; buf[0][i][j] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
+  __syncthreads();
+  int cur = 0, pos = 0, bad = 0;
+  for (int p = 0; p < kGjK; p++) {
+    const double piv = buf[cur][p][p], ip = 1.0 / piv;
+    for (int e = t; e < kGjK * kGjK; e += 256) {
+      const int i = e % kGjK, j = e / kGjK;
+      buf[cur ^ 1][i][j] = sweep_value(i == p, j == p, buf[cur][i][j], buf[cur][i][p], buf[cur][p][j], ip);
+    }
+    if (p0 + p < kD) { if (piv == 0.0 || piv != piv) bad = 1; else if (piv > 0.0) pos++; }
+    cur ^= 1;
+    __syncthreads();
+  }
+  for (int e = t; e < kGjK * kGjK; e += 256) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = buf[cur][i][j]; }
+  if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
+}
+// thread per column j of the array: W[k][j] = sum_l G[k][l] S[p0 + l][j], C[k][j] = S[p0 + k][j]  (G = -T)
+__global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *__restrict__ S, const double *__restrict__ T,
+                                                  double *__restrict__ Wp, double *__restrict__ Cp) {
+  __shared__ double G[kGjK][kGjK];
+  for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e % kGjK][e / kGjK] = -T[e];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ld) return;
+  double s[kGjK];
+#pragma unroll
+  for (int l = 0; l < kGjK; l++) s[l] = S[(size_t)(p0 + l) + (size_t)j * ld];
+#pragma unroll 4
+  for (int k = 0; k < kGjK; k++) {
+    double w = 0.0;
+#pragma unroll
+    for (int l = 0; l < kGjK; l++) w = __builtin_fma(G[k][l], s[l], w);
+    Wp[(size_t)k * ld + j] = w;
+    Cp[(size_t)k * ld + j] = s[k];
+  }
+}
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
+// workgroup (I, J), I >= J: the 64 x 64 tile of rows I, columns J and its mirror; wavefront w its 32 x 32 quadrant
+__global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__restrict__ S, const double *__restrict__ T,
+                                                   const double *__restrict__ Wp, const double *__restrict__ Cp) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  __shared__ double tr[4][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1;
+  if (I == J && wi < wj) return;  // the upper quadrant of a diagonal tile is the mirror of the lower one
+  const int lr = lane >> 4, lc = lane & 15;
+  const int r0 = I * 64 + wi * 32, c0 = J * 64 + wj * 32;  // rows r0 .. r0 + 32, columns c0 .. c0 + 32
+  const bool rowsB = r0 == p0, colsB = c0 == p0;           // the pivot block is 32 wide and 32-aligned
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      const int ri = r0 + ti * 16, cj = c0 + tj * 16;
+      if (ri < cj) continue;  // above the diagonal inside a diagonal quadrant: written by its mirror
+      gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      double nv[4];
+      if (!rowsB && !colsB) {
+#pragma unroll
+        for (int kk = 0; kk < kGjK / 4; kk++) {
+          const double aop = Wp[(size_t)(4 * kk + lr) * ld + cj + lc];  // A[m = lane & 15][k = lane >> 4] = W[k][cj + m]
+          const double bop = Cp[(size_t)(4 * kk + lr) * ld + ri + lc];  // B[k = lane >> 4][n = lane & 15] = C[ri + n][k]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) nv[r] = S[(size_t)(ri + lc) + (size_t)(cj + lr + 4 * r) * ld] - acc[r];  // D[m = lr + 4 r][n = lc]
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = ri + lc, j = cj + lr + 4 * r;
+          nv[r] = (rowsB && colsB) ? T[(i - p0) + (j - p0) * kGjK] : (rowsB ? Wp[(size_t)(i - p0) * ld + j] : Wp[(size_t)(j - p0) * ld + i]);
+        }
+      }
+      // both triangles: the tile as computed (rows contiguous across the lanes) and its transpose through LDS
+#pragma unroll
+      for (int r = 0; r < 4; r++) tr[w][lr + 4 * r][lc] = nv[r];  // tr[column offset][row offset]
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes before its reads (one wavefront per slab)
+      if (ri == cj) {  // a diagonal 16 x 16 tile: the lower triangle decides
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int m = lr + 4 * r; if (lc < m) nv[r] = tr[w][lc][m]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) S[(size_t)(ri + lc) + (size_t)(cj + lr + 4 * r) * ld] = nv[r];
+      if (ri != cj) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[(size_t)(cj + lc) + (size_t)(ri + lr + 4 * r) * ld] = tr[w][lc][lr + 4 * r];  // S[j][i] = value of (i, j)
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gj_pad(int kD, int ld, double *__restrict__ S) {
+  const int i = kD + blockIdx.x * kBlock + threadIdx.x;
+  if (i < ld) S[(size_t)i * (ld + 1)] = 1.0;
 }
 __global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
                                                        double *__restrict__ Rx) {
@@ -865,9 +976,10 @@ struct LdlFactor {
   double sigma = 0, cconst = 0;
   DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit, Lsplit;
   DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
-  DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2;
+  DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2, gjT, gjW, gjC;  // gj*: pivot block, row panel and panel copy of the block sweeps
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
+  int ldD = 0;                  // leading dimension of the dense block's array (kD, or kD padded to 64 for the block sweeps)
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
   size_t w_half = 0;            // doubles in one half of W
   std::vector<Step> fwd, bwd;
@@ -896,12 +1008,18 @@ struct LdlFactor {
             double flops_limit = 0.0)
       : e(en), sigma(sigma_), cconst(cconst_) {
     e.fetch_host_pattern();
+    e.setup_mark("  host pattern");
     symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
+    e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
     // A deep level schedule under min-degree (banded / multi-stage structure: the elimination tree is a chain) gets a
     // second analysis with nested dissection; the cheaper triangular solve by the model below wins.
     static const bool try_nd = !(getenv("OSQP_AMD_ND") && atoi(getenv("OSQP_AMD_ND")) == 0);
-    if (try_nd && (int)S.level_ptr.size() - 1 > 400) {
+    // (not when the depth is a dense trailing block -- a dense P: no ordering shortens that, and the block is inverted
+    // explicitly anyway)
+    int lD0 = 0, cD0 = 0, kD0 = 0;
+    choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD0, cD0, kD0);
+    if (try_nd && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
       Symbolic S2;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
       if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
@@ -914,6 +1032,7 @@ struct LdlFactor {
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 2, S3);
       if (!S3.too_large && S3.nnzL <= S.nnzL + S.nnzL / 10 && solve_cost_us(S3) < 0.9 * solve_cost_us(S)) S = std::move(S3);
     }
+    e.setup_mark("  other orderings");
     hipStream_t s = e.stream;
     N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
@@ -939,10 +1058,21 @@ struct LdlFactor {
       if (kD) wmax = std::max(wmax, (size_t)dense_batch() * (size_t)N);
       w_half = wmax;
       if (wmax) { W.alloc(2 * wmax); W.zero(s); }  // two halves: the work rows of a level are cleared while the next level fills its own
-      if (kD) { S0a.alloc((size_t)kD * kD); S0b.alloc((size_t)kD * kD); x2.alloc(kD); }
+      if (kD) {
+        // from kDenseBlocked pivots on the inverse is formed in place by block sweeps on the matrix cores (k_gj_*), below
+        // by single / double sweeps between two copies of the array
+        const bool blocked = kD >= kDenseBlocked;
+        ldD = blocked ? (kD + 63) / 64 * 64 : kD;
+        S0a.alloc((size_t)ldD * ldD);
+        if (blocked) { gjT.alloc(kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD); }
+        else S0b.alloc((size_t)kD * kD);
+        x2.alloc(kD);
+      }
     }
     e.sync();
+    e.setup_mark("  factor pattern on the device");
     build_schedule();
+    e.setup_mark("  solve schedule");
     // the big index arrays are only needed on the device from here on
     std::vector<int>().swap(S.Li); std::vector<int>().swap(S.Rj); std::vector<int64_t>().swap(S.Rmap);
     std::vector<int64_t>().swap(S.PtoL); std::vector<int64_t>().swap(S.AtoL);
@@ -1011,15 +1141,19 @@ struct LdlFactor {
   static int pick(double mean) { return mean <= 2.0 ? 1 : (mean <= 8.0 ? 4 : (mean <= 32.0 ? 16 : 64)); }
 
   static double solve_cost_us(const Symbolic &Y, double chain_level_us = 1.4) {
-    return level_solve_cost_us(Y, kChainRows, kDenseMax, kDenseMin, chain_level_us);
+    return level_solve_cost_us(Y, kChainRows, dense_max(), kDenseMin, chain_level_us);
   }
 
   // The dense top block (symbolic.hpp, choose_dense_top)
-  static constexpr int kDenseMax = 2048, kDenseSparseMax = 1024, kDenseMin = 32;
+  // Largest block: 12288 pivots (1.2 GB of inverse, a 1.2 GB product per solve -- ~0.2 ms -- against 24 000 dependent steps
+  // of the chain it replaces); up to round 3 the limit was 2048 because the inversion was one pass over the array per two
+  // pivots.  OSQP_AMD_DENSE_MAX overrides.
+  static constexpr int kDenseSparseMax = 1024, kDenseMin = 32, kDenseBlocked = 512;
+  static int dense_max() { static const int v = getenv("OSQP_AMD_DENSE_MAX") ? atoi(getenv("OSQP_AMD_DENSE_MAX")) : 12288; return v; }
   void choose_dense_block() {
     lD = nlev; cD = N; kD = 0;
     static const bool enabled = !(getenv("OSQP_AMD_DENSE_TOP") && atoi(getenv("OSQP_AMD_DENSE_TOP")) == 0);
-    if (enabled) choose_dense_top(S, kChainRows, kDenseMax, kDenseSparseMax, kDenseMin, lD, cD, kD);
+    if (enabled) choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD, cD, kD);
   }
   // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
   int dense_batch() const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)kD, ((size_t)256 << 20) / ((size_t)N * sizeof(double)))); }
@@ -1128,7 +1262,9 @@ struct LdlFactor {
     if (p1 > p0)  // the last work rows
       OQ_LAUNCH(k_ldl_wrow, dim3(blocks_for((int64_t)(p1 - p0) * 64)), dim3(kBlock), 0, s, p0, p1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(),
                 D.get(), W.get() + (size_t)half * w_half, 0);
+    if (factorizations == 0) e.setup_mark("  numeric: levels");
     if (kD) factor_dense_block();
+    if (factorizations == 0) e.setup_mark("  numeric: dense block");
     if (sn) {
       const int64_t nf = T.Fp[N], big = std::max<int64_t>(N, nf);
       OQ_LAUNCH(k_sn_gather, dim3(blocks_for(big)), dim3(kBlock), 0, s, nf, sn_Fpos.get(), sn_Fx.get(), nf, sn_Gpos.get(), sn_Gx.get(), N,
@@ -1155,10 +1291,22 @@ struct LdlFactor {
       OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, b0, b1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 1);
       const int64_t entries = S.Lp[b1] - S.Lp[b0];
       if (entries > 0)
-        OQ_LAUNCH(k_dense_entries, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, b0, b1, cD, kD, N, Lp.get(), Li.get(), Lx.get(),
+        OQ_LAUNCH(k_dense_entries, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, b0, b1, cD, kD, ldD, N, Lp.get(), Li.get(), Lx.get(),
                   Rp.get(), Rj.get(), Rmap.get(), W.get(), S0a.get());
-      OQ_LAUNCH(k_dense_diag, gw, dim3(kBlock), 0, s, b0, b1, cD, kD, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), S0a.get());
+      OQ_LAUNCH(k_dense_diag, gw, dim3(kBlock), 0, s, b0, b1, cD, kD, ldD, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), S0a.get());
       OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, b0, b1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 0);
+    }
+    if (factorizations == 0) e.setup_mark("  numeric: Schur complement of the block");
+    if (kD >= kDenseBlocked) {  // block sweeps of kGjK pivots on the matrix cores, in place
+      if (ldD > kD) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - kD)), dim3(kBlock), 0, s, kD, ldD, S0a.get());
+      const dim3 gp(blocks_for(ldD, 256)), gu(ldD / 64, ldD / 64);
+      for (int p0 = 0; p0 < ldD; p0 += kGjK) {
+        OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(256), 0, s, kD, ldD, p0, S0a.get(), gjT.get(), status.get());
+        OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+      }
+      Sinv = S0a.get();
+      return;
     }
     double *cur = S0a.get(), *nxt = S0b.get();
     const dim3 gs(blocks_for((int64_t)kD * kD));
@@ -1261,7 +1409,7 @@ struct LdlFactor {
     if (kD) {  // x2 = S0^-1 (b2 - L21 y1)
       // the reduced right-hand side goes to x2, the product straight back into the block's slots of the solution
       OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), x2.get());
-      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, Sinv, x2.get(), bp.get() + cD);
+      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, ldD, Sinv, x2.get(), bp.get() + cD);
     }
     for (size_t si = 0; si < bwd.size(); si++) {
       const Step &t = bwd[si];

@@ -6,6 +6,7 @@
 #include <climits>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 #include "engine.hpp"
 
@@ -257,6 +258,15 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
                       double flops_limit, int ordering, Symbolic &S) {
   const int n = P.cols, N = n + mr;
   S.n = n; S.mr = mr; S.N = N; S.too_large = false;
+  // OSQP_AMD_SYMBOLIC_TRACE=1: wall time of every stage on stderr
+  static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char *what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[symbolic %d] %-34s %8.1f ms\n", ordering, what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   const int64_t nnzP = P.p[n], nnzA = A.p[n];
 
   // ---- 1. upper-triangular pattern of K with origins --------------------------------
@@ -287,6 +297,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
     }
   for (int r = 0; r < mr; r++) { int64_t q = fill[n + r]++; K.i[q] = n + r; K.origin[q] = -1; }
 
+  stage("upper pattern of K");
   // ---- 2. fill-reducing ordering -------------------------------------------------------
   // Nodes of very high degree (a dense constraint row such as a budget 1'x = 1, a dense column of P) are kept out
   // of the quotient graph and eliminated last: pruning their adjacency at every step would make the ordering
@@ -337,6 +348,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   }
   std::vector<int> pinv(N);
   for (int k = 0; k < N; k++) pinv[order[k]] = k;
+  stage("ordering");
 
   // ---- 3. elimination tree of the permuted matrix, node heights, level renumbering ----
   // row-wise access to the permuted upper pattern: for column c (permuted), the rows r < c
@@ -397,6 +409,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   etree_of(cp, ci, parent);
   S.parent = parent;
 
+  stage("elimination tree, levels");
   // ---- 4. pattern of L: row patterns by climbing the tree from each entry of the row ----
   std::vector<int64_t> colcount(N, 0);
   {
@@ -412,6 +425,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
     S.flops = 0.0;
     for (int k = 0; k < N; k++) S.flops += (double)colcount[k] * (double)colcount[k];
   }
+  stage("column counts");
   S.Lp.assign(N + 1, 0);
   for (int j = 0; j < N; j++) S.Lp[j + 1] = S.Lp[j] + colcount[j];
   S.Li.resize(S.nnzL);
@@ -427,6 +441,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       S.Rp[k + 1] = S.Rp[k] + rc;
     }
   }
+  stage("row indices of L");
   // CSR view (row k: columns ascending) with the position of each entry in the CSC arrays
   S.Rj.resize(S.nnzL); S.Rmap.resize(S.nnzL);
   {
@@ -435,24 +450,47 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       for (int64_t t = S.Lp[j]; t < S.Lp[j + 1]; t++) { int r = S.Li[t]; int64_t q = f[r]++; S.Rj[q] = j; S.Rmap[q] = t; }
   }
 
+  stage("CSR view of L");
   // ---- 5. scatter maps from the caller's nnz order into Lx / D ------------------------
   S.PtoL.assign(nnzP, 0);
   S.AtoL.assign(nnzA, INT64_MIN);
-  for (int j = 0; j < N; j++)
-    for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
-      int64_t org = K.origin[q];
-      if (org == -1) continue;
-      int a = S.pinv[K.i[q]], b = S.pinv[j];
-      int64_t target;
-      if (a == b) target = -(int64_t)a - 1;
-      else {
-        int c = std::min(a, b), r = std::max(a, b);
-        const int *beg = S.Li.data() + S.Lp[c], *end = S.Li.data() + S.Lp[c + 1];
-        const int *it = std::lower_bound(beg, end, r);
-        target = S.Lp[c] + (it - beg);
+  // every entry of K on its own (a binary search in its column of L; distinct targets): columns dealt to host threads --
+  // 3.4 s on one core for a 6000 x 6000 dense P (1.6e7 searches that miss the cache), the largest piece of that setup
+  auto map_columns = [&](int j0, int j1) {
+    for (int j = j0; j < j1; j++)
+      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+        int64_t org = K.origin[q];
+        if (org == -1) continue;
+        int a = S.pinv[K.i[q]], b = S.pinv[j];
+        int64_t target;
+        if (a == b) target = -(int64_t)a - 1;
+        else {
+          int c = std::min(a, b), r = std::max(a, b);
+          const int *beg = S.Li.data() + S.Lp[c], *end = S.Li.data() + S.Lp[c + 1];
+          const int *it = std::lower_bound(beg, end, r);
+          target = S.Lp[c] + (it - beg);
+        }
+        if (org >= 0) S.PtoL[org] = target; else S.AtoL[-(org + 2)] = target;
       }
-      if (org >= 0) S.PtoL[org] = target; else S.AtoL[-(org + 2)] = target;
+  };
+  {
+    const int64_t entries = K.p[N];
+    int nt = entries < (int64_t)1 << 20 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt == 1) map_columns(0, N);
+    else {
+      std::vector<std::thread> pool;
+      int j0 = 0;
+      for (int t = 0; t < nt; t++) {  // equal shares of the entries
+        const int64_t goal = entries * (t + 1) / nt;
+        int j1 = t + 1 == nt ? N : (int)(std::lower_bound(K.p.begin(), K.p.end(), goal) - K.p.begin());
+        j1 = std::max(j0, std::min(N, j1));
+        pool.emplace_back(map_columns, j0, j1);
+        j0 = j1;
+      }
+      for (auto &th : pool) th.join();
     }
+  }
+  stage("scatter maps");
 }
 
 void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
@@ -588,15 +626,16 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
 
 double level_solve_cost_us(const Symbolic &Y, int chain_rows, int dense_max, int dense_min, double chain_level_us) {
   const auto &lp = Y.level_ptr;
-  const int nl = (int)lp.size() - 1, NN = Y.N;
-  int l = nl;
-  while (l > 1 && lp[l] - lp[l - 1] <= chain_rows && NN - lp[l - 1] <= dense_max) l--;
-  const int k = NN - lp[l];
-  const int top = k >= dense_min ? l : nl;
+  const int nl = (int)lp.size() - 1;
+  // the block the factor would really get (choose_dense_top): a block-sparse top chain -- the separators of a banded
+  // problem under min-degree -- is NOT taken as one large dense block just because the limit for dense blocks is generous
+  int lD, cD, kD;
+  choose_dense_top(Y, chain_rows, dense_max, 1024, dense_min, lD, cD, kD);
+  const int top = kD ? lD : nl;
   double us = 0.0;
   for (int q = 0; q < top; q++) us += (lp[q + 1] - lp[q] > chain_rows) ? 6.0 : chain_level_us;
   us += (double)Y.nnzL * 24.0 / 2.0e6;
-  if (top < nl) us += (double)k * (double)k * 8.0 / 4.0e6 + 10.0;
+  if (kD) us += (double)kD * (double)kD * 8.0 / 4.0e6 + 10.0;
   return us;
 }
 
