@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ADMM iterations/sec of the HIP engine on BASELINE.json's workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rand-1e6|rand-1e5|lasso-5e5|mpc-batch]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rand-1e6|rand-1e5|lasso-5e5|control-1e6|mpc-batch]
 
 A "step" is one ADMM iteration of the hot path (rhs build, KKT solve by the back-end the workload needs, fused
 x/z/y update, residual evaluation every `check_termination` = 25 iterations) on a synthetic QP generated in HBM
@@ -53,6 +53,10 @@ WORKLOADS = {
     "rand-1e5": (0, 100_000, 100, "pcg"),
     "rand-2e4": (0, 20_000, 20, "pcg"),
     "lasso-5e5": (1, 500_000, 0, "qdldl"),
+    # long-horizon linear MPC as ONE banded QP (tests/qp_zoo.py `control`, nx = 12, nu = 6, T = 55 555: n = 1 000 002,
+    # m = 1 666 674): nested dissection + supernodal triangular solves -- the trisolve path on a factor with real fill
+    # (nnz(L) = 6.7e7, 519 pivot levels, 11 supernode levels).  Built on the host and handed to osqp_setup as CSC arrays.
+    "control-1e6": ("control", 55_555, 0, "direct"),
 }
 
 SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25, adaptive_rho_interval=50,
@@ -227,16 +231,53 @@ def main():
     replica_bench(ctx)
 
 
+def control_problem(T, nx=12, nu=6, seed=6):
+    """Linear MPC over T stages as one QP (the statement of tests/qp_zoo.py `control`): min sum x_t'Q x_t + u_t'R u_t
+    s.t. x_{t+1} = A x_t + B u_t, x_0 given, box bounds; variables [x_0 .. x_T; u_0 .. u_{T-1}]."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    Ad = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx))
+    Ad *= 0.95 / max(1.0, np.max(np.abs(np.linalg.eigvals(Ad))))
+    Bd = rng.standard_normal((nx, nu))
+    Q = sp.diags(rng.random(nx) * 10.0)
+    R = 0.1 * sp.eye(nu)
+    x0 = rng.standard_normal(nx)
+    P = sp.block_diag([sp.kron(sp.eye(T + 1), Q), sp.kron(sp.eye(T), R)], format="csc")
+    q = np.zeros((T + 1) * nx + T * nu)
+    Ax = sp.kron(sp.eye(T + 1), -sp.eye(nx)) + sp.kron(sp.eye(T + 1, k=-1), sp.csc_matrix(Ad))
+    Bu = sp.kron(sp.vstack([sp.csc_matrix((1, T)), sp.eye(T)]), sp.csc_matrix(Bd))
+    Aeq = sp.hstack([Ax, Bu])
+    leq = np.concatenate([-x0, np.zeros(T * nx)])
+    A = sp.vstack([Aeq, sp.eye((T + 1) * nx + T * nu)], format="csc")
+    lo = np.concatenate([-5.0 * np.ones((T + 1) * nx), -0.5 * np.ones(T * nu)])
+    return dict(P=P, q=q, A=A, l=np.concatenate([leq, lo]), u=np.concatenate([leq, -lo]))
+
+
+def build_model(oq, lib, workload, seed, oracle=False):
+    """A workspace of `lib` (the HIP engine, or the oracle in the CPU leg) for a workload: generated in place by the
+    library's own generator, or -- control-1e6 -- built on the host and handed over through the reference entry point
+    osqp_setup (CSC arrays), which is how a drop-in caller would.  Returns (model, n, setup seconds)."""
+    kind, n, per_row, linsys = WORKLOADS[workload]
+    model = oq.Model(lib)
+    if kind == "control":
+        os.environ.setdefault("OSQP_AMD_FIRST_ORDERING", "1")  # the factor of a long banded problem: nested dissection at once
+        prob = control_problem(n)
+        t0 = time.time()
+        oq.setup(model, linsys_solver="qdldl" if oracle else linsys, **prob, **SETTINGS)
+        return model, int(prob["P"].shape[0]), time.time() - t0
+    t0 = time.time()
+    oq.setup_generated(model, kind, n, per_row, seed, linsys_solver=linsys, **SETTINGS)
+    return model, n, time.time() - t0
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # headline leg: one independent QP per rank
 # ----------------------------------------------------------------------------------------------------------------
 def replica_bench(ctx):
     args, oq, lib, torch, dist, rank, world = (ctx[k] for k in ("args", "oq", "lib", "torch", "dist", "rank", "world"))
-    kind, n, per_row, linsys = WORKLOADS[args.workload]
-    model = oq.Model(lib)
-    t0 = time.time()
-    oq.setup_generated(model, kind, n, per_row, 1 + rank, linsys_solver=linsys, **SETTINGS)
-    setup_s = time.time() - t0
+    model, n, setup_s = build_model(oq, lib, args.workload, 1 + rank)
     ws = model.workspace
 
     def barrier():
@@ -286,7 +327,11 @@ def replica_bench(ctx):
     else:            # direct back-end: the kernels of one iteration (right-hand side | triangular solves | update, fused as the factor allows)
         kname, which = "direct ADMM iteration: rhs + forward | backward + update around the LDL' factor (k_direct2_fwd + k_direct2_bwd_update on a two-level factor)", 5
         abytes = st[11] + 8.0 * (6 * n + 12 * int(oq.dimensions(model)[1]))  # trisolve bytes + the vector updates
-        pmc_names = ["k_direct2_fwd", "k_direct2_bwd_update"]  # the two-launch iteration; another factor shape: no live traffic (None)
+        pmc_names = ["k_direct2_fwd", "k_direct2_bwd_update"]  # the two-launch iteration of a two-level factor
+        if int(st[19]) > 0:  # supernodal solves: right-hand side | level 0 | tree (forward, backward) | level 0 | update
+            kname = ("direct ADMM iteration on a supernodal factor: k_direct_rhs | k_sn_level (level 0) | k_sn_tree forward | k_sn_tree backward | "
+                     "k_sn_level | k_direct_update")
+            pmc_names = ["k_direct_rhs", "k_sn_level", "k_sn_tree", "k_direct_update"]
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -402,9 +447,7 @@ def pmc_child(ctx):
         print("PMC_CHILD_OK 0")
         b.close()
         return
-    kind, n, per_row, linsys = WORKLOADS[args.workload]
-    model = oq.Model(lib)
-    oq.setup_generated(model, kind, n, per_row, 1, linsys_solver=linsys, **SETTINGS)
+    model, _, _ = build_model(oq, lib, args.workload, 1)
     which = 0 if oq.stats(model)[0] == 2 else 5  # the product of the indirect back-end / the iteration kernels of the direct one
     ms = float(lib.osqp_amd_time_kernel(model.workspace, which, 6))
     print("PMC_CHILD_OK %.4f" % ms)
@@ -835,11 +878,7 @@ def all_cores_bound(step_bytes):
 
 def cpu_live(oq, args, sample):
     ora = oq.load_library(oq.ORACLE_LIB_PATH)
-    kind, n, per_row, linsys = WORKLOADS[sample]
-    m = oq.Model(ora)
-    t0 = time.perf_counter()
-    oq.setup_generated(m, kind, n, per_row, 1, linsys_solver=linsys, **SETTINGS)
-    setup_s = time.perf_counter() - t0
+    m, _, setup_s = build_model(oq, ora, sample, 1, oracle=True)
     ws = m.workspace
     ora.osqp_amd_iterate(ws, 5)  # warm the caches
     st0 = oq.stats(m)

@@ -20,6 +20,13 @@ struct Error : std::runtime_error {
   int code;
   Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
+// panel_build declines a matrix BEFORE it has released or rewritten anything (a layout it does not support, a copy that
+// would be mostly padding): the caller keeps the matrix on its CSR arrays.  Any other Error out of panel_build (allocation,
+// launch, synchronisation) can come after the CSR columns went and the nnz-index maps were folded into slot ids -- that one
+// must reach the caller of osqp_setup as a failure, not be swallowed.
+struct PanelRefused : Error {
+  using Error::Error;
+};
 // a wait inside k_sn_tree timed out (direct.hip): the iterations since the last residual evaluation cannot be trusted.
 // Engine::solve catches it, cold-starts and runs the solve again on the per-level form of the triangular solves.
 struct TreeFault : Error {

@@ -21,7 +21,9 @@ double g_alloc_s = 0., g_free_s = 0.;
 
 namespace {
 std::mutex g_mu;
-int g_depth = 0;
+int g_depth = 0;               // open scopes in the process: released chunks of mapped blocks go to the (shared) chunk pool
+thread_local int t_depth = 0;  // open scopes of THIS thread: only its own frees are parked in its (thread-local) list -- a thread
+                               // outside any scope would otherwise park blocks nobody trims (its list is not the scope owner's)
 constexpr size_t kParkMin = size_t(1) << 20;
 constexpr size_t kChunk = size_t(64) << 20;
 const size_t kVmMin = getenv("OSQP_AMD_VMM_MIN_MB") ? (size_t)atol(getenv("OSQP_AMD_VMM_MIN_MB")) << 20 : size_t(256) << 20;
@@ -42,9 +44,22 @@ int g_vm_state = (getenv("OSQP_AMD_VMM") && atoi(getenv("OSQP_AMD_VMM")) == 0) ?
 // when a reservation fails the block comes from hipMalloc.  OSQP_AMD_VMM_VA=0 frees ranges at once (the defect, for the record).
 const bool g_va_free_at_once = getenv("OSQP_AMD_VMM_VA") && atoi(getenv("OSQP_AMD_VMM_VA")) == 0;
 
+size_t g_va_reserved = 0;  // address space taken so far (never returned: see above); OSQP_AMD_ALLOC_TRACE prints it
 void *va_get(size_t size) {
   void *va = nullptr;
-  if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    // Said once, loudly: from here on large blocks come from hipMalloc again -- correct, but with the driver's 1-5 s stalls
+    // this allocator exists to avoid.  A long-lived process that sets up thousands of large workspaces gets here.
+    static bool told = false;
+    if (!told) {
+      told = true;
+      fprintf(stderr, "[osqp_amd] device allocator: no address range of %.2f GB left after %.1f TB of reservations; large blocks fall "
+                      "back to hipMalloc for the rest of this process (slower setups, same results)\n", size / 1e9, g_va_reserved / 1e12);
+    }
+    return nullptr;
+  }
+  g_va_reserved += size;
   return va;
 }
 void va_retire(void *va, size_t size) {
@@ -238,7 +253,7 @@ void dev_free(void *p, size_t granted) {
     return;
   }
   g_device_bytes -= granted;
-  if (g_depth > 0 && granted >= kParkMin) {
+  if (t_depth > 0 && granted >= kParkMin) {
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) {  // reused in stream order: a scope's work is on one stream
       g_parked[{dev, granted}].push_back(p);
@@ -258,10 +273,12 @@ void dev_cache_trim() {
 DevCacheScope::DevCacheScope() {
   std::lock_guard<std::mutex> lock(g_mu);
   ++g_depth;
+  ++t_depth;
 }
 DevCacheScope::~DevCacheScope() {
   std::lock_guard<std::mutex> lock(g_mu);
   --g_depth;
+  --t_depth;
   trim_locked();
 }
 

@@ -125,6 +125,34 @@ __global__ __launch_bounds__(kBlock) void k_ldl_diag_w(int c0, int c1, int N, co
     for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) w[Rj[q]] = 0.0;
   }
 }
+// phase 1 for levels of SHORT rows (no work rows involved): G lanes per column instead of a wavefront -- a level of 10^6
+// columns with two entries each (the constraint rows of a lasso / box-constrained problem) is 10^6 wavefronts of which 62
+// lanes idle in k_ldl_diag_w: 2.9 ms per factorisation on lasso-5e5 where the whole ADMM iteration takes 31 us.  G = 1 adds
+// the terms in column order, the order of the oracle's update.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_ldl_diag_g(int c0, int c1, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
+                                                       const int *__restrict__ Rj, const int64_t *__restrict__ Rmap, double *__restrict__ D,
+                                                       double *__restrict__ Dinv, int *__restrict__ status) {
+  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
+  const int lane = threadIdx.x & (G - 1);
+  const bool live = g < c1 - c0;
+  const int k = c0 + (int)(live ? g : 0);
+  double acc = 0.0;
+  if (live)
+    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += G) {
+      const double l = Lx[Rmap[q]];
+      acc += l * l * D[Rj[q]];
+    }
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (live && lane == 0) {
+    const double dk = D[k] - acc;
+    const bool bad = (dk == 0.0) || (dk != dk);
+    D[k] = dk; Dinv[k] = 1.0 / dk;
+    if (bad) atomicOr(&status[0], 1);
+    else if (dk > 0.0) atomicAdd(&status[1], 1);
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                           double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                           const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
@@ -1009,7 +1037,10 @@ struct LdlFactor {
       : e(en), sigma(sigma_), cconst(cconst_) {
     e.fetch_host_pattern();
     e.setup_mark("  host pattern");
-    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
+    // OSQP_AMD_FIRST_ORDERING=1: nested dissection at once (a caller who knows the problem is a long banded one saves the
+    // min-degree analysis that would only establish that: ~half of the setup of the control-1e6 bench workload)
+    static const int first_ordering = getenv("OSQP_AMD_FIRST_ORDERING") ? atoi(getenv("OSQP_AMD_FIRST_ORDERING")) : 0;
+    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S);
     e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
     // A deep level schedule under min-degree (banded / multi-stage structure: the elimination tree is a chain) gets a
@@ -1019,7 +1050,7 @@ struct LdlFactor {
     // explicitly anyway)
     int lD0 = 0, cD0 = 0, kD0 = 0;
     choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD0, cD0, kD0);
-    if (try_nd && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
+    if (try_nd && first_ordering != 1 && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
       Symbolic S2;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
       if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
@@ -1248,6 +1279,11 @@ struct LdlFactor {
       const int64_t entries = S.Lp[c1] - S.Lp[c0];
       const bool through_w = entries > 0 && long_rows[l];
       double *wf = through_w ? W.get() + (size_t)(half ^ 1) * w_half : nullptr, *wc = p1 > p0 ? W.get() + (size_t)half * w_half : nullptr;
+      const int G = (through_w || p1 > p0) ? 64 : pick((double)(S.Rp[c1] - S.Rp[c0]) / (double)std::max(1, c1 - c0));
+      if (G == 1) OQ_LAUNCH(k_ldl_diag_g<1>, dim3(blocks_for(c1 - c0)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), Dinv.get(), status.get());
+      else if (G == 4) OQ_LAUNCH(k_ldl_diag_g<4>, dim3(blocks_for((int64_t)(c1 - c0) * 4)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), Dinv.get(), status.get());
+      else if (G == 16) OQ_LAUNCH(k_ldl_diag_g<16>, dim3(blocks_for((int64_t)(c1 - c0) * 16)), dim3(kBlock), 0, s, c0, c1, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), Dinv.get(), status.get());
+      else
       OQ_LAUNCH(k_ldl_diag_w, dim3(blocks_for((int64_t)(c1 - c0 + (p1 - p0)) * 64)), dim3(kBlock), 0, s, c0, c1, N, Lx.get(), Rp.get(), Rj.get(),
                 Rmap.get(), D.get(), Dinv.get(), status.get(), wf, p0, p1, wc);
       p0 = p1 = 0;

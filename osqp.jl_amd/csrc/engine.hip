@@ -464,7 +464,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     // the slot array go, BEFORE the slice values are allocated (the high-water mark of the setup is in here)
     auto fold = [&]() { if (!comm) { fold_slot_maps(which, p2s); maps_done = true; } };
     try { panel_build(M, stream, p2s.get(), true, fold); }
-    catch (const Error &) { M.panel = DevPanel(); return; }  // stays on its CSR arrays
+    catch (const PanelRefused &) { M.panel = DevPanel(); return; }  // declined before anything was released: stays on its CSR arrays
     compact_one(which, &p2s, maps_done);
   };
   auto transpose_A = [&]() {
@@ -701,7 +701,7 @@ void Engine::refresh_panels() {
       // the sliced-ELL copy is an optimisation: a layout it cannot express (more than 2^32 padded entries, ...) leaves the
       // matrix on the CSR kernel instead of failing the setup
       try { panel_build(*M, stream); }
-      catch (const Error &) { M->panel = DevPanel(); }
+      catch (const Error &) { M->panel = DevPanel(); }  // nothing of the matrix is released on this (non-compacting) path: any failure is survivable
     }
   }
 }

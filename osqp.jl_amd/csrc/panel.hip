@@ -825,7 +825,7 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot, bool will_compact, co
   DevPanel &P = M.panel;
   P.wide = panel_mode(M) == 2;
   P.shift = P.wide ? (wide_shift(M) ? wide_shift(M) : 18) : panel_shift(); P.W = 1 << P.shift;
-  if (!P.wide && P.shift > 15) throw Error(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
+  if (!P.wide && P.shift > 15) throw PanelRefused(6, "panel width above 2^15 columns is not supported (16-bit local column ids, LDS size)");
   P.B = (M.cols + P.W - 1) >> P.shift;
   const int64_t cells = (int64_t)P.B * M.rows;
   // per-(panel, row) counts and their offsets
@@ -860,7 +860,7 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot, bool will_compact, co
   OQ_LAUNCH(k_tile_starts, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, gcells, tid.get(), budget, gcnt.get());
   exclusive_scan(gcnt.get(), tid.get(), gcells, s);
   const int64_t ntiles = read_i64(tid.get() + gcells, s);
-  if (ntiles <= 0 || ntiles * P.Gp >= 2147483647LL) throw Error(6, "panel layout: bad tile count");
+  if (ntiles <= 0 || ntiles * P.Gp >= 2147483647LL) throw PanelRefused(6, "panel layout: bad tile count");
   P.ntiles = (int)ntiles;
   P.tile_g.alloc((size_t)ntiles); P.tile_r0.alloc((size_t)ntiles); P.tile_r1.alloc((size_t)ntiles);
   OQ_LAUNCH(k_tile_fill, dim3(blocks_for(gcells)), dim3(kBlock), 0, s, M.rows, gcells, gcnt.get(), tid.get(), P.tile_g.get(), P.tile_r0.get());
@@ -877,11 +877,11 @@ void panel_build(DevCsr &M, hipStream_t s, uint32_t *slot, bool will_compact, co
   exclusive_scan(nsl.get(), slice0.get(), nunits, s);
   exclusive_scan(pad.get(), padded0.get(), nunits, s);
   const int64_t nslices = read_i64(slice0.get() + nunits, s), padded = read_i64(padded0.get() + nunits, s);
-  if (padded >= 4294967295LL) throw Error(6, "sliced-ELL copy exceeds 2^32 entries");
+  if (padded >= 4294967295LL) throw PanelRefused(6, "sliced-ELL copy exceeds 2^32 entries");
   // A few very long rows among short ones (a factor model, a budget row) leave slices of 64 lanes with a handful of rows:
   // the copy is mostly padding and the product several times slower than the CSR kernel (portfolio, n = 20 k: 374 us
   // instead of 16 per product).  Unless the layout was asked for by name, such a matrix stays on the CSR kernel.
-  if (!getenv("OSQP_AMD_PANEL") && (double)padded > 1.5 * (double)M.nnz) throw Error(6, "sliced-ELL copy would be mostly padding");
+  if (!getenv("OSQP_AMD_PANEL") && (double)padded > 1.5 * (double)M.nnz) throw PanelRefused(6, "sliced-ELL copy would be mostly padding");
   P.padded = (size_t)padded;
   P.unit_s0.alloc((size_t)nunits); P.unit_ns.alloc((size_t)nunits);
   P.slice_base.alloc((size_t)nslices); P.slice_len.alloc((size_t)nslices); P.slice_rows.alloc((size_t)nslices * 64);

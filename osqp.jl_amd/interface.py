@@ -121,7 +121,11 @@ class ManagedCcsc:
 
     def __init__(self, M):
         M = sp.csc_matrix(M)
-        M.sort_indices()
+        if not M.has_canonical_format:
+            # rows of a column ascending and unique, as a Julia SparseMatrixCSC always is (the library refuses anything else
+            # with exit flag 1); on a copy: sp.csc_matrix(M) of a CSC input shares the caller's arrays
+            M = M.copy()
+            M.sum_duplicates()
         self.m, self.n = M.shape
         self.x = np.ascontiguousarray(M.data, dtype=np.float64)
         self.i = np.ascontiguousarray(M.indices, dtype=np.int64)
