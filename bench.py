@@ -275,8 +275,37 @@ def build_model(oq, lib, workload, seed, oracle=False):
 # ----------------------------------------------------------------------------------------------------------------
 # headline leg: one independent QP per rank
 # ----------------------------------------------------------------------------------------------------------------
+def start_cpu_full(args, rank, world):
+    """The CPU oracle on the headline workload ITSELF, in this run: started as a child process before the GPU legs (one host
+    thread and ~46 GiB against the GPU's work: different resources), collected by cpu_leg with a 20-minute cap.  Only when
+    the host can afford it (>= 64 GiB available) and OSQP_AMD_BENCH_CPU_FULL is not 0; otherwise the committed record."""
+    if rank != 0 or world != 1 or args.no_cpu or args.child is not None or args.workload not in CPU_RECORDS:
+        return None
+    if os.environ.get("OSQP_AMD_BENCH_CPU_FULL", "1") == "0" and not getattr(args, "cpu_full", False):
+        return {"proc": None, "reason": "OSQP_AMD_BENCH_CPU_FULL=0"}
+    try:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1048576.0
+    except Exception:
+        avail = 0.0
+    if avail < 64.0:
+        return {"proc": None, "reason": "host has %.0f GiB available, the CPU run needs 46" % avail}
+    W, K = CPU_RECORD_WINDOW
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    rec = os.path.join(ROOT, "gpurun_out", "cpu_full_record.json")
+    try:
+        os.remove(rec)
+    except OSError:
+        pass
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_rand1e6.py"), "--phases", "cpu", "--warm", str(W), "--iters", str(K),
+           "--out", os.path.join(ROOT, "gpurun_out", "cpu_full_run.json"), "--cpu-record", rec]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    return {"proc": subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), "t0": time.time(), "record": rec}
+
+
 def replica_bench(ctx):
     args, oq, lib, torch, dist, rank, world = (ctx[k] for k in ("args", "oq", "lib", "torch", "dist", "rank", "world"))
+    ctx["cpu_full"] = start_cpu_full(args, rank, world)
     model, n, setup_s = build_model(oq, lib, args.workload, 1 + rank)
     ws = model.workspace
 
@@ -331,7 +360,7 @@ def replica_bench(ctx):
         if int(st[19]) > 0:  # supernodal solves: right-hand side | level 0 | tree (forward, backward) | level 0 | update
             kname = ("direct ADMM iteration on a supernodal factor: k_direct_rhs | k_sn_level (level 0) | k_sn_tree forward | k_sn_tree backward | "
                      "k_sn_level | k_direct_update")
-            pmc_names = ["k_direct_rhs", "k_sn_level", "k_sn_tree", "k_direct_update"]
+            pmc_names = {"sum": ["k_direct_rhs", "k_sn_level", "k_sn_tree", "k_direct_update"], "per": "k_direct_rhs"}
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -388,7 +417,7 @@ def replica_bench(ctx):
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, src
 
     if rank == 0 and not args.no_cpu and world == 1:  # the CPU leg belongs to the 1-GPU line only
-        out["cpu_baseline"] = cpu_leg(oq, args)
+        out["cpu_baseline"] = cpu_leg(oq, args, ctx.get("cpu_full"))
         out["cpu_baseline"]["all_cores_bandwidth_bound"] = all_cores_bound(out["roofline"]["step"]["algorithmic_bytes_per_step"])
 
     if world > 1:
@@ -479,7 +508,7 @@ def live_traffic(args, names, limit_s=240.0):
         write = sum(per_counter["WRITE_SIZE"].values()) * 1024.0
         return fetch + write, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --child pmc`; "
                                "per launch = sum over %s of the per-dispatch averages; FETCH_SIZE x2 (gfx950), KB -> B; fetch %.4g B, write %.4g B"
-                               % (" + ".join(names), fetch, write))
+                               % (" + ".join(names["sum"] if isinstance(names, dict) else names), fetch, write))
     except Exception:
         return None, None
     finally:
@@ -505,6 +534,20 @@ def pmc_average(db, counter, names):
         f"join {disp} d on e.event_id = d.event_id join {sym} s on d.kernel_id = s.id where p.name = ? group by s.kernel_name",
         (counter,)).fetchall()
     out = {}
+    if isinstance(names, dict):
+        # an iteration made of MANY launches of a few templates (the per-level supernodal solves): every dispatch of the
+        # listed kernels summed, divided by the dispatches of the kernel that runs exactly once per iteration
+        tot = c.execute(
+            f"select s.kernel_name, sum(e.value), count(*) from {ev} e join {info} p on e.pmc_id = p.id "
+            f"join {disp} d on e.event_id = d.event_id join {sym} s on d.kernel_id = s.id where p.name = ? group by s.kernel_name",
+            (counter,)).fetchall()
+        per = sum(n_ for k, _, n_ in tot if names["per"] in k)
+        if not per:
+            return None
+        for nm in names["sum"]:
+            vals = [v for k, v, _ in tot if nm in k]
+            out[nm] = sum(vals) / per
+        return out
     for nm in names:
         vals = [v for k, v in rows if nm in k]
         if not vals:
@@ -767,7 +810,7 @@ def batch_cpu_leg(oq, args):
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline of the single-QP workloads
 # ----------------------------------------------------------------------------------------------------------------
-def cpu_leg(oq, args):
+def cpu_leg(oq, args, cpu_full=None):
     """CPU oracle (oracle/, a port of the published algorithm; libosqp itself is not available in this image), 1 thread.
     Workloads the bounded leg can hold are timed live.  rand-1e6 (2.5e9 stored entries: 90 s of setup, ~16 s per ADMM
     iteration) is measured on the workload itself by tools/cpu_rand1e6.py at the driver's window; its record
@@ -782,15 +825,24 @@ def cpu_leg(oq, args):
         return cpu_live(oq, args, name)
     out = {"value": None, "unit": "iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port", "config": name, "live": False}
     W, K = CPU_RECORD_WINDOW
-    if getattr(args, "cpu_full", False):
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_rand1e6.py"), "--phases", "cpu", "--warm", str(W), "--iters", str(K),
-               "--out", os.path.join(ROOT, "gpurun_out", "cpu_full_run.json"), "--cpu-record", CPU_RECORDS[name]]
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        out["live"] = p.returncode == 0
-        if p.returncode != 0:
-            out["cpu_full_error"] = (p.stderr.decode(errors="replace").strip().splitlines() or ["?"])[-1][:200]
+    record_path = CPU_RECORDS[name]
+    if cpu_full and cpu_full.get("proc") is not None:  # started before the GPU legs (start_cpu_full): collect it, 20-minute cap
+        p = cpu_full["proc"]
+        try:
+            _, err = p.communicate(timeout=max(1.0, 1200.0 - (time.time() - cpu_full["t0"])))
+            out["live"] = p.returncode == 0 and os.path.exists(cpu_full["record"])
+            if not out["live"]:
+                out["cpu_full_error"] = ((err or b"").decode(errors="replace").strip().splitlines() or ["exit %s" % p.returncode])[-1][:200]
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out["cpu_full_error"] = "the CPU run did not finish within 20 minutes of this run: committed record used"
+        if out["live"]:
+            record_path = cpu_full["record"]
+            out["cpu_full_wall_s"] = round(time.time() - cpu_full["t0"], 1)
+    elif cpu_full:
+        out["cpu_full_skipped"] = cpu_full.get("reason")
     try:
-        rec = json.load(open(CPU_RECORDS[name]))
+        rec = json.load(open(record_path))
         out["value"] = rec.get("value")
         if rec.get("value") is None:
             out["reason"] = rec.get("reason", "not run")
@@ -798,8 +850,7 @@ def cpu_leg(oq, args):
             out["sample"] = (f"{name} itself: K = {rec['iters']} ADMM iterations of the CPU oracle after W = {rec.get('warm')} (PCG back-end, 1 thread of "
                              f"{rec.get('host_cores')} cores, {rec.get('cpu_model', 'host CPU')}) in {rec['seconds']} s after a {rec['setup_s']} s setup, "
                              f"{rec['cg_iters_per_admm_iter']} CG iterations per ADMM iteration, peak RSS {rec['peak_rss_gib']} GiB; measured by "
-                             f"tools/cpu_rand1e6.py on the GPU box's host ({'in this run' if out['live'] else 'record committed'} as "
-                             f"profiles/{os.path.basename(CPU_RECORDS[name])})")
+                             f"tools/cpu_rand1e6.py on the GPU box's host ({'IN THIS RUN, concurrently with the GPU legs' if out['live'] else 'record committed as profiles/' + os.path.basename(CPU_RECORDS[name])})")
             out["cg_iters_per_admm_iter"] = rec["cg_iters_per_admm_iter"]
             now = {"oracle_sha16": oracle_sha16(), "protocol_sha16": protocol_sha16(name, W, K)}
             out["stale"] = any(rec.get(k) != v for k, v in now.items())

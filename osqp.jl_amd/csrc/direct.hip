@@ -1623,7 +1623,8 @@ __global__ __launch_bounds__(kBlock) void k_normal_cone(int m, double *__restric
 }
 
 int polish_run(Engine &e) {
-  if (e.compact) return -1;  // the reduced KKT system is assembled from the CSR arrays, which a compact workspace has released
+  // the reduced KKT system is assembled from the CSR arrays, which a compact workspace has released: iterative form (pcg.hip)
+  if (e.compact) return polish_run_pcg(e);
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;
   OSQPInfo *info = e.ws->info;
@@ -1643,7 +1644,7 @@ int polish_run(Engine &e) {
   for (int k = 0; k < n_upp; k++) act[n_low + k] = ind_upp[k];
 
   LdlFactor F(e, row_map, mr, e.st.delta, -e.st.delta, 400000000LL);
-  if (F.S.too_large) return -1;
+  if (F.S.too_large) return e.lin && e.lin->kind() == 2 ? polish_run_pcg(e) : -1;  // no factor of the reduced system that fits: iterate instead
   if (F.refactor(nullptr) != 0) return -1;
   const int nr = n + mr;
   DevBuf<double> rhs_red(nr), sol(nr), rhs(nr), yfull(m), Axv(m), px(n), pz(m), py(m);

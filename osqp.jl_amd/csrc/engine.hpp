@@ -224,6 +224,8 @@ std::unique_ptr<Linsys> make_pcg(Engine &e);
 std::unique_ptr<Linsys> make_direct(Engine &e, int *err);
 // polish: returns status_polish (1 success, -1 failed, 0 not attempted)
 int polish_run(Engine &e);
+// the same without a factorisation, on the operator of the indirect back-end (pcg.hip): compact workspaces, factors that do not fit
+int polish_run_pcg(Engine &e);
 const char *last_error_cstr();
 
 // device generators (gen.hip)

@@ -247,6 +247,7 @@ struct Pcg : Linsys {
   bool extrapolate = true, have_prev = false;
   long long total_iters = 0;
   int max_iter = 20000;
+  double rel_tol = -1.0;            // >= 0: solve() stops at rel_tol * ||rhs||inf instead of the ADMM rule (polish_run_pcg)
   bool carried_valid = false;
   int since_refresh = 0;
   bool fused_on = false;            // the fused kernels apply (single device, panel kernels on all three matrices)
@@ -360,6 +361,7 @@ struct Pcg : Linsys {
     if (cand >= 0.0) tol = cand;
     if (!(tol < hi)) tol = hi;
     if (tol < lo) tol = lo;
+    if (rel_tol >= 0.0) tol = rel_tol * bnorm + 1e-300;  // polish: a plain relative tolerance on the reduced residual
     double rn = e.h_slots[S_T1];
     int it = 0, cur = 0;  // cur: which pair holds the current r'z
     int status = 0;
@@ -712,5 +714,138 @@ struct Pcg : Linsys {
 }  // namespace
 
 std::unique_ptr<Linsys> make_pcg(Engine &e) { return std::unique_ptr<Linsys>(new Pcg(e)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Polish without a factorisation (SURVEY.md A.6 on a workspace that runs the indirect back-end -- compact ones have no CSR
+// arrays to assemble a reduced KKT matrix from, the large ones no factor that fits).  With the active rows as a mask the
+// regularised system [P + delta I, A_act'; A_act, -delta I] [x; y] = [r1; r2] is the operator this back-end already applies:
+//   (P + delta I + A' diag(mask / delta) A) x = r1 + A' (mask / delta .* r2),   y = mask .* (A x - r2) / delta
+// i.e. Pcg::solve with sigma = delta and rho = mask / delta (inactive rows: rho = 0, they drop out of every product).  The
+// refinement steps of the reference run against the unregularised matrix exactly as in polish_run.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_polish_sets(int m, double delta, const double *__restrict__ z, const double *__restrict__ y,
+                                                        const double *__restrict__ l, const double *__restrict__ u, double *__restrict__ rho,
+                                                        double *__restrict__ bound, int *__restrict__ count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const bool low = z[i] - l[i] < -y[i], upp = u[i] - z[i] < y[i];
+  rho[i] = (low || upp) ? 1.0 / delta : 0.0;
+  bound[i] = low ? l[i] : (upp ? u[i] : 0.0);  // a row active on both sides keeps its lower bound, as the reduced matrix of polish_run does
+  if (low || upp) atomicAdd(count, 1);
+}
+// y = mask .* (Ax - r2) / delta  (mask = rho > 0)
+__global__ __launch_bounds__(kBlock) void k_polish_dual(int m, double delta, const double *__restrict__ rho, const double *__restrict__ Ax,
+                                                        const double *__restrict__ r2, double *__restrict__ y, int accumulate) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const double v = rho[i] > 0.0 ? (Ax[i] - r2[i]) / delta : 0.0;
+  y[i] = accumulate ? y[i] + v : v;
+}
+// r2 = mask .* (bound - A x)
+__global__ __launch_bounds__(kBlock) void k_polish_r2(int m, const double *__restrict__ rho, const double *__restrict__ bound,
+                                                      const double *__restrict__ Ax, double *__restrict__ r2) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < m) r2[i] = rho[i] > 0.0 ? bound[i] - Ax[i] : 0.0;
+}
+__global__ __launch_bounds__(kBlock) void k_polish_cone(int m, double *__restrict__ z, double *__restrict__ y, const double *__restrict__ l,
+                                                        const double *__restrict__ u) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const double sv = z[i] + y[i];
+  const double zn = fmin(fmax(sv, l[i]), u[i]);
+  z[i] = zn; y[i] = sv - zn;
+}
+
+int polish_run_pcg(Engine &e) {
+  Pcg *P = dynamic_cast<Pcg *>(e.lin.get());
+  if (!P || e.comm) return -1;
+  if (P->flush()) return -1;
+  hipStream_t s = e.stream;
+  const int n = e.n, m = e.m;
+  OSQPInfo *info = e.ws->info;
+  const double delta = e.st.delta;
+  DevBuf<double> rho_keep(m ? m : 1), rho_pol(m ? m : 1), bound(m ? m : 1), xz(n + m), px(n), py(m ? m : 1), pz(m ? m : 1), tmp(n), r2(m ? m : 1);
+  DevBuf<int> count(1);
+  count.zero(s);
+  if (m > 0) {
+    vec_copy(rho_keep.get(), e.rho.get(), m, s);
+    OQ_LAUNCH(k_polish_sets, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.z.get(), e.y.get(), e.l.get(), e.u.get(), rho_pol.get(), bound.get(),
+              count.get());
+    vec_copy(e.rho.get(), rho_pol.get(), m, s);
+  }
+  const double sigma_keep = e.st.sigma, rel_keep = P->rel_tol;
+  const bool extrap_keep = P->extrapolate;
+  const int iter_keep = P->max_iter;
+  e.st.sigma = delta;
+  P->precond();
+  P->extrapolate = false; P->carried_valid = false; P->have_prev = false; P->rhs_ready = false;
+  P->rel_tol = 1e-10;
+  P->max_iter = 4000;  // an ill-conditioned reduced system ends here; what it reached goes through the acceptance test like any other
+  P->xs.zero(s);
+  auto restore = [&]() {
+    if (m > 0) vec_copy(e.rho.get(), rho_keep.get(), m, s);
+    e.st.sigma = sigma_keep;
+    P->precond();
+    P->extrapolate = extrap_keep; P->rel_tol = rel_keep; P->max_iter = iter_keep;
+    P->carried_valid = false; P->have_prev = false; P->rhs_ready = false;
+    vec_copy(P->xs.get(), e.x.get(), n, s);
+  };
+  // [x; y] = K_reg^-1 [-q; bound]
+  vec_copy(xz.get(), e.q.get(), n, s);
+  vec_scale(xz.get(), -1.0, n, s);
+  if (m > 0) vec_copy(xz.get() + n, bound.get(), m, s);
+  if (P->solve(xz.get(), -1.0)) { restore(); return -1; }
+  vec_copy(px.get(), xz.get(), n, s);
+  if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.rho.get(), xz.get() + n, bound.get(), py.get(), 0);
+  // refinement against the unregularised matrix: r1 = -q - (P x + A' y), r2 = bound - A x on the active rows
+  for (int it = 0; it < e.st.polish_refine_iter; it++) {
+    vec_copy(xz.get(), e.q.get(), n, s);
+    vec_scale(xz.get(), -1.0, n, s);
+    spmv(e.Pf, px.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+    vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
+    if (m > 0) {
+      spmv(e.At, py.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+      vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
+      spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+      OQ_LAUNCH(k_polish_r2, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, e.rho.get(), bound.get(), pz.get(), r2.get());
+      vec_copy(xz.get() + n, r2.get(), m, s);
+    }
+    P->xs.zero(s);
+    P->carried_valid = false; P->have_prev = false;
+    if (P->solve(xz.get(), -1.0)) { restore(); return -1; }
+    vec_axpy(px.get(), 1.0, xz.get(), n, s);
+    if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.rho.get(), xz.get() + n, r2.get(), py.get(), 1);
+  }
+  restore();
+  // polished (x, z, y) and its residuals, as in polish_run
+  if (m > 0) {
+    spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+    OQ_LAUNCH(k_polish_cone, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, pz.get(), py.get(), e.l.get(), e.u.get());
+  }
+  spmv(e.A, px.get(), e.Ax.get(), nullptr, 0.0, 0.0, nullptr, s);
+  spmv(e.Pf, px.get(), e.Px_.get(), nullptr, 0.0, 0.0, nullptr, s);
+  if (m > 0) spmv(e.At, py.get(), e.Aty.get(), nullptr, 0.0, 0.0, nullptr, s);
+  residual_norms(n, m, px.get(), pz.get(), e.Ax.get(), e.Px_.get(), e.Aty.get(), e.q.get(), e.Dinv.get(), e.Einv.get(), e.slots.get(),
+                 e.partials.get(), s);
+  e.fetch_slots(0, 16, (1u << S_XPX) | (1u << S_QX));
+  const double *r = e.h_slots;
+  const bool uns = e.st.scaling && !e.st.scaled_termination;
+  const double pol_pri = m == 0 ? 0.0 : (uns ? r[S_PRI_UNS] : r[S_PRI]);
+  const double pol_dua = uns ? e.cinv * r[S_DUA_UNS] : r[S_DUA];
+  double pol_obj = 0.5 * r[S_XPX] + r[S_QX];
+  if (e.st.scaling) pol_obj *= e.cinv;
+  const bool ok = (pol_pri < info->pri_res && pol_dua < info->dua_res) || (pol_pri < info->pri_res && info->dua_res < 1e-10) ||
+                  (pol_dua < info->dua_res && info->pri_res < 1e-10);
+  if (!ok) {
+    set_last_error("polish (iterative, indirect back-end): the polished point did not improve both residuals (pri " + std::to_string(pol_pri) +
+                   " vs " + std::to_string(info->pri_res) + ", dua " + std::to_string(pol_dua) + " vs " + std::to_string(info->dua_res) + ")");
+    return -1;
+  }
+  info->obj_val = pol_obj; info->pri_res = pol_pri; info->dua_res = pol_dua;
+  vec_copy(e.x.get(), px.get(), n, s);
+  if (m > 0) { vec_copy(e.z.get(), pz.get(), m, s); vec_copy(e.y.get(), py.get(), m, s); }
+  P->set_guess(e.x.get());
+  return 1;
+}
 
 }  // namespace oq

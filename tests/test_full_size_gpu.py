@@ -166,3 +166,20 @@ def test_rand1e6_solution_meets_osqp_criteria_on_host_regenerated_data(product_l
     assert abs(res["objective"] - r.info.obj_val) <= 1e-6 * max(1.0, abs(res["objective"]))
     # the engine's own residuals are the ones the host sees (unscaled termination)
     assert abs(res["dua_res"] - r.info.dua_res) <= 1e-6 * max(res["eps_dua"], 1e-300)
+
+
+@pytest.mark.skipif(os.environ.get("OSQP_AMD_TEST_HOST_SETUP") != "1" or _mem_available_gib() < 120.0,
+                    reason="set OSQP_AMD_TEST_HOST_SETUP=1 on a host with 120 GiB free: 24 GB of CSC arrays through osqp_setup (~2 minutes)")
+def test_rand1e6_through_osqp_setup_from_host_arrays(product_lib, oracle_lib):
+    """The reference entry point at the headline size [REF src/interface.jl:113-155]: the rand-1e6 instance built on the
+    host (oracle/gen.c), handed to osqp_setup as CSC arrays, must solve to the very solution of the device-generated
+    instance of the same seed (same arithmetic behind two front doors)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("host_setup_rand1e6", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "host_setup_rand1e6.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = mod.run()
+    assert rec["status"] == rec["generated_status"] == "Solved"
+    assert rec["iter"] == rec["generated_iter"]
+    assert rec["bit_identical"], (rec["max_abs_dx"], rec["max_abs_dy"])

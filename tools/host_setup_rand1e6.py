@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""The reference entry point at the headline size: rand-1e6 (n = m = 1e6, nnz(A) = 1e9) generated ON THE HOST by
+oracle/gen.c, handed to osqp_setup as CSC arrays through interface.setup (what a drop-in OSQP.jl caller does
+[REF src/interface.jl:113-155]: 24 GB of arrays cross PCIe), solved, and compared with the device-generated instance
+of the same seed.  Writes a JSON record: seconds on the host side (generation, scipy wrapping), inside osqp_setup
+(info.setup_time, with the OSQP_AMD_SETUP_TRACE stages when asked for), solve, and the comparison.
+
+    python tools/host_setup_rand1e6.py [--n 1000000] [--per-row 1000] [--out profiles/r04_host_setup_rand1e6.json]
+"""
+import argparse
+import json
+import os
+import resource
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(n=1_000_000, per_row=1000, seed=1):
+    import bench
+    import osqp_jl_amd as oq
+    from test_gpu_parity import _data_to_scipy
+
+    lib = oq.load_library()
+    orc = oq.load_library(oq.ORACLE_LIB_PATH)  # only its generator (oracle/gen.c) is used: the problem data of the host side
+    rec = {"n": n, "per_row": per_row, "seed": seed}
+    t0 = time.time()
+    d = orc.oracle_generate(0, n, per_row, seed)
+    rec["host_generate_s"] = round(time.time() - t0, 2)
+    t0 = time.time()
+    P, q, A, l, u = _data_to_scipy(d.contents)
+    orc.oracle_data_free(d)
+    rec["host_wrap_s"] = round(time.time() - t0, 2)
+    rec["nnz_A"], rec["nnz_P_triu"] = int(A.nnz), int(P.nnz)
+    rec["host_array_gb"] = round((A.nnz + P.nnz) * 16 / 1e9, 2)  # what the ABI receives: fp64 values + 64-bit row indices
+    mh = oq.Model(lib)
+    t0 = time.time()
+    oq.setup(mh, P=P, q=q, A=A, l=l, u=u, linsys_solver="pcg", **bench.SETTINGS)
+    rec["setup_from_host_wall_s"] = round(time.time() - t0, 3)
+    del P, A
+    rh = oq.solve(mh)
+    sth = oq.stats(mh)
+    rec["setup_from_host_s"] = round(float(rh.info.setup_time), 3)  # inside osqp_setup: upload + device stages
+    rec["solve_s"], rec["iter"], rec["status"] = round(float(rh.info.solve_time), 4), int(rh.info.iter), rh.info.status
+    rec["device_gb"], rec["device_peak_gb"] = round(sth[9] / 1e9, 2), round(sth[20] / 1e9, 2)
+    xh, yh = rh.x.copy(), rh.y.copy()
+    oq.clean(mh)
+    mg = oq.Model(lib)
+    t0 = time.time()
+    oq.setup_generated(mg, 0, n, per_row, seed, linsys_solver="pcg", **bench.SETTINGS)
+    rec["setup_generated_wall_s"] = round(time.time() - t0, 3)
+    rg = oq.solve(mg)
+    rec["setup_generated_s"] = round(float(rg.info.setup_time), 3)
+    rec["generated_iter"], rec["generated_status"] = int(rg.info.iter), rg.info.status
+    rec["max_abs_dx"] = float(np.max(np.abs(xh - rg.x)))
+    rec["max_abs_dy"] = float(np.max(np.abs(yh - rg.y)))
+    rec["bit_identical"] = bool(np.array_equal(xh, rg.x) and np.array_equal(yh, rg.y))
+    rec["upload_and_narrow_s"] = round(rec["setup_from_host_s"] - rec["setup_generated_s"], 3)  # what the host arrays cost on top
+    rec["host_peak_rss_gib"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 1)
+    oq.clean(mg)
+    return rec
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--per-row", type=int, default=1000)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_host_setup_rand1e6.json"))
+    a = ap.parse_args()
+    r = run(a.n, a.per_row)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(r, open(a.out, "w"), indent=1)
+    print(json.dumps(r))
