@@ -63,7 +63,7 @@ SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25,
                 polish=False, max_iter=4000)
 
 BATCH_TOTAL = 4096
-CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r03_cpu_rand1e6.json")}
+CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r04_cpu_rand1e6.json")}
 CPU_RECORD_WINDOW = (5, 20)  # W, K of the committed CPU record (the driver's protocol)
 
 

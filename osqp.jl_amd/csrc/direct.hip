@@ -801,6 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, dou
 //   backward  u = D_J^-1 y_J - G_J x (entries of the columns of J outside its block),  x_J = W' u
 // A deep elimination tree (nested dissection of a long banded problem: 300 pivot levels) is 15 such levels.
 constexpr int kSnMax = 64, kSnThreads = 256;
+constexpr int kSnWaveLevel = 2048;  // supernodes in a level from which each gets a wavefront instead of a workgroup
 
 __global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                           const int64_t *__restrict__ wmap, const double *__restrict__ Lx,
@@ -864,6 +865,47 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
   const double *Wj = W + woff[J];
   const int part = threadIdx.x & 3;
   for (int a = threadIdx.x >> 2; a < s; a += kSnThreads / 4) {
+    double acc = 0.0;
+    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s + a] * t[j]; }
+    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * s + a] * t[j]; }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0) b[q0 + a] = acc;
+  }
+}
+
+// The same step with a WAVEFRONT per supernode (four per workgroup), for levels of many small supernodes: level 0 of a
+// nested-dissection tree is the leaves -- 540 000 subtrees of five pivots on average for control-1e6 -- and a 256-thread
+// workgroup each leaves 250 of them idle (533 us for the forward level 0 of that problem).  Same lanes per row, same order
+// of every sum as k_sn_level: bit-identical results.  The wavefront's t vector sits in its own slab of LDS; its writes are
+// drained (s_waitcnt) before its reads, no workgroup barrier.
+template <int LA, bool kForward>
+__global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                           const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
+                                                           const double *__restrict__ Ex, const double *__restrict__ W,
+                                                           const double *__restrict__ Dinv_s, double *__restrict__ b) {
+  __shared__ double tt[kSnThreads / 64][kSnMax];
+  const int wv = threadIdx.x >> 6, l64 = threadIdx.x & 63;
+  const int J = J0 + blockIdx.x * (kSnThreads / 64) + wv;
+  if (J >= J1) return;
+  double *t = tt[wv];
+  const int q0 = ptr[J], s = ptr[J + 1] - q0;
+  {
+    const int lane = l64 % LA;
+    for (int a = l64 / LA; a < s; a += 64 / LA) {
+      const int q = q0 + a;
+      double acc = gather_dot(Ep[q] + lane, Ep[q + 1], LA, Ej, Ex, b);
+#pragma unroll
+      for (int o = LA / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's LDS writes are done before any of its lanes reads them
+  __builtin_amdgcn_wave_barrier();
+  const double *Wj = W + woff[J];
+  const int part = l64 & 3;
+  for (int a = l64 >> 2; a < s; a += 16) {
     double acc = 0.0;
     if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s + a] * t[j]; }
     else { for (int j = a + part; j < s; j += 4) acc += Wj[j * s + a] * t[j]; }
@@ -1377,10 +1419,19 @@ struct LdlFactor {
   void launch_bwd_chain(const Step &t, hipStream_t s) { launch_chain(t, false, s); }
 
   // skip_first_fwd / skip_last_bwd: those two level steps are folded into the kernels around the solve (fused_ends)
+  // a level of many supernodes: a wavefront each (k_sn_level_w); a level of few: a workgroup each
 #define OQ_SN_LEVEL(LA, FWD, L)                                                                                                   \
-  OQ_LAUNCH((k_sn_level<LA, FWD>), dim3(T.lvl_ptr[L + 1] - T.lvl_ptr[L]), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(),     \
-            sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),      \
-            FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get())
+  do {                                                                                                                            \
+    const int cnt_ = T.lvl_ptr[L + 1] - T.lvl_ptr[L];                                                                             \
+    if (cnt_ >= kSnWaveLevel)                                                                                                     \
+      OQ_LAUNCH((k_sn_level_w<LA, FWD>), dim3((cnt_ + 3) / 4), dim3(kSnThreads), 0, s, T.lvl_ptr[L], T.lvl_ptr[L + 1], sn_ptr.get(), \
+                sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
+                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
+    else                                                                                                                          \
+      OQ_LAUNCH((k_sn_level<LA, FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(),                           \
+                sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
+                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
+  } while (0)
 #define OQ_SN_TREE(FWD)                                                                                                           \
   OQ_LAUNCH((k_sn_tree<FWD>), dim3(T.count - T.lvl_ptr[1]), dim3(kSnTreeThreads), 0, s, T.lvl_ptr[1], T.count, sn_ptr.get(),    \
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
@@ -1624,7 +1675,10 @@ __global__ __launch_bounds__(kBlock) void k_normal_cone(int m, double *__restric
 
 int polish_run(Engine &e) {
   // the reduced KKT system is assembled from the CSR arrays, which a compact workspace has released: iterative form (pcg.hip)
-  if (e.compact) return polish_run_pcg(e);
+  // OSQP_AMD_POLISH_ITERATIVE=1 (tests): the iterative form wherever the indirect back-end runs, so that it can be compared
+  // with a factorisation-based polish on problems small enough to have one
+  static const bool force_iterative = getenv("OSQP_AMD_POLISH_ITERATIVE") && atoi(getenv("OSQP_AMD_POLISH_ITERATIVE")) != 0;
+  if (e.compact || (force_iterative && e.lin && e.lin->kind() == 2)) return polish_run_pcg(e);
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;
   OSQPInfo *info = e.ws->info;

@@ -773,15 +773,26 @@ int polish_run_pcg(Engine &e) {
               count.get());
     vec_copy(e.rho.get(), rho_pol.get(), m, s);
   }
+  // Conjugate gradients cannot work on the operator at the reference's delta = 1e-6 (P + delta I + A_act' A_act / delta:
+  // condition ~ 1e8 and worse -- 4000 iterations left the residuals where they started).  The inner regularisation is
+  // therefore delta_in = max(delta, 1e-3) (condition ~ 1e5: a few hundred iterations) and the refinement against the
+  // UNREGULARISED matrix -- the reference's own device for removing the effect of delta, here a method of multipliers on the
+  // equality-constrained QP -- runs until the residual of that system has dropped by 1e-10 (at most kPolishRefine steps, at
+  // least the caller's polish_refine_iter) instead of a fixed three times: same fixed point, reached by cheaper solves.
+  const double delta_in = std::max(delta, 1e-3);
+  constexpr int kPolishRefine = 40;
+  if (m > 0) {  // rho of the active rows at the inner regularisation
+    vec_scale(rho_pol.get(), delta / delta_in, m, s);
+    vec_copy(e.rho.get(), rho_pol.get(), m, s);
+  }
   const double sigma_keep = e.st.sigma, rel_keep = P->rel_tol;
   const bool extrap_keep = P->extrapolate;
   const int iter_keep = P->max_iter;
-  e.st.sigma = delta;
+  e.st.sigma = delta_in;
   P->precond();
   P->extrapolate = false; P->carried_valid = false; P->have_prev = false; P->rhs_ready = false;
-  P->rel_tol = 1e-10;
-  P->max_iter = 4000;  // an ill-conditioned reduced system ends here; what it reached goes through the acceptance test like any other
-  P->xs.zero(s);
+  P->rel_tol = 1e-6;
+  P->max_iter = 2000;
   auto restore = [&]() {
     if (m > 0) vec_copy(e.rho.get(), rho_keep.get(), m, s);
     e.st.sigma = sigma_keep;
@@ -790,31 +801,34 @@ int polish_run_pcg(Engine &e) {
     P->carried_valid = false; P->have_prev = false; P->rhs_ready = false;
     vec_copy(P->xs.get(), e.x.get(), n, s);
   };
-  // [x; y] = K_reg^-1 [-q; bound]
-  vec_copy(xz.get(), e.q.get(), n, s);
-  vec_scale(xz.get(), -1.0, n, s);
-  if (m > 0) vec_copy(xz.get() + n, bound.get(), m, s);
-  if (P->solve(xz.get(), -1.0)) { restore(); return -1; }
-  vec_copy(px.get(), xz.get(), n, s);
-  if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.rho.get(), xz.get() + n, bound.get(), py.get(), 0);
-  // refinement against the unregularised matrix: r1 = -q - (P x + A' y), r2 = bound - A x on the active rows
-  for (int it = 0; it < e.st.polish_refine_iter; it++) {
+  px.zero(s);
+  if (m > 0) py.zero(s);
+  double first_norm = -1.0;
+  for (int it = 0; it < kPolishRefine; it++) {
+    // residual of the unregularised system at (x, y): r1 = -q - (P x + A' y), r2 = bound - A x on the active rows
     vec_copy(xz.get(), e.q.get(), n, s);
     vec_scale(xz.get(), -1.0, n, s);
-    spmv(e.Pf, px.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
-    vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
-    if (m > 0) {
-      spmv(e.At, py.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+    if (it > 0) {
+      spmv(e.Pf, px.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
       vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
-      spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+    }
+    if (m > 0) {
+      if (it > 0) {
+        spmv(e.At, py.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+        vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
+        spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+      } else pz.zero(s);
       OQ_LAUNCH(k_polish_r2, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, e.rho.get(), bound.get(), pz.get(), r2.get());
       vec_copy(xz.get() + n, r2.get(), m, s);
     }
     P->xs.zero(s);
     P->carried_valid = false; P->have_prev = false;
     if (P->solve(xz.get(), -1.0)) { restore(); return -1; }
+    const double rn = e.h_slots[S_T5];  // ||r1 + A' rho r2||inf of the system just solved: how far (x, y) was from the fixed point
     vec_axpy(px.get(), 1.0, xz.get(), n, s);
-    if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.rho.get(), xz.get() + n, r2.get(), py.get(), 1);
+    if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta_in, e.rho.get(), xz.get() + n, r2.get(), py.get(), 1);
+    if (first_norm < 0.0) first_norm = rn;
+    if (it >= e.st.polish_refine_iter && rn <= 1e-10 * first_norm) break;
   }
   restore();
   // polished (x, z, y) and its residuals, as in polish_run
