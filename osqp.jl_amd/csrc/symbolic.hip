@@ -3,6 +3,8 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <numeric>
@@ -13,6 +15,25 @@
 namespace oq {
 
 namespace {
+
+// Host threads for the passes of the analysis that are independent per row / column / subtree (round 4: at 2.7e6 pivots and
+// 6.7e7 entries of L -- control-1e6 -- the single-threaded analysis was 4.7 s of a 7.2 s setup).  Small problems stay on one.
+inline int host_threads(int64_t work) {
+  if (work < ((int64_t)1 << 20)) return 1;
+  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+// blocks [b0, b1) of [0, n) dealt to threads through a counter; fn(block index, begin, end, thread index)
+template <typename F>
+void parallel_blocks(int n, int nblocks, int nthreads, F fn) {
+  nblocks = std::max(1, std::min(nblocks, std::max(n, 1)));
+  auto range = [&](int b) { return std::pair<int, int>((int)((int64_t)n * b / nblocks), (int)((int64_t)n * (b + 1) / nblocks)); };
+  if (nthreads <= 1) { for (int b = 0; b < nblocks; b++) { auto r = range(b); fn(b, r.first, r.second, 0); } return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; t++)
+    pool.emplace_back([&, t]() { for (int b = next++; b < nblocks; b = next++) { auto r = range(b); fn(b, r.first, r.second, t); } });
+  for (auto &th : pool) th.join();
+}
 
 // ---------------------------------------------------------------------------
 // Fill-reducing ordering: approximate minimum degree on a quotient graph.
@@ -140,58 +161,70 @@ struct NestedDissection {
   int N;
   const std::vector<int64_t> &xadj;
   const std::vector<int> &adj;
+  // tag: the piece a node currently belongs to; dist: the stamp of the last search that reached it (or its local index
+  // inside a leaf).  Pieces handled by different threads are disjoint node sets: a thread writes only its own nodes and
+  // reads a foreign node's tag at most (never equal to its own: tags are unique), through relaxed atomics.
   std::vector<int> tag, dist, order;
-  int next_tag = 0;
+  std::atomic<int> next_tag{0}, stamp{0}, spare_threads{0};
   int leaf_size;
+  size_t parallel_min = (size_t)1 << 62;  // pieces from this size on put their two sides on two threads
 
   NestedDissection(int n, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf)
       : N(n), xadj(xa), adj(ad), tag(n, -1), dist(n, -1), leaf_size(leaf) {}
+
+  int tag_of(int w) const { return __atomic_load_n(&tag[w], __ATOMIC_RELAXED); }
+  void set_tag(int v, int t) { __atomic_store_n(&tag[v], t, __ATOMIC_RELAXED); }
 
   // breadth-first levels of the piece marked `t` from root r; returns the level sets
   void bfs(int r, int t, std::vector<std::vector<int>> &levels) {
     levels.clear();
     std::vector<int> cur{r};
-    dist[r] = ++stamp;
+    const int st = ++stamp;
+    dist[r] = st;
     while (!cur.empty()) {
       levels.push_back(cur);
       std::vector<int> nxt;
       for (int v : cur)
         for (int64_t q = xadj[v]; q < xadj[v + 1]; q++) {
           int w = adj[q];
-          if (tag[w] == t && dist[w] != stamp) { dist[w] = stamp; nxt.push_back(w); }
+          if (tag_of(w) == t && dist[w] != st) { dist[w] = st; nxt.push_back(w); }
         }
       cur.swap(nxt);
     }
   }
-  int stamp = 0;
 
-  void leaf(const std::vector<int> &V) {  // min-degree on the induced subgraph
+  void leaf(const std::vector<int> &V, std::vector<int> &out) {  // min-degree on the induced subgraph
     const int k = (int)V.size();
-    if (k <= 2) { for (int v : V) order.push_back(v); return; }
+    if (k <= 2) { for (int v : V) out.push_back(v); return; }
     std::vector<int> local(k);
     const int t = ++next_tag;
-    for (int i = 0; i < k; i++) { tag[V[i]] = t; dist[V[i]] = i; }
+    for (int i = 0; i < k; i++) { set_tag(V[i], t); dist[V[i]] = i; }
     MinDegree md(k);
     for (int i = 0; i < k; i++)
       for (int64_t q = xadj[V[i]]; q < xadj[V[i] + 1]; q++) {
         int w = adj[q];
-        if (tag[w] == t) md.var_adj[i].push_back(dist[w]);
+        if (tag_of(w) == t) md.var_adj[i].push_back(dist[w]);
         else md.extra[i]++;  // neighbours outside the leaf (separators above it) are eliminated later
       }
     md.run(local);
-    for (int i = 0; i < k; i++) order.push_back(V[local[i]]);
+    for (int i = 0; i < k; i++) out.push_back(V[local[i]]);
     for (int v : V) dist[v] = -1;
   }
 
-  void dissect(std::vector<int> V) {
-    if ((int)V.size() <= leaf_size) { leaf(V); return; }
+  void run(std::vector<int> V) {
+    order.clear();
+    order.reserve(V.size());
+    dissect(std::move(V), order);
+  }
+
+  void dissect(std::vector<int> V, std::vector<int> &out) {
+    if ((int)V.size() <= leaf_size) { leaf(V, out); return; }
     // connected components, one after the other (a loop: a graph can fall into thousands of pieces)
     const int t = ++next_tag;
-    for (int v : V) tag[v] = t;
+    for (int v : V) set_tag(v, t);
     std::vector<std::vector<int>> levels;
-    size_t first_unseen = 0;
     std::vector<std::vector<int>> comps;
-    const int base = stamp;
+    const int base = stamp;  // stamps handed out from here on that land on THIS piece's nodes come from this call's searches
     for (size_t i = 0; i < V.size(); i++) {
       if (dist[V[i]] > base) continue;  // reached by one of this call's searches
       bfs(V[i], t, levels);
@@ -199,16 +232,15 @@ struct NestedDissection {
       for (auto &L : levels) comp.insert(comp.end(), L.begin(), L.end());
       comps.push_back(std::move(comp));
     }
-    (void)first_unseen;
     if (comps.size() > 1) {
-      for (auto &c : comps) dissect(std::move(c));
+      for (auto &c : comps) dissect(std::move(c), out);
       return;
     }
     // a single connected piece: levels from V[0] are in `levels`
-    connected(std::move(comps[0]), t, levels);
+    connected(std::move(comps[0]), t, levels, out);
   }
 
-  void connected(std::vector<int> V, int t, std::vector<std::vector<int>> &levels) {
+  void connected(std::vector<int> V, int t, std::vector<std::vector<int>> &levels, std::vector<int> &out) {
     // pseudo-peripheral root: restart from a smallest-degree node of the last level while the depth grows
     for (int pass = 0; pass < 4; pass++) {
       const auto &last = levels.back();
@@ -221,7 +253,7 @@ struct NestedDissection {
       if (!deeper) break;
     }
     const int nl = (int)levels.size();
-    if (nl < 3) { leaf(V); return; }
+    if (nl < 3) { leaf(V, out); return; }
     // separator: the smallest level whose sides both hold at least 30 % of the piece; otherwise the level at the median
     const double total = (double)V.size();
     int best = -1;
@@ -239,9 +271,25 @@ struct NestedDissection {
     for (int l = 0; l < best; l++) A.insert(A.end(), levels[l].begin(), levels[l].end());
     for (int l = best + 1; l < nl; l++) B.insert(B.end(), levels[l].begin(), levels[l].end());
     std::vector<std::vector<int>>().swap(levels);
-    dissect(std::move(A));
-    dissect(std::move(B));
-    for (int v : Sep) order.push_back(v);
+    std::vector<int>().swap(V);
+    // the two sides are independent: a large piece hands one of them to another thread while threads are to be had
+    if (A.size() + B.size() >= parallel_min && spare_threads.fetch_sub(1) > 0) {
+      std::vector<int> outA;
+      outA.reserve(A.size());
+      std::thread other([&]() { dissect(std::move(A), outA); });
+      std::vector<int> outB;
+      outB.reserve(B.size());
+      dissect(std::move(B), outB);
+      other.join();
+      spare_threads.fetch_add(1);
+      out.insert(out.end(), outA.begin(), outA.end());
+      out.insert(out.end(), outB.begin(), outB.end());
+    } else {
+      if (A.size() + B.size() >= parallel_min) spare_threads.fetch_add(1);  // none was to be had: give the claim back
+      dissect(std::move(A), out);
+      dissect(std::move(B), out);
+    }
+    for (int v : Sep) out.push_back(v);
   }
 };
 
@@ -304,7 +352,6 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   // quadratic, and wherever they are eliminated they fill their whole row anyway.
   std::vector<int> order;
   {
-    MinDegree md(N);
     std::vector<int> deg(N, 0);
     for (int j = 0; j < N; j++)
       for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) if (K.i[q] < j) { deg[K.i[q]]++; deg[j]++; }
@@ -317,27 +364,37 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       for (int j = 0; j < N; j++)
         for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) { int i = K.i[q]; if (i < j && !dense[i] && !dense[j]) { deg[i]++; deg[j]++; } }
     }
-    for (int i = 0; i < N; i++) md.var_adj[i].reserve(deg[i]);
-    for (int j = 0; j < N; j++)
-      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
-        int i = K.i[q];
-        if (i >= j) continue;
-        if (!dense[i] && !dense[j]) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
-        else { if (!dense[i]) md.extra[i]++; if (!dense[j]) md.extra[j]++; }
-      }
-    if (ordering == 1) {  // nested dissection of the graph without its dense nodes
+    if (ordering == 1) {  // nested dissection of the graph without its dense nodes (adjacency as plain CSR arrays)
       std::vector<int64_t> xadj(N + 1, 0);
-      for (int i = 0; i < N; i++) xadj[i + 1] = xadj[i] + (int64_t)md.var_adj[i].size();
+      for (int i = 0; i < N; i++) xadj[i + 1] = xadj[i] + deg[i];
       std::vector<int> adj((size_t)xadj[N]);
-      for (int i = 0; i < N; i++) std::copy(md.var_adj[i].begin(), md.var_adj[i].end(), adj.begin() + xadj[i]);
+      {
+        std::vector<int64_t> f(xadj.begin(), xadj.end() - 1);
+        for (int j = 0; j < N; j++)
+          for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+            int i = K.i[q];
+            if (i < j && !dense[i] && !dense[j]) { adj[f[i]++] = j; adj[f[j]++] = i; }
+          }
+      }
       NestedDissection nd(N, xadj, adj, 64);
+      const int nt = host_threads(xadj[N]);
+      if (nt > 1) { nd.spare_threads = nt - 1; nd.parallel_min = std::max<size_t>((size_t)N / (4 * (size_t)nt), 20000); }
       std::vector<int> all;
       all.reserve(N);
       for (int i = 0; i < N; i++) if (!dense[i]) all.push_back(i);
-      if (!all.empty()) nd.dissect(std::move(all));
+      if (!all.empty()) nd.run(std::move(all));
       order = nd.order;
       for (int i = 0; i < N; i++) if (dense[i]) order.push_back(i);
     } else {
+      MinDegree md(N);
+      for (int i = 0; i < N; i++) md.var_adj[i].reserve(deg[i]);
+      for (int j = 0; j < N; j++)
+        for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+          int i = K.i[q];
+          if (i >= j) continue;
+          if (!dense[i] && !dense[j]) { md.var_adj[i].push_back(j); md.var_adj[j].push_back(i); }
+          else { if (!dense[i]) md.extra[i]++; if (!dense[j]) md.extra[j]++; }
+        }
       md.nnz_limit = (double)nnzL_limit; md.flops_limit = flops_limit;
       md.fifo = ordering == 2;
       md.run(order);
@@ -411,44 +468,71 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
 
   stage("elimination tree, levels");
   // ---- 4. pattern of L: row patterns by climbing the tree from each entry of the row ----
-  std::vector<int64_t> colcount(N, 0);
+  // Row k of L = the nodes met climbing from every entry of row k of K towards k.  The rows are independent: blocks of
+  // consecutive rows go to host threads (own mark array), each block keeps its rows' patterns and counts its entries per
+  // column; a block's first position inside column i is Lp[i] + the counts of the blocks before it, so the second pass
+  // writes the CSC row lists (ascending: blocks and rows in order), and the CSR view with the CSC position of every entry
+  // (row k: columns ascending after a sort of its small buffer), without any two threads touching the same slot.
+  const int nt4 = host_threads(cp[N] * 8);
+  const int nblk = nt4 == 1 ? 1 : 2 * nt4;
   {
-    std::vector<int> mark(N, -1);
-    int64_t total = 0;
-    for (int k = 0; k < N; k++) {
-      mark[k] = k;
-      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
-        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; colcount[i]++; total++; }
-      if (total > nnzL_limit) { S.too_large = true; S.nnzL = total; return; }
-    }
+    std::vector<std::vector<int>> blk_cols(nblk), blk_cnt(nblk);
+    std::vector<int> rowlen(N, 0);
+    std::vector<std::vector<int>> marks(nt4);
+    std::atomic<int64_t> total{0};
+    std::atomic<bool> over{false};
+    parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int t) {
+      if (marks[t].empty()) marks[t].assign(N, -1);
+      std::vector<int> &mark = marks[t], &cols = blk_cols[b], &cnt = blk_cnt[b];
+      cnt.assign(N, 0);
+      for (int k = k0; k < k1 && !over.load(std::memory_order_relaxed); k++) {
+        mark[k] = k;
+        const size_t c0 = cols.size();
+        for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+          for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); cnt[i]++; }
+        rowlen[k] = (int)(cols.size() - c0);
+        if (total.fetch_add(rowlen[k]) + rowlen[k] > nnzL_limit) over = true;
+      }
+    });
+    if (over) { S.too_large = true; S.nnzL = total; return; }
     S.nnzL = total;
+    std::vector<int64_t> colcount(N, 0);
+    // counts -> first positions, block after block, in place (the counts become offsets relative to the column's start)
+    parallel_blocks(N, 4 * nt4, nt4, [&](int, int i0, int i1, int) {
+      for (int i = i0; i < i1; i++) {
+        int64_t run = 0;
+        for (int b = 0; b < nblk; b++) { const int c = blk_cnt[b][i]; blk_cnt[b][i] = (int)run; run += c; }
+        colcount[i] = run;
+      }
+    });
     S.flops = 0.0;
     for (int k = 0; k < N; k++) S.flops += (double)colcount[k] * (double)colcount[k];
-  }
-  stage("column counts");
-  S.Lp.assign(N + 1, 0);
-  for (int j = 0; j < N; j++) S.Lp[j + 1] = S.Lp[j] + colcount[j];
-  S.Li.resize(S.nnzL);
-  S.Rp.assign(N + 1, 0);
-  // CSC row lists and the CSR view (row k: columns ascending, with the position of each entry in the CSC arrays) in one
-  // pass over the rows: row k's entries are found by the climb, so its (column, CSC position) pairs are sorted in a small
-  // buffer and written out in sequence -- the transposition of the finished CSC arrays was 6.7e7 scattered writes (8.9 s)
-  // on the long-horizon control problem
-  S.Rj.resize(S.nnzL); S.Rmap.resize(S.nnzL);
-  {
-    std::vector<int> mark(N, -1);
-    std::vector<int64_t> f(S.Lp.begin(), S.Lp.end() - 1);
-    std::vector<std::pair<int, int64_t>> rowbuf;
-    for (int k = 0; k < N; k++) {  // rows in increasing order => every column's row list comes out ascending
-      mark[k] = k;
-      rowbuf.clear();
-      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
-        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; const int64_t t = f[i]++; S.Li[t] = k; rowbuf.emplace_back(i, t); }
-      std::sort(rowbuf.begin(), rowbuf.end());
-      int64_t w = S.Rp[k];
-      for (const auto &e : rowbuf) { S.Rj[w] = e.first; S.Rmap[w] = e.second; w++; }
-      S.Rp[k + 1] = w;
-    }
+    stage("column counts");
+    S.Lp.assign(N + 1, 0);
+    for (int j = 0; j < N; j++) S.Lp[j + 1] = S.Lp[j] + colcount[j];
+    S.Rp.assign(N + 1, 0);
+    for (int k = 0; k < N; k++) S.Rp[k + 1] = S.Rp[k] + rowlen[k];
+    S.Li.resize(S.nnzL); S.Rj.resize(S.nnzL); S.Rmap.resize(S.nnzL);
+    stage("(arrays of L allocated)");
+    parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int) {
+      const std::vector<int> &cols = blk_cols[b];
+      std::vector<int> &off = blk_cnt[b];
+      std::vector<std::pair<int, int64_t>> rowbuf;
+      size_t c = 0;
+      for (int k = k0; k < k1; k++) {
+        rowbuf.clear();
+        for (int e = 0; e < rowlen[k]; e++) {
+          const int i = cols[c++];
+          const int64_t t = S.Lp[i] + off[i]++;
+          S.Li[t] = k;
+          rowbuf.emplace_back(i, t);
+        }
+        std::sort(rowbuf.begin(), rowbuf.end());
+        int64_t w = S.Rp[k];
+        for (const auto &e : rowbuf) { S.Rj[w] = e.first; S.Rmap[w] = e.second; w++; }
+      }
+    });
+    stage("(row lists and CSR view written)");
   }
   stage("CSR view of L");
   // ---- 5. scatter maps from the caller's nnz order into Lx / D ------------------------
@@ -496,6 +580,14 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
 void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
   const int N = S.N;
   const std::vector<int> &parent = S.parent;
+  static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char *what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[supernodes] %-36s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   out = Supernodes();
   out.smax = smax;
   // subtree sizes (parents have larger indices than their children)
@@ -577,45 +669,52 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
     out.woff[J + 1] = out.woff[J] + s * s;
     out.flops += (double)(s * s);
   }
+  stage("partition, levels, slots");
   out.wmap.assign(out.woff[count], -1);
-  // split the entries of L (column v, rows r > v) into block entries and the rest
+  // The entries of L (column v, rows r > v) split into block entries (both ends in one supernode: their place in the dense
+  // block) and the rest, which every row lists by the slot of the column (F, forward) and every column by the slot of the row
+  // (G, backward).  Columns and rows are independent: host threads take ranges of them -- a column's entries from the CSC
+  // arrays, a row's from the CSR view of the same pattern -- and sort each short list by slot (= by level, then supernode).
+  const int nt = host_threads(S.nnzL);
   out.Fp.assign(N + 1, 0); out.Gp.assign(N + 1, 0);
-  for (int v = 0; v < N; v++)
-    for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
-      const int r = S.Li[t];
-      if (sn[r] == sn[v]) {
-        const int J = newid[sn[v]], s = out.ptr[J + 1] - out.ptr[J];
-        out.wmap[out.woff[J] + (int64_t)(out.slot[r] - out.ptr[J]) * s + (out.slot[v] - out.ptr[J])] = t;
-      } else {
-        out.Fp[out.slot[r] + 1]++;
-        out.Gp[out.slot[v] + 1]++;
-      }
-    }
-  for (int q = 0; q < N; q++) { out.Fp[q + 1] += out.Fp[q]; out.Gp[q + 1] += out.Gp[q]; }
-  out.Fj.resize(out.Fp[N]); out.Fpos.resize(out.Fp[N]); out.Gi.resize(out.Gp[N]); out.Gpos.resize(out.Gp[N]);
-  {
-    // visiting the columns / rows in slot order leaves every list sorted by slot (= by level, then supernode)
-    std::vector<int64_t> ff(out.Fp.begin(), out.Fp.end() - 1), gf(out.Gp.begin(), out.Gp.end() - 1);
-    for (int qv = 0; qv < N; qv++) {
-      const int v = out.piv[qv];
+  parallel_blocks(N, 8 * nt, nt, [&](int, int v0, int v1, int) {
+    for (int v = v0; v < v1; v++) {
+      const int J = newid[sn[v]], s = out.ptr[J + 1] - out.ptr[J];
+      int64_t g = 0;
       for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
         const int r = S.Li[t];
-        if (sn[r] == sn[v]) continue;
-        const int64_t a = ff[out.slot[r]]++;
-        out.Fj[a] = qv; out.Fpos[a] = t;
+        if (sn[r] == sn[v]) out.wmap[out.woff[J] + (int64_t)(out.slot[r] - out.ptr[J]) * s + (out.slot[v] - out.ptr[J])] = t;
+        else g++;
       }
+      out.Gp[out.slot[v] + 1] = g;
+      int64_t f = 0;
+      for (int64_t w = S.Rp[v]; w < S.Rp[v + 1]; w++) f += sn[S.Rj[w]] != sn[v];
+      out.Fp[out.slot[v] + 1] = f;
     }
-    std::vector<std::pair<int, int64_t>> col;
-    for (int qv = 0; qv < N; qv++) {
-      const int v = out.piv[qv];
-      col.clear();
-      for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++)
-        if (sn[S.Li[t]] != sn[v]) col.push_back({out.slot[S.Li[t]], t});
-      std::sort(col.begin(), col.end());
-      int64_t b = gf[qv];
-      for (auto &c : col) { out.Gi[b] = c.first; out.Gpos[b] = c.second; b++; }
+  });
+  for (int q = 0; q < N; q++) { out.Fp[q + 1] += out.Fp[q]; out.Gp[q + 1] += out.Gp[q]; }
+  stage("block maps, list lengths");
+  out.Fj.resize(out.Fp[N]); out.Fpos.resize(out.Fp[N]); out.Gi.resize(out.Gp[N]); out.Gpos.resize(out.Gp[N]);
+  stage("(lists allocated)");
+  parallel_blocks(N, 8 * nt, nt, [&](int, int q0, int q1, int) {
+    std::vector<std::pair<int, int64_t>> buf;
+    for (int q = q0; q < q1; q++) {
+      const int v = out.piv[q];
+      buf.clear();
+      for (int64_t w = S.Rp[v]; w < S.Rp[v + 1]; w++)       // row v: the columns outside its supernode, by slot
+        if (sn[S.Rj[w]] != sn[v]) buf.push_back({out.slot[S.Rj[w]], S.Rmap[w]});
+      std::sort(buf.begin(), buf.end());
+      int64_t a = out.Fp[q];
+      for (auto &c : buf) { out.Fj[a] = c.first; out.Fpos[a] = c.second; a++; }
+      buf.clear();
+      for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++)       // column v: the rows outside its supernode, by slot
+        if (sn[S.Li[t]] != sn[v]) buf.push_back({out.slot[S.Li[t]], t});
+      std::sort(buf.begin(), buf.end());
+      int64_t b = out.Gp[q];
+      for (auto &c : buf) { out.Gi[b] = c.first; out.Gpos[b] = c.second; b++; }
     }
-  }
+  });
+  stage("row and column lists");
   // forward rows: where the entries that point above level 0 begin
   const int q_upper = nlev > 1 ? out.ptr[out.lvl_ptr[1]] : N;
   out.Fsplit.resize(N);
