@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, dou
 //   backward  u = D_J^-1 y_J - G_J x (entries of the columns of J outside its block),  x_J = W' u
 // A deep elimination tree (nested dissection of a long banded problem: 300 pivot levels) is 15 such levels.
 constexpr int kSnMax = 64, kSnThreads = 256;
-constexpr int kSnWaveLevel = 2048;  // supernodes in a level from which each gets a wavefront instead of a workgroup
+constexpr int kSnWaveLevel = 16384;  // supernodes in a level from which each gets a wavefront instead of a workgroup (below: the device is not full either way and a workgroup finishes its supernode sooner)
 
 __global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                           const int64_t *__restrict__ wmap, const double *__restrict__ Lx,
@@ -1066,7 +1066,8 @@ struct LdlFactor {
     return *(volatile int *)sn_fault_host != 0;
   }
   mutable bool inject_fault = getenv("OSQP_AMD_SNODE_FAULT_TEST") && atoi(getenv("OSQP_AMD_SNODE_FAULT_TEST")) == 1;
-  bool sn_tree = false;     // levels >= 1 in one launch per direction (k_sn_tree) instead of one per level
+  bool sn_tree = false;     // the levels from sn_tree_L0 on in one launch per direction (k_sn_tree) instead of one per level
+  int sn_tree_L0 = 1;       // first level of that launch: the lowest one from which all supernodes above fit the device at once
   DevBuf<int64_t> sn_woff, sn_wmap, sn_Fp, sn_Fpos, sn_Gp, sn_Gpos, sn_Fsplit;
   DevBuf<double> sn_Wc, sn_Wr, sn_Fx, sn_Gx, sn_Dinv;
   std::vector<int> sn_lanes_f, sn_lanes_b;  // per level: lanes per row for the entries outside the blocks
@@ -1177,20 +1178,37 @@ struct LdlFactor {
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     up32(sn_ptr, T.ptr); up32(sn_piv, T.piv); up32(sn_Fj, T.Fj); up32(sn_Gi, T.Gi);
-    up32(sn_up, T.up); up32(sn_waits, T.waits); up32(sn_pending, T.waits);
-    sn_ready.alloc(T.count); sn_ready.zero(s);
     sn_tree = T.nlev > 2 && !(getenv("OSQP_AMD_SNODE_TREE") && atoi(getenv("OSQP_AMD_SNODE_TREE")) == 0);
+    sn_tree_L0 = 1;
     if (sn_tree) {
       // every workgroup of the launch must be resident at once: then a waiting workgroup can never keep the one it waits
       // for off the device, whatever order the dispatcher picks (the blockIdx-order argument in the kernel's comment is
-      // the second line of defence, the 200 ms flag the third)
+      // the second line of defence, the 200 ms flag the third).  Round 4: when the levels from 1 on are too many
+      // supernodes for that (control-1e6: 7 000), the launch takes the TOP of the tree -- the levels from the lowest one
+      // on from which everything above fits -- and the wide levels below it stay one plain launch each: those have the
+      // parallelism to fill the device anyway, the narrow top is where a launch per level is all latency.
       int per_cu_f = 0, per_cu_b = 0, cus = 0, dev = 0;
       HIP_CHECK(hipGetDevice(&dev));
       HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true>, kSnTreeThreads, 0));
       HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false>, kSnTreeThreads, 0));
-      if ((long long)std::min(per_cu_f, per_cu_b) * cus < (long long)(T.count - T.lvl_ptr[1])) sn_tree = false;
+      const long long cap = (long long)std::min(per_cu_f, per_cu_b) * cus;
+      while (sn_tree_L0 < T.nlev && (long long)(T.count - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
+      if (T.nlev - sn_tree_L0 < 2) sn_tree = false;  // a single level (or none) left: nothing to fuse
     }
+    if (sn_tree && sn_tree_L0 > 1) {
+      // the counters and the split of the forward rows are relative to the first level of the launch: children below it
+      // have finished in earlier launches (not waited for), entries that point below it are read through the caches
+      const int J0 = T.lvl_ptr[sn_tree_L0];
+      std::fill(T.waits.begin(), T.waits.end(), 0);
+      for (int J = J0; J < T.count; J++)
+        if (T.up[J] >= 0) T.waits[T.up[J]]++;
+      const int q_upper = T.ptr[J0];
+      for (int q = 0; q < N; q++)
+        T.Fsplit[q] = T.Fp[q] + (std::lower_bound(T.Fj.begin() + T.Fp[q], T.Fj.begin() + T.Fp[q + 1], q_upper) - (T.Fj.begin() + T.Fp[q]));
+    }
+    up32(sn_up, T.up); up32(sn_waits, T.waits); up32(sn_pending, T.waits);
+    sn_ready.alloc(T.count); sn_ready.zero(s);
     if (sn_tree) {
       HIP_CHECK(hipHostMalloc((void **)&sn_fault_host, sizeof(int), hipHostMallocMapped));
       *sn_fault_host = 0;
@@ -1433,36 +1451,21 @@ struct LdlFactor {
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
   } while (0)
 #define OQ_SN_TREE(FWD)                                                                                                           \
-  OQ_LAUNCH((k_sn_tree<FWD>), dim3(T.count - T.lvl_ptr[1]), dim3(kSnTreeThreads), 0, s, T.lvl_ptr[1], T.count, sn_ptr.get(),    \
+  OQ_LAUNCH((k_sn_tree<FWD>), dim3(T.count - T.lvl_ptr[sn_tree_L0]), dim3(kSnTreeThreads), 0, s, T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get())
   void run_supernodes() {
     hipStream_t s = e.stream;
-    if (sn_tree) {
-      switch (sn_lanes_f[0]) {
-      case 1: OQ_SN_LEVEL(1, true, 0); break;
-      case 4: OQ_SN_LEVEL(4, true, 0); break;
-      case 16: OQ_SN_LEVEL(16, true, 0); break;
-      default: OQ_SN_LEVEL(64, true, 0); break;
-      }
-      OQ_SN_TREE(true);
-      OQ_SN_TREE(false);
-      switch (sn_lanes_b[0]) {
-      case 1: OQ_SN_LEVEL(1, false, 0); break;
-      case 4: OQ_SN_LEVEL(4, false, 0); break;
-      case 16: OQ_SN_LEVEL(16, false, 0); break;
-      default: OQ_SN_LEVEL(64, false, 0); break;
-      }
-      return;
-    }
-    for (int L = 0; L < T.nlev; L++) switch (sn_lanes_f[L]) {
+    const int plain = sn_tree ? sn_tree_L0 : T.nlev;  // levels [0, plain): one launch each; the rest: one launch per direction
+    for (int L = 0; L < plain; L++) switch (sn_lanes_f[L]) {
       case 1: OQ_SN_LEVEL(1, true, L); break;
       case 4: OQ_SN_LEVEL(4, true, L); break;
       case 16: OQ_SN_LEVEL(16, true, L); break;
       default: OQ_SN_LEVEL(64, true, L); break;
     }
-    for (int L = T.nlev - 1; L >= 0; L--) switch (sn_lanes_b[L]) {
+    if (sn_tree) { OQ_SN_TREE(true); OQ_SN_TREE(false); }
+    for (int L = plain - 1; L >= 0; L--) switch (sn_lanes_b[L]) {
       case 1: OQ_SN_LEVEL(1, false, L); break;
       case 4: OQ_SN_LEVEL(4, false, L); break;
       case 16: OQ_SN_LEVEL(16, false, L); break;
