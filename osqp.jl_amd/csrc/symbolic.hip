@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <exception>
 #include <cmath>
 #include <numeric>
 #include <thread>
@@ -19,6 +20,7 @@ namespace {
 // Host threads for the passes of the analysis that are independent per row / column / subtree (round 4: at 2.7e6 pivots and
 // 6.7e7 entries of L -- control-1e6 -- the single-threaded analysis was 4.7 s of a 7.2 s setup).  Small problems stay on one.
 inline int host_threads(int64_t work) {
+  if (const char *v = getenv("OSQP_AMD_HOST_THREADS")) return std::max(1, std::min(64, atoi(v)));  // tests: the threaded passes on small problems
   if (work < ((int64_t)1 << 20)) return 1;
   return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
 }
@@ -30,9 +32,15 @@ void parallel_blocks(int n, int nblocks, int nthreads, F fn) {
   if (nthreads <= 1) { for (int b = 0; b < nblocks; b++) { auto r = range(b); fn(b, r.first, r.second, 0); } return; }
   std::atomic<int> next{0};
   std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> failed(nthreads);  // an exception of a worker (out of memory) is the caller's, not std::terminate's
   for (int t = 0; t < nthreads; t++)
-    pool.emplace_back([&, t]() { for (int b = next++; b < nblocks; b = next++) { auto r = range(b); fn(b, r.first, r.second, t); } });
+    pool.emplace_back([&, t]() {
+      try {
+        for (int b = next++; b < nblocks; b = next++) { auto r = range(b); fn(b, r.first, r.second, t); }
+      } catch (...) { failed[t] = std::current_exception(); next = nblocks; }
+    });
   for (auto &th : pool) th.join();
+  for (auto &f : failed) if (f) std::rethrow_exception(f);
 }
 
 // ---------------------------------------------------------------------------
@@ -276,12 +284,17 @@ struct NestedDissection {
     if (A.size() + B.size() >= parallel_min && spare_threads.fetch_sub(1) > 0) {
       std::vector<int> outA;
       outA.reserve(A.size());
-      std::thread other([&]() { dissect(std::move(A), outA); });
+      std::exception_ptr failed, mine;
+      std::thread other([&]() { try { dissect(std::move(A), outA); } catch (...) { failed = std::current_exception(); } });
       std::vector<int> outB;
-      outB.reserve(B.size());
-      dissect(std::move(B), outB);
+      try {
+        outB.reserve(B.size());
+        dissect(std::move(B), outB);
+      } catch (...) { mine = std::current_exception(); }
       other.join();
       spare_threads.fetch_add(1);
+      if (failed) std::rethrow_exception(failed);
+      if (mine) std::rethrow_exception(mine);
       out.insert(out.end(), outA.begin(), outA.end());
       out.insert(out.end(), outB.begin(), outB.end());
     } else {
@@ -378,7 +391,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       }
       NestedDissection nd(N, xadj, adj, 64);
       const int nt = host_threads(xadj[N]);
-      if (nt > 1) { nd.spare_threads = nt - 1; nd.parallel_min = std::max<size_t>((size_t)N / (4 * (size_t)nt), 20000); }
+      if (nt > 1) { nd.spare_threads = nt - 1; nd.parallel_min = std::max<size_t>((size_t)N / (4 * (size_t)nt), getenv("OSQP_AMD_HOST_THREADS") ? 200 : 20000); }
       std::vector<int> all;
       all.reserve(N);
       for (int i = 0; i < N; i++) if (!dense[i]) all.push_back(i);

@@ -60,3 +60,19 @@ def test_long_horizon_control_takes_supernodes(product_lib):
     for name, kw in (("portfolio", dict(n=4000, k=100)), ("svm", dict(n=100, m=4000)), ("lasso_data", dict(n=200, m=4000))):
         r = probe(product_lib, qp_zoo.ZOO[name](**kw), 0)
         assert r["ok"] and not r["pays"], (name, r)
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_threaded_analysis_is_the_single_threaded_one(product_lib, monkeypatch, ordering):
+    """Round 4: nested dissection hands the two sides of a large piece to two threads, the pattern of L and the supernode
+    lists are built by row / column ranges on host threads (control-1e6: 4.7 -> 2.0 s).  Forced onto small problems
+    (OSQP_AMD_HOST_THREADS) every number the probe reports -- fill, levels, the supernode partition and the invariants it
+    checks entry by entry -- is the single-threaded one."""
+    probs = [qp_zoo.control(nx=12, nu=6, T=300), qp_zoo.portfolio(n=1500, k=40), qp_zoo.svm(n=60, m=1500)]
+    for prob in probs:
+        monkeypatch.setenv("OSQP_AMD_HOST_THREADS", "1")
+        one = probe(product_lib, prob, ordering)
+        for nt in ("3", "8"):
+            monkeypatch.setenv("OSQP_AMD_HOST_THREADS", nt)
+            assert probe(product_lib, prob, ordering) == one
+        assert one["ok"]
