@@ -158,29 +158,34 @@ __global__ __launch_bounds__(kBlock) void k_ldl_diag_g(int c0, int c1, const dou
 // merge walks both rows (2 x 300 dependent loads per entry on the separators of a nested-dissection tree).  For levels whose
 // rows are long but whose work rows (one dense N-vector per column) would not fit: control-1e6 has hundreds of separator
 // columns per level at N = 2.7e6 (0.47 ms per level with the merge).
+template <int G>  // lanes per entry: 64 on narrow levels (all latency), 16 on wide ones
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_bs(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                            double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                            const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
                                                            const double *__restrict__ D, const double *__restrict__ Dinv) {
-  const int lane = threadIdx.x & 63;
-  const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (e >= Lp[c1]) return;
-  int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
-  const int k = lo, i = Li[e];
-  int64_t a0 = Rp[i], a1 = Rp[i + 1], b0 = Rp[k], b1 = Rp[k + 1];
-  if (a1 - a0 > b1 - b0) { int64_t t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }  // [a0, a1): the shorter row
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
+  const bool live = e < Lp[c1];  // all lanes of a group agree; dead groups still take part in the shuffles
   double acc = 0.0;
-  for (int64_t q = a0 + lane; q < a1; q += 64) {
-    const int j = Rj[q];
-    if (j >= k) break;  // row i holds columns up to i > k; only those below k meet row k
-    int64_t l = b0, h = b1;
-    while (l < h) { const int64_t mid = (l + h) >> 1; if (Rj[mid] < j) l = mid + 1; else h = mid; }
-    if (l < b1 && Rj[l] == j) acc += Lx[Rmap[q]] * Lx[Rmap[l]] * D[j];
+  int k = c0;
+  if (live) {
+    int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
+    k = lo;
+    const int i = Li[e];
+    int64_t a0 = Rp[i], a1 = Rp[i + 1], b0 = Rp[k], b1 = Rp[k + 1];
+    if (a1 - a0 > b1 - b0) { int64_t t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }  // [a0, a1): the shorter row
+    for (int64_t q = a0 + lane; q < a1; q += G) {
+      const int j = Rj[q];
+      if (j >= k) break;  // row i holds columns up to i > k; only those below k meet row k
+      int64_t l = b0, h = b1;
+      while (l < h) { const int64_t mid = (l + h) >> 1; if (Rj[mid] < j) l = mid + 1; else h = mid; }
+      if (l < b1 && Rj[l] == j) acc += Lx[Rmap[q]] * Lx[Rmap[l]] * D[j];
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
+  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (live && lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
 }
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                           double *__restrict__ Lx, const int64_t *__restrict__ Rp,
@@ -1384,7 +1389,10 @@ struct LdlFactor {
         // long rows, too many columns for work rows: a wavefront per entry, bisection instead of the merge
         const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)std::max(1, c1 - c0);
         if (mean >= long_row_mean() && entries <= ((int64_t)1 << 18))  // few entries: the level is latency, not throughput
-          OQ_LAUNCH(k_ldl_entries_bs, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
+          OQ_LAUNCH(k_ldl_entries_bs<64>, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
+                    Rj.get(), Rmap.get(), D.get(), Dinv.get());
+        else if (mean >= long_row_mean() && entries * 16 < ((int64_t)1 << 31))
+          OQ_LAUNCH(k_ldl_entries_bs<16>, dim3(blocks_for(entries * 16)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
                     Rj.get(), Rmap.get(), D.get(), Dinv.get());
         else
           OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
