@@ -746,7 +746,7 @@ def batch_leg(ctx, want_cpu):
         rec["cpu_baseline"] = batch_cpu_leg(oq, args)
     b.close()
     if rank == 0 and world == 1 and args.child is None and args.traffic == "live":  # HBM bytes of one launch, two --pmc passes over a child
-        tr, src = live_traffic(args, ["k_batch_quad", "k_batch_solve"])
+        tr, src = live_traffic(args, ["k_batch_solve" if os.environ.get("OSQP_AMD_BATCH_QUAD") == "0" else "k_batch_quad"])
         rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr, src
     if comm is not None:
         comm.close()
