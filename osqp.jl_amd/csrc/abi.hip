@@ -331,8 +331,8 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
     for (int J = 0; J < T.count && ok; J++) {
       const int s = T.ptr[J + 1] - T.ptr[J];
       for (int a = 0; a < s; a++)
-        for (int b = 0; b < s; b++) {
-          const int64_t t = T.wmap[T.woff[J] + (int64_t)a * s + b];
+        for (int b = 0; b <= a; b++) {
+          const int64_t t = T.wmap[T.woff[J] + (int64_t)a * (a + 1) / 2 + b];
           if (t < 0) continue;
           inside++;
           const int col = T.piv[T.ptr[J] + b], row = T.piv[T.ptr[J] + a];

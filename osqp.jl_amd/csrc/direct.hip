@@ -843,9 +843,13 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict_
   __shared__ double Ld[kSnMax * kSnMax], Wd[kSnMax * kSnMax];
   const int J = blockIdx.x, s = ptr[J + 1] - ptr[J];
   const int64_t w0 = woff[J];
+  // blocks are stored as packed lower triangles (round 4): wmap row-major (a (a + 1) / 2 + b, b <= a), the inverse twice --
+  // Wc column by column (what a forward row product walks with its lanes along the rows), Wr row by row (backward)
   for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
-    const int64_t t = wmap[w0 + e];
-    Ld[e] = t >= 0 ? Lx[t] : 0.0;
+    const int i = e / s, k = e - i * s;
+    double v = 0.0;
+    if (k < i) { const int64_t t = wmap[w0 + (int64_t)i * (i + 1) / 2 + k]; if (t >= 0) v = Lx[t]; }
+    Ld[e] = v;
   }
   __syncthreads();
   if ((int)threadIdx.x < s) {  // column j of the inverse by forward substitution: W(i,j) = -sum_{k=j}^{i-1} L(i,k) W(k,j)
@@ -862,8 +866,8 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict_
   __syncthreads();
   for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
     const int j = e / s, a = e - j * s;
-    Wc[w0 + e] = Wd[a * s + j];
-    Wr[w0 + e] = Wd[j * s + a];
+    if (a >= j) Wc[w0 + (int64_t)j * s - (int64_t)j * (j - 1) / 2 + (a - j)] = Wd[a * s + j];  // W(a, j), column j from its diagonal down
+    if (a <= j) Wr[w0 + (int64_t)j * (j + 1) / 2 + a] = Wd[j * s + a];                           // W(j, a), row j up to its diagonal
   }
 }
 
@@ -900,8 +904,8 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
   const int part = threadIdx.x & 3;
   for (int a = threadIdx.x >> 2; a < s; a += kSnThreads / 4) {
     double acc = 0.0;
-    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s + a] * t[j]; }
-    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * s + a] * t[j]; }
+    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s - j * (j - 1) / 2 + (a - j)] * t[j]; }  // W(a, j), packed columns
+    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * (j + 1) / 2 + a] * t[j]; }                       // W(j, a), packed rows
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (part == 0) b[q0 + a] = acc;
@@ -913,20 +917,22 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
 // workgroup each leaves 250 of them idle (533 us for the forward level 0 of that problem).  Same lanes per row, same order
 // of every sum as k_sn_level: bit-identical results.  The wavefront's t vector sits in its own slab of LDS; its writes are
 // drained (s_waitcnt) before its reads, no workgroup barrier.
-template <int LA, bool kForward>
+template <int LA, bool kForward, int GS>  // GS: lanes per supernode, 64 or 16 (supernodes of at most 16 pivots: four to a wavefront)
 __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                            const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
                                                            const double *__restrict__ Ex, const double *__restrict__ W,
                                                            const double *__restrict__ Dinv_s, double *__restrict__ b) {
-  __shared__ double tt[kSnThreads / 64][kSnMax];
-  const int wv = threadIdx.x >> 6, l64 = threadIdx.x & 63;
-  const int J = J0 + blockIdx.x * (kSnThreads / 64) + wv;
-  if (J >= J1) return;
-  double *t = tt[wv];
-  const int q0 = ptr[J], s = ptr[J + 1] - q0;
+  static_assert(LA <= GS, "the lanes of a row lie inside its supernode's group");
+  constexpr int NG = 64 / GS, TS = GS == 64 ? kSnMax : GS;
+  __shared__ double tt[kSnThreads / 64][NG][TS];
+  const int wv = threadIdx.x >> 6, l64 = threadIdx.x & 63, g = l64 / GS, gl = l64 % GS;
+  const int J = J0 + (blockIdx.x * (kSnThreads / 64) + wv) * NG + g;
+  const bool live = J < J1;  // dead groups run no loop; the lanes of a row (and of its shuffles) share a group: all in or all out
+  double *t = tt[wv][g];
+  const int q0 = live ? ptr[J] : 0, s = live ? ptr[J + 1] - q0 : 0;
   {
-    const int lane = l64 % LA;
-    for (int a = l64 / LA; a < s; a += 64 / LA) {
+    const int lane = gl % LA;
+    for (int a = gl / LA; a < s; a += GS / LA) {
       const int q = q0 + a;
       double acc = gather_dot(Ep[q] + lane, Ep[q + 1], LA, Ej, Ex, b);
 #pragma unroll
@@ -937,12 +943,12 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's LDS writes are done before any of its lanes reads them
   __builtin_amdgcn_wave_barrier();
-  const double *Wj = W + woff[J];
-  const int part = l64 & 3;
-  for (int a = l64 >> 2; a < s; a += 16) {
+  const double *Wj = W + (live ? woff[J] : 0);
+  const int part = gl & 3;
+  for (int a = gl >> 2; a < s; a += GS / 4) {
     double acc = 0.0;
-    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s + a] * t[j]; }
-    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * s + a] * t[j]; }
+    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s - j * (j - 1) / 2 + (a - j)] * t[j]; }  // W(a, j), packed columns
+    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * (j + 1) / 2 + a] * t[j]; }                       // W(j, a), packed rows
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (part == 0) b[q0 + a] = acc;
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
   }
   {
     const double *Wj = W + woff[J];
-    for (int e = threadIdx.x; e < s * s; e += kSnTreeThreads) Wl[e] = Wj[e];
+    for (int e = threadIdx.x; e < s * (s + 1) / 2; e += kSnTreeThreads) Wl[e] = Wj[e];
   }
   const double own = mine ? (kForward ? b[q] : b[q] * Dinv_s[q]) : 0.0;
   if (threadIdx.x == 0) {
@@ -1054,8 +1060,8 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
     const int part = threadIdx.x & 15, r = threadIdx.x >> 4;  // 64 rows x 16 lanes
     double acc = 0.0;
     if (r < s) {
-      if (kForward) { for (int j = part; j <= r; j += 16) acc += Wl[j * s + r] * t[j]; }
-      else { for (int j = r + part; j < s; j += 16) acc += Wl[j * s + r] * t[j]; }
+      if (kForward) { for (int j = part; j <= r; j += 16) acc += Wl[j * s - j * (j - 1) / 2 + (r - j)] * t[j]; }
+      else { for (int j = r + part; j < s; j += 16) acc += Wl[j * (j + 1) / 2 + r] * t[j]; }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -1481,15 +1487,20 @@ struct LdlFactor {
   void launch_bwd_chain(const Step &t, hipStream_t s) { launch_chain(t, false, s); }
 
   // skip_first_fwd / skip_last_bwd: those two level steps are folded into the kernels around the solve (fused_ends)
-  // a level of many supernodes: a wavefront each (k_sn_level_w); a level of few: a workgroup each
+  // a level of many supernodes: a wavefront each, a quarter wavefront for the small ones that come first in the level
+  // (k_sn_level_w); a level of few: a workgroup each
+#define OQ_SN_LEVEL_W(LA, FWD, GS, JA, JB)                                                                                            \
+  OQ_LAUNCH((k_sn_level_w<LA, FWD, GS>), dim3(((JB) - (JA) + 4 * (64 / GS) - 1) / (4 * (64 / GS))), dim3(kSnThreads), 0, s, JA, JB, sn_ptr.get(), \
+            sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),          \
+            FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get())
 #define OQ_SN_LEVEL(LA, FWD, L)                                                                                                   \
   do {                                                                                                                            \
     const int cnt_ = T.lvl_ptr[L + 1] - T.lvl_ptr[L];                                                                             \
-    if (cnt_ >= kSnWaveLevel)                                                                                                     \
-      OQ_LAUNCH((k_sn_level_w<LA, FWD>), dim3((cnt_ + 3) / 4), dim3(kSnThreads), 0, s, T.lvl_ptr[L], T.lvl_ptr[L + 1], sn_ptr.get(), \
-                sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
-                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
-    else                                                                                                                          \
+    if (cnt_ >= sn_wave_min()) {                                                                                                  \
+      const int mid_ = T.lvl_ptr[L] + T.lvl_small[L];                                                                             \
+      if (mid_ > T.lvl_ptr[L]) OQ_SN_LEVEL_W((LA > 16 ? 16 : LA), FWD, 16, T.lvl_ptr[L], mid_);                                    \
+      if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W(LA, FWD, 64, mid_, T.lvl_ptr[L + 1]);                                             \
+    } else                                                                                                                        \
       OQ_LAUNCH((k_sn_level<LA, FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(),                           \
                 sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
@@ -1499,6 +1510,8 @@ struct LdlFactor {
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get())
+  // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
+  static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
   void run_supernodes() {
     hipStream_t s = e.stream;
     const int plain = sn_tree ? sn_tree_L0 : T.nlev;  // levels [0, plain): one launch each; the rest: one launch per direction
@@ -1517,6 +1530,7 @@ struct LdlFactor {
     }
   }
 #undef OQ_SN_LEVEL
+#undef OQ_SN_LEVEL_W
 #undef OQ_SN_TREE
 
   void run_steps(bool skip_first_fwd = false, bool skip_last_bwd = false) {

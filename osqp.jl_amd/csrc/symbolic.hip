@@ -656,10 +656,14 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
   out.lvl_ptr.assign(nlev + 1, 0);
   for (int J = 0; J < count; J++) out.lvl_ptr[level[J] + 1]++;
   for (int l = 0; l < nlev; l++) out.lvl_ptr[l + 1] += out.lvl_ptr[l];
+  // inside a level the small supernodes (<= kSmall pivots) come first: a level of many small ones is solved with a quarter
+  // wavefront each (direct.hip k_sn_level_w), the rest with a whole one
   std::vector<int> newid(count);
+  out.lvl_small.assign(nlev, 0);
   {
     std::vector<int> f(out.lvl_ptr.begin(), out.lvl_ptr.end() - 1);
-    for (int J = 0; J < count; J++) newid[J] = f[level[J]]++;
+    for (int J = 0; J < count; J++) if (members[J] <= Supernodes::kSmall) { newid[J] = f[level[J]]++; out.lvl_small[level[J]]++; }
+    for (int J = 0; J < count; J++) if (members[J] > Supernodes::kSmall) newid[J] = f[level[J]]++;
   }
   out.ptr.assign(count + 1, 0);
   for (int J = 0; J < count; J++) out.ptr[newid[J] + 1] = members[J];
@@ -679,7 +683,7 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
   out.woff.assign(count + 1, 0);
   for (int J = 0; J < count; J++) {
     const int64_t s = out.ptr[J + 1] - out.ptr[J];
-    out.woff[J + 1] = out.woff[J] + s * s;
+    out.woff[J + 1] = out.woff[J] + s * (s + 1) / 2;  // the lower triangle, packed (round 4: the dense s x s blocks were 45 % zeros)
     out.flops += (double)(s * s);
   }
   stage("partition, levels, slots");
@@ -692,11 +696,11 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
   out.Fp.assign(N + 1, 0); out.Gp.assign(N + 1, 0);
   parallel_blocks(N, 8 * nt, nt, [&](int, int v0, int v1, int) {
     for (int v = v0; v < v1; v++) {
-      const int J = newid[sn[v]], s = out.ptr[J + 1] - out.ptr[J];
+      const int J = newid[sn[v]];
       int64_t g = 0;
       for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
         const int r = S.Li[t];
-        if (sn[r] == sn[v]) out.wmap[out.woff[J] + (int64_t)(out.slot[r] - out.ptr[J]) * s + (out.slot[v] - out.ptr[J])] = t;
+        if (sn[r] == sn[v]) { const int64_t a = out.slot[r] - out.ptr[J], b = out.slot[v] - out.ptr[J]; out.wmap[out.woff[J] + a * (a + 1) / 2 + b] = t; }
         else g++;
       }
       out.Gp[out.slot[v] + 1] = g;

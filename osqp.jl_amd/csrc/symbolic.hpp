@@ -59,8 +59,10 @@ struct Supernodes {
   std::vector<int> slot;      // pivot -> slot
   std::vector<int> up;        // supernode holding the elimination-tree parent of its top node (-1: a root)
   std::vector<int> waits;     // number of supernodes of level >= 1 that have it as `up`
-  std::vector<int64_t> woff;  // offset of the s x s block of supernode J in the W arrays (count + 1 entries)
-  std::vector<int64_t> wmap;  // per block entry a*s+b: position in Lx of L(slot a, slot b) for a > b, -1 if not in the pattern
+  static constexpr int kSmall = 16;  // supernodes of at most this many pivots are numbered first inside their level
+  std::vector<int> lvl_small;        // per level: how many of its supernodes are that small
+  std::vector<int64_t> woff;  // offset of the block of supernode J in the W arrays: its lower triangle, packed, s (s + 1) / 2 entries (count + 1 offsets)
+  std::vector<int64_t> wmap;  // per block entry a (a + 1) / 2 + b, b <= a: position in Lx of L(slot a, slot b) for a > b, -1 if not in the pattern (and on the diagonal)
   // the entries of L outside the diagonal blocks, by row (forward solve) and by column (backward solve), rows and
   // columns in slot order; the index stored is the slot of the other end, pos the position of the value in Lx
   std::vector<int64_t> Fp, Fpos, Gp, Gpos;   // every list ascending by slot

@@ -90,6 +90,33 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["1", "0"])
+def test_wavefront_forms_of_the_supernode_levels(product_lib, oracle_lib, monkeypatch, tree):
+    """Round 4 (control-1e6): levels of many supernodes give each a wavefront, the small ones (<= 16 pivots, numbered first
+    inside their level) a quarter wavefront (csrc/direct.hip k_sn_level_w); blocks are packed triangles.  Forced onto a small
+    problem (OSQP_AMD_SNODE_WAVE_MIN=1: every level takes that form), with and without the one-launch top of the tree: the
+    oracle's trajectory, and the same iterate as the workgroup-per-supernode form (same order of every sum: bit-identical)."""
+    prob = qp_zoo.control(nx=8, nu=4, T=400)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **opts, **prob)
+    ro = oq.solve(mo)
+    monkeypatch.setenv("OSQP_AMD_SNODE_TREE", tree)
+    res = []
+    for wave_min in ("1000000000", "1"):
+        monkeypatch.setenv("OSQP_AMD_SNODE_WAVE_MIN", wave_min)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", **opts, **prob)
+        assert oq.stats(m)[19] > 2
+        res.append(oq.solve(m))
+        oq.clean(m)
+    for rp in res:
+        assert rp.info.status == ro.info.status == "Solved" and rp.info.iter == ro.info.iter
+        assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+    oq.clean(mo)
+
+
+@pytest.mark.gpu
 def test_a_timed_out_wait_in_the_tree_kernels_restarts_the_solve_on_the_level_path(product_lib, oracle_lib, monkeypatch):
     """k_sn_tree waits inside a kernel (csrc/direct.hip); a wait that times out raises a flag in mapped host memory.
     The host side of that: the factor goes back to one launch per level and the solve in progress starts again from a
