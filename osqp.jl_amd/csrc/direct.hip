@@ -835,6 +835,7 @@ __global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, dou
 //   backward  u = D_J^-1 y_J - G_J x (entries of the columns of J outside its block),  x_J = W' u
 // A deep elimination tree (nested dissection of a long banded problem: 300 pivot levels) is 15 such levels.
 constexpr int kSnMax = 64, kSnThreads = 256;
+constexpr int kSnBusyLevel = 2048;   // supernodes in a level from which its workgroups no longer fit the device at once
 constexpr int kSnWaveLevel = 16384;  // supernodes in a level from which each gets a wavefront instead of a workgroup (below: the device is not full either way and a workgroup finishes its supernode sooner)
 
 __global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict__ ptr, const int64_t *__restrict__ woff,
@@ -914,9 +915,9 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
 
 // The same step with a WAVEFRONT per supernode (four per workgroup), for levels of many small supernodes: level 0 of a
 // nested-dissection tree is the leaves -- 540 000 subtrees of five pivots on average for control-1e6 -- and a 256-thread
-// workgroup each leaves 250 of them idle (533 us for the forward level 0 of that problem).  Same lanes per row, same order
-// of every sum as k_sn_level: bit-identical results.  The wavefront's t vector sits in its own slab of LDS; its writes are
-// drained (s_waitcnt) before its reads, no workgroup barrier.
+// workgroup each leaves 250 of them idle (533 us for the forward level 0 of that problem).  Same arithmetic as k_sn_level.  The wavefront's t vector sits in its own slab of LDS; its writes are
+// drained (s_waitcnt) before its reads, no workgroup barrier.  (The caller gives wide levels a notch fewer lanes per row
+// than narrow ones -- rows in flight x latency is what bounds them -- so the order of a row's sum may differ between forms.)
 template <int LA, bool kForward, int GS>  // GS: lanes per supernode, 64 or 16 (supernodes of at most 16 pivots: four to a wavefront)
 __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                            const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
@@ -1498,9 +1499,14 @@ struct LdlFactor {
     const int cnt_ = T.lvl_ptr[L + 1] - T.lvl_ptr[L];                                                                             \
     if (cnt_ >= sn_wave_min()) {                                                                                                  \
       const int mid_ = T.lvl_ptr[L] + T.lvl_small[L];                                                                             \
-      if (mid_ > T.lvl_ptr[L]) OQ_SN_LEVEL_W((LA > 16 ? 16 : LA), FWD, 16, T.lvl_ptr[L], mid_);                                    \
-      if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W(LA, FWD, 64, mid_, T.lvl_ptr[L + 1]);                                             \
-    } else                                                                                                                        \
+      /* a wide level is bound by rows in flight x latency, not by the latency of one row: a notch fewer lanes per row */         \
+      if (mid_ > T.lvl_ptr[L]) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 16, T.lvl_ptr[L], mid_);                  \
+      if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);          \
+    } else if (cnt_ >= kSnBusyLevel)  /* more workgroups than the device holds at once: rows in flight count, as above */         \
+      OQ_LAUNCH((k_sn_level<(LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), \
+                sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
+                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
+    else                                                                                                                          \
       OQ_LAUNCH((k_sn_level<LA, FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(),                           \
                 sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \

@@ -95,7 +95,8 @@ def test_wavefront_forms_of_the_supernode_levels(product_lib, oracle_lib, monkey
     """Round 4 (control-1e6): levels of many supernodes give each a wavefront, the small ones (<= 16 pivots, numbered first
     inside their level) a quarter wavefront (csrc/direct.hip k_sn_level_w); blocks are packed triangles.  Forced onto a small
     problem (OSQP_AMD_SNODE_WAVE_MIN=1: every level takes that form), with and without the one-launch top of the tree: the
-    oracle's trajectory, and the same iterate as the workgroup-per-supernode form (same order of every sum: bit-identical)."""
+    oracle's trajectory with either form (wide levels take a notch fewer lanes per row, so the order of a row's sum may
+    differ from the workgroup-per-supernode form's)."""
     prob = qp_zoo.control(nx=8, nu=4, T=400)
     opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
     mo = oq.Model(oracle_lib)
