@@ -1,6 +1,7 @@
 """Standard QP classes (tests/qp_zoo.py): the CPU oracle against an independent evaluation of the stopping criteria
 (CPU), and the HIP engine against the oracle and the same evaluation (GPU)."""
 import numpy as np
+import scipy.sparse as sp
 import pytest
 
 import osqp_jl_amd as oq
@@ -165,3 +166,38 @@ def test_polish_on_zoo(product_lib, oracle_lib, name):
     if ro.info.status_polish == 1:
         pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, rp.x, rp.y, 1e-7)
         assert pri <= 1e-6 and dua <= 1e-5, (pri, dua)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [600, 1100])
+def test_inertia_inside_a_large_dense_block(product_lib, n):
+    """[REF test/non_convex.jl:6-21] at the size where the dense top block is inverted by block sweeps on the matrix cores
+    (csrc/direct.hip k_gj_*, from 512 pivots): an indefinite dense P -- one negative direction buried in the middle of the
+    block -- must fail `osqp_setup` (a pivot of the block's own sweeps has the wrong sign), the same P shifted to be positive
+    definite must set up, report the block and solve to the closed-form answer of its equality-constrained problem."""
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = 0.5 + rng.random(n)
+    ev[n // 2] = -0.3
+    Pind = (Q * ev) @ Q.T
+    Pind = 0.5 * (Pind + Pind.T)
+    m = 20
+    A = sp.csc_matrix(rng.standard_normal((m, n)))
+    b = rng.standard_normal(m)
+    q = rng.standard_normal(n)
+    opts = dict(verbose=False, eps_abs=1e-7, eps_rel=1e-7, max_iter=4000, adaptive_rho_interval=25, sigma=1e-6, linsys_solver="direct")
+    mdl = oq.Model(product_lib)
+    with pytest.raises(oq.OSQPError):
+        oq.setup(mdl, P=sp.csc_matrix(Pind), q=q, A=A, l=b, u=b, **opts)
+    ev[n // 2] = 0.3
+    Ppd = (Q * ev) @ Q.T
+    Ppd = 0.5 * (Ppd + Ppd.T)
+    mdl = oq.Model(product_lib)
+    oq.setup(mdl, P=sp.csc_matrix(Ppd), q=q, A=A, l=b, u=b, **opts)
+    assert oq.stats(mdl)[5] > 500  # one level per pivot of the block: the dense path is what ran
+    r = oq.solve(mdl)
+    assert r.info.status == "Solved"
+    K = np.block([[Ppd, A.toarray().T], [A.toarray(), np.zeros((m, m))]])
+    sol = np.linalg.solve(K, np.concatenate([-q, b]))
+    assert np.max(np.abs(r.x - sol[:n])) <= 1e-5 * max(1.0, np.max(np.abs(sol[:n])))
+    oq.clean(mdl)
