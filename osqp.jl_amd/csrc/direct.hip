@@ -1745,7 +1745,7 @@ int polish_run(Engine &e) {
   // OSQP_AMD_POLISH_ITERATIVE=1 (tests): the iterative form wherever the indirect back-end runs, so that it can be compared
   // with a factorisation-based polish on problems small enough to have one
   static const bool force_iterative = getenv("OSQP_AMD_POLISH_ITERATIVE") && atoi(getenv("OSQP_AMD_POLISH_ITERATIVE")) != 0;
-  if (e.compact || (force_iterative && e.lin && e.lin->kind() == 2)) return polish_run_pcg(e);
+  if (e.compact || e.comm || (force_iterative && e.lin && e.lin->kind() == 2)) return polish_run_pcg(e);  // a row block has no reduced KKT matrix either
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;
   OSQPInfo *info = e.ws->info;

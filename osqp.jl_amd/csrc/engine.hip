@@ -1184,7 +1184,7 @@ int Engine::solve_attempt(bool restarted) {
   info->rho_estimate = compute_rho_estimate();
   sync();
   info->solve_time = toc();
-  if (st.polish && info->status_val == OSQP_SOLVED && !comm) polish();  // polish needs the direct back-end: not on a row block
+  if (st.polish && info->status_val == OSQP_SOLVED) polish();  // a row block polishes iteratively on the operator of its indirect back-end (pcg.hip)
   if (ws->first_run) info->run_time = info->setup_time + info->solve_time + info->polish_time;
   else info->run_time = info->update_time + info->solve_time + info->polish_time;
   ws->first_run = 0;

@@ -758,7 +758,7 @@ __global__ __launch_bounds__(kBlock) void k_polish_cone(int m, double *__restric
 
 int polish_run_pcg(Engine &e) {
   Pcg *P = dynamic_cast<Pcg *>(e.lin.get());
-  if (!P || e.comm) return -1;
+  if (!P) return -1;  // row-sharded workspaces included (round 4): every product takes its input through the all-gather of the rank blocks
   if (P->flush()) return -1;
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;
@@ -809,14 +809,14 @@ int polish_run_pcg(Engine &e) {
     vec_copy(xz.get(), e.q.get(), n, s);
     vec_scale(xz.get(), -1.0, n, s);
     if (it > 0) {
-      spmv(e.Pf, px.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+      spmv(e.Pf, e.full_n(px.get()), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
       vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
     }
     if (m > 0) {
       if (it > 0) {
-        spmv(e.At, py.get(), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
+        spmv(e.At, e.full_m(py.get()), tmp.get(), nullptr, 0.0, 0.0, nullptr, s);
         vec_axpy(xz.get(), -1.0, tmp.get(), n, s);
-        spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+        spmv(e.A, e.full_n(px.get()), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
       } else pz.zero(s);
       OQ_LAUNCH(k_polish_r2, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, e.rho.get(), bound.get(), pz.get(), r2.get());
       vec_copy(xz.get() + n, r2.get(), m, s);
@@ -833,12 +833,15 @@ int polish_run_pcg(Engine &e) {
   restore();
   // polished (x, z, y) and its residuals, as in polish_run
   if (m > 0) {
-    spmv(e.A, px.get(), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
+    spmv(e.A, e.full_n(px.get()), pz.get(), nullptr, 0.0, 0.0, nullptr, s);
     OQ_LAUNCH(k_polish_cone, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, pz.get(), py.get(), e.l.get(), e.u.get());
   }
-  spmv(e.A, px.get(), e.Ax.get(), nullptr, 0.0, 0.0, nullptr, s);
-  spmv(e.Pf, px.get(), e.Px_.get(), nullptr, 0.0, 0.0, nullptr, s);
-  if (m > 0) spmv(e.At, py.get(), e.Aty.get(), nullptr, 0.0, 0.0, nullptr, s);
+  {
+    const double *xg = e.full_n(px.get());
+    spmv(e.A, xg, e.Ax.get(), nullptr, 0.0, 0.0, nullptr, s);
+    spmv(e.Pf, xg, e.Px_.get(), nullptr, 0.0, 0.0, nullptr, s);
+  }
+  if (m > 0) spmv(e.At, e.full_m(py.get()), e.Aty.get(), nullptr, 0.0, 0.0, nullptr, s);
   residual_norms(n, m, px.get(), pz.get(), e.Ax.get(), e.Px_.get(), e.Aty.get(), e.q.get(), e.Dinv.get(), e.Einv.get(), e.slots.get(),
                  e.partials.get(), s);
   e.fetch_slots(0, 16, (1u << S_XPX) | (1u << S_QX));

@@ -103,6 +103,8 @@ SHARDABLE_CASES = [
     "case_dual_infeasible_lp", "case_dual_infeasible_qp", "case_primal_dual_infeasible_warm",
     "case_primal_dual_infeasible_cold", "case_primal_infeasible_random", "case_unconstrained", "case_feasibility",
     "case_warm_start", "case_moi_lp", "case_equality_lsq", "case_bounds_validation",
+    # round 4: polish on a row block (the iterative form on the operator of the indirect back-end, csrc/pcg.hip)
+    "case_polish_basic", "case_polish_unconstrained", "case_polish_random",
 ]
 
 
