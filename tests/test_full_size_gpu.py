@@ -40,6 +40,39 @@ def kkt_check(oracle_lib, kind, n, k, seed, x, y, eps=1e-4, slack=2.0):
     return 0.5 * x @ (Pfull @ x) + q @ x
 
 
+def test_control_1e6_matches_oracle_at_full_size(product_lib, oracle_lib, monkeypatch):
+    """Round 4: the trisolve path at scale (bench.py `control-1e6`: n = 1 000 002, m = 1 666 674, nnz(L) = 6.7e7, nested
+    dissection, supernodal solves with the wavefront forms and the top-of-tree launch, packed blocks, numeric factorisation
+    by bisection on long-row levels) against the CPU oracle on the same host-built data: an exact solve on both sides, so the
+    same status and the SAME iteration count, x / y to 2e-4 of scale, objective; then OSQP's stopping criteria and the dual
+    sign convention re-evaluated in numpy on the unscaled data."""
+    import qp_zoo
+
+    monkeypatch.setenv("OSQP_AMD_FIRST_ORDERING", "1")
+    T = bench.WORKLOADS["control-1e6"][1]
+    prob = bench.control_problem(T)
+    res = []
+    for lib, ls in ((product_lib, "direct"), (oracle_lib, "qdldl")):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver=ls, **prob, **bench.SETTINGS)
+        if lib is product_lib:
+            st = oq.stats(m)
+            assert st[0] == 0 and st[19] > 2  # direct back-end, supernodal solves
+        res.append(oq.solve(m))
+        oq.clean(m)
+    rp, ro = res
+    assert rp.info.status == ro.info.status == "Solved"
+    assert rp.info.iter == ro.info.iter, (rp.info.iter, ro.info.iter)
+    assert np.max(np.abs(rp.x - ro.x)) <= 2e-4 * max(1.0, np.max(np.abs(ro.x)))
+    assert np.max(np.abs(rp.y - ro.y)) <= 2e-4 * max(1.0, np.max(np.abs(ro.y)))
+    assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-4 * max(1.0, abs(ro.info.obj_val))
+    pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, rp.x, rp.y, 1e-4)
+    assert pri <= 2.0 * eps_pri and dua <= 2.0 * eps_dua, (pri, eps_pri, dua, eps_dua)
+    Ax = prob["A"] @ rp.x
+    tol = 1e-3 * max(1.0, np.max(np.abs(rp.y)))
+    assert np.all((rp.y > -tol) | (Ax - prob["l"] < 20 * eps_pri)) and np.all((rp.y < tol) | (prob["u"] - Ax < 20 * eps_pri))
+
+
 @pytest.mark.parametrize("name", ["rand-1e5", "lasso-5e5"])
 def test_bench_config_matches_oracle_at_full_size(product_lib, oracle_lib, name):
     kind, n, k, linsys = bench.WORKLOADS[name]
