@@ -227,23 +227,25 @@ __global__ __launch_bounds__(kBlock) void k_shard_pick_A(int64_t E, int j0, cons
                                                         const double *__restrict__ Ax, int n0, int n1, int m0, int m1, int fill,
                                                         unsigned long long *__restrict__ counters, int *__restrict__ tr,
                                                         int *__restrict__ tc, double *__restrict__ tv, int *__restrict__ ar,
-                                                        int *__restrict__ ac, double *__restrict__ av) {
+                                                        int *__restrict__ ac, double *__restrict__ av, int64_t base,
+                                                        int *__restrict__ to, int *__restrict__ ao) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool in = e < E;
   const int j = in ? j0 + colid[e] : -1, i = in ? Ai[e] : -1;
   const double v = (in && fill) ? Ax[e] : 0.0;
   const bool kt = in && j >= n0 && j < n1, ka = in && i >= m0 && i < m1;
   long long p = block_reserve(kt, &counters[0], fill);
-  if (fill && kt) { tr[p] = j - n0; tc[p] = i; tv[p] = v; }
+  if (fill && kt) { tr[p] = j - n0; tc[p] = i; tv[p] = v; to[p] = (int)(base + e); }  // base + e: the caller's nnz index
   p = block_reserve(ka, &counters[1], fill);
-  if (fill && ka) { ar[p] = i - m0; ac[p] = j; av[p] = v; }
+  if (fill && ka) { ar[p] = i - m0; ac[p] = j; av[p] = v; ao[p] = (int)(base + e); }
 }
 // entries (i, j), i <= j, of columns [j0, ...) of triu(P): rows [n0, n1) of the full symmetric P get (j, i) and, off the
 // diagonal, the mirror (i, j)
 __global__ __launch_bounds__(kBlock) void k_shard_pick_P(int64_t E, int j0, const int *__restrict__ colid, const int *__restrict__ Pi,
                                                         const double *__restrict__ Px, int n0, int n1, int fill,
                                                         unsigned long long *__restrict__ counter, int *__restrict__ pr,
-                                                        int *__restrict__ pc, double *__restrict__ pv, int *__restrict__ bad) {
+                                                        int *__restrict__ pc, double *__restrict__ pv, int *__restrict__ bad, int64_t base,
+                                                        int *__restrict__ po) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool in = e < E;
   const int j = in ? j0 + colid[e] : -1, i = in ? Pi[e] : -1;
@@ -251,9 +253,14 @@ __global__ __launch_bounds__(kBlock) void k_shard_pick_P(int64_t E, int j0, cons
   if (in && i > j) *bad = 1;  // not upper triangular
   const bool kl = in && j >= n0 && j < n1, ku = in && i != j && i >= n0 && i < n1;
   long long p = block_reserve(kl, counter, fill);
-  if (fill && kl) { pr[p] = j - n0; pc[p] = i; pv[p] = v; }
+  if (fill && kl) { pr[p] = j - n0; pc[p] = i; pv[p] = v; po[p] = (int)(base + e); }
   p = block_reserve(ku, counter, fill);
-  if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; }
+  if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; po[p] = (int)(base + e); }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_ints(int64_t n, const int *__restrict__ src, const int *__restrict__ in, int *__restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) out[k] = in[src[k]];
 }
 
 void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
@@ -266,7 +273,7 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
   const int step = std::max(64, (ng + 4 * comm->world - 1) / (4 * comm->world));
   DevBuf<unsigned long long> counters(3);
   counters.zero(stream);
-  DevBuf<int> tr, tc, ar, ac, pr, pc;
+  DevBuf<int> tr, tc, ar, ac, pr, pc, to, ao, po;
   DevBuf<double> tv, av, pv;
   unsigned long long total[3] = {0, 0, 0};
   for (int fill = 0; fill < 2; fill++) {
@@ -278,8 +285,10 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
       tr.alloc(total[0]); tc.alloc(total[0]); tv.alloc(total[0]);
       ar.alloc(total[1]); ac.alloc(total[1]); av.alloc(total[1]);
       pr.alloc(total[2]); pc.alloc(total[2]); pv.alloc(total[2]);
+      to.alloc(total[0]); ao.alloc(total[1]); po.alloc(total[2]);
       counters.zero(stream);
     }
+    int64_t baseA = 0, baseP = 0;  // the caller's nnz index of the first entry of the column range (ranges come in column order)
     for (int j0 = 0; j0 < ng; j0 += step) {
       const int j1 = std::min(ng, j0 + step);
       DevBuf<int64_t> p;
@@ -291,8 +300,9 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
           DevBuf<int> colid((size_t)E);
           expand_colptr(j1 - j0, p.get(), E, colid.get(), stream);
           OQ_LAUNCH(k_shard_pick_A, dim3(blocks_for(E)), dim3(kBlock), 0, stream, E, j0, colid.get(), idx.get(), val.get(), n0, n1, m0, m1, fill,
-                    counters.get(), tr.get(), tc.get(), tv.get(), ar.get(), ac.get(), av.get());
+                    counters.get(), tr.get(), tc.get(), tv.get(), ar.get(), ac.get(), av.get(), baseA, to.get(), ao.get());
           sync();
+          baseA += E;
         }
       }
       {
@@ -301,8 +311,9 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
           DevBuf<int> colid((size_t)E);
           expand_colptr(j1 - j0, p.get(), E, colid.get(), stream);
           OQ_LAUNCH(k_shard_pick_P, dim3(blocks_for(E)), dim3(kBlock), 0, stream, E, j0, colid.get(), idx.get(), val.get(), n0, n1, fill,
-                    counters.get() + 2, pr.get(), pc.get(), pv.get(), flag.get());
+                    counters.get() + 2, pr.get(), pc.get(), pv.get(), flag.get(), baseP, po.get());
           sync();
+          baseP += E;
         }
       }
     }
@@ -311,16 +322,19 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
   flag.download(&bad, 1, stream);
   sync();
   if (bad) throw Error(1, "P is not upper triangular");
-  auto build = [&](DevCsr &M, int rows, int cols, unsigned long long E, DevBuf<int> &er, DevBuf<int> &ec, DevBuf<double> &ev) {
+  auto build = [&](DevCsr &M, int rows, int cols, unsigned long long E, DevBuf<int> &er, DevBuf<int> &ec, DevBuf<double> &ev, DevBuf<int> &eo,
+                   DevBuf<int> &org) {
     DevBuf<int> order;
     csr_from_coo(rows, cols, (int64_t)E, er.get(), ec.get(), M, order, stream);
     gather_values(M.nnz, order.get(), ev.get(), M.val.get(), 0, stream);
+    org.alloc(std::max<size_t>(1, (size_t)M.nnz));
+    if (M.nnz > 0) OQ_LAUNCH(k_gather_ints, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, stream, (int64_t)M.nnz, order.get(), eo.get(), org.get());
     sync();
-    er.release(); ec.release(); ev.release();
+    er.release(); ec.release(); ev.release(); eo.release();
   };
-  build(At, n1 - n0, mg, total[0], tr, tc, tv);
-  build(A, m1 - m0, ng, total[1], ar, ac, av);
-  build(Pf, n1 - n0, ng, total[2], pr, pc, pv);
+  build(At, n1 - n0, mg, total[0], tr, tc, tv, to, At_org);
+  build(A, m1 - m0, ng, total[1], ar, ac, av, ao, A_org);
+  build(Pf, n1 - n0, ng, total[2], pr, pc, pv, po, Pf_org);
   DevBuf<double> q_, l_, u_;
   src.vectors(q_, l_, u_, stream);
   sync();
@@ -772,11 +786,12 @@ void Engine::compact_matrices() {
 
 void Engine::unscale_data() {
   csr_scale_rows_cols(Pf, nullptr, nullptr, 0, cinv, stream);
-  csr_scale_rows_cols(Pf, Dinv.get(), Dinv.get(), 1, 1.0, stream);
+  const double *Dg = full_n(Dinv.get());  // column scalings are indexed by global ids (a row block: the gathered vector)
+  csr_scale_rows_cols(Pf, Dinv.get(), Dg, 1, 1.0, stream, n0);
   vec_scale_by_vec_scalar(q.get(), Dinv.get(), cinv, n, stream);
   if (m > 0) {
-    csr_scale_rows_cols(A, Einv.get(), Dinv.get(), 0, 1.0, stream);
-    csr_scale_rows_cols(At, Dinv.get(), Einv.get(), 2, 1.0, stream);
+    csr_scale_rows_cols(A, Einv.get(), Dg, 0, 1.0, stream);
+    csr_scale_rows_cols(At, Dinv.get(), full_m(Einv.get()), 2, 1.0, stream);
     vec_ew_prod(l.get(), l.get(), Einv.get(), m, stream);
     vec_ew_prod(u.get(), u.get(), Einv.get(), m, stream);
   }
@@ -1291,9 +1306,16 @@ __global__ __launch_bounds__(kBlock) void k_scatter_vals_slot(int64_t k, const l
   if (p2 != 0xFFFFFFFFu) t2[p2] = val;
 }
 
+// a row block's entry takes the value at its caller-order index unless that one carries the "not updated" mark (all ones)
+__global__ __launch_bounds__(kBlock) void k_pick_new_vals(int64_t n, const int *__restrict__ org, const double *__restrict__ all, double *__restrict__ val) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n) return;
+  const double v = all[org[q]];
+  if (__double_as_longlong(v) != -1LL) val[q] = v;
+}
+
 int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const double *Ax_new, const c_int *Aidx, c_int An,
                       bool doP, bool doA) {
-  if (comm) throw Error(6, "osqp_update_P / osqp_update_A are not available on a row-sharded workspace");
   begin_update();
   if (doP) { if (Pidx) { if (Pn > nnzPtriu) return 1; } else if (Pn != nnzPtriu && Pn != 0) return 1; }
   if (doA) { if (Aidx) { if (An > nnzA) return 2; } else if (An != nnzA && An != 0) return 2; }
@@ -1322,6 +1344,33 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
   };
   // every copy through its own map: slots of the sliced-ELL copy where the CSR arrays are gone, CSR positions otherwise
   const c_int kP = Pidx ? Pn : (c_int)nnzPtriu, kA = Aidx ? An : (c_int)nnzA;
+  if (comm) {
+    // a row block (round 4): every rank is handed the same new values; they go into a device array in the caller's nnz order
+    // (by index: behind a fill that marks the untouched entries) and every entry of this rank's blocks picks its own by
+    // the index recorded at setup (At_org / A_org / Pf_org)
+    auto replace = [&](const double *vals, const c_int *idx, c_int k, int64_t nnz_all, std::initializer_list<std::pair<DevCsr *, DevBuf<int> *>> blocks) {
+      if (k <= 0 || nnz_all <= 0) return;
+      DevBuf<double> all((size_t)nnz_all);
+      if (idx) {
+        HIP_CHECK(hipMemsetAsync(all.get(), 0xFF, sizeof(double) * (size_t)nnz_all, stream));  // all ones: "not updated"
+        DevBuf<double> dv((size_t)k);
+        DevBuf<long long> di((size_t)k);
+        dv.upload(vals, (size_t)k, stream);
+        di.upload((const long long *)idx, (size_t)k, stream);
+        OQ_LAUNCH(k_scatter_vals, dim3(blocks_for(k)), dim3(kBlock), 0, stream, (int64_t)k, (const long long *)di.get(), (const double *)dv.get(),
+                  all.get(), (const int *)nullptr, (double *)nullptr, (const int *)nullptr);
+        sync();
+      } else all.upload(vals, (size_t)nnz_all, stream);
+      for (auto &b : blocks)
+        if (b.first->nnz > 0)
+          OQ_LAUNCH(k_pick_new_vals, dim3(blocks_for(b.first->nnz)), dim3(kBlock), 0, stream, (int64_t)b.first->nnz, (const int *)b.second->get(),
+                    (const double *)all.get(), b.first->val.get());
+      sync();
+    };
+    if ((Pf.nnz > 0 && Pf_org.n == 0) || (A.nnz > 0 && A_org.n == 0)) throw Error(6, "osqp_update_P / osqp_update_A: this row-sharded workspace was not set up by column ranges");
+    if (doP) replace(Px_new, Pidx, kP, nnzPtriu, {{&Pf, &Pf_org}});
+    if (doA) replace(Ax_new, Aidx, kA, nnzA, {{&At, &At_org}, {&A, &A_org}});
+  } else {
   if (doP) {
     if (Pf.compact) scatter_slots(Px_new, Pidx, kP, Pf.panel.sval.get(), (const uint32_t *)P_k2lo.get(), Pf.panel.sval.get(), (const uint32_t *)P_k2up.get());
     else scatter(Px_new, Pidx, kP, Pf.val.get(), P_k2lo.get(), Pf.val.get(), P_k2up.get());
@@ -1335,6 +1384,7 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
       if (A.compact) scatter_slots(Ax_new, Aidx, kA, A.panel.sval.get(), (const uint32_t *)A_k2pos.get(), A.panel.sval.get(), (const uint32_t *)A_k2pos.get());
       else scatter(Ax_new, Aidx, kA, A.val.get(), A_k2pos.get(), nullptr, nullptr);
     }
+  }
   }
   if (st.scaling) scale_data();
   refresh_panels();

@@ -88,6 +88,8 @@ struct Engine {
   DevCsr A, At, Pf;
   DevBuf<int> A_k2pos, P_k2lo, P_k2up;
   // compact mode (compact_matrices): the same maps as positions in the sliced-ELL value arrays (0xFFFFFFFF: none)
+  // row-sharded workspaces: the caller's nnz index of every entry of this rank's blocks (osqp_update_P / _A pick their new values by it)
+  DevBuf<int> At_org, A_org, Pf_org;
   DevBuf<uint32_t> At_k2slot;  // slot of A' entry k in its sliced copy; A and P keep theirs in A_k2pos / P_k2lo / P_k2up (compact_one)
   bool compact = false;
   DevBuf<int64_t> Pp_keep;  // caller's triu(P) CSC pattern, kept for the direct back-end's symbolic phase

@@ -2,7 +2,8 @@
 
 usage: _sharded_worker.py RANK WORLD PORT OUT_JSON TRANSPORT CASE
   TRANSPORT: host (gloo, any number of ranks on one GPU) | rccl
-  CASE: gen:<kind>:<n>:<per_row>:<seed> | cases:<name,name,...> (functions of tests/qp_cases.py, run with every
+  CASE: gen:<kind>:<n>:<per_row>:<seed> | update:<kind>:<n>:<per_row>:<seed> (host-array setup, solve, osqp_update_P_A by
+        index / in full, solve again) | cases:<name,name,...> (functions of tests/qp_cases.py, run with every
         setup routed through the communicator) | batch:<total>:<seed> (the sharded MPC batch, osqp_jl_amd.batch.MpcBatch)
 """
 import json
@@ -38,6 +39,17 @@ def main():
             json.dump({"first": b.first, "per": b.per, "same": bool(np.array_equal(again.numpy(), packed.numpy())),
                        "exchanges": 0}, f)
         b.close()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if case.startswith("update:"):
+        from test_sharded_gpu import update_sequence
+
+        _, kind, n, per_row, seed = case.split(":")
+        rec = update_sequence(oq, lib, oq.load_library(oq.ORACLE_LIB_PATH), int(kind), int(n), int(per_row), int(seed), settings, comm)
+        with open("%s.%d" % (out, rank), "w") as f:
+            json.dump(rec, f)
         comm.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -123,3 +123,50 @@ def test_rccl_transport_one_rank(product_lib, tmp_path):
     assert rec["status"] == "Solved" and rec["iter"] == ref["iter"]
     assert np.max(np.abs(np.array(rec["x"]) - ref["x"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["x"])))
     assert rec["stats"][14] > 0
+
+
+def update_sequence(oq, lib, oracle_lib, kind, n, per_row, seed, settings, comm=None):
+    """Host-array setup of a generated instance, a solve, new matrix values -- some diagonal entries of P by index, all of A
+    in full [REF src/interface.jl:330-406] -- and a second solve.  Run by every rank of the sharded test and by the
+    single-device reference."""
+    import scipy.sparse as sp
+    from test_gpu_parity import _data_to_scipy
+
+    d = oracle_lib.oracle_generate(kind, n, per_row, seed)
+    P, q, A, l, u = _data_to_scipy(d.contents)
+    oracle_lib.oracle_data_free(d)
+    P = sp.triu(P).tocsc(); A = A.tocsc()
+    P.sort_indices(); A.sort_indices()
+    m = oq.Model(lib)
+    kw = dict(comm=comm) if comm is not None else {}
+    oq.setup(m, P=P, q=q, A=A, l=l, u=u, **kw, **settings)
+    r1 = oq.solve(m)
+    cols = np.arange(0, P.shape[0], 7)
+    diag_pos = P.indptr[cols + 1] - 1  # the diagonal is the last entry of a column of triu(P)
+    assert np.all(P.indices[diag_pos] == cols)
+    oq.update_P_A(m, P.data[diag_pos] * 1.5 + 0.25, diag_pos.astype(np.int64), A.data * 1.1, None)
+    r2 = oq.solve(m)
+    rec = {"status1": r1.info.status, "iter1": int(r1.info.iter), "status2": r2.info.status, "iter2": int(r2.info.iter),
+           "obj1": float(r1.info.obj_val), "obj2": float(r2.info.obj_val), "x2": np.asarray(r2.x).tolist(), "y2": np.asarray(r2.y).tolist()}
+    oq.clean(m)
+    return rec
+
+
+@pytest.mark.parametrize("world,kind,n,per_row", [(2, 0, 3000, 12), (3, 0, 2501, 9)])
+def test_update_matrices_on_a_sharded_workspace(product_lib, oracle_lib, tmp_path, world, kind, n, per_row):
+    """Round 4: osqp_update_P / _A / _P_A on a row block (refused until round 3): every rank is handed the new values, each
+    entry of its blocks picks its own by the caller's nnz index recorded at setup, then unscale / rescale / refresh as on one
+    device.  Against the single-device workspace driven through the same sequence."""
+    import osqp_jl_amd as oq
+
+    ref = update_sequence(oq, product_lib, oracle_lib, kind, n, per_row, 7, SETTINGS)
+    recs = run_ranks(tmp_path, world, "host", "update:%d:%d:%d:7" % (kind, n, per_row), SETTINGS)
+    assert ref["status1"] == ref["status2"] == "Solved" and abs(ref["obj2"] - ref["obj1"]) > 1e-6 * abs(ref["obj1"])  # the update matters
+    for rec in recs:
+        assert rec["status1"] == rec["status2"] == "Solved"
+        assert abs(rec["iter2"] - ref["iter2"]) <= 25
+        assert abs(rec["obj2"] - ref["obj2"]) <= 1e-5 * max(1.0, abs(ref["obj2"]))
+        assert np.max(np.abs(np.array(rec["x2"]) - np.array(ref["x2"]))) <= 1e-4 * max(1.0, np.max(np.abs(ref["x2"])))
+        assert np.max(np.abs(np.array(rec["y2"]) - np.array(ref["y2"]))) <= 1e-4 * max(1.0, np.max(np.abs(ref["y2"])))
+    for rec in recs[1:]:
+        assert rec["x2"] == recs[0]["x2"] and rec["iter2"] == recs[0]["iter2"]
