@@ -338,7 +338,8 @@ c_float osqp_amd_time_kernel(OSQPWorkspace *work, c_int which, c_int reps);
  * arguments (full-length vectors; each rank reads its slice) and receives the full solution.  Setup walks the
  * problem column range by column range and keeps only the rank's row blocks, so the peak device memory of a rank is
  * about 1/R of the single-device workspace (stats[20]; the device generator never materialises the rest at all).  Not available on a
- * sharded workspace: the direct back-end, polish (skipped), osqp_update_P / _A / _P_A, osqp_amd_apply.
+ * sharded workspace: the direct back-end, osqp_amd_apply.  (Round 4: polish runs in its iterative form; osqp_update_P / _A / _P_A
+ * take the same full-length value arrays on every rank.)
  *
  * The communicator is one in-place all-gather of doubles; it must outlive the workspaces that use it.
  *   host:  `fn(ctx, host_buf, count)` is called with world*count doubles, chunk `rank` filled in, and fills in the
