@@ -1107,6 +1107,9 @@ void Engine::store_solution() {
 // that cannot be trusted: the factor has gone back to one launch per level (Direct::flush), the solve starts again from
 // a cold start.  A second fault cannot happen (nothing waits inside a kernel any more); if it does it is error 6.
 int Engine::solve() {
+  // what an abandoned attempt may have changed besides the iterate: rho (adaptive updates) and the interval it settled on
+  const double rho_at_entry = st.rho;
+  const c_int interval_at_entry = st.adaptive_rho_interval;
   for (int attempt = 0;; attempt++) {
     try {
       int rc = solve_attempt(attempt > 0);
@@ -1116,6 +1119,10 @@ int Engine::solve() {
       if (attempt >= 1) throw;
       tree_restarts++;
       deferred_error = 0;
+      // the second attempt is the solve the caller asked for, from the state the caller left: rho and the adaptive-rho
+      // interval go back to their values at entry (a refactorisation when rho had moved)
+      st.adaptive_rho_interval = interval_at_entry;
+      if (st.rho != rho_at_entry) { const int rc = update_rho(rho_at_entry); if (rc) return rc; }
     }
   }
 }

@@ -141,7 +141,7 @@ def test_a_timed_out_wait_in_the_tree_kernels_restarts_the_solve_on_the_level_pa
         assert np.max(np.abs(ro.x - rp.x)) <= 1e-4 * max(1.0, np.max(np.abs(ro.x)))
         assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-5 * max(1.0, abs(ro.info.obj_val))
         if k == 0:
-            assert abs(rp.info.iter - ro.info.iter) <= 25  # the restart is the oracle's cold-start solve
+            assert rp.info.iter == ro.info.iter  # the restart is the oracle's cold-start solve: rho and its interval are back at their entry values
         assert oq.stats(m)[19] > 2   # still a supernodal factor, now one launch per level
         assert oq.stats(m)[21] == 1  # one restart, none after it
     assert oq.stats(m)[21] == 1
