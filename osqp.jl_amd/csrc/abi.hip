@@ -5,6 +5,9 @@
 #include "engine.hpp"
 #include "symbolic.hpp"
 
+#include <cstring>
+#include <thread>
+#include <atomic>
 #include <cmath>
 
 using namespace oq;
@@ -158,7 +161,60 @@ void osqp_set_default_settings(OSQPSettings *s) {
 
 const char *osqp_version(void) { return "0.6.2"; }
 
+// The columns of A sorted by row on the host (host threads over column ranges), with the map caller index -> sorted index.
+// false: a column holds a row twice (refused: the two entries would have to be one).
+static bool sort_columns_of_A(const csc *A, std::vector<c_int> &rows, std::vector<c_float> &vals, std::vector<int64_t> &to_sorted) {
+  const c_int n = A->n;
+  const int64_t nnz = A->p[n];
+  rows.resize((size_t)nnz); vals.resize((size_t)nnz); to_sorted.resize((size_t)nnz);
+  const int nt = nnz < (1 << 20) ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  std::atomic<bool> repeated{false};
+  auto work = [&](c_int j0, c_int j1) {
+    std::vector<std::pair<c_int, int64_t>> col;
+    for (c_int j = j0; j < j1; j++) {
+      col.clear();
+      for (int64_t k = A->p[j]; k < A->p[j + 1]; k++) col.push_back({A->i[k], k});
+      std::sort(col.begin(), col.end());
+      int64_t s = A->p[j];
+      for (size_t t = 0; t < col.size(); t++, s++) {
+        if (t > 0 && col[t].first == col[t - 1].first) repeated = true;
+        rows[(size_t)s] = col[t].first; vals[(size_t)s] = A->x[col[t].second]; to_sorted[(size_t)col[t].second] = s;
+      }
+    }
+  };
+  if (nt == 1) work(0, n);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back(work, (c_int)((int64_t)n * t / nt), (c_int)((int64_t)n * (t + 1) / nt));
+    for (auto &th : pool) th.join();
+  }
+  return !repeated;
+}
+
+static c_int setup_from_host_once(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, Comm *comm);
+
+// [REF src/interface.jl:132-155].  libosqp takes the columns of A with their rows in any order; this library's layouts want them
+// ascending (what SparseMatrixCSC always hands over).  A caller whose columns are not sorted gets the same behaviour as from
+// libosqp at the price of one sorted host copy: the setup is repeated on it and osqp_update_A translates nnz indices.
 static c_int setup_from_host(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, Comm *comm) {
+  c_int rc = setup_from_host_once(workp, data, settings, comm);
+  if (rc != 1 || !data || !data->A) return rc;
+  const char *why = last_error_cstr();
+  if (!why || !strstr(why, "must ascend")) return rc;
+  std::vector<c_int> rows;
+  std::vector<c_float> vals;
+  std::vector<int64_t> to_sorted;
+  if (!sort_columns_of_A(data->A, rows, vals, to_sorted)) { set_last_error("a column of A holds the same row twice"); return 1; }
+  csc A2 = *data->A;
+  A2.i = rows.data(); A2.x = vals.data();
+  OSQPData d2 = *data;
+  d2.A = &A2;
+  rc = setup_from_host_once(workp, &d2, settings, comm);
+  if (rc == 0) E(*workp)->A_to_sorted = std::move(to_sorted);
+  return rc;
+}
+
+static c_int setup_from_host_once(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, Comm *comm) {
   if (!workp) return 1;
   *workp = nullptr;
   if (validate_data(data)) { set_last_error("invalid problem data"); return 1; }

@@ -1328,6 +1328,20 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
   if (doA) { if (Aidx) { if (An > nnzA) return 2; } else if (An != nnzA && An != 0) return 2; }
   if (doP && Pidx) for (c_int i = 0; i < Pn; i++) if (Pidx[i] < 0 || Pidx[i] >= nnzPtriu) return 1;
   if (doA && Aidx) for (c_int i = 0; i < An; i++) if (Aidx[i] < 0 || Aidx[i] >= nnzA) return 2;
+  // a workspace built from a sorted copy of the caller's A (unsorted columns at setup): the caller's nnz indices -> ours
+  std::vector<c_int> Aidx_sorted;
+  std::vector<double> Ax_sorted;
+  if (doA && !A_to_sorted.empty() && Ax_new) {
+    if (Aidx) {
+      Aidx_sorted.resize((size_t)An);
+      for (c_int i = 0; i < An; i++) Aidx_sorted[(size_t)i] = (c_int)A_to_sorted[(size_t)Aidx[i]];
+      Aidx = Aidx_sorted.data();
+    } else if (An == nnzA) {
+      Ax_sorted.resize((size_t)nnzA);
+      for (int64_t k = 0; k < nnzA; k++) Ax_sorted[(size_t)A_to_sorted[(size_t)k]] = Ax_new[k];
+      Ax_new = Ax_sorted.data();
+    }
+  }
   if (st.scaling) unscale_data();
   auto scatter = [&](const double *vals, const c_int *idx, c_int k, double *t1, const int *map1, double *t2, const int *map2) {
     if (k <= 0) return;

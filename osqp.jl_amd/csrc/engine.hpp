@@ -88,6 +88,10 @@ struct Engine {
   DevCsr A, At, Pf;
   DevBuf<int> A_k2pos, P_k2lo, P_k2up;
   // compact mode (compact_matrices): the same maps as positions in the sliced-ELL value arrays (0xFFFFFFFF: none)
+  // the caller handed over columns of A whose row indices do not ascend (libosqp accepts that; the panel layout and the
+  // CSR view of A' need them sorted): the workspace was built from a sorted copy, and osqp_update_A translates the caller's
+  // nnz indices through this map (caller index -> index in the sorted copy); empty otherwise
+  std::vector<int64_t> A_to_sorted;
   // row-sharded workspaces: the caller's nnz index of every entry of this rank's blocks (osqp_update_P / _A pick their new values by it)
   DevBuf<int> At_org, A_org, Pf_org;
   DevBuf<uint32_t> At_k2slot;  // slot of A' entry k in its sliced copy; A and P keep theirs in A_k2pos / P_k2lo / P_k2up (compact_one)

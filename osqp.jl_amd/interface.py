@@ -119,9 +119,9 @@ class ManagedCcsc:
     """[REF src/types.jl:21-47]  0-based CSC arrays with Cc_int indices, kept alive
     for the duration of the call; nz = -1 marks compressed-column form."""
 
-    def __init__(self, M):
+    def __init__(self, M, canonical=True):
         M = sp.csc_matrix(M)
-        if not M.has_canonical_format:
+        if canonical and not M.has_canonical_format:
             # rows of a column ascending and unique, as a Julia SparseMatrixCSC always is (the library refuses anything else
             # with exit flag 1); on a copy: sp.csc_matrix(M) of a CSC input shares the caller's arrays
             M = M.copy()
@@ -199,9 +199,11 @@ def _istriu(P):
     return not np.any(P.indices > cols)
 
 
-def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, **settings):
+def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, keep_A_order=False, **settings):
     """[REF src/interface.jl:35-162].  Extension: `comm` (sharded.HostComm / sharded.RcclComm) makes this rank keep
-    its row block of one QP shared by all ranks of the communicator (osqp_amd_setup_sharded)."""
+    its row block of one QP shared by all ranks of the communicator (osqp_amd_setup_sharded).  `keep_A_order` (tests): the
+    CSC arrays of A go to the library as they are, rows of a column in the caller's order (a plain-C caller of libosqp may
+    hand them over unsorted; Julia's SparseMatrixCSC never does)."""
     if P is None:
         if q is not None:
             n = len(q)
@@ -241,7 +243,7 @@ def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, **settings):
     model.lcache = np.empty(m)
     model.ucache = np.empty(m)
     managedP = ManagedCcsc(P)
-    managedA = ManagedCcsc(sp.csc_matrix(A))
+    managedA = ManagedCcsc(sp.csc_matrix(A), canonical=not keep_A_order)
     stgs = make_settings(model.lib, settings)
     data = T.Data(n, m, C.pointer(managedP.ccsc), C.pointer(managedA.ccsc), _fptr(q), _fptr(l), _fptr(u))
     workspace = T.Workspace_p()

@@ -461,3 +461,51 @@ def test_polish_on_a_compact_workspace(product_lib, oracle_lib, monkeypatch):
     assert rg.info.pri_res < 1e-3 * r0.info.pri_res + 1e-9 and rg.info.dua_res < 1e-3 * r0.info.dua_res + 1e-8
     assert rg.info.obj_val <= r0.info.obj_val + 1e-3 * abs(r0.info.obj_val)
     oq.clean(mg); oq.clean(m0)
+
+
+@pytest.mark.parametrize("linsys", ["qdldl", "pcg"])
+def test_unsorted_columns_of_A_are_accepted_as_libosqp_accepts_them(product_lib, linsys):
+    """Boundary [REF src/interface.jl:132-155 hands csc arrays over verbatim]: libosqp takes the rows of a column of A in any
+    order; until round 3 this library answered exit flag 1.  Now the setup is repeated on a sorted host copy and
+    osqp_update_A translates the caller's nnz indices: the workspace built from shuffled columns gives bit for bit the
+    results of the one built from sorted columns, before and after updates by index and in full."""
+    rng = np.random.default_rng(11)
+    n, m = 60, 90
+    A = sp.random(m, n, density=0.15, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    A.sort_indices()
+    M = sp.random(n, n, density=0.1, random_state=rng, data_rvs=rng.standard_normal)
+    P = sp.triu(M @ M.T + 0.1 * sp.eye(n), format="csc")
+    q = rng.standard_normal(n)
+    l, u = -rng.random(m), rng.random(m)
+    # the same matrix with the entries of every column in a random order, and where each sorted entry went
+    perm = np.concatenate([A.indptr[j] + rng.permutation(A.indptr[j + 1] - A.indptr[j]) for j in range(n)])
+    Ash = sp.csc_matrix((A.data[perm], A.indices[perm], A.indptr.copy()), shape=A.shape)
+    assert not Ash.has_sorted_indices
+    pos_of_sorted = np.empty_like(perm)
+    pos_of_sorted[perm] = np.arange(len(perm))  # shuffled position of sorted entry k
+    opts = dict(verbose=False, eps_abs=1e-7, eps_rel=1e-7, adaptive_rho_interval=25, max_iter=8000, linsys_solver=linsys)
+    ms, mu = oq.Model(product_lib), oq.Model(product_lib)
+    oq.setup(ms, P=P, q=q, A=A, l=l, u=u, **opts)
+    oq.setup(mu, P=P, q=q, A=Ash, l=l, u=u, keep_A_order=True, **opts)
+    rs, ru = oq.solve(ms), oq.solve(mu)
+    assert rs.info.status == ru.info.status == "Solved" and rs.info.iter == ru.info.iter
+    assert np.array_equal(rs.x, ru.x) and np.array_equal(rs.y, ru.y)
+    # by index: sorted entries k get new values; the same entries in the caller's (shuffled) numbering
+    k = rng.choice(A.nnz, size=40, replace=False).astype(np.int64)
+    newv = rng.standard_normal(40)
+    oq.update_A(ms, newv, k)
+    oq.update_A(mu, newv, pos_of_sorted[k].astype(np.int64))
+    rs, ru = oq.solve(ms), oq.solve(mu)
+    assert rs.info.status == ru.info.status and rs.info.iter == ru.info.iter and np.array_equal(rs.x, ru.x)
+    # in full: values in each model's own entry order
+    full = A.data * 1.3
+    oq.update_A(ms, full, None)
+    oq.update_A(mu, full[perm], None)
+    rs, ru = oq.solve(ms), oq.solve(mu)
+    assert rs.info.status == ru.info.status and rs.info.iter == ru.info.iter and np.array_equal(rs.x, ru.x)
+    # a column that holds a row twice stays refused
+    dup = sp.csc_matrix((np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1]), np.array([0, 3] + [3] * (n - 1))), shape=(m, n))
+    md = oq.Model(product_lib)
+    with pytest.raises(oq.OSQPError):
+        oq.setup(md, P=P, q=q, A=dup, l=l, u=u, keep_A_order=True, **opts)
+    oq.clean(ms); oq.clean(mu)
