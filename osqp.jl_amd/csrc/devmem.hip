@@ -166,11 +166,12 @@ bool vm_free(void *p) {
   auto it = g_vm.find(p);
   if (it == g_vm.end()) return false;
   VmBlock &b = it->second;
-  // the range disappears at once: everything queued on ITS device that may touch it has to be through (hipFree waits too)
+  // the range disappears at once: everything queued on ITS device that may touch it has to be through (hipFree waits too).
+  // dev_free has drained the device BEFORE taking the allocator's lock (vm_drain), so that other threads' allocations do
+  // not wait behind a device drain.
   int cur = b.dev;
   (void)hipGetDevice(&cur);
   if (cur != b.dev) (void)hipSetDevice(b.dev);
-  (void)hipDeviceSynchronize();
   hipError_t e1 = hipMemUnmap(p, b.size);
   if (cur != b.dev) (void)hipSetDevice(cur);
   if (e1 != hipSuccess) fprintf(stderr, "[osqp-amd] hipMemUnmap: %s\n", hipGetErrorString(e1));
@@ -244,8 +245,25 @@ static void *dev_alloc_raw(size_t bytes, size_t &granted) {
   return p;
 }
 
+// a mapped block is about to be unmapped: wait, outside the lock, for the work queued on its device
+static void vm_drain(void *p) {
+  int dev = -1;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_vm.find(p);
+    if (it != g_vm.end()) dev = it->second.dev;
+  }
+  if (dev < 0) return;
+  int cur = dev;
+  (void)hipGetDevice(&cur);
+  if (cur != dev) (void)hipSetDevice(dev);
+  (void)hipDeviceSynchronize();
+  if (cur != dev) (void)hipSetDevice(cur);
+}
+
 void dev_free(void *p, size_t granted) {
   if (!p) return;
+  vm_drain(p);
   std::lock_guard<std::mutex> lock(g_mu);
   const double t0 = wall_now();
   if (vm_free(p)) {

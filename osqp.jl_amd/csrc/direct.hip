@@ -1123,7 +1123,7 @@ struct LdlFactor {
     e.setup_mark("  host pattern");
     // OSQP_AMD_FIRST_ORDERING=1: nested dissection at once (a caller who knows the problem is a long banded one saves the
     // min-degree analysis that would only establish that: ~half of the setup of the control-1e6 bench workload)
-    static const int first_ordering = getenv("OSQP_AMD_FIRST_ORDERING") ? atoi(getenv("OSQP_AMD_FIRST_ORDERING")) : 0;
+    const int first_ordering = getenv("OSQP_AMD_FIRST_ORDERING") ? atoi(getenv("OSQP_AMD_FIRST_ORDERING")) : 0;  // read per setup: a process may set up problems of both kinds
     symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S);
     e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
@@ -1744,7 +1744,7 @@ int polish_run(Engine &e) {
   // the reduced KKT system is assembled from the CSR arrays, which a compact workspace has released: iterative form (pcg.hip)
   // OSQP_AMD_POLISH_ITERATIVE=1 (tests): the iterative form wherever the indirect back-end runs, so that it can be compared
   // with a factorisation-based polish on problems small enough to have one
-  static const bool force_iterative = getenv("OSQP_AMD_POLISH_ITERATIVE") && atoi(getenv("OSQP_AMD_POLISH_ITERATIVE")) != 0;
+  const bool force_iterative = getenv("OSQP_AMD_POLISH_ITERATIVE") && atoi(getenv("OSQP_AMD_POLISH_ITERATIVE")) != 0;
   if (e.compact || e.comm || (force_iterative && e.lin && e.lin->kind() == 2)) return polish_run_pcg(e);  // a row block has no reduced KKT matrix either
   hipStream_t s = e.stream;
   const int n = e.n, m = e.m;

@@ -243,7 +243,7 @@ def setup(model, P=None, q=None, A=None, l=None, u=None, comm=None, keep_A_order
     model.lcache = np.empty(m)
     model.ucache = np.empty(m)
     managedP = ManagedCcsc(P)
-    managedA = ManagedCcsc(sp.csc_matrix(A), canonical=not keep_A_order)
+    managedA = ManagedCcsc(sp.csc_matrix(A), canonical=False) if keep_A_order else ManagedCcsc(sp.csc_matrix(A))
     stgs = make_settings(model.lib, settings)
     data = T.Data(n, m, C.pointer(managedP.ccsc), C.pointer(managedA.ccsc), _fptr(q), _fptr(l), _fptr(u))
     workspace = T.Workspace_p()
