@@ -5,7 +5,7 @@ affine constraints) with 17 exclusions -- everything that needs infeasibility-ce
 attributes OSQP does not carry.  MathOptInterface is a dependency of the reference, not part of it, and is not in this image;
 the cases below restate, by the names MathOptInterface gives them, the known-answer problems of that suite which OSQP's
 wrapper can express and which the reference does not exclude: the linear and quadratic integration problems, the
-modification tests, the objective tests.  Every expected value is the suite's published one AND is re-derived here with scipy
+modification tests, the objective tests, the conic-linear family over Zeros / Nonnegatives / Nonpositives (round 4).  Every expected value is the suite's published one AND is re-derived here with scipy
 (`linprog` for the LPs, an SLSQP solve for the QPs) before the wrapper's answer is compared with it -- so a mis-remembered
 number cannot pass silently.  Tolerances: MOI.Test.Config(atol = 1e-4, rtol = 1e-4) [REF test/MOI_wrapper.jl:28-39].
 Every case takes the loaded C-ABI library: the CPU oracle in the CPU suite, the HIP engine in the GPU suite."""
@@ -640,5 +640,127 @@ def case_objective_ObjectiveSense_MAX_and_MIN(lib):
     m.set_objective_sense(MOI.MIN_SENSE)
     opt, idx = solve(lib, m)
     expect_optimal(opt, idx, 0, [0, 0], [x, y])
+
+# ------------------------------------------------------------------------------------------------ conic linear (round 4)
+# MathOptInterface's `test_conic_linear_*` family: the vector sets OSQP's wrapper supports (Zeros, Nonnegatives, Nonpositives over
+# VectorAffineFunction [REF src/MOI_wrapper.jl:31-36]).  The suite's VectorOfVariables variants reach the wrapper through the
+# bridge optimizer as the same affine functions with identity coefficients, which is how they are stated here.
+def vaf(rows, constants):
+    """rows: list of (row, coef, variable)"""
+    return MOI.VectorAffineFunction([MOI.VectorAffineTerm(r, term(c, v)) for r, c, v in rows], list(constants))
+
+
+def _lin1(m, x, y, z):
+    c_eq = m.add_constraint(vaf([(1, 1.0, x), (1, 1.0, y), (1, 1.0, z), (2, 1.0, y), (2, 1.0, z)], [-3.0, -2.0]), MOI.Zeros(2))
+    c_nn = m.add_constraint(vaf([(1, 1.0, x), (2, 1.0, y), (3, 1.0, z)], [0.0, 0.0, 0.0]), MOI.Nonnegatives(3))
+    m.set_objective_function(saf([-3.0, -2.0, -4.0], [x, y, z]))
+    m.set_objective_sense(MOI.MIN_SENSE)
+    return c_eq, c_nn
+
+
+def case_conic_linear_VectorAffineFunction(lib):
+    """min -3x - 2y - 4z  s.t.  x + y + z = 3, y + z = 2 (Zeros), x, y, z >= 0 (Nonnegatives)  ->  -11 at (1, 0, 2); duals
+    (-3, -1) on the equalities and (0, 2, 0) on the cone -- re-derived from linprog's marginals."""
+    r = linprog([-3, -2, -4], A_eq=[[1, 1, 1], [0, 1, 1]], b_eq=[3, 2], bounds=[(0, None)] * 3, method="highs")
+    assert r.status == 0 and approx(r.fun, -11) and approx(r.x, [1, 0, 2])
+    assert approx(r.eqlin.marginals, [-3, -1]) and approx(r.lower.marginals, [0, 2, 0])
+    m = MOI.Model()
+    x, y, z = m.add_variables(3)
+    c_eq, c_nn = _lin1(m, x, y, z)
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, -11, [1, 0, 2], [x, y, z], duals=[(c_eq, [-3, -1]), (c_nn, [0, 2, 0])])
+
+
+def case_conic_linear_VectorOfVariables(lib):
+    """The same problem as the suite states it with [x, y, z] in Nonnegatives(3) as a vector of variables (bridged: identity
+    coefficients, zero constants), solved twice on one optimizer (the suite re-optimizes after reading the results)."""
+    m = MOI.Model()
+    x, y, z = m.add_variables(3)
+    c_eq, c_nn = _lin1(m, x, y, z)
+    opt, idx = solve(lib, m)
+    opt.optimize()
+    expect_optimal(opt, idx, -11, [1, 0, 2], [x, y, z], duals=[(c_eq, [-3, -1]), (c_nn, [0, 2, 0])])
+    assert opt.result_count() == 1
+
+
+def case_conic_linear_VectorAffineFunction_2(lib):
+    """min 3x + 2y - 4z + 0s  s.t.  x - s = -4, y = -3, x + z = 12 (Zeros, one row each), y <= 0 (Nonpositives), z >= 0
+    (Nonnegatives), s = 0 (Zeros)  ->  -82 at (x, y, z, s) = (-4, -3, 16, 0)."""
+    r = linprog([3, 2, -4, 0], A_eq=[[1, 0, 0, -1], [0, 1, 0, 0], [1, 0, 1, 0], [0, 0, 0, 1]], b_eq=[-4, -3, 12, 0],
+                bounds=[(None, None), (None, 0), (0, None), (None, None)], method="highs")
+    assert r.status == 0 and approx(r.fun, -82) and approx(r.x, [-4, -3, 16, 0])
+    m = MOI.Model()
+    x, y, z, s = m.add_variables(4)
+    m.add_constraint(vaf([(1, 1.0, x), (1, -1.0, s)], [4.0]), MOI.Zeros(1))
+    m.add_constraint(vaf([(1, 1.0, y)], [3.0]), MOI.Zeros(1))
+    m.add_constraint(vaf([(1, 1.0, x), (1, 1.0, z)], [-12.0]), MOI.Zeros(1))
+    m.add_constraint(vaf([(1, 1.0, y)], [0.0]), MOI.Nonpositives(1))
+    m.add_constraint(vaf([(1, 1.0, z)], [0.0]), MOI.Nonnegatives(1))
+    m.add_constraint(vaf([(1, 1.0, s)], [0.0]), MOI.Zeros(1))
+    m.set_objective_function(saf([3.0, 2.0, -4.0, 0.0], [x, y, z, s]))
+    m.set_objective_sense(MOI.MIN_SENSE)
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, -82, [-4, -3, 16, 0], [x, y, z, s])
+
+
+def _expect_infeasible(opt):
+    assert opt.termination_status() in (MOI.INFEASIBLE, MOI.ALMOST_INFEASIBLE)
+    assert opt.primal_status() in (MOI.NO_SOLUTION, MOI.UNKNOWN_RESULT_STATUS)
+    assert opt.dual_status() in (MOI.INFEASIBILITY_CERTIFICATE, MOI.NEARLY_INFEASIBILITY_CERTIFICATE)
+
+
+def case_conic_linear_INFEASIBLE(lib):
+    """min 0  s.t.  x - 1 in Nonnegatives, x + 1 in Nonpositives: x >= 1 and x <= -1."""
+    m = MOI.Model()
+    (x,) = m.add_variables(1)
+    m.add_constraint(vaf([(1, 1.0, x)], [-1.0]), MOI.Nonnegatives(1))
+    m.add_constraint(vaf([(1, 1.0, x)], [1.0]), MOI.Nonpositives(1))
+    opt, _ = solve(lib, m)
+    _expect_infeasible(opt)
+
+
+def case_conic_linear_INFEASIBLE_2(lib):
+    """min 0  s.t.  x - 1 in Nonnegatives, [x] in Nonpositives: x >= 1 and x <= 0."""
+    m = MOI.Model()
+    (x,) = m.add_variables(1)
+    m.add_constraint(vaf([(1, 1.0, x)], [-1.0]), MOI.Nonnegatives(1))
+    m.add_constraint(vaf([(1, 1.0, x)], [0.0]), MOI.Nonpositives(1))
+    opt, _ = solve(lib, m)
+    _expect_infeasible(opt)
+
+
+# --------------------------------------------------------------------------------------- quadratic objective edge cases (round 4)
+def _qp_edge(lib, qterms, obj, xs):
+    """x^2 + y^2 (+ what the caller adds) over x >= 1, y >= 2, the objective given as the list of quadratic terms
+    (MathOptInterface's convention: 1/2 x'Qx, a diagonal term c x_i x_i contributes c / 2 x_i^2)."""
+    m = MOI.Model()
+    x, y = m.add_variables(2)
+    m.add_constraint(saf([1], [x]), MOI.GreaterThan(1.0))
+    m.add_constraint(saf([1], [y]), MOI.GreaterThan(2.0))
+    m.set_objective_function(MOI.ScalarQuadraticFunction([term(c, (x, y)[a], (x, y)[b]) for c, a, b in qterms], [], 0.0))
+    m.set_objective_sense(MOI.MIN_SENSE)
+    opt, idx = solve(lib, m)
+    expect_optimal(opt, idx, obj, xs, [x, y])
+
+
+def case_objective_qp_ObjectiveFunction_edge_cases(lib):
+    """x^2 + y^2 over x >= 1, y >= 2 stated four ways: plainly, with the diagonal term of x split in two, with the cross term
+    as two entries that cancel, and with a cross term given twice (x^2 + xy + y^2: the bounds stay active, 1 + 2 + 4)."""
+    cons = [dict(type="ineq", fun=lambda v: v[0] - 1), dict(type="ineq", fun=lambda v: v[1] - 2)]
+    ref, xr = qp_reference(np.diag([2.0, 2.0]), np.zeros(2), cons, np.array([2.0, 3.0]))
+    assert approx(ref, 5) and approx(xr, [1, 2])
+    ref2, xr2 = qp_reference(np.array([[2.0, 1.0], [1.0, 2.0]]), np.zeros(2), cons, np.array([2.0, 3.0]))
+    assert approx(ref2, 7) and approx(xr2, [1, 2])
+    _qp_edge(lib, [(2.0, 0, 0), (2.0, 1, 1)], 5, [1, 2])
+    _qp_edge(lib, [(1.0, 0, 0), (1.0, 0, 0), (2.0, 1, 1)], 5, [1, 2])
+    _qp_edge(lib, [(2.0, 0, 0), (0.25, 0, 1), (-0.25, 1, 0), (2.0, 1, 1)], 5, [1, 2])
+    _qp_edge(lib, [(2.0, 0, 0), (0.5, 0, 1), (0.5, 1, 0), (2.0, 1, 1)], 7, [1, 2])
+
+
+def case_objective_qp_ObjectiveFunction_zero_ofdiag(lib):
+    """The same objective with an EXPLICIT zero off-diagonal term: the wrapper keeps the zero in the pattern of P [REF
+    src/MOI_wrapper.jl:151-182] and the answer is unchanged."""
+    _qp_edge(lib, [(2.0, 0, 0), (0.0, 0, 1), (2.0, 1, 1)], 5, [1, 2])
+
 
 ALL = [f for name, f in sorted(globals().items()) if name.startswith("case_") and callable(f)]
