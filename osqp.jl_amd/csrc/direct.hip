@@ -61,12 +61,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter_A(int64_t nnz, const int64_t
 __global__ __launch_bounds__(kBlock) void k_ldl_entries(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                         double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                         const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                        const double *__restrict__ D, const double *__restrict__ Dinv) {
+                                                        const double *__restrict__ D, const double *__restrict__ Dinv,
+                                                        const int *__restrict__ Lcol) {
   const int64_t e = Lp[c0] + (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= Lp[c1]) return;
-  int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
-  const int k = lo, i = Li[e];
+  const int k = Lcol[e], i = Li[e];  // the entry's column from a table built once (a bisection in Lp was ~8 dependent loads per entry)
   int64_t a = Rp[i], ae = Rp[i + 1], b = Rp[k], be = Rp[k + 1];
   double acc = 0.0;
   while (a < ae && b < be) {
@@ -162,16 +161,15 @@ template <int G>  // lanes per entry: 64 on narrow levels (all latency), 16 on w
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_bs(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                            double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                            const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                           const double *__restrict__ D, const double *__restrict__ Dinv) {
+                                                           const double *__restrict__ D, const double *__restrict__ Dinv,
+                                                           const int *__restrict__ Lcol) {
   const int lane = threadIdx.x & (G - 1);
   const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
   const bool live = e < Lp[c1];  // all lanes of a group agree; dead groups still take part in the shuffles
   double acc = 0.0;
   int k = c0;
   if (live) {
-    int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
-    k = lo;
+    k = Lcol[e];
     const int i = Li[e];
     int64_t a0 = Rp[i], a1 = Rp[i + 1], b0 = Rp[k], b1 = Rp[k + 1];
     if (a1 - a0 > b1 - b0) { int64_t t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }  // [a0, a1): the shorter row
@@ -190,13 +188,12 @@ __global__ __launch_bounds__(kBlock) void k_ldl_entries_bs(int c0, int c1, const
 __global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
                                                           double *__restrict__ Lx, const int64_t *__restrict__ Rp,
                                                           const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                          const double *__restrict__ W, const double *__restrict__ Dinv) {
+                                                          const double *__restrict__ W, const double *__restrict__ Dinv,
+                                                          const int *__restrict__ Lcol) {
   const int lane = threadIdx.x & 63;
   const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
   if (e >= Lp[c1]) return;
-  int lo = c0, hi = c1;  // column k with Lp[k] <= e < Lp[k+1]
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
-  const int k = lo, i = Li[e];
+  const int k = Lcol[e], i = Li[e];
   const double *w = W + (size_t)(k - c0) * N;
   double acc = 0.0;
   for (int64_t q = Rp[i] + lane; q < Rp[i + 1]; q += 64) {
@@ -1086,7 +1083,7 @@ struct LdlFactor {
   int N = 0, n = 0, mr = 0, nlev = 0;
   double sigma = 0, cconst = 0;
   DevBuf<int64_t> Lp, Rp, Rmap, PtoL, AtoL, Rsplit, Lsplit;
-  DevBuf<int> Li, Rj, perm, pinv, level_ptr, status;
+  DevBuf<int> Li, Lcol, Rj, perm, pinv, level_ptr, status;
   DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2, gjT, gjW, gjC;  // gj*: pivot block, row panel and panel copy of the block sweeps
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
@@ -1154,6 +1151,8 @@ struct LdlFactor {
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
     up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
     up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
+    Lcol.alloc(std::max<size_t>(1, (size_t)S.nnzL));  // the column of every entry of L: what the entry kernels of the factorisation start from
+    expand_colptr(N, Lp.get(), S.nnzL, Lcol.get(), s);
     Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
     choose_dense_block();
     choose_supernodes();
@@ -1390,20 +1389,20 @@ struct LdlFactor {
       p0 = p1 = 0;
       if (through_w) {
         OQ_LAUNCH(k_ldl_entries_w, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, N, Lp.get(), Li.get(), Lx.get(),
-                  Rp.get(), Rj.get(), Rmap.get(), wf, Dinv.get());
+                  Rp.get(), Rj.get(), Rmap.get(), wf, Dinv.get(), (const int *)Lcol.get());
         p0 = c0; p1 = c1; half ^= 1;
       } else if (entries > 0) {
         // long rows, too many columns for work rows: a wavefront per entry, bisection instead of the merge
         const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)std::max(1, c1 - c0);
         if (mean >= long_row_mean() && entries <= ((int64_t)1 << 18))  // few entries: the level is latency, not throughput
           OQ_LAUNCH(k_ldl_entries_bs<64>, dim3(blocks_for(entries * 64)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
-                    Rj.get(), Rmap.get(), D.get(), Dinv.get());
+                    Rj.get(), Rmap.get(), D.get(), Dinv.get(), (const int *)Lcol.get());
         else if (mean >= long_row_mean() && entries * 16 < ((int64_t)1 << 31))
           OQ_LAUNCH(k_ldl_entries_bs<16>, dim3(blocks_for(entries * 16)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
-                    Rj.get(), Rmap.get(), D.get(), Dinv.get());
+                    Rj.get(), Rmap.get(), D.get(), Dinv.get(), (const int *)Lcol.get());
         else
           OQ_LAUNCH(k_ldl_entries, dim3(blocks_for(entries)), dim3(kBlock), 0, s, c0, c1, Lp.get(), Li.get(), Lx.get(), Rp.get(),
-                    Rj.get(), Rmap.get(), D.get(), Dinv.get());
+                    Rj.get(), Rmap.get(), D.get(), Dinv.get(), (const int *)Lcol.get());
       }
     }
     if (p1 > p0)  // the last work rows
