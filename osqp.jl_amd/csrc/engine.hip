@@ -853,9 +853,18 @@ int Engine::admm_step() {
 // A chunk = `check_termination` iterations of the direct back-end (no host round trip inside), captured once
 // in a hipGraph and replayed: removes the per-launch host cost that dominates problems whose iteration is a
 // few short kernels.  Only when nothing has to happen between two residual evaluations.
+// iterations per chunk: the distance between two residual evaluations; with the evaluations switched off
+// (check_termination = 0 [REF test/basic.jl:168-171]) the adaptive-rho interval, or 50 -- nothing else happens between iterations
+int Engine::chunk_k() const {
+  const long long k = st.check_termination;
+  if (k >= 2) return (int)k;
+  if (k != 0) return 0;
+  if (!st.adaptive_rho) return 50;
+  return st.adaptive_rho_interval > 1 ? (int)std::min<long long>(st.adaptive_rho_interval, 100) : 0;
+}
 bool Engine::can_chunk(long long iter, long long max_iter) const {
   static const bool enabled = !(getenv("OSQP_AMD_GRAPH") && atoi(getenv("OSQP_AMD_GRAPH")) == 0);
-  const long long k = st.check_termination;
+  const long long k = chunk_k();
   if (!enabled || g_debug_sync || lin->kind() != 0 || k < 2 || st.verbose || st.time_limit != 0.0) return false;
   if ((iter - 1) % k != 0 || iter + k - 1 > max_iter) return false;
   if (st.adaptive_rho && (st.adaptive_rho_interval == 0 || st.adaptive_rho_interval % k != 0)) return false;
@@ -871,7 +880,7 @@ void Engine::settings_changed() {
 }
 
 void Engine::run_chunk() {
-  const int k = (int)st.check_termination;
+  const int k = chunk_k();
   if (chunk_exec && chunk_len != k) { (void)hipGraphExecDestroy(chunk_exec); chunk_exec = nullptr; }
   if (!chunk_exec) {
     hipGraph_t graph = nullptr;
@@ -1159,7 +1168,7 @@ int Engine::solve_attempt(bool restarted) {
     }
     if (can_chunk(iter, max_iter)) {
       run_chunk();
-      iter += st.check_termination - 1;
+      iter += chunk_k() - 1;
     } else if (admm_step()) {  // negative curvature in the indirect solve
       update_status(info, OSQP_NON_CVX); info->obj_val = NAN; info->iter = iter;
       break;
@@ -1235,7 +1244,7 @@ int Engine::iterate(long long iters) {
   tic();
   lin->set_guess(x.get());
   for (long long it = 1; it <= iters; it++) {
-    if (can_chunk(it, iters)) { run_chunk(); it += st.check_termination - 1; }
+    if (can_chunk(it, iters)) { run_chunk(); it += chunk_k() - 1; }
     else admm_step();
     if (st.check_termination && (it % st.check_termination == 0)) update_info(it, false);
   }

@@ -169,6 +169,7 @@ struct Engine {
   int solve();
   int iterate(long long iters);
   int admm_step();
+  int chunk_k() const;
   bool can_chunk(long long iter, long long max_iter) const;
   void run_chunk();
   // The captured chunk bakes the scalar launch arguments (alpha, sigma) and the kernel choice into its nodes:
