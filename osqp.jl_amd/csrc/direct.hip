@@ -1199,6 +1199,7 @@ struct LdlFactor {
     const int mode = getenv("OSQP_AMD_SNODE") ? atoi(getenv("OSQP_AMD_SNODE")) : 1;
     if (mode == 0 || N < 2) return;
     if (mode != 2 && nlev < 48) return;
+    if (mode != 2 && kD > 0 && lD < 48) return;  // the depth IS the dense block: the few levels below it stay a level schedule (no partition to build)
     int smax = kSnMax;  // OSQP_AMD_SNODE_MAX: smaller supernodes (tests: many levels on small problems)
     if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
     build_supernodes(S, smax, T);

@@ -487,7 +487,9 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   // writes the CSC row lists (ascending: blocks and rows in order), and the CSR view with the CSC position of every entry
   // (row k: columns ascending after a sort of its small buffer), without any two threads touching the same slot.
   const int nt4 = host_threads(cp[N] * 8);
-  const int nblk = nt4 == 1 ? 1 : 2 * nt4;
+  // more blocks than threads, dealt through a counter: the rows of a factor with a dense block differ in length by orders of
+  // magnitude (a block holds one count per column: N ints, which bounds how many a long problem can afford)
+  const int nblk = nt4 == 1 ? 1 : std::max(2 * nt4, std::min(8 * nt4, (int)(((int64_t)1 << 27) / std::max(1, N))));
   {
     std::vector<std::vector<int>> blk_cols(nblk), blk_cnt(nblk);
     std::vector<int> rowlen(N, 0);
@@ -531,17 +533,39 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
       const std::vector<int> &cols = blk_cols[b];
       std::vector<int> &off = blk_cnt[b];
       std::vector<std::pair<int, int64_t>> rowbuf;
+      std::vector<uint64_t> bits;  // long rows (a dense block: thousands of columns) come out ascending from a bitmap, not a sort
       size_t c = 0;
       for (int k = k0; k < k1; k++) {
+        const int len = rowlen[k];
+        int64_t w = S.Rp[k];
+        if (len > 64 && (int64_t)len * 32 > k) {
+          if (bits.empty()) bits.assign((size_t)N / 64 + 1, 0);
+          int lo = N, hi = -1;
+          for (int e = 0; e < len; e++) {
+            const int i = cols[c++];
+            bits[(size_t)i >> 6] |= (uint64_t)1 << (i & 63);
+            lo = std::min(lo, i); hi = std::max(hi, i);
+          }
+          for (int wd = lo >> 6; wd <= hi >> 6; wd++) {
+            uint64_t b = bits[(size_t)wd];
+            bits[(size_t)wd] = 0;
+            while (b) {
+              const int i = wd * 64 + __builtin_ctzll(b);
+              b &= b - 1;
+              const int64_t t = S.Lp[i] + off[i]++;
+              S.Li[t] = k; S.Rj[w] = i; S.Rmap[w] = t; w++;
+            }
+          }
+          continue;
+        }
         rowbuf.clear();
-        for (int e = 0; e < rowlen[k]; e++) {
+        for (int e = 0; e < len; e++) {
           const int i = cols[c++];
           const int64_t t = S.Lp[i] + off[i]++;
           S.Li[t] = k;
           rowbuf.emplace_back(i, t);
         }
         std::sort(rowbuf.begin(), rowbuf.end());
-        int64_t w = S.Rp[k];
         for (const auto &e : rowbuf) { S.Rj[w] = e.first; S.Rmap[w] = e.second; w++; }
       }
     });
