@@ -111,6 +111,43 @@ c_int pcg_solve(pcg_solver *s, c_float *b, c_float tol_abs) {
     rz += s->r[j] * s->z[j];
   }
   c_int status = 0;
+  /* EXPERIMENT (OSQP_ORACLE_PCG_SINGLE_REDUCTION=1; not the statement the HIP path is checked against): the recurrence of
+   * Chronopoulos & Gear -- one product (of u = M^-1-preconditioned r, not of p) and ONE reduction point per iteration
+   * (gamma = r'u and delta = w'u together) instead of two (p'w, then r'z).  On the device it would fold two vector
+   * kernels of a CG iteration into one.  Used by tools/cg_recurrence_counts.py to answer what the recurrence costs in CG
+   * iterations on the bench matrices (profiles/r04_cg_recurrence_counts.md). */
+  {
+    const char *sr = getenv("OSQP_ORACLE_PCG_SINGLE_REDUCTION");
+    if (sr && atoi(sr) == 1) {
+      c_float *u = s->z, *q = (c_float *)malloc(sizeof(c_float) * (size_t)(n > 0 ? n : 1));  /* q = M p, carried */
+      c_float gamma = rz, gamma_old = 0.0, alpha = 0.0, delta;
+      int first = 1;
+      while (it < s->max_iter) {
+        if (vec_norm_inf(s->r, n) <= tol_abs) break;
+        apply_M(s, u, s->w);                       /* w = M u */
+        delta = vec_prod(s->w, u, n);              /* the one reduction point: gamma (carried from the update) and delta */
+        c_float beta = first ? 0.0 : gamma / gamma_old;
+        c_float denom = first ? delta : delta - beta * gamma / alpha;
+        if (!(denom > 0.0)) { status = -1; break; }
+        alpha = gamma / denom;
+        c_float gamma_new = 0.0;
+        for (j = 0; j < n; j++) {
+          s->p[j] = first ? u[j] : u[j] + beta * s->p[j];
+          q[j] = first ? s->w[j] : s->w[j] + beta * q[j];
+          s->x[j] += alpha * s->p[j];
+          s->r[j] -= alpha * q[j];
+        }
+        for (j = 0; j < n; j++) { u[j] = s->dinv[j] * s->r[j]; gamma_new += s->r[j] * u[j]; }
+        gamma_old = gamma; gamma = gamma_new; first = 0;
+        it++;
+      }
+      free(q);
+      s->total_iters += it;
+      for (j = 0; j < n; j++) b[j] = s->x[j];
+      mat_vec(s->A, s->x, b + n, 0);
+      return status < 0 ? -1 - it : it;
+    }
+  }
   while (it < s->max_iter) {
     if (vec_norm_inf(s->r, n) <= tol_abs) break;
     apply_M(s, s->p, s->w);
