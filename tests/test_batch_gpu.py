@@ -172,3 +172,45 @@ def test_batch_detects_infeasible_instance(product_lib, oracle_lib):
     P, qq, A, _, _ = probs[2]
     oq.setup(m, P=P, q=qq, A=A, l=l[2], u=u[2], **OPTS)
     assert oq.solve(m).info.status.startswith("Primal_infeasible")
+
+
+SETTINGS_VARIANTS = [
+    dict(scaling=0),
+    dict(scaled_termination=1),
+    dict(adaptive_rho=0),
+    dict(alpha=1.0, rho=1.0, sigma=1e-4),
+    dict(check_termination=10, adaptive_rho_interval=30),
+    dict(max_iter=40),
+    dict(eps_abs=1e-8, eps_rel=1e-8),
+    dict(scaling=3, adaptive_rho_tolerance=2.0, rho=0.01),
+]
+
+
+@pytest.mark.parametrize("variant", range(len(SETTINGS_VARIANTS)))
+def test_mpc_batch_follows_the_settings_as_the_oracle_does(product_lib, oracle_lib, variant):
+    """Round 4: the four-wavefront kernel (csrc/batch_quad.hpp) under settings other than the bench's -- no scaling, scaled
+    termination, no / eager rho adaptation, other alpha / rho / sigma, a check interval that does not divide the adaptation
+    interval, an iteration limit that is hit, tight tolerances: status and iteration count of every instance are the CPU
+    oracle's (iteration counts within one check), solutions within the requested accuracy."""
+    opts = dict(OPTS)
+    opts.update(SETTINGS_VARIANTS[variant])
+    count = 8
+    probs = _mpc_instances(oracle_lib, 40, count, 3)
+    P0, _, A0, _, _ = probs[0]
+    Px = np.array([sp.triu(p[0]).tocsc().data for p in probs]); Ax = np.array([p[2].data for p in probs])
+    q = np.array([p[1] for p in probs]); l = np.array([p[3] for p in probs]); u = np.array([p[4] for p in probs])
+    x, y, info = batch.solve_batch(product_lib, P0, A0, Px, Ax, q, l, u, **opts)
+    check = int(opts.get("check_termination", 25))
+    for i, (P, qq, A, ll, uu) in enumerate(probs):
+        m = oq.Model(oracle_lib)
+        oq.setup(m, P=P, q=qq, A=A, l=ll, u=uu, **opts)
+        r = oq.solve(m)
+        assert int(info[i, 1]) == r.info.status_val, (variant, i, info[i, :2], r.info.status)
+        assert abs(r.info.iter - info[i, 0]) <= check, (variant, i, info[i, 0], r.info.iter)
+        if r.info.status_val in (1, 2):
+            tol = 50 * max(opts["eps_abs"], 1e-7) if r.info.status_val == 1 else 1e-2
+            if opts.get("max_iter", 4000) < 100:
+                tol = 5e-2  # stopped early on both sides: the iterates agree as far as the trajectories do
+            assert np.max(np.abs(x[i] - r.x)) <= tol * max(1.0, np.max(np.abs(r.x))), (variant, i)
+            assert np.max(np.abs(y[i] - r.y)) <= tol * max(1.0, np.max(np.abs(r.y))), (variant, i)
+        oq.clean(m)
