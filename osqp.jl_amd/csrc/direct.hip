@@ -1077,6 +1077,7 @@ struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row 
                                          // G threads per row for the part of its rows that lies before the chain
 
 // ------------------------------------------------------------------ factor object
+int level_limit();
 struct LdlFactor {
   Engine &e;
   Symbolic S;
@@ -1120,8 +1121,20 @@ struct LdlFactor {
     e.setup_mark("  host pattern");
     // OSQP_AMD_FIRST_ORDERING=1: nested dissection at once (a caller who knows the problem is a long banded one saves the
     // min-degree analysis that would only establish that: ~half of the setup of the control-1e6 bench workload)
-    const int first_ordering = getenv("OSQP_AMD_FIRST_ORDERING") ? atoi(getenv("OSQP_AMD_FIRST_ORDERING")) : 0;  // read per setup: a process may set up problems of both kinds
+    int first_ordering = getenv("OSQP_AMD_FIRST_ORDERING") ? atoi(getenv("OSQP_AMD_FIRST_ORDERING")) : -1;  // read per setup: a process may set up problems of both kinds
+    // unset (round 4): on a LARGE problem whose KKT graph is long -- a breadth-first level structure hundreds of levels
+    // deep: banded, multi-stage, grid-like; random sparsity is ~log N deep -- nested dissection goes first without being
+    // asked (the min-degree analysis of such a graph only finds the chain: 2 - 3 s at 2.7e6 nodes), and min-degree is the
+    // second opinion when the dissection comes out deep
+    bool nd_by_depth = false;
+    if (first_ordering < 0 && e.hP.cols + mr_ >= 200000) nd_by_depth = kkt_graph_depth(e.hP, e.hA, row_map, mr_) >= 400;
+    if (first_ordering < 0) first_ordering = nd_by_depth ? 1 : 0;
     symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S);
+    if (nd_by_depth && (S.too_large || (int)S.level_ptr.size() - 1 > level_limit())) {  // the dissection did not deliver: as before
+      first_ordering = 0;
+      S = Symbolic();
+      symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
+    }
     e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
     // A deep level schedule under min-degree (banded / multi-stage structure: the elimination tree is a chain) gets a

@@ -315,6 +315,44 @@ struct Upper {  // upper-triangular pattern, column compressed, with the origin 
 
 }  // namespace
 
+int kkt_graph_depth(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr) {
+  const int n = P.cols, N = n + mr;
+  if (N < 2) return 0;
+  // adjacency of the KKT graph: variable - variable through P, variable - row through A
+  std::vector<int64_t> xadj(N + 1, 0);
+  for (int j = 0; j < n; j++)
+    for (int64_t k = P.p[j]; k < P.p[j + 1]; k++) if (P.i[k] != j) { xadj[P.i[k] + 1]++; xadj[j + 1]++; }
+  for (int j = 0; j < n; j++)
+    for (int64_t k = A.p[j]; k < A.p[j + 1]; k++) { const int r = row_map[A.i[k]]; if (r >= 0) { xadj[j + 1]++; xadj[n + r + 1]++; } }
+  for (int i = 0; i < N; i++) xadj[i + 1] += xadj[i];
+  std::vector<int> adj((size_t)xadj[N]);
+  {
+    std::vector<int64_t> f(xadj.begin(), xadj.end() - 1);
+    for (int j = 0; j < n; j++)
+      for (int64_t k = P.p[j]; k < P.p[j + 1]; k++) if (P.i[k] != j) { adj[f[P.i[k]]++] = j; adj[f[j]++] = P.i[k]; }
+    for (int j = 0; j < n; j++)
+      for (int64_t k = A.p[j]; k < A.p[j + 1]; k++) { const int r = row_map[A.i[k]]; if (r >= 0) { adj[f[j]++] = n + r; adj[f[n + r]++] = j; } }
+  }
+  std::vector<int> dist(N, -1), cur, nxt;
+  int root = 0, depth = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    std::fill(dist.begin(), dist.end(), -1);
+    cur.assign(1, root);
+    dist[root] = 0;
+    int d = 0, last = root;
+    while (!cur.empty()) {
+      nxt.clear();
+      for (int v : cur)
+        for (int64_t q = xadj[v]; q < xadj[v + 1]; q++) { const int w = adj[q]; if (dist[w] < 0) { dist[w] = d + 1; nxt.push_back(w); } }
+      if (!nxt.empty()) { d++; last = nxt[0]; }
+      cur.swap(nxt);
+    }
+    depth = std::max(depth, d);
+    root = last;
+  }
+  return depth;
+}
+
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
                       double flops_limit, int ordering, Symbolic &S) {
   const int n = P.cols, N = n + mr;

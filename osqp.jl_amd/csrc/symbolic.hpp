@@ -42,6 +42,11 @@ struct Symbolic {
 // ordering: 0 approximate minimum degree, 1 nested dissection by level structures (banded / chain-like graphs),
 // 2 approximate minimum degree with updated nodes queued behind their equals (multiple-elimination tie-breaking:
 // flatter elimination trees on graphs with many degree-1 nodes, e.g. bound constraints).
+// Depth of a breadth-first level structure of the KKT graph (two passes towards a pseudo-peripheral root, component of node 0):
+// large on banded / multi-stage / grid-like problems (the graph is long), ~log N on random sparsity.  What the direct back-end
+// looks at to decide, on large problems, whether nested dissection should be the FIRST ordering it tries.
+int kkt_graph_depth(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr);
+
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
                       double flops_limit, int ordering, Symbolic &out);
 
