@@ -404,6 +404,7 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
     }
     ok = ok && inside + T.Fp[S.N] == S.nnzL && T.Gp[S.N] == T.Fp[S.N];
     out[0] = S.N; out[1] = (double)S.nnzL; out[2] = (double)S.level_ptr.size() - 1; out[3] = T.count; out[4] = T.nlev;
+    if (count >= 14) out[13] = (double)kkt_graph_depth(P, A, ident, (int)m);  // what decides the first ordering on large problems
     out[5] = (double)T.Fp[S.N]; out[6] = (double)T.woff[T.count]; out[7] = largest; out[8] = ok ? 1.0 : 0.0; out[9] = (double)inside;
     int lD, cD, kD;
     choose_dense_top(S, 512, getenv("OSQP_AMD_DENSE_MAX") ? atoi(getenv("OSQP_AMD_DENSE_MAX")) : 12288, 1024, 32, lD, cD, kD);

@@ -16,13 +16,13 @@ def probe(lib, prob, ordering, smax=64):
     P.sort_indices(); A.sort_indices()
     n, m = P.shape[0], A.shape[0]
     arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (P.indptr, P.indices, A.indptr, A.indices)]
-    out = np.zeros(13)
+    out = np.zeros(14)
     ptrs = [a.ctypes.data_as(C.POINTER(C.c_longlong)) for a in arrs]
-    rc = lib.osqp_amd_symbolic_probe(n, m, *ptrs, ordering, smax, out.ctypes.data_as(C.POINTER(C.c_double)), 13)
+    rc = lib.osqp_amd_symbolic_probe(n, m, *ptrs, ordering, smax, out.ctypes.data_as(C.POINTER(C.c_double)), 14)
     assert rc == 0
     return dict(N=int(out[0]), nnzL=int(out[1]), levels=int(out[2]), supernodes=int(out[3]), sn_levels=int(out[4]),
                 outside=int(out[5]), block_doubles=int(out[6]), largest=int(out[7]), ok=bool(out[8]), inside=int(out[9]),
-                cost_levels=out[10], cost_supernodes=out[11], pays=bool(out[12]))
+                cost_levels=out[10], cost_supernodes=out[11], pays=bool(out[12]), graph_depth=int(out[13]))
 
 
 @pytest.mark.parametrize("ordering", [0, 1, 2])
@@ -76,3 +76,11 @@ def test_threaded_analysis_is_the_single_threaded_one(product_lib, monkeypatch, 
             monkeypatch.setenv("OSQP_AMD_HOST_THREADS", nt)
             assert probe(product_lib, prob, ordering) == one
         assert one["ok"]
+
+
+def test_graph_depth_separates_long_graphs_from_random_ones(product_lib):
+    """What sends nested dissection first on large problems (csrc/direct.hip: breadth-first depth of the KKT graph >= 400):
+    a multi-stage control problem is as deep as its horizon, the dense-row classes a handful of levels."""
+    assert probe(product_lib, qp_zoo.control(nx=8, nu=4, T=500), 0)["graph_depth"] >= 500
+    for name, kw in (("portfolio", dict(n=1500, k=40)), ("svm", dict(n=60, m=1500)), ("equality_qp", dict(n=300))):
+        assert probe(product_lib, qp_zoo.ZOO[name](**kw), 0)["graph_depth"] <= 12, name
