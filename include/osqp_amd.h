@@ -439,7 +439,9 @@ c_int osqp_amd_set_device(c_int device);
  * ordering: 0 minimum degree, 1 nested dissection, 2 minimum degree with queued ties; smax: largest supernode.
  * out[0..12]: N, nnz(L), pivot levels, supernodes, supernode levels, entries outside the diagonal blocks,
  *            doubles in the inverted blocks, largest supernode, 1 if every structural invariant holds, nnz in blocks,
- *            modelled microseconds of a solve by levels / by supernodes, 1 if the engine would take supernodes */
+ *            modelled microseconds of a solve by levels / by supernodes, 1 if the engine would take supernodes;
+ * out[13] (when count >= 14): depth of a breadth-first level structure of the KKT graph (>= 400 on a problem of >= 2e5
+ *            pivots sends nested dissection first) */
 c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_int *Ap, const c_int *Ai,
                               c_int ordering, c_int smax, c_float *out, c_int count);
 
