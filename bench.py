@@ -262,7 +262,7 @@ def build_model(oq, lib, workload, seed, oracle=False):
     kind, n, per_row, linsys = WORKLOADS[workload]
     model = oq.Model(lib)
     if kind == "control":
-        os.environ.setdefault("OSQP_AMD_FIRST_ORDERING", "1")  # the factor of a long banded problem: nested dissection at once
+        # no hint: the library finds the long KKT graph itself and sends nested dissection first (csrc/direct.hip)
         prob = control_problem(n)
         t0 = time.time()
         oq.setup(model, linsys_solver="qdldl" if oracle else linsys, **prob, **SETTINGS)
