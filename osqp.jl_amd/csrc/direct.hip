@@ -1113,6 +1113,14 @@ struct LdlFactor {
   const int *vec_perm() const { return sn ? perm_s.get() : perm.get(); }   // order of the solve vector bp
   const int *vec_pinv() const { return sn ? pinv_s.get() : pinv.get(); }
   int solve_levels() const { return sn ? T.nlev : lD; }
+  // multiply-adds of a numeric factorisation WITHOUT the dense top block (sum of squared column counts of the columns below
+  // it): the block itself is inverted on the matrix cores at ~10 TFLOP/s and is bounded by dense_max()
+  double flops_below_dense_block() const {
+    if (!kD) return S.flops;
+    double f = 0.0;
+    for (int c = 0; c < cD; c++) { const double cc = (double)(S.Lp[c + 1] - S.Lp[c]); f += cc * cc; }
+    return f;
+  }
 
   LdlFactor(Engine &en, const std::vector<int> &row_map, int mr_, double sigma_, double cconst_, int64_t limit,
             double flops_limit = 0.0)
@@ -1725,7 +1733,9 @@ std::unique_ptr<Linsys> make_direct(Engine &e, int *err) {
   // (sum of squared column counts ~ multiply-adds of one numeric factorisation; it is redone at every rho update)
   // or when the level schedule below the dense top block is so deep that the triangular solves are a serial chain
   // (measured, n = m = 5000 with 10 per row: 4623 levels, 60 ms per iteration -- PCG needs a fraction of a millisecond there)
-  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->S.flops > factor_flops_limit() || d->F->solve_levels() > level_limit())) { *err = -1; return nullptr; }
+  // (round 4: a dense top block is priced by what inverting it costs now -- 31 ms for 6000 pivots -- not by its n^3 / 3 in the
+  // sum: a dense P no longer sends a problem to PCG once its analysis has been paid for; equality_qp: 9 k it/s instead of 260)
+  if (e.st.linsys_solver != AMD_DIRECT_SOLVER && (d->F->flops_below_dense_block() > factor_flops_limit() || d->F->solve_levels() > level_limit())) { *err = -1; return nullptr; }
   int rc = d->F->refactor(e.rho_inv.get());
   if (rc) { *err = rc; return nullptr; }
   return std::unique_ptr<Linsys>(d.release());
