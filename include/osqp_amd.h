@@ -318,6 +318,7 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 19 levels of the supernode graph when the triangular solves run by supernodes (0: by the level schedule)
  * 20 high-water mark of the device bytes allocated by this process (a sharded setup stays near 1/ranks of the whole)
  * 21 solves that were run again from a cold start because a wait inside the one-launch supernodal solve timed out
+ * 22 the numeric factorisation runs by supernodes (multifrontal, one launch per supernode level and size class) 0 / 1
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 24
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);

@@ -420,7 +420,23 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
         }
         fprintf(stderr, "level %d: %d supernodes, %lld rows (largest %d), per row: %.1f entries at level 0, %.1f above, %.1f backward\n", L,
                 T.lvl_ptr[L + 1] - T.lvl_ptr[L], (long long)rows, smax_l, (double)pre / rows, (double)post / rows, (double)back / rows);
+        // fronts: border = pattern of the top node's column
+        int64_t sb = 0, sb2 = 0, spanel = 0, bmax = 0, fmax = 0; double fl = 0;
+        std::vector<int> nch(T.count, 0);
+        for (int J = 0; J < T.count; J++) if (T.up[J] >= 0) nch[T.up[J]]++;
+        int chmax = 0; int64_t chsum = 0;
+        for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+          const int top = T.piv[T.ptr[J + 1] - 1];
+          const int64_t b = S.Lp[top + 1] - S.Lp[top], s = T.ptr[J + 1] - T.ptr[J];
+          sb += b; sb2 += b * b; spanel += (s + b) * s; bmax = std::max(bmax, b); fmax = std::max(fmax, s + b);
+          fl += (double)s * (s + b) * (s + b);
+          chmax = std::max(chmax, nch[J]); chsum += nch[J];
+        }
+        fprintf(stderr, "   fronts: border mean %.1f max %lld, front max %lld, sum b^2 %.3g, panel doubles %.3g, dense flops %.3g, children mean %.1f max %d\n",
+                (double)sb / (T.lvl_ptr[L + 1] - T.lvl_ptr[L]), (long long)bmax, (long long)fmax, (double)sb2, (double)spanel, fl,
+                (double)chsum / (T.lvl_ptr[L + 1] - T.lvl_ptr[L]), chmax);
       }
+    if (getenv("OSQP_AMD_PROBE_VERBOSE")) fprintf(stderr, "sum colcount^2 = %.4g\n", S.flops);
     return 0;
   });
 }
@@ -586,6 +602,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[19] = e.lin->supernode_levels();
   v[20] = (c_float)g_device_peak;
   v[21] = (c_float)e.tree_restarts;
+  v[22] = e.lin->multifrontal();
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

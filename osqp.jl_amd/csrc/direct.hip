@@ -19,6 +19,7 @@
 
 #include "engine.hpp"
 #include "symbolic.hpp"
+#include "mfront.hpp"
 
 namespace oq {
 
@@ -1110,6 +1111,19 @@ struct LdlFactor {
   DevBuf<int64_t> sn_woff, sn_wmap, sn_Fp, sn_Fpos, sn_Gp, sn_Gpos, sn_Fsplit;
   DevBuf<double> sn_Wc, sn_Wr, sn_Fx, sn_Gx, sn_Dinv;
   std::vector<int> sn_lanes_f, sn_lanes_b;  // per level: lanes per row for the entries outside the blocks
+  // multifrontal numeric factorisation on the supernode partition (mfront.hpp): one launch per supernode level and size
+  // class instead of two per pivot level
+  bool mf = false;
+  DevBuf<int> mf_snof, mf_slot, mf_bsz, mf_chp, mf_chl, mf_list, mf_err;
+  DevBuf<int64_t> mf_uoff, mf_reloff;
+  DevBuf<uint16_t> mf_rel, mf_loc;
+  DevBuf<double> mf_U;
+  struct MfLaunch { int cls, off, count, fcap; };
+  std::vector<MfLaunch> mf_launches;  // in level order
+  int mf_fmax = 0;
+  bool mf_ok = false;                 // the host plan exists (mf_plan): every front fits LDS
+  std::vector<int> mfh_bsz, mfh_snof, mfh_chp, mfh_chl, mfh_list;
+  std::vector<int64_t> mfh_uoff, mfh_reloff;
   const int *vec_perm() const { return sn ? perm_s.get() : perm.get(); }   // order of the solve vector bp
   const int *vec_pinv() const { return sn ? pinv_s.get() : pinv.get(); }
   int solve_levels() const { return sn ? T.nlev : lD; }
@@ -1178,10 +1192,11 @@ struct LdlFactor {
     choose_dense_block();
     choose_supernodes();
     if (sn) { lD = nlev; cD = N; kD = 0; }
+    build_mf();
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
-      for (int l = 0; l < lD; l++) {
+      for (int l = 0; l < (mf ? 0 : lD); l++) {
         const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1], width = c1 - c0;
         if (width == 0 || S.Lp[c1] == S.Lp[c0]) continue;
         const double mean = (double)(S.Rp[c1] - S.Rp[c0]) / (double)width;
@@ -1223,7 +1238,7 @@ struct LdlFactor {
     if (mode != 2 && kD > 0 && lD < 48) return;  // the depth IS the dense block: the few levels below it stay a level schedule (no partition to build)
     int smax = kSnMax;  // OSQP_AMD_SNODE_MAX: smaller supernodes (tests: many levels on small problems)
     if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
-    build_supernodes(S, smax, T);
+    build_supernodes(S, smax, T, false);
     sn_lanes_f.assign(T.nlev, 1); sn_lanes_b.assign(T.nlev, 1);
     for (int L = 0; L < T.nlev; L++) {
       int64_t ef = 0, eb = 0, rows = 0;
@@ -1236,6 +1251,8 @@ struct LdlFactor {
     }
     sn = mode == 2 || supernodes_pay(S, T, kChainRows, lD, kD, kSnThreads);
     if (!sn) { T = Supernodes(); return; }
+    mf_ok = mf_plan();
+    if (!mf_ok) supernode_wmap(S, T);  // k_sn_invert gathers the blocks through it; the fronts invert theirs in place
     hipStream_t s = e.stream;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
@@ -1276,7 +1293,7 @@ struct LdlFactor {
       *sn_fault_host = 0;
       HIP_CHECK(hipHostGetDevicePointer((void **)&sn_fault, sn_fault_host, 0));
     }
-    up64(sn_woff, T.woff); up64(sn_wmap, T.wmap); up64(sn_Fp, T.Fp); up64(sn_Fpos, T.Fpos); up64(sn_Gp, T.Gp); up64(sn_Gpos, T.Gpos); up64(sn_Fsplit, T.Fsplit);
+    up64(sn_woff, T.woff); if (!mf_ok) up64(sn_wmap, T.wmap); up64(sn_Fp, T.Fp); up64(sn_Fpos, T.Fpos); up64(sn_Gp, T.Gp); up64(sn_Gpos, T.Gpos); up64(sn_Fsplit, T.Fsplit);
     std::vector<int> ps(N), pis(N);
     for (int q = 0; q < N; q++) { ps[q] = S.perm[T.piv[q]]; pis[ps[q]] = q; }
     up32(perm_s, ps); up32(pinv_s, pis);
@@ -1286,6 +1303,100 @@ struct LdlFactor {
     // only the shapes are needed on the host from here on
     std::vector<int64_t>().swap(T.wmap); std::vector<int64_t>().swap(T.Fpos); std::vector<int64_t>().swap(T.Gpos);
     std::vector<int>().swap(T.Fj); std::vector<int>().swap(T.Gi);
+  }
+
+  // Plan of the multifrontal factorisation (mfront.hpp): fronts, update-matrix offsets, children lists, launches by level
+  // and size class on the host (arrays of one entry per supernode); the two index maps that have one entry per entry of L /
+  // per border row are built by device kernels.  Not taken (the level-by-level factorisation stays) when a front does not
+  // fit LDS or the update matrices would need more than 8 GB.  OSQP_AMD_MF=0 switches it off.
+  static constexpr int kMfMaxFront = 192;
+  bool mf_plan() {
+    const int mode = getenv("OSQP_AMD_MF") ? atoi(getenv("OSQP_AMD_MF")) : 1;
+    if (mode == 0) return false;
+    const int count = T.count;
+    mfh_bsz.assign(count, 0); mfh_snof.assign(N, 0);
+    mfh_uoff.assign(count + 1, 0); mfh_reloff.assign(count + 1, 0);
+    mf_fmax = 0;
+    for (int J = 0; J < count; J++) {
+      const int top = T.piv[T.ptr[J + 1] - 1], s_ = T.ptr[J + 1] - T.ptr[J];
+      const int64_t b = S.Lp[top + 1] - S.Lp[top];
+      if (s_ + b > kMfMaxFront) return false;
+      mfh_bsz[J] = (int)b;
+      mf_fmax = std::max(mf_fmax, s_ + (int)b);
+      mfh_uoff[J + 1] = mfh_uoff[J] + b * (b + 1) / 2;
+      mfh_reloff[J + 1] = mfh_reloff[J] + b;
+      for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) mfh_snof[T.piv[q]] = J;
+    }
+    if (mfh_uoff[count] > ((int64_t)1 << 30)) return false;
+    mfh_chp.assign(count + 1, 0);
+    for (int J = 0; J < count; J++) if (T.up[J] >= 0) mfh_chp[T.up[J] + 1]++;
+    for (int J = 0; J < count; J++) mfh_chp[J + 1] += mfh_chp[J];
+    mfh_chl.resize(mfh_chp[count]);
+    {
+      std::vector<int> f(mfh_chp.begin(), mfh_chp.end() - 1);
+      for (int J = 0; J < count; J++) if (T.up[J] >= 0) mfh_chl[f[T.up[J]]++] = J;  // ascending: the order of the sums
+    }
+    mfh_list.clear();
+    mfh_list.reserve(count);
+    mf_launches.clear();
+    for (int L = 0; L < T.nlev; L++) {
+      std::vector<int> cls[kMfClasses];
+      int cap[kMfClasses] = {0};
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+        const int f = T.ptr[J + 1] - T.ptr[J] + mfh_bsz[J];
+        int c = 0;
+        while (f > kMfClassCap[c]) c++;
+        cls[c].push_back(J);
+        cap[c] = std::max(cap[c], f);
+      }
+      for (int c = 0; c < kMfClasses; c++) {
+        if (cls[c].empty()) continue;
+        mf_launches.push_back({c, (int)mfh_list.size(), (int)cls[c].size(), c < 2 ? kMfClassCap[c] : cap[c]});
+        mfh_list.insert(mfh_list.end(), cls[c].begin(), cls[c].end());
+      }
+    }
+    return true;
+  }
+  // size classes of the fronts: rows at most 16 / 48 (16 lanes / a wavefront each, fixed slabs), then workgroups with the
+  // slab of the launch's largest front -- cut at 96 so that a few large fronts do not take the occupancy of many mid-size ones
+  static constexpr int kMfClasses = 4;
+  static constexpr int kMfClassCap[kMfClasses] = {16, 48, 96, kMfMaxFront};
+  void build_mf() {
+    mf = false;
+    if (!sn || !mf_ok) return;
+    const int count = T.count;
+    hipStream_t s = e.stream;
+    auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    up32(mf_snof, mfh_snof); up32(mf_slot, T.slot); up32(mf_bsz, mfh_bsz); up32(mf_chp, mfh_chp); up32(mf_chl, mfh_chl); up32(mf_list, mfh_list);
+    up64(mf_uoff, mfh_uoff); up64(mf_reloff, mfh_reloff);
+    mf_rel.alloc(std::max<int64_t>(1, mfh_reloff[count])); mf_loc.alloc(std::max<int64_t>(1, S.nnzL)); mf_U.alloc(std::max<int64_t>(1, mfh_uoff[count]));
+    mf_err.alloc(1); mf_err.zero(s);
+    OQ_LAUNCH(k_mf_rel, dim3(blocks_for(count)), dim3(kBlock), 0, s, count, sn_ptr.get(), sn_piv.get(), sn_up.get(), mf_snof.get(), mf_slot.get(),
+              Lp.get(), Li.get(), mf_reloff.get(), mf_rel.get(), mf_err.get());
+    if (S.nnzL > 0)
+      OQ_LAUNCH(k_mf_loc, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, (const int *)Lcol.get(), Li.get(), Lp.get(), sn_ptr.get(), sn_piv.get(),
+                mf_snof.get(), mf_slot.get(), mf_loc.get(), mf_err.get());
+    int err = 0;
+    mf_err.download(&err, 1, s);
+    e.sync();
+    if (err) throw Error(6, "internal: the fronts of the supernodes do not cover the pattern of L (code " + std::to_string(err) + ")");
+    const int lds = (int)(mf_slab_doubles(mf_fmax) * sizeof(double));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
+    if (getenv("OSQP_AMD_SETUP_TRACE"))
+      for (const MfLaunch &l : mf_launches) fprintf(stderr, "[fronts] class %d: %d fronts, slab for %d rows\n", l.cls, l.count, l.fcap);
+    std::vector<int>().swap(mfh_snof); std::vector<int>().swap(mfh_list); std::vector<int>().swap(mfh_chl);
+    mf = true;
+  }
+  void run_mf(hipStream_t s) {
+    for (const MfLaunch &l : mf_launches) {
+      MfArgs a{mf_list.get() + l.off, l.count, l.fcap, sn_ptr.get(), sn_piv.get(), mf_bsz.get(), mf_uoff.get(), mf_reloff.get(), mf_rel.get(),
+               mf_chp.get(), mf_chl.get(), Lp.get(), mf_loc.get(), Lx.get(), D.get(), Dinv.get(), mf_U.get(), status.get(),
+               sn_Wc.get(), sn_Wr.get(), sn_woff.get()};
+      if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+      else if (l.cls == 1) OQ_LAUNCH(k_mf_front<64>, dim3((l.count + 3) / 4), dim3(kMfBlock), 4 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+      else OQ_LAUNCH(k_mf_front<256>, dim3(l.count), dim3(kMfBlock), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+    }
   }
 
   // rows at least this long (mean over a level) go through the work-row form of phase 2: the thread-per-entry merge
@@ -1396,7 +1507,8 @@ struct LdlFactor {
     if (e.nnzA > 0)
       OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
     int p0 = 0, p1 = 0, half = 0;  // the previous level that went through work rows, and the half of W it used
-    for (int l = 0; l < lD; l++) {
+    if (mf) run_mf(s);
+    for (int l = 0; l < (mf ? 0 : lD); l++) {
       const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
       const int64_t entries = S.Lp[c1] - S.Lp[c0];
       const bool through_w = entries > 0 && long_rows[l];
@@ -1437,9 +1549,11 @@ struct LdlFactor {
       const int64_t nf = T.Fp[N], big = std::max<int64_t>(N, nf);
       OQ_LAUNCH(k_sn_gather, dim3(blocks_for(big)), dim3(kBlock), 0, s, nf, sn_Fpos.get(), sn_Fx.get(), nf, sn_Gpos.get(), sn_Gx.get(), N,
                 sn_piv.get(), Dinv.get(), sn_Dinv.get(), Lx.get());
-      OQ_LAUNCH(k_sn_invert, dim3(T.count), dim3(kSnThreads), 0, s, sn_ptr.get(), sn_woff.get(), sn_wmap.get(), Lx.get(), sn_Wc.get(), sn_Wr.get());
+      if (!mf)  // (the fronts leave the inverted blocks behind themselves)
+        OQ_LAUNCH(k_sn_invert, dim3(T.count), dim3(kSnThreads), 0, s, sn_ptr.get(), sn_woff.get(), sn_wmap.get(), Lx.get(), sn_Wc.get(), sn_Wr.get());
     }
-    if (S.nnzL > 0) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
+    // (the CSR copy of the values serves the level-scheduled solves only)
+    if (S.nnzL > 0 && !sn) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
     int st[2] = {0, 0};
     status.download(st, 2, s);
     e.sync();
@@ -1687,6 +1801,7 @@ struct Direct : Linsys {
   double nnzL() const override { return (double)F->S.nnzL; }
   double levels() const override { return (double)F->nlev; }
   double supernode_levels() const override { return F->sn ? (double)F->T.nlev : 0.0; }
+  double multifrontal() const override { return F->mf ? 1.0 : 0.0; }
   double trisolve_bytes() const override { return F->trisolve_bytes(); }
   double factorizations() const override { return (double)F->factorizations; }
   float time_solve(int reps) override {

@@ -235,9 +235,9 @@ __global__ __launch_bounds__(kBlock) void k_shard_pick_A(int64_t E, int j0, cons
   const double v = (in && fill) ? Ax[e] : 0.0;
   const bool kt = in && j >= n0 && j < n1, ka = in && i >= m0 && i < m1;
   long long p = block_reserve(kt, &counters[0], fill);
-  if (fill && kt) { tr[p] = j - n0; tc[p] = i; tv[p] = v; to[p] = (int)(base + e); }  // base + e: the caller's nnz index
+  if (fill && kt) { tr[p] = j - n0; tc[p] = i; tv[p] = v; if (to) to[p] = (int)(base + e); }  // base + e: the caller's nnz index
   p = block_reserve(ka, &counters[1], fill);
-  if (fill && ka) { ar[p] = i - m0; ac[p] = j; av[p] = v; ao[p] = (int)(base + e); }
+  if (fill && ka) { ar[p] = i - m0; ac[p] = j; av[p] = v; if (ao) ao[p] = (int)(base + e); }
 }
 // entries (i, j), i <= j, of columns [j0, ...) of triu(P): rows [n0, n1) of the full symmetric P get (j, i) and, off the
 // diagonal, the mirror (i, j)
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(kBlock) void k_shard_pick_P(int64_t E, int j0, cons
   if (in && i > j) *bad = 1;  // not upper triangular
   const bool kl = in && j >= n0 && j < n1, ku = in && i != j && i >= n0 && i < n1;
   long long p = block_reserve(kl, counter, fill);
-  if (fill && kl) { pr[p] = j - n0; pc[p] = i; pv[p] = v; po[p] = (int)(base + e); }
+  if (fill && kl) { pr[p] = j - n0; pc[p] = i; pv[p] = v; if (po) po[p] = (int)(base + e); }
   p = block_reserve(ku, counter, fill);
-  if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; po[p] = (int)(base + e); }
+  if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; if (po) po[p] = (int)(base + e); }
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather_ints(int64_t n, const int *__restrict__ src, const int *__restrict__ in, int *__restrict__ out) {
@@ -276,6 +276,11 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
   DevBuf<int> tr, tc, ar, ac, pr, pc, to, ao, po;
   DevBuf<double> tv, av, pv;
   unsigned long long total[3] = {0, 0, 0};
+  // The caller's nnz index of every kept entry (what osqp_update_P / _A pick their new values by): 4 B per stored entry on
+  // the path whose purpose is memory headroom, so OSQP_AMD_SHARD_UPDATES=0 leaves them out (value updates are then refused
+  // with exit flag 6), as does a problem whose nnz indices do not fit 32 bits; a block that goes compact releases its map.
+  const bool keep_org = src.nnzA < 2147483647LL && src.nnzP < 2147483647LL &&
+                        !(getenv("OSQP_AMD_SHARD_UPDATES") && atoi(getenv("OSQP_AMD_SHARD_UPDATES")) == 0);
   for (int fill = 0; fill < 2; fill++) {
     if (fill) {
       counters.download(total, 3, stream);
@@ -285,7 +290,7 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
       tr.alloc(total[0]); tc.alloc(total[0]); tv.alloc(total[0]);
       ar.alloc(total[1]); ac.alloc(total[1]); av.alloc(total[1]);
       pr.alloc(total[2]); pc.alloc(total[2]); pv.alloc(total[2]);
-      to.alloc(total[0]); ao.alloc(total[1]); po.alloc(total[2]);
+      if (keep_org) { to.alloc(total[0]); ao.alloc(total[1]); po.alloc(total[2]); }
       counters.zero(stream);
     }
     int64_t baseA = 0, baseP = 0;  // the caller's nnz index of the first entry of the column range (ranges come in column order)
@@ -327,8 +332,8 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
     DevBuf<int> order;
     csr_from_coo(rows, cols, (int64_t)E, er.get(), ec.get(), M, order, stream);
     gather_values(M.nnz, order.get(), ev.get(), M.val.get(), 0, stream);
-    org.alloc(std::max<size_t>(1, (size_t)M.nnz));
-    if (M.nnz > 0) OQ_LAUNCH(k_gather_ints, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, stream, (int64_t)M.nnz, order.get(), eo.get(), org.get());
+    if (keep_org) org.alloc(std::max<size_t>(1, (size_t)M.nnz));
+    if (keep_org && M.nnz > 0) OQ_LAUNCH(k_gather_ints, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, stream, (int64_t)M.nnz, order.get(), eo.get(), org.get());
     sync();
     er.release(); ec.release(); ev.release(); eo.release();
   };
@@ -759,6 +764,7 @@ void Engine::compact_one(int which, DevBuf<uint32_t> *known_slots, bool maps_don
     fold_slot_maps(which, (known_slots && known_slots->n > 0) ? *known_slots : own);
   }
   if (which == 2) Pi_keep.release();  // the direct back-end's symbolic phase is out of reach at this size
+  if (comm) (which == 0 ? A_org : (which == 1 ? At_org : Pf_org)).release();  // a compact row block refuses value updates (update_PA)
   panel_compact(M);
   compact = true;
 }
@@ -1345,11 +1351,18 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
       Aidx_sorted.resize((size_t)An);
       for (c_int i = 0; i < An; i++) Aidx_sorted[(size_t)i] = (c_int)A_to_sorted[(size_t)Aidx[i]];
       Aidx = Aidx_sorted.data();
-    } else if (An == nnzA) {
+    } else {  // a full replace in the caller's order, whatever A_new_n says (0 and nnz are both accepted above, as libosqp ignores it)
       Ax_sorted.resize((size_t)nnzA);
       for (int64_t k = 0; k < nnzA; k++) Ax_sorted[(size_t)A_to_sorted[(size_t)k]] = Ax_new[k];
       Ax_new = Ax_sorted.data();
     }
+  }
+  if (comm) {
+    // a compact row block has released its CSR values (and its origin map with them): refused before anything is touched
+    if ((doP && Pf.compact) || (doA && (A.compact || At.compact)))
+      throw Error(6, "osqp_update_P / osqp_update_A: not available on a compact row-sharded workspace (set OSQP_AMD_COMPACT_NNZ=-1 to keep the CSR arrays)");
+    if ((doP && Pf.nnz > 0 && Pf_org.n == 0) || (doA && ((A.nnz > 0 && A_org.n == 0) || (At.nnz > 0 && At_org.n == 0))))
+      throw Error(6, "osqp_update_P / osqp_update_A: this row-sharded workspace keeps no nnz-index maps (not set up by column ranges, OSQP_AMD_SHARD_UPDATES=0, or nnz >= 2^31)");
   }
   if (st.scaling) unscale_data();
   auto scatter = [&](const double *vals, const c_int *idx, c_int k, double *t1, const int *map1, double *t2, const int *map2) {
@@ -1397,7 +1410,7 @@ int Engine::update_PA(const double *Px_new, const c_int *Pidx, c_int Pn, const d
                     (const double *)all.get(), b.first->val.get());
       sync();
     };
-    if ((Pf.nnz > 0 && Pf_org.n == 0) || (A.nnz > 0 && A_org.n == 0)) throw Error(6, "osqp_update_P / osqp_update_A: this row-sharded workspace was not set up by column ranges");
+
     if (doP) replace(Px_new, Pidx, kP, nnzPtriu, {{&Pf, &Pf_org}});
     if (doA) replace(Ax_new, Aidx, kA, nnzA, {{&At, &At_org}, {&A, &A_org}});
   } else {

@@ -1,0 +1,227 @@
+// mfront.hpp -- numeric LDL' by supernodes (row K2 of SURVEY.md section 8a), included by direct.hip.
+//
+// The level-by-level factorisation (k_ldl_diag_* / k_ldl_entries_*) needs two launches per PIVOT level and every entry of
+// a level pays the latency of a sparse row intersection: control-1e6 has 519 levels, 84 ms per refactorisation = 85 ADMM
+// iterations of time, and every rho update / matrix update pays it [REF src/interface.jl:330-406, 539-550].
+// The supernode partition of the triangular solves (symbolic.hpp, Supernodes) supports a MULTIFRONTAL factorisation with
+// one launch per SUPERNODE level and size class (11 levels there).  A supernode J is a connected piece of the elimination
+// tree with a single top node, so every row its columns touch outside J lies in the pattern of the top node's column
+// (col struct(v) \ {parent} is a subset of struct(parent), by induction along the piece): its FRONT is the dense symmetric
+// matrix over   rows(J) = [ the s pivots of J in slot order | the b rows of the top column, ascending ]   (f = s + b).
+//   1. F = entries of K in the columns of J (they sit in Lx / D after the scatter kernels of the assembly);
+//   2. F += the update matrices of the children of J (extend-add, children in ascending order: a fixed order of sums --
+//      no floating-point atomics, two factorisations of the same data give the same bits);
+//   3. s pivots eliminated inside LDS (right-looking over the f x s panel, then the b x b Schur complement as ONE rank-s
+//      product with the sums in registers);
+//   4. columns of L back to Lx (sparse positions through loc[]), pivots to D / Dinv, the Schur complement = update matrix
+//      U_J to a global array for the parent.
+// The front lives in LDS as a packed lower triangle, column-major: entry (i, j), i >= j, at j (2f - j - 1) / 2 + i.
+// Three size classes: fronts of at most 16 rows take 16 lanes (sixteen to a workgroup, no workgroup barrier), at most 48
+// rows a wavefront, larger ones a 256-thread workgroup with the slab sized by the largest front of the launch.
+#pragma once
+#include "engine.hpp"
+
+namespace oq {
+namespace {
+
+struct MfArgs {
+  const int *list;            // supernodes of this launch
+  int count;
+  int fcap;                   // every front of the launch has at most this many rows
+  const int *ptr, *piv;       // supernode -> slots, slot -> pivot
+  const int *bsz;             // rows of the border (pattern of the top node's column)
+  const int64_t *uoff;        // update matrix of supernode J: U + uoff[J], packed lower triangle of order bsz[J]
+  const int64_t *reloff;      // rel + reloff[J]: row of the PARENT's front for each border row of J
+  const uint16_t *rel;
+  const int *chp, *chl;       // children lists
+  const int64_t *Lp;
+  const uint16_t *loc;        // per entry of L: row of its column's front
+  double *Lx, *D, *Dinv, *U;
+  int *status;                // [0] |= 1: zero / NaN pivot; [1] += positive pivots
+  // the inverse of the supernode's own unit lower triangular block, for the supernodal solves (direct.hip k_sn_*): packed
+  // by columns (Wc) and by rows (Wr) at woff[J]; null: not wanted
+  double *Wc, *Wr;
+  const int64_t *woff;
+};
+
+template <int TF>
+__device__ __forceinline__ void mf_sync() {
+  if constexpr (TF > 64) __syncthreads();
+  else {  // the lanes of a front share a wavefront: its LDS writes are drained before any of its lanes reads them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+constexpr int kMfBlock = 256;
+__host__ __device__ inline size_t mf_slab_doubles(int fcap) { return (size_t)fcap * (fcap + 1) / 2 + (size_t)(fcap < 64 ? fcap : 64); }
+
+template <int TF>
+__global__ __launch_bounds__(kMfBlock) void k_mf_front(MfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mf_lds[];
+  __shared__ int blk_pos;
+  constexpr int NFB = kMfBlock / TF;         // fronts per workgroup
+  constexpr int RW = TF >= 256 ? 32 : 16;    // lanes along the rows of a tile of work, CW along its columns
+  constexpr int CW = TF / RW;
+  constexpr int G = TF >= 64 ? 16 : 1;       // lanes per column when the columns of L are read / written
+  const int fr = threadIdx.x / TF, tid = threadIdx.x % TF;
+  const int ta = tid % RW, tb = tid / RW;
+  const int li = blockIdx.x * NFB + fr;
+  const bool live = li < a.count;
+  const int J = live ? a.list[li] : 0;
+  const int q0 = live ? a.ptr[J] : 0, s = live ? a.ptr[J + 1] - q0 : 0, b = live ? a.bsz[J] : 0, f = s + b;
+  double *F = mf_lds + (size_t)fr * mf_slab_doubles(a.fcap);
+  double *dv = F + (size_t)a.fcap * (a.fcap + 1) / 2;  // reciprocal pivots
+  auto cs = [&](int j) { return j * (2 * f - j - 1) / 2; };
+  if (threadIdx.x == 0) blk_pos = 0;
+  for (int e = tid; e < f * (f + 1) / 2; e += TF) F[e] = 0.0;
+  mf_sync<TF>();
+  if (TF <= 64) __syncthreads();  // blk_pos
+  // 1. the entries of K in the columns of the supernode
+  for (int c = tid / G; c < s; c += TF / G) {
+    const int k = a.piv[q0 + c], cc = cs(c);
+    if (tid % G == 0) F[cc + c] = a.D[k];
+    for (int64_t t = a.Lp[k] + tid % G; t < a.Lp[k + 1]; t += G) F[cc + a.loc[t]] = a.Lx[t];
+  }
+  mf_sync<TF>();
+  // 2. extend-add of the children's update matrices, one child after the other (its entries go to distinct places)
+  {
+    const int c0 = live ? a.chp[J] : 0, c1 = live ? a.chp[J + 1] : 0;
+    int cn = c0 < c1 ? a.chl[c0] : 0;
+    int bn = c0 < c1 ? a.bsz[cn] : 0;
+    int64_t un = c0 < c1 ? a.uoff[cn] : 0, rn = c0 < c1 ? a.reloff[cn] : 0;
+    for (int ci = c0; ci < c1; ci++) {
+      const int bc = bn;
+      const double *Uc = a.U + un;
+      const uint16_t *rl = a.rel + rn;
+      if (ci + 1 < c1) { cn = a.chl[ci + 1]; bn = a.bsz[cn]; un = a.uoff[cn]; rn = a.reloff[cn]; }  // the next child's header rides along
+      for (int bb = tb; bb < bc; bb += CW) {
+        const int cb = cs(rl[bb]), ub = bb * (2 * bc - bb - 1) / 2;
+        for (int r = bb + ta; r < bc; r += RW) F[cb + rl[r]] += Uc[ub + r];
+      }
+      mf_sync<TF>();
+    }
+  }
+  // 3. the pivots of the supernode: right-looking over the columns of the panel
+  int bad = 0;
+  for (int p = 0; p < s; p++) {
+    const int cp = cs(p);
+    const double d = F[cp + p];
+    const double dinv = 1.0 / d;
+    if (tid == 0) { dv[p] = dinv; bad |= (d == 0.0) || (d != d); }
+    for (int j = p + 1 + tb; j < s; j += CW) {
+      const double w = F[cp + j] * dinv;
+      const int cj = cs(j);
+      for (int i = j + ta; i < f; i += RW) F[cj + i] -= F[cp + i] * w;
+    }
+    mf_sync<TF>();
+  }
+  // 4. update matrix: U(r, c) = F(s + r, s + c) - sum_p F(s + r, p) dinv_p F(s + c, p), sums in registers
+  if (b > 0) {
+    double *Uj = a.U + a.uoff[J];
+    for (int c = tb; c < b; c += CW) {
+      const int cc = cs(s + c), uc = c * (2 * b - c - 1) / 2;
+      for (int r = c + ta; r < b; r += RW) {
+        double acc = F[cc + s + r];
+        for (int p = 0; p < s; p++) { const int cp = cs(p); acc -= F[cp + s + r] * (F[cp + s + c] * dv[p]); }
+        Uj[uc + r] = acc;
+      }
+    }
+  }
+  // 5. the columns of L, the pivots, the inertia
+  int pos = 0;
+  for (int c = tid / G; c < s; c += TF / G) {
+    const int k = a.piv[q0 + c], cc = cs(c);
+    const double dinv = dv[c];
+    if (tid % G == 0) { const double d = F[cc + c]; a.D[k] = d; a.Dinv[k] = dinv; pos += d > 0.0; }
+    for (int64_t t = a.Lp[k] + tid % G; t < a.Lp[k + 1]; t += G) a.Lx[t] = F[cc + a.loc[t]] * dinv;
+  }
+  // 6. W = L_JJ^-1 in place.  With B = -W below the diagonal, eliminating column p of the unit lower triangular block from
+  //    the rows below it is   B(i, c) -= B(i, p) B(p, c),  c < p < i   (B(i, p) is still the entry of L when step p reads it:
+  //    it only becomes a target in later steps) -- every update of a step is independent, one barrier per step.
+  if (a.Wc) {
+    mf_sync<TF>();
+    for (int j = tb; j < s; j += CW) {
+      const int cj = cs(j);
+      const double dj = dv[j];
+      for (int i = j + 1 + ta; i < s; i += RW) F[cj + i] *= dj;
+    }
+    mf_sync<TF>();
+    for (int p = 1; p + 1 < s; p++) {
+      const int cp = cs(p);
+      for (int c = tb; c < p; c += CW) {
+        const int cc = cs(c);
+        const double w = F[cc + p];
+        for (int i = p + 1 + ta; i < s; i += RW) F[cc + i] -= F[cp + i] * w;
+      }
+      mf_sync<TF>();
+    }
+    double *Wc = a.Wc + (live ? a.woff[J] : 0), *Wr = a.Wr + (live ? a.woff[J] : 0);
+    for (int j = tb; j < s; j += CW) {
+      const int cj = cs(j), cw = j * (2 * s - j - 1) / 2;
+      for (int i = j + ta; i < s; i += RW) {
+        const double v = i == j ? 1.0 : -F[cj + i];
+        Wc[cw + i] = v;
+        Wr[i * (i + 1) / 2 + j] = v;
+      }
+    }
+  }
+  if (bad) atomicOr(&a.status[0], 1);
+  if (pos) atomicAdd(&blk_pos, pos);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_pos) atomicAdd(&a.status[1], blk_pos);
+}
+
+// setup: row of the PARENT's front for every border row of every supernode (one thread per supernode)
+__global__ __launch_bounds__(kBlock) void k_mf_rel(int count, const int *__restrict__ ptr, const int *__restrict__ piv,
+                                                   const int *__restrict__ up, const int *__restrict__ snof, const int *__restrict__ slot,
+                                                   const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                   const int64_t *__restrict__ reloff, uint16_t *__restrict__ rel, int *__restrict__ err) {
+  const int J = blockIdx.x * kBlock + threadIdx.x;
+  if (J >= count) return;
+  const int P = up[J];
+  const int top = piv[ptr[J + 1] - 1];
+  const int64_t t0 = Lp[top], t1 = Lp[top + 1];
+  if (P < 0) { if (t1 > t0) atomicOr(err, 1); return; }
+  const int q0 = ptr[P], sP = ptr[P + 1] - q0, topP = piv[ptr[P + 1] - 1];
+  const int64_t p0 = Lp[topP], p1 = Lp[topP + 1];
+  int64_t lo = p0;  // the border rows ascend, so does their place in the parent's list
+  for (int64_t t = t0; t < t1; t++) {
+    const int i = Li[t];
+    int r;
+    if (snof[i] == P) r = slot[i] - q0;
+    else {
+      int64_t l = lo, h = p1;
+      while (l < h) { const int64_t mid = (l + h) >> 1; if (Li[mid] < i) l = mid + 1; else h = mid; }
+      if (l >= p1 || Li[l] != i) { atomicOr(err, 2); l = p0; }
+      lo = l;
+      r = sP + (int)(l - p0);
+    }
+    rel[reloff[J] + (t - t0)] = (uint16_t)r;
+  }
+}
+// setup: row of its column's front for every entry of L (one thread per entry)
+__global__ __launch_bounds__(kBlock) void k_mf_loc(int64_t nnzL, const int *__restrict__ Lcol, const int *__restrict__ Li,
+                                                   const int64_t *__restrict__ Lp, const int *__restrict__ ptr, const int *__restrict__ piv,
+                                                   const int *__restrict__ snof, const int *__restrict__ slot, uint16_t *__restrict__ loc,
+                                                   int *__restrict__ err) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nnzL) return;
+  const int k = Lcol[t], i = Li[t], J = snof[k];
+  const int q0 = ptr[J], s = ptr[J + 1] - q0;
+  int r;
+  if (snof[i] == J) r = slot[i] - q0;
+  else {
+    const int top = piv[ptr[J + 1] - 1];
+    const int64_t p0 = Lp[top], p1 = Lp[top + 1];
+    int64_t l = p0, h = p1;
+    while (l < h) { const int64_t mid = (l + h) >> 1; if (Li[mid] < i) l = mid + 1; else h = mid; }
+    if (l >= p1 || Li[l] != i) { atomicOr(err, 4); l = p0; }
+    r = s + (int)(l - p0);
+  }
+  loc[t] = (uint16_t)r;
+}
+
+}  // namespace
+}  // namespace oq

@@ -652,7 +652,27 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   stage("scatter maps");
 }
 
-void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
+void supernode_wmap(const Symbolic &S, Supernodes &out) {
+  const int N = S.N;
+  std::vector<int> owner(N);
+  for (int J = 0; J < out.count; J++)
+    for (int q = out.ptr[J]; q < out.ptr[J + 1]; q++) owner[q] = J;
+  out.wmap.assign(out.woff[out.count], -1);
+  const int nt = host_threads(S.nnzL);
+  parallel_blocks(N, 8 * nt, nt, [&](int, int v0, int v1, int) {
+    for (int v = v0; v < v1; v++) {
+      const int J = owner[out.slot[v]];
+      for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
+        const int r = S.Li[t];
+        if (owner[out.slot[r]] != J) continue;
+        const int64_t a = out.slot[r] - out.ptr[J], b = out.slot[v] - out.ptr[J];
+        out.wmap[out.woff[J] + a * (a + 1) / 2 + b] = t;
+      }
+    }
+  });
+}
+
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap) {
   const int N = S.N;
   const std::vector<int> &parent = S.parent;
   static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
@@ -749,7 +769,7 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
     out.flops += (double)(s * s);
   }
   stage("partition, levels, slots");
-  out.wmap.assign(out.woff[count], -1);
+  if (with_wmap) out.wmap.assign(out.woff[count], -1);
   // The entries of L (column v, rows r > v) split into block entries (both ends in one supernode: their place in the dense
   // block) and the rest, which every row lists by the slot of the column (F, forward) and every column by the slot of the row
   // (G, backward).  Columns and rows are independent: host threads take ranges of them -- a column's entries from the CSC
@@ -762,7 +782,7 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out) {
       int64_t g = 0;
       for (int64_t t = S.Lp[v]; t < S.Lp[v + 1]; t++) {
         const int r = S.Li[t];
-        if (sn[r] == sn[v]) { const int64_t a = out.slot[r] - out.ptr[J], b = out.slot[v] - out.ptr[J]; out.wmap[out.woff[J] + a * (a + 1) / 2 + b] = t; }
+        if (sn[r] == sn[v]) { if (with_wmap) { const int64_t a = out.slot[r] - out.ptr[J], b = out.slot[v] - out.ptr[J]; out.wmap[out.woff[J] + a * (a + 1) / 2 + b] = t; } }
         else g++;
       }
       out.Gp[out.slot[v] + 1] = g;

@@ -75,7 +75,10 @@ struct Supernodes {
   std::vector<int> Fj, Gi;
   double flops = 0.0;         // multiply-adds of one forward + backward solve
 };
-void build_supernodes(const Symbolic &S, int smax, Supernodes &out);
+// with_wmap = false leaves `wmap` empty (the multifrontal factorisation inverts the blocks inside its fronts and never
+// looks at it); supernode_wmap fills it in afterwards
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap = true);
+void supernode_wmap(const Symbolic &S, Supernodes &out);
 
 // The dense top block of the level schedule: the longest suffix of the top chain (levels of at most chain_rows pivots)
 // with at most dense_max pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when

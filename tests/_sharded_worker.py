@@ -43,11 +43,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    if case.startswith("update:"):
+    if case.startswith("update:") or case.startswith("updaterefused:"):
         from test_sharded_gpu import update_sequence
 
         _, kind, n, per_row, seed = case.split(":")
-        rec = update_sequence(oq, lib, oq.load_library(oq.ORACLE_LIB_PATH), int(kind), int(n), int(per_row), int(seed), settings, comm)
+        rec = update_sequence(oq, lib, oq.load_library(oq.ORACLE_LIB_PATH), int(kind), int(n), int(per_row), int(seed), settings, comm,
+                              refused=case.startswith("updaterefused:"))
         with open("%s.%d" % (out, rank), "w") as f:
             json.dump(rec, f)
         comm.close()

@@ -1,0 +1,114 @@
+"""Numeric LDL' by supernodes (csrc/mfront.hpp, row K2): the multifrontal factorisation against the level-by-level one on
+the same workspace layout -- one KKT solve with each factor on a random right-hand side, before and after a rho update
+(every `update_settings!(rho=...)`, `update_P!/A!` refactors [REF src/interface.jl:330-406, 539-550]) -- and against the
+CPU oracle's trajectory."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import osqp_jl_amd as oq
+import qp_zoo
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _kkt_solve(m, rhs):
+    out = np.empty_like(rhs)
+    assert m.lib.osqp_amd_apply(m.workspace, 3, _fptr(rhs), _fptr(out)) == 0
+    return out
+
+
+def _random_problem(rng, n, m, dens):
+    M = sp.random(n, n, density=dens, random_state=rng, data_rvs=rng.standard_normal)
+    P = sp.triu((M @ M.T + 0.1 * sp.eye(n)).tocsc(), format="csc")
+    A = sp.random(m, n, density=dens, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    l = -rng.random(m) - 0.1
+    u = rng.random(m) + 0.1
+    eq = rng.random(m) < 0.2
+    u[eq] = l[eq]
+    return dict(P=P, q=rng.standard_normal(n), A=A, l=l, u=u)
+
+
+CASES = {
+    "control-400": (lambda: qp_zoo.control(nx=8, nu=4, T=400), 64),
+    "control-300-small-supernodes": (lambda: qp_zoo.control(nx=12, nu=6, T=300), 5),
+    "control-200-singletons": (lambda: qp_zoo.control(nx=6, nu=3, T=200), 1),
+    "portfolio": (lambda: qp_zoo.portfolio(n=300, k=10), 16),
+    "svm": (lambda: qp_zoo.svm(n=20, m=150), 64),
+    "random-60": (lambda: _random_problem(np.random.default_rng(5), 60, 90, 0.08), 64),
+    "random-200": (lambda: _random_problem(np.random.default_rng(6), 200, 150, 0.02), 24),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_multifrontal_factor_is_the_level_factor(product_lib, monkeypatch, case):
+    make, smax = CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(11).standard_normal(n + mm)
+    sols = {}
+    for mf in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_MF", mf)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        st = oq.stats(m)
+        assert st[19] >= 1 and st[22] == float(mf == "1"), (st[19], st[22])
+        first = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.731)
+        second = _kkt_solve(m, rhs)
+        assert oq.stats(m)[8] == 2
+        sols[mf] = (first, second)
+        oq.clean(m)
+    for k in range(2):
+        a, b = sols["0"][k], sols["1"][k]
+        assert np.all(np.isfinite(b))
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (case, k, np.max(np.abs(a - b)), np.max(np.abs(a)))
+    assert np.max(np.abs(sols["1"][0] - sols["1"][1])) > 1e-6  # the rho update did change the factor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mf", ["0", "1"])
+def test_multifrontal_factor_reports_wrong_inertia(product_lib, monkeypatch, mf):
+    """A non-convex P must fail osqp_setup through the inertia count of the fronts' pivots [REF test/non_convex.jl:11-21]
+    (an entry far below -rho |A_j|^2, so that the reduced matrix P + sigma I + A' rho A is indefinite too)."""
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_MF", mf)
+    prob = qp_zoo.control(nx=6, nu=3, T=100)
+    m = oq.Model(product_lib)
+    oq.setup(m, linsys_solver="direct", verbose=False, scaling=0, **prob)
+    assert oq.stats(m)[22] == float(mf == "1")
+    oq.clean(m)
+    P = prob["P"].tolil()
+    P[3, 3] = -1e6
+    prob["P"] = sp.triu(P.tocsc(), format="csc")
+    m = oq.Model(product_lib)
+    with pytest.raises(oq.OSQPError):
+        oq.setup(m, linsys_solver="direct", verbose=False, scaling=0, **prob)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smax", [4, 64])
+def test_multifrontal_solve_follows_the_oracle(product_lib, oracle_lib, monkeypatch, smax):
+    """Whole solves with adaptive rho (several refactorisations): the oracle's iteration count and solution."""
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    prob = qp_zoo.control(nx=8, nu=4, T=400)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **opts, **prob)
+    ro = oq.solve(mo)
+    m = oq.Model(product_lib)
+    oq.setup(m, linsys_solver="direct", **opts, **prob)
+    assert oq.stats(m)[22] == 1.0
+    rp = oq.solve(m)
+    assert rp.info.status == ro.info.status == "Solved" and rp.info.iter == ro.info.iter
+    assert rp.info.rho_updates == ro.info.rho_updates and oq.stats(m)[8] == 1 + rp.info.rho_updates
+    assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+    oq.clean(m); oq.clean(mo)

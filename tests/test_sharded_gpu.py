@@ -125,7 +125,7 @@ def test_rccl_transport_one_rank(product_lib, tmp_path):
     assert rec["stats"][14] > 0
 
 
-def update_sequence(oq, lib, oracle_lib, kind, n, per_row, seed, settings, comm=None):
+def update_sequence(oq, lib, oracle_lib, kind, n, per_row, seed, settings, comm=None, refused=False):
     """Host-array setup of a generated instance, a solve, new matrix values -- some diagonal entries of P by index, all of A
     in full [REF src/interface.jl:330-406] -- and a second solve.  Run by every rank of the sharded test and by the
     single-device reference."""
@@ -144,6 +144,17 @@ def update_sequence(oq, lib, oracle_lib, kind, n, per_row, seed, settings, comm=
     cols = np.arange(0, P.shape[0], 7)
     diag_pos = P.indptr[cols + 1] - 1  # the diagonal is the last entry of a column of triu(P)
     assert np.all(P.indices[diag_pos] == cols)
+    if refused:  # a compact row block: the update must come back as an error before anything was touched, the workspace stays usable
+        try:
+            oq.update_P_A(m, P.data[diag_pos] * 1.5 + 0.25, diag_pos.astype(np.int64), A.data * 1.1, None)
+            raised, msg = False, ""
+        except oq.OSQPError:
+            raised, msg = True, lib.osqp_amd_last_error().decode()
+        r2 = oq.solve(m)
+        rec = {"raised": raised, "message": msg, "compact": oq.stats(m)[18], "status1": r1.info.status, "status2": r2.info.status,
+               "x1": np.asarray(r1.x).tolist(), "x2": np.asarray(r2.x).tolist()}
+        oq.clean(m)
+        return rec
     oq.update_P_A(m, P.data[diag_pos] * 1.5 + 0.25, diag_pos.astype(np.int64), A.data * 1.1, None)
     r2 = oq.solve(m)
     rec = {"status1": r1.info.status, "iter1": int(r1.info.iter), "status2": r2.info.status, "iter2": int(r2.info.iter),
@@ -170,3 +181,16 @@ def test_update_matrices_on_a_sharded_workspace(product_lib, oracle_lib, tmp_pat
         assert np.max(np.abs(np.array(rec["y2"]) - np.array(ref["y2"]))) <= 1e-4 * max(1.0, np.max(np.abs(ref["y2"])))
     for rec in recs[1:]:
         assert rec["x2"] == recs[0]["x2"] and rec["iter2"] == recs[0]["iter2"]
+
+
+def test_update_matrices_is_refused_cleanly_on_a_compact_row_block(tmp_path, monkeypatch):
+    """Advisor (round 4, high): a row block that went compact (OSQP_AMD_COMPACT_NNZ) has released its CSR values, so
+    osqp_update_P / _A must refuse with exit flag 6 BEFORE unscaling anything -- not write through a released array and leave
+    the other ranks hanging in the next collective.  The workspace stays usable: the next solve returns the first one's answer."""
+    monkeypatch.setenv("OSQP_AMD_PANEL", "2")  # sliced copies whatever the size (they are what a compact block keeps)
+    monkeypatch.setenv("OSQP_AMD_COMPACT_NNZ", "0")
+    recs = run_ranks(tmp_path, 2, "host", "updaterefused:0:3000:12:7", SETTINGS)
+    for rec in recs:
+        assert rec["compact"] == 1.0 and rec["raised"] and "compact" in rec["message"], rec["message"]
+        assert rec["status1"] == rec["status2"] == "Solved"
+        assert np.max(np.abs(np.array(rec["x1"]) - np.array(rec["x2"]))) <= 1e-5 * max(1.0, np.max(np.abs(rec["x1"])))

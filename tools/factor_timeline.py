@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Busy / idle time of the device inside the numeric factorisations of a rocprofv3 kernel trace (rocpd sqlite): every span from a
-k_diag_init to the next k_gather_csr.   python tools/factor_timeline.py results.db"""
+k_diag_init to the next k_gather_csr (level-scheduled solves) or k_sn_invert (supernodal solves).   python tools/factor_timeline.py results.db"""
 import re
 import sqlite3
 import sys
@@ -23,7 +23,7 @@ for st, en, name in rows:
         busy += (en - st) / 1e3
         prev_end = max(prev_end, en)
         n += 1
-        if "k_gather_csr" in name:
+        if "k_gather_csr" in name or "k_sn_invert" in name:
             span = (en - t0) / 1e3
             print("factorisation: %d launches, span %.1f ms, kernels %.1f ms, idle %.1f ms" % (n, span / 1e3, busy / 1e3, (span - busy) / 1e3))
             for kk, (cnt, dur, idle) in sorted(by.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:8]:
