@@ -319,8 +319,12 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 20 high-water mark of the device bytes allocated by this process (a sharded setup stays near 1/ranks of the whole)
  * 21 solves that were run again from a cold start because a wait inside the one-launch supernodal solve timed out
  * 22 the numeric factorisation runs by supernodes (multifrontal, one launch per supernode level and size class) 0 / 1
+ * 23 the factor's index arrays (CSC pattern of L, scatter maps, supernode lists) were built on the device from a lean host analysis 0 / 1
+ * 24 bytes of device address space this process has reserved for mapped blocks and never handed back (ranges are not reused
+ *    -- a ROCm 7 re-map defect, csrc/devmem.hip -- so a long-lived process grows this until reservations fail and blocks fall
+ *    back to hipMalloc; 128 TiB per process)
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
-#define OSQP_AMD_STATS_COUNT 24
+#define OSQP_AMD_STATS_COUNT 26
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);
 
 /* Time `reps` launches of one hot-path kernel with HIP events on the engine's

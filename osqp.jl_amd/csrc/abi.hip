@@ -405,6 +405,25 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
     ok = ok && inside + T.Fp[S.N] == S.nnzL && T.Gp[S.N] == T.Fp[S.N];
     out[0] = S.N; out[1] = (double)S.nnzL; out[2] = (double)S.level_ptr.size() - 1; out[3] = T.count; out[4] = T.nlev;
     if (count >= 14) out[13] = (double)kkt_graph_depth(P, A, ident, (int)m);  // what decides the first ordering on large problems
+    if (count >= 15) {  // a lean analysis completed on the host must be the full analysis, array for array
+      Symbolic S2;
+      symbolic_analyse(P, A, ident, (int)m, (int64_t)4000000000LL, 0.0, (int)ordering, S2, true);
+      bool same = S2.lean && S2.Lp == S.Lp && S2.Rp == S.Rp && S2.perm == S.perm && S2.level_ptr == S.level_ptr && S2.parent == S.parent &&
+                  S2.nnzL == S.nnzL && S2.flops == S.flops && S2.Li.empty() && S2.lean_rows;
+      if (same) {
+        int64_t held = 0;
+        for (const auto *c : S2.lean_rows->cols) held += (int64_t)c->size();
+        same = held == S.nnzL;
+        Supernodes T2;  // the partition does not depend on the lists
+        build_supernodes(S2, (int)smax, T2, false, true);
+        same = same && T2.count == T.count && T2.ptr == T.ptr && T2.piv == T.piv && T2.up == T.up && T2.lvl_ptr == T.lvl_ptr && T2.woff == T.woff;
+        for (int q = 0; q < S.N && same; q++) same = T2.Fp[q + 1] - T2.Fp[q] >= T.Fp[q + 1] - T.Fp[q] && T2.Gp[q + 1] - T2.Gp[q] >= T.Gp[q + 1] - T.Gp[q];
+      }
+      symbolic_complete(S2);
+      same = same && !S2.lean && S2.Lp == S.Lp && S2.Li == S.Li && S2.Rp == S.Rp && S2.Rj == S.Rj && S2.Rmap == S.Rmap && S2.PtoL == S.PtoL &&
+             S2.AtoL == S.AtoL;
+      out[14] = same ? 1.0 : 0.0;
+    }
     out[5] = (double)T.Fp[S.N]; out[6] = (double)T.woff[T.count]; out[7] = largest; out[8] = ok ? 1.0 : 0.0; out[9] = (double)inside;
     int lD, cD, kD;
     choose_dense_top(S, 512, getenv("OSQP_AMD_DENSE_MAX") ? atoi(getenv("OSQP_AMD_DENSE_MAX")) : 12288, 1024, 32, lD, cD, kD);
@@ -603,6 +622,8 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[20] = (c_float)g_device_peak;
   v[21] = (c_float)e.tree_restarts;
   v[22] = e.lin->multifrontal();
+  v[23] = e.lin->lean_setup();
+  v[24] = (c_float)dev_va_reserved();
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

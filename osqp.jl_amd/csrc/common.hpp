@@ -80,6 +80,7 @@ size_t dev_size_class(size_t bytes);
 void *dev_alloc(size_t bytes, size_t &granted);
 void dev_free(void *p, size_t granted);
 void dev_cache_trim();
+size_t dev_va_reserved();  // bytes of device address space reserved so far and never handed back (ranges are not reused: devmem.hip)
 struct DevCacheScope {
   DevCacheScope();
   ~DevCacheScope();

@@ -283,6 +283,7 @@ void dev_free(void *p, size_t granted) {
   g_free_s += wall_now() - t0;
 }
 
+size_t dev_va_reserved() { return g_va_reserved; }
 void dev_cache_trim() {
   std::lock_guard<std::mutex> lock(g_mu);
   trim_locked();

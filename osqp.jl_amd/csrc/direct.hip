@@ -1122,6 +1122,7 @@ struct LdlFactor {
   std::vector<MfLaunch> mf_launches;  // in level order
   int mf_fmax = 0;
   bool mf_ok = false;                 // the host plan exists (mf_plan): every front fits LDS
+  bool lean_built = false;            // the index arrays of the factor were built on the device (lean_device_*)
   std::vector<int> mfh_bsz, mfh_snof, mfh_chp, mfh_chl, mfh_list;
   std::vector<int64_t> mfh_uoff, mfh_reloff;
   const int *vec_perm() const { return sn ? perm_s.get() : perm.get(); }   // order of the solve vector bp
@@ -1151,11 +1152,26 @@ struct LdlFactor {
     bool nd_by_depth = false;
     if (first_ordering < 0 && e.hP.cols + mr_ >= 200000) nd_by_depth = kkt_graph_depth(e.hP, e.hA, row_map, mr_) >= 400;
     if (first_ordering < 0) first_ordering = nd_by_depth ? 1 : 0;
-    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S);
+    // Round 5: a large long problem (the class nested dissection goes first on) gets a LEAN analysis -- numbering, tree,
+    // levels, counts and the unsorted rows of the pattern -- and, when the factor is a supernodal one with fronts that fit
+    // LDS, everything else (CSC arrays of L, scatter maps, row / column lists of the supernodes) is built on the device from
+    // the rows (lean_device): control-1e6 spent 1.5 of its 3 s of setup writing, sorting and uploading those arrays on the
+    // host.  Any other outcome completes the analysis on the host (symbolic_complete: the same arrays as a full analysis).
+    // OSQP_AMD_LEAN = 0 never, 1 whenever the row map is the identity (tests: the path on small problems).
+    const int lean_mode = getenv("OSQP_AMD_LEAN") ? atoi(getenv("OSQP_AMD_LEAN")) : -1;
+    bool lean_try = lean_mode != 0 && (lean_mode == 1 || nd_by_depth) && mr_ == e.m;
+    for (int i = 0; lean_try && i < mr_; i++) lean_try = row_map[i] == i;
+    symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S, lean_try);
     if (nd_by_depth && (S.too_large || (int)S.level_ptr.size() - 1 > level_limit())) {  // the dissection did not deliver: as before
       first_ordering = 0;
       S = Symbolic();
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
+    }
+    if (S.lean && !S.too_large) {  // the decision a full analysis takes in choose_supernodes, from the counts
+      N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
+      lD = nlev; cD = N; kD = 0;
+      decide_supernodes(true);
+      if (!(sn && mf_ok)) { sn = false; mf_ok = false; T = Supernodes(); symbolic_complete(S); }
     }
     e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
@@ -1165,8 +1181,8 @@ struct LdlFactor {
     // (not when the depth is a dense trailing block -- a dense P: no ordering shortens that, and the block is inverted
     // explicitly anyway)
     int lD0 = 0, cD0 = 0, kD0 = 0;
-    choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD0, cD0, kD0);
-    if (try_nd && first_ordering != 1 && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
+    if (!S.lean) choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD0, cD0, kD0);
+    if (!S.lean && try_nd && first_ordering != 1 && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
       Symbolic S2;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
       if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
@@ -1174,7 +1190,7 @@ struct LdlFactor {
     // A short level schedule is launch-bound: the tie-breaking variant of the same ordering (symbolic.hpp, ordering 2)
     // often folds it further (bound constraints: row - variable - row chains of height 2 become height 1).
     static const bool try_fifo = !(getenv("OSQP_AMD_MD_FIFO") && atoi(getenv("OSQP_AMD_MD_FIFO")) == 0);
-    if (try_fifo && (int)S.level_ptr.size() - 1 >= 3 && (int)S.level_ptr.size() - 1 <= 400) {
+    if (!S.lean && try_fifo && (int)S.level_ptr.size() - 1 >= 3 && (int)S.level_ptr.size() - 1 <= 400) {
       Symbolic S3;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 2, S3);
       if (!S3.too_large && S3.nnzL <= S.nnzL + S.nnzL / 10 && solve_cost_us(S3) < 0.9 * solve_cost_us(S)) S = std::move(S3);
@@ -1184,14 +1200,20 @@ struct LdlFactor {
     N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
-    up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
-    up32(Li, S.Li); up32(Rj, S.Rj); up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
+    up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
+    const bool lean = S.lean;
+    lean_built = lean;
+    if (lean) lean_device_pattern();
+    else {
+      up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
+      up32(Li, S.Li); up32(Rj, S.Rj);
+    }
     Lcol.alloc(std::max<size_t>(1, (size_t)S.nnzL));  // the column of every entry of L: what the entry kernels of the factorisation start from
     expand_colptr(N, Lp.get(), S.nnzL, Lcol.get(), s);
-    Lx.alloc(S.nnzL); Rx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
-    choose_dense_block();
-    choose_supernodes();
-    if (sn) { lD = nlev; cD = N; kD = 0; }
+    Lx.alloc(S.nnzL); D.alloc(N); Dinv.alloc(N); bp.alloc(N); status.alloc(2);
+    if (!lean) { choose_dense_block(); decide_supernodes(false); }
+    if (sn) { lD = nlev; cD = N; kD = 0; supernodes_on_device(); }
+    else Rx.alloc(S.nnzL);  // (the CSR copy of the values serves the level-scheduled solves only)
     build_mf();
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
@@ -1221,8 +1243,9 @@ struct LdlFactor {
     }
     e.sync();
     e.setup_mark("  factor pattern on the device");
-    build_schedule();
+    if (!sn) build_schedule();  // (supernodal solves have their own schedule: levels of the supernode graph)
     e.setup_mark("  solve schedule");
+    if (lean) { S.lean_rows.reset(); S.lean_state.reset(); }
     // the big index arrays are only needed on the device from here on
     std::vector<int>().swap(S.Li); std::vector<int>().swap(S.Rj); std::vector<int64_t>().swap(S.Rmap);
     std::vector<int64_t>().swap(S.PtoL); std::vector<int64_t>().swap(S.AtoL);
@@ -1231,32 +1254,29 @@ struct LdlFactor {
   // Supernodal solves when their modelled time (a launch per level; the slowest workgroup of each level walks its
   // entries outside the blocks with 256 threads, then its s x s block) is well below the level schedule's.
   // OSQP_AMD_SNODE = 0 never, 2 always (tests), otherwise by the model.
-  void choose_supernodes() {
+  void decide_supernodes(bool lean) {
     const int mode = getenv("OSQP_AMD_SNODE") ? atoi(getenv("OSQP_AMD_SNODE")) : 1;
     if (mode == 0 || N < 2) return;
     if (mode != 2 && nlev < 48) return;
     if (mode != 2 && kD > 0 && lD < 48) return;  // the depth IS the dense block: the few levels below it stay a level schedule (no partition to build)
     int smax = kSnMax;  // OSQP_AMD_SNODE_MAX: smaller supernodes (tests: many levels on small problems)
     if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
-    build_supernodes(S, smax, T, false);
-    sn_lanes_f.assign(T.nlev, 1); sn_lanes_b.assign(T.nlev, 1);
-    for (int L = 0; L < T.nlev; L++) {
-      int64_t ef = 0, eb = 0, rows = 0;
-      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
-        const int q0 = T.ptr[J], q1 = T.ptr[J + 1];
-        ef += T.Fp[q1] - T.Fp[q0]; eb += T.Gp[q1] - T.Gp[q0]; rows += q1 - q0;
-      }
-      sn_lanes_f[L] = pick((double)ef / (double)std::max<int64_t>(1, rows));
-      sn_lanes_b[L] = pick((double)eb / (double)std::max<int64_t>(1, rows));
-    }
+    build_supernodes(S, smax, T, false, lean);  // lean: the partition, list lengths as upper bounds from the counts
     sn = mode == 2 || supernodes_pay(S, T, kChainRows, lD, kD, kSnThreads);
     if (!sn) { T = Supernodes(); return; }
     mf_ok = mf_plan();
-    if (!mf_ok) supernode_wmap(S, T);  // k_sn_invert gathers the blocks through it; the fronts invert theirs in place
+    if (!mf_ok && !lean) supernode_wmap(S, T);  // k_sn_invert gathers the blocks through it; the fronts invert theirs in place
+  }
+
+  // The device side of a supernodal factor: the lists of the entries outside the blocks (uploaded from a full analysis,
+  // built by lean_device_lists otherwise), the counters of the one-launch tree, the arrays of the inverted blocks.
+  void supernodes_on_device() {
     hipStream_t s = e.stream;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
-    up32(sn_ptr, T.ptr); up32(sn_piv, T.piv); up32(sn_Fj, T.Fj); up32(sn_Gi, T.Gi);
+    const bool lean = S.lean;
+    up32(sn_ptr, T.ptr); up32(sn_piv, T.piv);
+    if (!lean) { up32(sn_Fj, T.Fj); up32(sn_Gi, T.Gi); }
     sn_tree = T.nlev > 2 && !(getenv("OSQP_AMD_SNODE_TREE") && atoi(getenv("OSQP_AMD_SNODE_TREE")) == 0);
     sn_tree_L0 = 1;
     if (sn_tree) {
@@ -1275,16 +1295,20 @@ struct LdlFactor {
       while (sn_tree_L0 < T.nlev && (long long)(T.count - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
       if (T.nlev - sn_tree_L0 < 2) sn_tree = false;  // a single level (or none) left: nothing to fuse
     }
+    // the split of the forward rows: where the entries that point at the first level of the one-launch tree (level 1
+    // without it) begin -- children below that level have finished in earlier launches (not waited for), entries that
+    // point below it are read through the caches
+    const int split_level = (sn_tree && sn_tree_L0 > 1) ? sn_tree_L0 : std::min(1, T.nlev);
+    const int q_upper = split_level < T.nlev ? T.ptr[T.lvl_ptr[split_level]] : N;
     if (sn_tree && sn_tree_L0 > 1) {
-      // the counters and the split of the forward rows are relative to the first level of the launch: children below it
-      // have finished in earlier launches (not waited for), entries that point below it are read through the caches
+      // the counters are relative to the first level of the launch
       const int J0 = T.lvl_ptr[sn_tree_L0];
       std::fill(T.waits.begin(), T.waits.end(), 0);
       for (int J = J0; J < T.count; J++)
         if (T.up[J] >= 0) T.waits[T.up[J]]++;
-      const int q_upper = T.ptr[J0];
-      for (int q = 0; q < N; q++)
-        T.Fsplit[q] = T.Fp[q] + (std::lower_bound(T.Fj.begin() + T.Fp[q], T.Fj.begin() + T.Fp[q + 1], q_upper) - (T.Fj.begin() + T.Fp[q]));
+      if (!lean)
+        for (int q = 0; q < N; q++)
+          T.Fsplit[q] = T.Fp[q] + (std::lower_bound(T.Fj.begin() + T.Fp[q], T.Fj.begin() + T.Fp[q + 1], q_upper) - (T.Fj.begin() + T.Fp[q]));
     }
     up32(sn_up, T.up); up32(sn_waits, T.waits); up32(sn_pending, T.waits);
     sn_ready.alloc(T.count); sn_ready.zero(s);
@@ -1293,16 +1317,106 @@ struct LdlFactor {
       *sn_fault_host = 0;
       HIP_CHECK(hipHostGetDevicePointer((void **)&sn_fault, sn_fault_host, 0));
     }
-    up64(sn_woff, T.woff); if (!mf_ok) up64(sn_wmap, T.wmap); up64(sn_Fp, T.Fp); up64(sn_Fpos, T.Fpos); up64(sn_Gp, T.Gp); up64(sn_Gpos, T.Gpos); up64(sn_Fsplit, T.Fsplit);
+    up64(sn_woff, T.woff);
+    if (lean) lean_device_lists(q_upper);
+    else {
+      if (!mf_ok) up64(sn_wmap, T.wmap);
+      up64(sn_Fp, T.Fp); up64(sn_Fpos, T.Fpos); up64(sn_Gp, T.Gp); up64(sn_Gpos, T.Gpos); up64(sn_Fsplit, T.Fsplit);
+    }
+    sn_lanes_f.assign(T.nlev, 1); sn_lanes_b.assign(T.nlev, 1);
+    for (int L = 0; L < T.nlev; L++) {
+      int64_t ef = 0, eb = 0, rows = 0;
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+        const int q0 = T.ptr[J], q1 = T.ptr[J + 1];
+        ef += T.Fp[q1] - T.Fp[q0]; eb += T.Gp[q1] - T.Gp[q0]; rows += q1 - q0;
+      }
+      sn_lanes_f[L] = pick((double)ef / (double)std::max<int64_t>(1, rows));
+      sn_lanes_b[L] = pick((double)eb / (double)std::max<int64_t>(1, rows));
+    }
     std::vector<int> ps(N), pis(N);
     for (int q = 0; q < N; q++) { ps[q] = S.perm[T.piv[q]]; pis[ps[q]] = q; }
     up32(perm_s, ps); up32(pinv_s, pis);
     sn_Wc.alloc(T.woff[T.count]); sn_Wr.alloc(T.woff[T.count]);
-    sn_Fx.alloc(std::max<size_t>(1, T.Fj.size())); sn_Gx.alloc(std::max<size_t>(1, T.Gi.size())); sn_Dinv.alloc(N);
+    sn_Fx.alloc(std::max<size_t>(1, (size_t)T.Fp[N])); sn_Gx.alloc(std::max<size_t>(1, (size_t)T.Gp[N])); sn_Dinv.alloc(N);
     e.sync();
     // only the shapes are needed on the host from here on
     std::vector<int64_t>().swap(T.wmap); std::vector<int64_t>().swap(T.Fpos); std::vector<int64_t>().swap(T.Gpos);
     std::vector<int>().swap(T.Fj); std::vector<int>().swap(T.Gi);
+  }
+
+  // ---- the device side of a LEAN analysis (symbolic.hpp): from the unsorted rows of the pattern of L ----------------------
+  // CSC arrays of L: the rows go up as they were found, every entry with its row id beside it, and one sort by (column, row)
+  // -- the transposition the setup already runs on A (kernels.hip csr_from_coo: counting / LSD radix sort, rows of the
+  // result ascending) -- gives Lp / Li.  The scatter maps are one bisection per entry of triu(P) / A in its column of L.
+  void lean_device_pattern() {
+    hipStream_t s = e.stream;
+    const int64_t nnzL = S.nnzL;
+    DevBuf<int> ecol(std::max<int64_t>(1, nnzL)), erow(std::max<int64_t>(1, nnzL));
+    {
+      DevBuf<int64_t> rp((size_t)N + 1);
+      rp.upload(S.Rp.data(), (size_t)N + 1, s);
+      const LeanRows &R = *S.lean_rows;
+      for (size_t b = 0; b + 1 < R.first.size(); b++) {
+        const std::vector<int> &c = *R.cols[b];
+        if (!c.empty()) HIP_CHECK(hipMemcpyAsync(ecol.get() + S.Rp[R.first[b]], c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice, s));
+      }
+      expand_colptr(N, rp.get(), nnzL, erow.get(), s);  // the row of every entry
+      e.sync();
+    }
+    DevCsr Lc;
+    DevBuf<int> src;
+    csr_from_coo(N, N, nnzL, ecol.get(), erow.get(), Lc, src, s);  // "rows" of the result = columns of L
+    if (Lc.nnz != nnzL) throw Error(6, "internal: the transposed pattern of L lost entries");
+    Lc.val.release(); src.release(); ecol.release(); erow.release();
+    Lp = std::move(Lc.rowptr); Li = std::move(Lc.col);
+    PtoL.alloc(std::max<int64_t>(1, e.nnzPtriu)); AtoL.alloc(std::max<int64_t>(1, e.nnzA));
+    if (e.nnzPtriu > 0) {
+      DevBuf<int> pcol((size_t)e.nnzPtriu);
+      expand_colptr(n, e.Pp_keep.get(), e.nnzPtriu, pcol.get(), s);
+      OQ_LAUNCH(k_lean_map, dim3(blocks_for(e.nnzPtriu)), dim3(kBlock), 0, s, e.nnzPtriu, (const int *)pcol.get(), (const int *)e.Pi_keep.get(), 0, pinv.get(),
+                Lp.get(), Li.get(), PtoL.get());
+      e.sync();
+    }
+    if (e.nnzA > 0) {
+      DevBuf<int> acol((size_t)e.nnzA);
+      expand_colptr(n, e.At.rowptr.get(), e.nnzA, acol.get(), s);
+      OQ_LAUNCH(k_lean_map, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, (const int *)acol.get(), (const int *)e.At.col.get(), n, pinv.get(),
+                Lp.get(), Li.get(), AtoL.get());
+      e.sync();
+    }
+  }
+  // Row and column lists of the entries outside the diagonal blocks, in slot order: two more sorts of the entries of L,
+  // keyed (slot of the row, slot of the column) and the other way round; an entry inside a block carries row -1 (dropped).
+  void lean_device_lists(int q_upper) {
+    hipStream_t s = e.stream;
+    const int64_t nnzL = S.nnzL;
+    auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    up32(mf_snof, mfh_snof); up32(mf_slot, T.slot);
+    DevBuf<int> lcol(std::max<int64_t>(1, nnzL)), er(std::max<int64_t>(1, nnzL)), ec(std::max<int64_t>(1, nnzL));
+    expand_colptr(N, Lp.get(), nnzL, lcol.get(), s);
+    for (int pass = 0; pass < 2; pass++) {  // 0: rows (forward lists F), 1: columns (backward lists G)
+      if (nnzL > 0)
+        OQ_LAUNCH(k_lean_keys, dim3(blocks_for(nnzL)), dim3(kBlock), 0, s, nnzL, (const int *)lcol.get(), (const int *)Li.get(), (const int *)mf_snof.get(),
+                  (const int *)mf_slot.get(), pass, er.get(), ec.get());
+      DevCsr M;
+      DevBuf<int> src;
+      csr_from_coo(N, N, nnzL, er.get(), ec.get(), M, src, s);
+      M.val.release();
+      DevBuf<int64_t> pos(std::max<int64_t>(1, M.nnz));
+      if (M.nnz > 0) OQ_LAUNCH(k_widen, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, s, M.nnz, (const int *)src.get(), pos.get());
+      std::vector<int64_t> &hp = pass == 0 ? T.Fp : T.Gp;
+      hp.resize((size_t)N + 1);
+      M.rowptr.download(hp.data(), (size_t)N + 1, s);
+      e.sync();
+      if (pass == 0) { sn_Fp = std::move(M.rowptr); sn_Fj = std::move(M.col); sn_Fpos = std::move(pos); }
+      else { sn_Gp = std::move(M.rowptr); sn_Gi = std::move(M.col); sn_Gpos = std::move(pos); }
+    }
+    sn_Fsplit.alloc((size_t)N);
+    OQ_LAUNCH(k_lean_split, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, (const int64_t *)sn_Fp.get(), (const int *)sn_Fj.get(), q_upper, sn_Fsplit.get());
+    T.flops = 0.0;
+    for (int J = 0; J < T.count; J++) { const double sz = (double)(T.ptr[J + 1] - T.ptr[J]); T.flops += sz * sz; }
+    T.flops = 2.0 * (T.flops + (double)T.Fp[N]);
+    e.sync();
   }
 
   // Plan of the multifrontal factorisation (mfront.hpp): fronts, update-matrix offsets, children lists, launches by level
@@ -1368,7 +1482,8 @@ struct LdlFactor {
     hipStream_t s = e.stream;
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
-    up32(mf_snof, mfh_snof); up32(mf_slot, T.slot); up32(mf_bsz, mfh_bsz); up32(mf_chp, mfh_chp); up32(mf_chl, mfh_chl); up32(mf_list, mfh_list);
+    if (!mf_snof.n) { up32(mf_snof, mfh_snof); up32(mf_slot, T.slot); }
+    up32(mf_bsz, mfh_bsz); up32(mf_chp, mfh_chp); up32(mf_chl, mfh_chl); up32(mf_list, mfh_list);
     up64(mf_uoff, mfh_uoff); up64(mf_reloff, mfh_reloff);
     mf_rel.alloc(std::max<int64_t>(1, mfh_reloff[count])); mf_loc.alloc(std::max<int64_t>(1, S.nnzL)); mf_U.alloc(std::max<int64_t>(1, mfh_uoff[count]));
     mf_err.alloc(1); mf_err.zero(s);
@@ -1802,6 +1917,7 @@ struct Direct : Linsys {
   double levels() const override { return (double)F->nlev; }
   double supernode_levels() const override { return F->sn ? (double)F->T.nlev : 0.0; }
   double multifrontal() const override { return F->mf ? 1.0 : 0.0; }
+  double lean_setup() const override { return F->lean_built ? 1.0 : 0.0; }
   double trisolve_bytes() const override { return F->trisolve_bytes(); }
   double factorizations() const override { return (double)F->factorizations; }
   float time_solve(int reps) override {

@@ -223,5 +223,47 @@ __global__ __launch_bounds__(kBlock) void k_mf_loc(int64_t nnzL, const int *__re
   loc[t] = (uint16_t)r;
 }
 
+// ---- device side of a lean analysis (direct.hip LdlFactor::lean_device_*) ------------------------------------------------
+// where entry k of triu(P) (row_offset 0: KKT nodes rowidx, colid) or of A (row_offset n: nodes colid = the variable,
+// n + rowidx = the constraint row) sits in L: position in Lx, or -(pivot) - 1 for a diagonal entry
+__global__ __launch_bounds__(kBlock) void k_lean_map(int64_t nnz, const int *__restrict__ colid, const int *__restrict__ rowidx, int row_offset,
+                                                     const int *__restrict__ pinv, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                     int64_t *__restrict__ map) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  const int a = pinv[colid[k]], b = pinv[rowidx[k] + row_offset];
+  if (a == b) { map[k] = -(int64_t)a - 1; return; }
+  const int c = a < b ? a : b, r = a < b ? b : a;
+  int64_t l = Lp[c], h = Lp[c + 1];
+  while (l < h) { const int64_t mid = (l + h) >> 1; if (Li[mid] < r) l = mid + 1; else h = mid; }
+  map[k] = l;  // present by construction: every entry of K is an entry of L
+}
+// sort keys of the entries of L outside the diagonal blocks: pass 0 (slot of the row, slot of the column), pass 1 the other
+// way round; row -1 = inside a block (dropped by the sort)
+__global__ __launch_bounds__(kBlock) void k_lean_keys(int64_t nnzL, const int *__restrict__ Lcol, const int *__restrict__ Li,
+                                                      const int *__restrict__ snof, const int *__restrict__ slot, int pass,
+                                                      int *__restrict__ er, int *__restrict__ ec) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nnzL) return;
+  const int j = Lcol[t], k = Li[t];
+  const bool inside = snof[j] == snof[k];
+  const int sr = slot[k], sc = slot[j];
+  er[t] = inside ? -1 : (pass == 0 ? sr : sc);
+  ec[t] = pass == 0 ? sc : sr;
+}
+__global__ __launch_bounds__(kBlock) void k_widen(int64_t n, const int *__restrict__ in, int64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+// per forward row: the first entry that points at a slot >= q_upper
+__global__ __launch_bounds__(kBlock) void k_lean_split(int N, const int64_t *__restrict__ Fp, const int *__restrict__ Fj, int q_upper,
+                                                       int64_t *__restrict__ Fsplit) {
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= N) return;
+  int64_t l = Fp[q], h = Fp[q + 1];
+  while (l < h) { const int64_t mid = (l + h) >> 1; if (Fj[mid] < q_upper) l = mid + 1; else h = mid; }
+  Fsplit[q] = l;
+}
+
 }  // namespace
 }  // namespace oq

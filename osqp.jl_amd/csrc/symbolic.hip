@@ -7,6 +7,8 @@
 #include <chrono>
 #include <climits>
 #include <exception>
+#include <functional>
+#include <memory>
 #include <cmath>
 #include <numeric>
 #include <thread>
@@ -353,14 +355,28 @@ int kkt_graph_depth(const HostCsc &P, const HostCsc &A, const std::vector<int> &
   return depth;
 }
 
+namespace {
+// What a lean analysis (symbolic.hpp) keeps for symbolic_complete: the pattern of K with its origins and the row patterns
+struct LeanState {
+  Upper K;
+  std::vector<std::vector<int>> blk_cols;
+  std::vector<int> rowlen;
+  int nblk = 0, nt4 = 1;
+  int64_t nnzP = 0, nnzA = 0;
+};
+void finish_pattern(Symbolic &S, const Upper &K, std::vector<std::vector<int>> &blk_cols, std::vector<std::vector<int>> &blk_cnt,
+                    const std::vector<int> &rowlen, int nblk, int nt4, int64_t nnzP, int64_t nnzA,
+                    const std::function<void(const char *)> &stage);
+}  // namespace
+
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
-                      double flops_limit, int ordering, Symbolic &S) {
+                      double flops_limit, int ordering, Symbolic &S, bool lean) {
   const int n = P.cols, N = n + mr;
-  S.n = n; S.mr = mr; S.N = N; S.too_large = false;
+  S.n = n; S.mr = mr; S.N = N; S.too_large = false; S.lean = false;
   // OSQP_AMD_SYMBOLIC_TRACE=1: wall time of every stage on stderr
   static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
   auto t_prev = std::chrono::steady_clock::now();
-  auto stage = [&](const char *what) {
+  std::function<void(const char *)> stage = [&](const char *what) {
     if (!trace) return;
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[symbolic %d] %-34s %8.1f ms\n", ordering, what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
@@ -369,7 +385,8 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   const int64_t nnzP = P.p[n], nnzA = A.p[n];
 
   // ---- 1. upper-triangular pattern of K with origins --------------------------------
-  Upper K;
+  std::shared_ptr<LeanState> keep = std::make_shared<LeanState>();
+  Upper &K = keep->K;
   K.N = N;
   std::vector<int64_t> cnt(N + 1, 0);
   std::vector<char> has_diag(n, 0);
@@ -527,28 +544,94 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   const int nt4 = host_threads(cp[N] * 8);
   // more blocks than threads, dealt through a counter: the rows of a factor with a dense block differ in length by orders of
   // magnitude (a block holds one count per column: N ints, which bounds how many a long problem can afford)
-  const int nblk = nt4 == 1 ? 1 : std::max(2 * nt4, std::min(8 * nt4, (int)(((int64_t)1 << 27) / std::max(1, N))));
+  const int nblk = std::max(1, std::min(std::max(N, 1), nt4 == 1 ? 1 : std::max(2 * nt4, std::min(8 * nt4, (int)(((int64_t)1 << 27) / std::max(1, N))))));
   {
-    std::vector<std::vector<int>> blk_cols(nblk), blk_cnt(nblk);
-    std::vector<int> rowlen(N, 0);
+    std::vector<std::vector<int>> &blk_cols = keep->blk_cols;
+    std::vector<std::vector<int>> blk_cnt(nblk);
+    blk_cols.assign(nblk, std::vector<int>());
+    std::vector<int> &rowlen = keep->rowlen;
+    rowlen.assign(N, 0);
     std::vector<std::vector<int>> marks(nt4);
     std::atomic<int64_t> total{0};
     std::atomic<bool> over{false};
+    // lean: the column counts through one shared array of relaxed atomics instead of one count array per block (those
+    // exist to hand every block its first position inside each column of the CSC arrays, which a lean analysis never writes)
+    std::unique_ptr<std::atomic<int>[]> acount;
+    if (lean) { acount.reset(new std::atomic<int>[(size_t)N]); for (int i = 0; i < N; i++) acount[i].store(0, std::memory_order_relaxed); }
     parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int t) {
       if (marks[t].empty()) marks[t].assign(N, -1);
       std::vector<int> &mark = marks[t], &cols = blk_cols[b], &cnt = blk_cnt[b];
-      cnt.assign(N, 0);
+      if (!lean) cnt.assign(N, 0);
       for (int k = k0; k < k1 && !over.load(std::memory_order_relaxed); k++) {
         mark[k] = k;
         const size_t c0 = cols.size();
-        for (int64_t q = cp[k]; q < cp[k + 1]; q++)
-          for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); cnt[i]++; }
+        if (lean) {
+          for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+            for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); acount[i].fetch_add(1, std::memory_order_relaxed); }
+        } else {
+          for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+            for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); cnt[i]++; }
+        }
         rowlen[k] = (int)(cols.size() - c0);
         if (total.fetch_add(rowlen[k]) + rowlen[k] > nnzL_limit) over = true;
       }
     });
     if (over) { S.too_large = true; S.nnzL = total; return; }
     S.nnzL = total;
+    if (lean) {
+      // everything a supernodal factor on the device needs from the host: numbering, tree, levels, counts, and the rows of
+      // the pattern as they were found (unsorted); the device sorts and transposes them (direct.hip, LdlFactor::lean_device)
+      S.Lp.assign(N + 1, 0); S.Rp.assign(N + 1, 0);
+      S.flops = 0.0;
+      for (int j = 0; j < N; j++) {
+        const int64_t c = acount[j].load(std::memory_order_relaxed);
+        S.Lp[j + 1] = S.Lp[j] + c;
+        S.flops += (double)c * (double)c;
+        S.Rp[j + 1] = S.Rp[j] + rowlen[j];
+      }
+      keep->nblk = nblk; keep->nt4 = nt4; keep->nnzP = nnzP; keep->nnzA = nnzA;
+      S.lean_rows.reset(new LeanRows());
+      S.lean_rows->first.resize(nblk + 1);
+      for (int b = 0; b <= nblk; b++) S.lean_rows->first[b] = (int)((int64_t)N * b / nblk);
+      S.lean_rows->cols.resize(nblk);
+      for (int b = 0; b < nblk; b++) S.lean_rows->cols[b] = &blk_cols[b];
+      S.lean_state = keep;
+      S.lean = true;
+      stage("row patterns, column counts (lean)");
+      return;
+    }
+    finish_pattern(S, K, blk_cols, blk_cnt, rowlen, nblk, nt4, nnzP, nnzA, stage);
+  }
+}
+
+void symbolic_complete(Symbolic &S) {
+  if (!S.lean) return;
+  std::shared_ptr<LeanState> keep = std::static_pointer_cast<LeanState>(S.lean_state);
+  static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
+  auto t_prev = std::chrono::steady_clock::now();
+  std::function<void(const char *)> stage = [&](const char *what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[symbolic +] %-34s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  const int N = S.N, nblk = keep->nblk;
+  std::vector<std::vector<int>> blk_cnt(nblk);
+  parallel_blocks(nblk, nblk, keep->nt4, [&](int b, int, int, int) {
+    blk_cnt[b].assign(N, 0);
+    for (int i : keep->blk_cols[b]) blk_cnt[b][i]++;
+  });
+  S.lean = false;
+  finish_pattern(S, keep->K, keep->blk_cols, blk_cnt, keep->rowlen, nblk, keep->nt4, keep->nnzP, keep->nnzA, stage);
+  S.lean_rows.reset(); S.lean_state.reset();
+}
+
+namespace {
+void finish_pattern(Symbolic &S, const Upper &K, std::vector<std::vector<int>> &blk_cols, std::vector<std::vector<int>> &blk_cnt,
+                    const std::vector<int> &rowlen, int nblk, int nt4, int64_t nnzP, int64_t nnzA,
+                    const std::function<void(const char *)> &stage) {
+  const int N = S.N;
+  {
     std::vector<int64_t> colcount(N, 0);
     // counts -> first positions, block after block, in place (the counts become offsets relative to the column's start)
     parallel_blocks(N, 4 * nt4, nt4, [&](int, int i0, int i1, int) {
@@ -651,6 +734,7 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   }
   stage("scatter maps");
 }
+}  // namespace
 
 void supernode_wmap(const Symbolic &S, Supernodes &out) {
   const int N = S.N;
@@ -672,7 +756,7 @@ void supernode_wmap(const Symbolic &S, Supernodes &out) {
   });
 }
 
-void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap) {
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap, bool partition_only) {
   const int N = S.N;
   const std::vector<int> &parent = S.parent;
   static const bool trace = getenv("OSQP_AMD_SYMBOLIC_TRACE") && atoi(getenv("OSQP_AMD_SYMBOLIC_TRACE")) == 1;
@@ -769,6 +853,18 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
     out.flops += (double)(s * s);
   }
   stage("partition, levels, slots");
+  if (partition_only) {
+    // list lengths from the counts alone (rows and columns including the entries inside the blocks: upper bounds, what the
+    // cost model of the solves is asked with before the lists exist -- they are built on the device, direct.hip)
+    out.Fp.assign(N + 1, 0); out.Gp.assign(N + 1, 0);
+    for (int q = 0; q < N; q++) {
+      const int v = out.piv[q];
+      out.Fp[q + 1] = out.Fp[q] + (S.Rp[v + 1] - S.Rp[v]);
+      out.Gp[q + 1] = out.Gp[q] + (S.Lp[v + 1] - S.Lp[v]);
+    }
+    out.flops = 2.0 * (out.flops + (double)out.Fp[N]);
+    return;
+  }
   if (with_wmap) out.wmap.assign(out.woff[count], -1);
   // The entries of L (column v, rows r > v) split into block entries (both ends in one supernode: their place in the dense
   // block) and the rest, which every row lists by the slot of the column (F, forward) and every column by the slot of the row

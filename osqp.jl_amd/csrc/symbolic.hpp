@@ -8,11 +8,19 @@
 // (direct.hip); this file only produces index arrays.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 namespace oq {
 
 struct HostCsc;
+
+// The rows of the pattern of L as a lean analysis leaves them: block b = rows [first[b], first[b + 1]), the columns of
+// every row in the order the tree walk met them (unsorted), rows back to back.
+struct LeanRows {
+  std::vector<int> first;
+  std::vector<const std::vector<int> *> cols;
+};
 
 struct Symbolic {
   int n = 0, mr = 0, N = 0;          // variables, selected constraint rows, n + mr
@@ -32,6 +40,12 @@ struct Symbolic {
   int64_t nnzL = 0;
   double flops = 0.0;                // sum of squared column counts of L (cost model of one numeric factorisation)
   bool too_large = false;            // predicted factor exceeds the limit: nothing else is filled in
+  // A LEAN analysis (symbolic_analyse(..., lean = true)) stops once the numbering, the tree, the levels, Lp / Rp (counts) and
+  // the unsorted rows of the pattern are known: Li, Rj, Rmap, PtoL, AtoL stay empty -- a supernodal factor builds them on
+  // the device from the rows (direct.hip LdlFactor::lean_device) -- until symbolic_complete fills them in on the host.
+  bool lean = false;
+  std::shared_ptr<LeanRows> lean_rows;
+  std::shared_ptr<void> lean_state;
 };
 
 // row_map[i] = index of constraint row i inside the reduced block (0..mr-1) or -1 when the row is left out
@@ -48,7 +62,8 @@ struct Symbolic {
 int kkt_graph_depth(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr);
 
 void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int> &row_map, int mr, int64_t nnzL_limit,
-                      double flops_limit, int ordering, Symbolic &out);
+                      double flops_limit, int ordering, Symbolic &out, bool lean = false);
+void symbolic_complete(Symbolic &S);  // the rest of a lean analysis on the host (identical arrays to a full analysis)
 
 // Supernodes for the triangular solves (direct.hip, k_sn_*): sets of at most `smax` pivots whose diagonal block of L is
 // inverted once per factorisation, so that a solve needs one step per supernode instead of one per pivot.  Two kinds:
@@ -77,7 +92,9 @@ struct Supernodes {
 };
 // with_wmap = false leaves `wmap` empty (the multifrontal factorisation inverts the blocks inside its fronts and never
 // looks at it); supernode_wmap fills it in afterwards
-void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap = true);
+// partition_only: stop after the partition (levels, slots, block offsets), with Fp / Gp as upper bounds from the row and
+// column counts -- all a lean analysis can give; the lists are then built on the device
+void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wmap = true, bool partition_only = false);
 void supernode_wmap(const Symbolic &S, Supernodes &out);
 
 // The dense top block of the level schedule: the longest suffix of the top chain (levels of at most chain_rows pivots)

@@ -506,7 +506,7 @@ def warm_start(model, x=None, y=None):
         warm_start_y(model, y)
 
 
-def stats(model, count=24):
+def stats(model, count=26):
     """Extension: osqp_amd_get_stats as a list of floats."""
     out = np.zeros(count)
     k = model.lib.osqp_amd_get_stats(model.workspace, _fptr(out), count)

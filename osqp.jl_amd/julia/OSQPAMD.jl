@@ -64,7 +64,7 @@ Back-end in use, non-zero counts, nnz(L), CG / ADMM iteration totals, device byt
 of the dominant kernels (see include/osqp_amd.h, `osqp_amd_get_stats`).
 """
 function stats(model::OSQP.Model)
-    out = zeros(Float64, 24)  # OSQP_AMD_STATS_COUNT (include/osqp_amd.h)
+    out = zeros(Float64, 26)  # OSQP_AMD_STATS_COUNT (include/osqp_amd.h)
     k = ccall((:osqp_amd_get_stats, lib), Cc_int, (Ptr{OSQP.Workspace}, Ptr{Cdouble}, Cc_int), model.workspace, out, length(out))
     return out[1:k]
 end

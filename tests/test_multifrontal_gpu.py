@@ -112,3 +112,49 @@ def test_multifrontal_solve_follows_the_oracle(product_lib, oracle_lib, monkeypa
     assert rp.info.rho_updates == ro.info.rho_updates and oq.stats(m)[8] == 1 + rp.info.rho_updates
     assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
     oq.clean(m); oq.clean(mo)
+
+
+LEAN_CASES = {
+    "control-400": (lambda: qp_zoo.control(nx=8, nu=4, T=400), 64, "1"),
+    "control-300-min-degree": (lambda: qp_zoo.control(nx=12, nu=6, T=300), 7, "0"),
+    "portfolio": (lambda: qp_zoo.portfolio(n=300, k=10), 16, "0"),
+    "random-200": (lambda: _random_problem(np.random.default_rng(6), 200, 150, 0.02), 24, "0"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "5"])
+@pytest.mark.parametrize("case", sorted(LEAN_CASES))
+def test_lean_setup_builds_the_same_factor_on_the_device(product_lib, monkeypatch, case, threads):
+    """Round 5 (setup time of the direct back-end): a lean host analysis hands over the unsorted rows of the pattern of L
+    and the device builds the CSC arrays, the scatter maps and the supernode lists from them (csrc/direct.hip
+    lean_device_*).  Same arrays as the host-built ones, so the KKT solves agree BIT FOR BIT, before and after a matrix
+    update (the scatter maps) and a rho update."""
+    make, smax, ordering = LEAN_CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    monkeypatch.setenv("OSQP_AMD_FIRST_ORDERING", ordering)
+    monkeypatch.setenv("OSQP_AMD_HOST_THREADS", threads)
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(12).standard_normal(n + mm)
+    A = sp.csc_matrix(prob["A"])
+    sols = {}
+    for lean in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_LEAN", lean)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        st = oq.stats(m)
+        assert st[19] >= 1 and st[22] == 1.0 and st[23] == float(lean == "1"), (st[19], st[22], st[23])
+        first = _kkt_solve(m, rhs)
+        oq.update_A(m, A.data * 1.25, None)
+        second = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.37)
+        third = _kkt_solve(m, rhs)
+        r = oq.solve(m)
+        sols[lean] = (first, second, third, r.x.copy(), r.info.iter, st[4], st[5], st[19], st[11])
+        oq.clean(m)
+    for k in range(4):
+        assert np.array_equal(sols["0"][k], sols["1"][k]), (case, k, np.max(np.abs(sols["0"][k] - sols["1"][k])))
+    assert sols["0"][4:] == sols["1"][4:]  # iterations, nnz(L), levels, supernode levels, bytes of a solve
+    assert np.max(np.abs(sols["1"][0] - sols["1"][1])) > 1e-9

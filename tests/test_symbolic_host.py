@@ -16,13 +16,13 @@ def probe(lib, prob, ordering, smax=64):
     P.sort_indices(); A.sort_indices()
     n, m = P.shape[0], A.shape[0]
     arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (P.indptr, P.indices, A.indptr, A.indices)]
-    out = np.zeros(14)
+    out = np.zeros(15)
     ptrs = [a.ctypes.data_as(C.POINTER(C.c_longlong)) for a in arrs]
-    rc = lib.osqp_amd_symbolic_probe(n, m, *ptrs, ordering, smax, out.ctypes.data_as(C.POINTER(C.c_double)), 14)
+    rc = lib.osqp_amd_symbolic_probe(n, m, *ptrs, ordering, smax, out.ctypes.data_as(C.POINTER(C.c_double)), 15)
     assert rc == 0
     return dict(N=int(out[0]), nnzL=int(out[1]), levels=int(out[2]), supernodes=int(out[3]), sn_levels=int(out[4]),
                 outside=int(out[5]), block_doubles=int(out[6]), largest=int(out[7]), ok=bool(out[8]), inside=int(out[9]),
-                cost_levels=out[10], cost_supernodes=out[11], pays=bool(out[12]), graph_depth=int(out[13]))
+                cost_levels=out[10], cost_supernodes=out[11], pays=bool(out[12]), graph_depth=int(out[13]), lean_same=bool(out[14]))
 
 
 @pytest.mark.parametrize("ordering", [0, 1, 2])
@@ -34,6 +34,9 @@ def test_supernode_partition_invariants(product_lib, name, ordering, smax):
     r = probe(product_lib, qp_zoo.ZOO[name](), ordering, smax)
     n, m = qp_zoo.ZOO[name]()["P"].shape[0], qp_zoo.ZOO[name]()["A"].shape[0]
     assert r["ok"] and r["N"] == n + m
+    # round 5: a lean analysis (rows of the pattern only; csrc/symbolic.hpp) completed on the host IS the full analysis, and
+    # its supernode partition is the full one's with list lengths that bound the real ones
+    assert r["lean_same"]
     assert r["largest"] <= smax and r["inside"] + r["outside"] == r["nnzL"]
     assert r["sn_levels"] <= r["levels"]
     if smax == 1:  # singletons: nothing inside a block and the supernode graph is the elimination tree
@@ -48,7 +51,7 @@ def test_supernodes_on_random_patterns(product_lib):
         prob = dict(P=(M @ M.T).tocsc(), A=sp.random(m, n, density=0.2, random_state=rng, format="csc"))
         for ordering in (0, 1, 2):
             r = probe(product_lib, prob, ordering, int(rng.integers(1, 12)))
-            assert r["ok"], (n, m, ordering, r)
+            assert r["ok"] and r["lean_same"], (n, m, ordering, r)
 
 
 def test_long_horizon_control_takes_supernodes(product_lib):
