@@ -250,6 +250,49 @@ struct NestedDissection {
     connected(std::move(comps[0]), t, levels, out);
   }
 
+  // levels [lo, hi) of a level structure as one piece: separator = the smallest level with 30 % of the piece on both sides
+  // (the median level otherwise), sides first, separator last; at most leaf_size nodes: min-degree; fewer than three levels
+  // but more nodes than a leaf: the general path (its own searches)
+  void range(const std::vector<std::vector<int>> &levels, int lo, int hi, std::vector<int> &out) {
+    size_t total = 0;
+    for (int l = lo; l < hi; l++) total += levels[l].size();
+    if (total == 0) return;
+    if (total <= (size_t)leaf_size || hi - lo < 3) {
+      std::vector<int> V;
+      V.reserve(total);
+      for (int l = lo; l < hi; l++) V.insert(V.end(), levels[l].begin(), levels[l].end());
+      if (total <= (size_t)leaf_size) leaf(V, out); else dissect(std::move(V), out);
+      return;
+    }
+    int best = -1, median = lo + 1;
+    size_t before = levels[lo].size();
+    double gap = 1e300;
+    for (int l = lo + 1; l + 1 < hi; l++) {
+      const double a = (double)before, b = (double)total - a - (double)levels[l].size();
+      if (a >= 0.3 * (double)total && b >= 0.3 * (double)total && (best < 0 || levels[l].size() < levels[best].size())) best = l;
+      if (std::fabs(a - b) < gap) { gap = std::fabs(a - b); median = l; }
+      before += levels[l].size();
+    }
+    if (best < 0) best = median;
+    if (total >= parallel_min && spare_threads.fetch_sub(1) > 0) {
+      std::vector<int> outA, outB;
+      std::exception_ptr failed, mine;
+      std::thread other([&]() { try { range(levels, lo, best, outA); } catch (...) { failed = std::current_exception(); } });
+      try { range(levels, best + 1, hi, outB); } catch (...) { mine = std::current_exception(); }
+      other.join();
+      spare_threads.fetch_add(1);
+      if (failed) std::rethrow_exception(failed);
+      if (mine) std::rethrow_exception(mine);
+      out.insert(out.end(), outA.begin(), outA.end());
+      out.insert(out.end(), outB.begin(), outB.end());
+    } else {
+      if (total >= parallel_min) spare_threads.fetch_add(1);  // none was to be had: give the claim back
+      range(levels, lo, best, out);
+      range(levels, best + 1, hi, out);
+    }
+    out.insert(out.end(), levels[best].begin(), levels[best].end());
+  }
+
   void connected(std::vector<int> V, int t, std::vector<std::vector<int>> &levels, std::vector<int> &out) {
     // pseudo-peripheral root: restart from a smallest-degree node of the last level while the depth grows
     for (int pass = 0; pass < 4; pass++) {
@@ -264,6 +307,17 @@ struct NestedDissection {
     }
     const int nl = (int)levels.size();
     if (nl < 3) { leaf(V, out); return; }
+    // Round 5: a LONG THIN piece (a banded / multi-stage problem: mean level width below a sixteenth of the depth) is
+    // dissected on this one level structure all the way down -- a middle level separates the levels before it from those
+    // after it whatever the sub-piece, so the sides need no searches of their own (every recursion step used to cost ~5
+    // breadth-first passes over its piece: 0.65 s of the 2 s setup of control-1e6).  Anything else -- grid-like pieces, whose
+    // sub-pieces have better roots than the parent's -- keeps the per-piece level structures.
+    static const bool reuse = !(getenv("OSQP_AMD_ND_REUSE") && atoi(getenv("OSQP_AMD_ND_REUSE")) == 0);
+    if (reuse && V.size() > (size_t)leaf_size && (double)nl * (double)nl >= 16.0 * (double)V.size()) {
+      std::vector<int>().swap(V);
+      range(levels, 0, nl, out);
+      return;
+    }
     // separator: the smallest level whose sides both hold at least 30 % of the piece; otherwise the level at the median
     const double total = (double)V.size();
     int best = -1;
@@ -531,7 +585,11 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   for (int k = 0; k < N; k++) S.perm[newpos[k]] = order[k];
   for (int k = 0; k < N; k++) S.pinv[S.perm[k]] = k;
   build_cols(S.pinv, cp, ci);
-  etree_of(cp, ci, parent);
+  {  // the tree of the final numbering is the same tree relabelled (the renumbering keeps children before parents)
+    std::vector<int> p2(N, -1);
+    for (int k = 0; k < N; k++) if (parent[k] >= 0) p2[newpos[k]] = newpos[parent[k]];
+    parent.swap(p2);
+  }
   S.parent = parent;
 
   stage("elimination tree, levels");

@@ -135,6 +135,8 @@ def test_lean_setup_builds_the_same_factor_on_the_device(product_lib, monkeypatc
     monkeypatch.setenv("OSQP_AMD_SNODE", "2")
     monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
     monkeypatch.setenv("OSQP_AMD_FIRST_ORDERING", ordering)
+    monkeypatch.setenv("OSQP_AMD_ND", "0")       # like with like: no second opinion of another ordering on the full analysis
+    monkeypatch.setenv("OSQP_AMD_MD_FIFO", "0")  # (a lean analysis keeps the ordering it was asked for)
     monkeypatch.setenv("OSQP_AMD_HOST_THREADS", threads)
     n, mm = prob["P"].shape[0], prob["A"].shape[0]
     rhs = np.random.default_rng(12).standard_normal(n + mm)
