@@ -412,8 +412,28 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
                   S2.nnzL == S.nnzL && S2.flops == S.flops && S2.Li.empty() && S2.lean_rows;
       if (same) {
         int64_t held = 0;
-        for (const auto *c : S2.lean_rows->cols) held += (int64_t)c->size();
-        same = held == S.nnzL;
+        for (const auto &c : S2.lean_rows->cols) held += (int64_t)c.size();
+        same = held == S.nnzL && (int)S2.lean_rows->rowid.size() == S.N;
+        {  // every row of the walk holds exactly the columns of the row of L it says it is
+          std::vector<char> seen((size_t)S.N, 0);
+          const LeanRows &R = *S2.lean_rows;
+          for (size_t b = 0; b + 1 < R.first.size() && same; b++) {
+            size_t c = 0;
+            for (int r = R.first[b]; r < R.first[b + 1] && same; r++) {
+              const int k = R.rowid[r];
+              same = k >= 0 && k < S.N && !seen[k];
+              if (!same) break;
+              seen[k] = 1;
+              const int64_t len = S.Rp[k + 1] - S.Rp[k];
+              same = c + (size_t)len <= R.cols[b].size();
+              if (!same) break;
+              std::vector<int> got(R.cols[b].begin() + c, R.cols[b].begin() + c + len);
+              std::sort(got.begin(), got.end());
+              same = std::equal(got.begin(), got.end(), S.Rj.begin() + S.Rp[k]);
+              c += (size_t)len;
+            }
+          }
+        }
         Supernodes T2;  // the partition does not depend on the lists
         build_supernodes(S2, (int)smax, T2, false, true);
         same = same && T2.count == T.count && T2.ptr == T.ptr && T2.piv == T.piv && T2.up == T.up && T2.lvl_ptr == T.lvl_ptr && T2.woff == T.woff;

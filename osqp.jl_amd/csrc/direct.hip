@@ -1170,6 +1170,7 @@ struct LdlFactor {
     if (S.lean && !S.too_large) {  // the decision a full analysis takes in choose_supernodes, from the counts
       N = S.N; n = S.n; mr = S.mr; nlev = (int)S.level_ptr.size() - 1;
       lD = nlev; cD = N; kD = 0;
+      e.setup_mark("  lean analysis");
       decide_supernodes(true);
       if (!(sn && mf_ok)) { sn = false; mf_ok = false; T = Supernodes(); symbolic_complete(S); }
     }
@@ -1177,7 +1178,7 @@ struct LdlFactor {
     if (S.too_large) return;
     // A deep level schedule under min-degree (banded / multi-stage structure: the elimination tree is a chain) gets a
     // second analysis with nested dissection; the cheaper triangular solve by the model below wins.
-    static const bool try_nd = !(getenv("OSQP_AMD_ND") && atoi(getenv("OSQP_AMD_ND")) == 0);
+    const bool try_nd = !(getenv("OSQP_AMD_ND") && atoi(getenv("OSQP_AMD_ND")) == 0);
     // (not when the depth is a dense trailing block -- a dense P: no ordering shortens that, and the block is inverted
     // explicitly anyway)
     int lD0 = 0, cD0 = 0, kD0 = 0;
@@ -1189,7 +1190,7 @@ struct LdlFactor {
     }
     // A short level schedule is launch-bound: the tie-breaking variant of the same ordering (symbolic.hpp, ordering 2)
     // often folds it further (bound constraints: row - variable - row chains of height 2 become height 1).
-    static const bool try_fifo = !(getenv("OSQP_AMD_MD_FIFO") && atoi(getenv("OSQP_AMD_MD_FIFO")) == 0);
+    const bool try_fifo = !(getenv("OSQP_AMD_MD_FIFO") && atoi(getenv("OSQP_AMD_MD_FIFO")) == 0);
     if (!S.lean && try_fifo && (int)S.level_ptr.size() - 1 >= 3 && (int)S.level_ptr.size() - 1 <= 400) {
       Symbolic S3;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 2, S3);
@@ -1203,7 +1204,7 @@ struct LdlFactor {
     up32(perm, S.perm); up32(pinv, S.pinv); up32(level_ptr, S.level_ptr);
     const bool lean = S.lean;
     lean_built = lean;
-    if (lean) lean_device_pattern();
+    if (lean) { lean_device_pattern(); e.setup_mark("    scatter maps"); }
     else {
       up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
       up32(Li, S.Li); up32(Rj, S.Rj);
@@ -1214,7 +1215,9 @@ struct LdlFactor {
     if (!lean) { choose_dense_block(); decide_supernodes(false); }
     if (sn) { lD = nlev; cD = N; kD = 0; supernodes_on_device(); }
     else Rx.alloc(S.nnzL);  // (the CSR copy of the values serves the level-scheduled solves only)
+    if (sn) e.setup_mark("    supernodes on the device");
     build_mf();
+    if (mf) e.setup_mark("    fronts");
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
@@ -1353,19 +1356,27 @@ struct LdlFactor {
     const int64_t nnzL = S.nnzL;
     DevBuf<int> ecol(std::max<int64_t>(1, nnzL)), erow(std::max<int64_t>(1, nnzL));
     {
-      DevBuf<int64_t> rp((size_t)N + 1);
-      rp.upload(S.Rp.data(), (size_t)N + 1, s);
       const LeanRows &R = *S.lean_rows;
+      std::vector<int64_t> wp((size_t)N + 1, 0);  // row pointers in the order of the walk
+      for (int r = 0; r < N; r++) wp[(size_t)r + 1] = wp[r] + (S.Rp[R.rowid[r] + 1] - S.Rp[R.rowid[r]]);
+      DevBuf<int64_t> rp((size_t)N + 1);
+      DevBuf<int> rowid((size_t)N), walk(std::max<int64_t>(1, nnzL));
+      rp.upload(wp.data(), (size_t)N + 1, s);
+      rowid.upload(R.rowid.data(), (size_t)N, s);
       for (size_t b = 0; b + 1 < R.first.size(); b++) {
-        const std::vector<int> &c = *R.cols[b];
-        if (!c.empty()) HIP_CHECK(hipMemcpyAsync(ecol.get() + S.Rp[R.first[b]], c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        const std::vector<int> &c = R.cols[b];
+        if ((int64_t)c.size() != wp[R.first[b + 1]] - wp[R.first[b]]) throw Error(6, "internal: a block of the lean analysis does not hold its rows");
+        if (!c.empty()) HIP_CHECK(hipMemcpyAsync(ecol.get() + wp[R.first[b]], c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice, s));
       }
-      expand_colptr(N, rp.get(), nnzL, erow.get(), s);  // the row of every entry
+      expand_colptr(N, rp.get(), nnzL, walk.get(), s);  // which row of the walk every entry belongs to ...
+      if (nnzL > 0) OQ_LAUNCH(k_lean_rowid, dim3(blocks_for(nnzL)), dim3(kBlock), 0, s, nnzL, (const int *)walk.get(), (const int *)rowid.get(), erow.get());  // ... and which row of L that is
       e.sync();
     }
     DevCsr Lc;
     DevBuf<int> src;
+    e.setup_mark("    rows of L uploaded");
     csr_from_coo(N, N, nnzL, ecol.get(), erow.get(), Lc, src, s);  // "rows" of the result = columns of L
+    e.setup_mark("    CSC arrays of L");
     if (Lc.nnz != nnzL) throw Error(6, "internal: the transposed pattern of L lost entries");
     Lc.val.release(); src.release(); ecol.release(); erow.release();
     Lp = std::move(Lc.rowptr); Li = std::move(Lc.col);
@@ -1410,6 +1421,7 @@ struct LdlFactor {
       e.sync();
       if (pass == 0) { sn_Fp = std::move(M.rowptr); sn_Fj = std::move(M.col); sn_Fpos = std::move(pos); }
       else { sn_Gp = std::move(M.rowptr); sn_Gi = std::move(M.col); sn_Gpos = std::move(pos); }
+      e.setup_mark(pass == 0 ? "    forward lists" : "    backward lists");
     }
     sn_Fsplit.alloc((size_t)N);
     OQ_LAUNCH(k_lean_split, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, (const int64_t *)sn_Fp.get(), (const int *)sn_Fj.get(), q_upper, sn_Fsplit.get());

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(kBlock) void k_lean_keys(int64_t nnzL, const int *_
   er[t] = inside ? -1 : (pass == 0 ? sr : sc);
   ec[t] = pass == 0 ? sc : sr;
 }
+__global__ __launch_bounds__(kBlock) void k_lean_rowid(int64_t n, const int *__restrict__ walk, const int *__restrict__ rowid, int *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = rowid[walk[i]];
+}
 __global__ __launch_bounds__(kBlock) void k_widen(int64_t n, const int *__restrict__ in, int64_t *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) out[i] = in[i];

@@ -413,11 +413,11 @@ namespace {
 // What a lean analysis (symbolic.hpp) keeps for symbolic_complete: the pattern of K with its origins and the row patterns
 struct LeanState {
   Upper K;
-  std::vector<std::vector<int>> blk_cols;
-  std::vector<int> rowlen;
-  int nblk = 0, nt4 = 1;
   int64_t nnzP = 0, nnzA = 0;
 };
+void build_cols(const Upper &K, const std::vector<int> &pv, std::vector<int64_t> &cp, std::vector<int> &ci);
+void etree_of(int N, const std::vector<int64_t> &cp, const std::vector<int> &ci, std::vector<int> &parent);
+void full_pattern(Symbolic &S, const Upper &K, int64_t nnzL_limit, int64_t nnzP, int64_t nnzA, const std::function<void(const char *)> &stage);
 void finish_pattern(Symbolic &S, const Upper &K, std::vector<std::vector<int>> &blk_cols, std::vector<std::vector<int>> &blk_cnt,
                     const std::vector<int> &rowlen, int nblk, int nt4, int64_t nnzP, int64_t nnzA,
                     const std::function<void(const char *)> &stage);
@@ -530,42 +530,10 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   stage("ordering");
 
   // ---- 3. elimination tree of the permuted matrix, node heights, level renumbering ----
-  // row-wise access to the permuted upper pattern: for column c (permuted), the rows r < c
-  auto build_cols = [&](const std::vector<int> &pv, std::vector<int64_t> &cp, std::vector<int> &ci) {
-    std::vector<int64_t> c2(N + 1, 0);
-    for (int j = 0; j < N; j++)
-      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
-        int a = pv[K.i[q]], b = pv[j];
-        if (a != b) c2[std::max(a, b) + 1]++;
-      }
-    for (int j = 0; j < N; j++) c2[j + 1] += c2[j];
-    cp = c2;
-    ci.resize(c2[N]);
-    std::vector<int64_t> f(c2.begin(), c2.end() - 1);
-    for (int j = 0; j < N; j++)
-      for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
-        int a = pv[K.i[q]], b = pv[j];
-        if (a != b) ci[f[std::max(a, b)]++] = std::min(a, b);
-      }
-  };
-  auto etree_of = [&](const std::vector<int64_t> &cp, const std::vector<int> &ci, std::vector<int> &parent) {
-    parent.assign(N, -1);
-    std::vector<int> anc(N, -1);
-    for (int k = 0; k < N; k++)
-      for (int64_t q = cp[k]; q < cp[k + 1]; q++) {
-        int i = ci[q];
-        while (i != -1 && i < k) {  // path compression towards k
-          int nx = anc[i];
-          anc[i] = k;
-          if (nx == -1) { parent[i] = k; break; }
-          i = nx;
-        }
-      }
-  };
   std::vector<int64_t> cp;
   std::vector<int> ci, parent;
-  build_cols(pinv, cp, ci);
-  etree_of(cp, ci, parent);
+  build_cols(K, pinv, cp, ci);
+  etree_of(N, cp, ci, parent);
   std::vector<int> height(N, 0);
   for (int k = 0; k < N; k++)
     if (parent[k] >= 0) height[parent[k]] = std::max(height[parent[k]], height[k] + 1);
@@ -584,82 +552,66 @@ void symbolic_analyse(const HostCsc &P, const HostCsc &A, const std::vector<int>
   S.perm.resize(N); S.pinv.resize(N);
   for (int k = 0; k < N; k++) S.perm[newpos[k]] = order[k];
   for (int k = 0; k < N; k++) S.pinv[S.perm[k]] = k;
-  build_cols(S.pinv, cp, ci);
-  {  // the tree of the final numbering is the same tree relabelled (the renumbering keeps children before parents)
-    std::vector<int> p2(N, -1);
-    for (int k = 0; k < N; k++) if (parent[k] >= 0) p2[newpos[k]] = newpos[parent[k]];
-    parent.swap(p2);
-  }
-  S.parent = parent;
-
+  // the tree of the final numbering is the same tree relabelled (the renumbering keeps children before parents)
+  S.parent.assign(N, -1);
+  for (int k = 0; k < N; k++) if (parent[k] >= 0) S.parent[newpos[k]] = newpos[parent[k]];
   stage("elimination tree, levels");
-  // ---- 4. pattern of L: row patterns by climbing the tree from each entry of the row ----
-  // Row k of L = the nodes met climbing from every entry of row k of K towards k.  The rows are independent: blocks of
-  // consecutive rows go to host threads (own mark array), each block keeps its rows' patterns and counts its entries per
-  // column; a block's first position inside column i is Lp[i] + the counts of the blocks before it, so the second pass
-  // writes the CSC row lists (ascending: blocks and rows in order), and the CSR view with the CSC position of every entry
-  // (row k: columns ascending after a sort of its small buffer), without any two threads touching the same slot.
+  if (!lean) { full_pattern(S, K, nnzL_limit, nnzP, nnzA, stage); return; }
+
+  // ---- 4 (lean). the rows of the pattern, walked in the numbering the ORDERING produced -----------------------------------
+  // Row k of L = the nodes met climbing the tree from every entry of row k of K towards k.  The final numbering is level by
+  // level -- a row's descendants lie all over it, and every step of a climb (mark, parent, count) is a cache miss: 0.3 - 0.7 s
+  // for the 6e7 entries of control-1e6 on 16 threads.  In the numbering of the ordering itself a subtree is a contiguous
+  // range (a dissection orders the two sides, then the separator; min-degree eliminates neighbours together), so the walk
+  // runs there and translates what it emits: the columns of a row through newpos, the row's own id likewise.  The rows
+  // leave in the order of the walk (LeanRows::rowid says which row each one is); the device sorts them anyway.
   const int nt4 = host_threads(cp[N] * 8);
-  // more blocks than threads, dealt through a counter: the rows of a factor with a dense block differ in length by orders of
-  // magnitude (a block holds one count per column: N ints, which bounds how many a long problem can afford)
-  const int nblk = std::max(1, std::min(std::max(N, 1), nt4 == 1 ? 1 : std::max(2 * nt4, std::min(8 * nt4, (int)(((int64_t)1 << 27) / std::max(1, N))))));
-  {
-    std::vector<std::vector<int>> &blk_cols = keep->blk_cols;
-    std::vector<std::vector<int>> blk_cnt(nblk);
-    blk_cols.assign(nblk, std::vector<int>());
-    std::vector<int> &rowlen = keep->rowlen;
-    rowlen.assign(N, 0);
-    std::vector<std::vector<int>> marks(nt4);
-    std::atomic<int64_t> total{0};
-    std::atomic<bool> over{false};
-    // lean: the column counts through one shared array of relaxed atomics instead of one count array per block (those
-    // exist to hand every block its first position inside each column of the CSC arrays, which a lean analysis never writes)
-    std::unique_ptr<std::atomic<int>[]> acount;
-    if (lean) { acount.reset(new std::atomic<int>[(size_t)N]); for (int i = 0; i < N; i++) acount[i].store(0, std::memory_order_relaxed); }
-    parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int t) {
-      if (marks[t].empty()) marks[t].assign(N, -1);
-      std::vector<int> &mark = marks[t], &cols = blk_cols[b], &cnt = blk_cnt[b];
-      if (!lean) cnt.assign(N, 0);
-      for (int k = k0; k < k1 && !over.load(std::memory_order_relaxed); k++) {
-        mark[k] = k;
-        const size_t c0 = cols.size();
-        if (lean) {
-          for (int64_t q = cp[k]; q < cp[k + 1]; q++)
-            for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); acount[i].fetch_add(1, std::memory_order_relaxed); }
-        } else {
-          for (int64_t q = cp[k]; q < cp[k + 1]; q++)
-            for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); cnt[i]++; }
-        }
-        rowlen[k] = (int)(cols.size() - c0);
-        if (total.fetch_add(rowlen[k]) + rowlen[k] > nnzL_limit) over = true;
-      }
-    });
-    if (over) { S.too_large = true; S.nnzL = total; return; }
-    S.nnzL = total;
-    if (lean) {
-      // everything a supernodal factor on the device needs from the host: numbering, tree, levels, counts, and the rows of
-      // the pattern as they were found (unsorted); the device sorts and transposes them (direct.hip, LdlFactor::lean_device)
-      S.Lp.assign(N + 1, 0); S.Rp.assign(N + 1, 0);
-      S.flops = 0.0;
-      for (int j = 0; j < N; j++) {
-        const int64_t c = acount[j].load(std::memory_order_relaxed);
-        S.Lp[j + 1] = S.Lp[j] + c;
-        S.flops += (double)c * (double)c;
-        S.Rp[j + 1] = S.Rp[j] + rowlen[j];
-      }
-      keep->nblk = nblk; keep->nt4 = nt4; keep->nnzP = nnzP; keep->nnzA = nnzA;
-      S.lean_rows.reset(new LeanRows());
-      S.lean_rows->first.resize(nblk + 1);
-      for (int b = 0; b <= nblk; b++) S.lean_rows->first[b] = (int)((int64_t)N * b / nblk);
-      S.lean_rows->cols.resize(nblk);
-      for (int b = 0; b < nblk; b++) S.lean_rows->cols[b] = &blk_cols[b];
-      S.lean_state = keep;
-      S.lean = true;
-      stage("row patterns, column counts (lean)");
-      return;
+  const int nblk = std::max(1, std::min(std::max(N, 1), nt4 == 1 ? 1 : 4 * nt4));
+  std::shared_ptr<LeanRows> rows = std::make_shared<LeanRows>();
+  rows->cols.assign(nblk, std::vector<int>());
+  rows->first.resize(nblk + 1);
+  for (int b = 0; b <= nblk; b++) rows->first[b] = (int)((int64_t)N * b / nblk);
+  std::vector<int> rowlen(N, 0);                      // by final id
+  std::vector<std::vector<int>> marks(nt4), cnts(nt4);  // by the ordering's id, one pair per thread
+  std::atomic<int64_t> total{0};
+  std::atomic<bool> over{false};
+  parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int t) {
+    if (marks[t].empty()) { marks[t].assign(N, -1); cnts[t].assign(N, 0); }
+    std::vector<int> &mark = marks[t], &cnt = cnts[t], &cols = rows->cols[b];
+    cols.reserve((size_t)(k1 - k0) * 24);
+    for (int k = k0; k < k1 && !over.load(std::memory_order_relaxed); k++) {
+      mark[k] = k;
+      const size_t c0 = cols.size();
+      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(newpos[i]); cnt[i]++; }
+      const int len = (int)(cols.size() - c0);
+      rowlen[newpos[k]] = len;
+      if (total.fetch_add(len) + len > nnzL_limit) over = true;
     }
-    finish_pattern(S, K, blk_cols, blk_cnt, rowlen, nblk, nt4, nnzP, nnzA, stage);
+  });
+  if (over) { S.too_large = true; S.nnzL = total; return; }
+  S.nnzL = total;
+  std::vector<int64_t> colcount(N, 0);
+  parallel_blocks(N, 4 * nt4, nt4, [&](int, int i0, int i1, int) {
+    for (int i = i0; i < i1; i++) {
+      int64_t c = 0;
+      for (int t = 0; t < nt4; t++) if (!cnts[t].empty()) c += cnts[t][i];
+      colcount[newpos[i]] = c;
+    }
+  });
+  S.Lp.assign(N + 1, 0); S.Rp.assign(N + 1, 0);
+  S.flops = 0.0;
+  for (int j = 0; j < N; j++) {
+    S.Lp[j + 1] = S.Lp[j] + colcount[j];
+    S.flops += (double)colcount[j] * (double)colcount[j];
+    S.Rp[j + 1] = S.Rp[j] + rowlen[j];
   }
+  rows->rowid = std::move(newpos);
+  keep->nnzP = nnzP; keep->nnzA = nnzA;
+  S.lean_rows = rows;
+  S.lean_state = keep;
+  S.lean = true;
+  stage("row patterns, column counts (lean)");
 }
 
 void symbolic_complete(Symbolic &S) {
@@ -673,16 +625,86 @@ void symbolic_complete(Symbolic &S) {
     fprintf(stderr, "[symbolic +] %-34s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-  const int N = S.N, nblk = keep->nblk;
-  std::vector<std::vector<int>> blk_cnt(nblk);
-  parallel_blocks(nblk, nblk, keep->nt4, [&](int b, int, int, int) {
-    blk_cnt[b].assign(N, 0);
-    for (int i : keep->blk_cols[b]) blk_cnt[b][i]++;
-  });
   S.lean = false;
-  finish_pattern(S, keep->K, keep->blk_cols, blk_cnt, keep->rowlen, nblk, keep->nt4, keep->nnzP, keep->nnzA, stage);
-  S.lean_rows.reset(); S.lean_state.reset();
+  S.lean_rows.reset();
+  full_pattern(S, keep->K, INT64_MAX, keep->nnzP, keep->nnzA, stage);  // the rows again, in the final numbering (the rare case)
+  S.lean_state.reset();
 }
+
+namespace {
+// rows r < c of every column c of the permuted upper pattern
+void build_cols(const Upper &K, const std::vector<int> &pv, std::vector<int64_t> &cp, std::vector<int> &ci) {
+  const int N = K.N;
+  std::vector<int64_t> c2(N + 1, 0);
+  for (int j = 0; j < N; j++)
+    for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+      int a = pv[K.i[q]], b = pv[j];
+      if (a != b) c2[std::max(a, b) + 1]++;
+    }
+  for (int j = 0; j < N; j++) c2[j + 1] += c2[j];
+  cp = c2;
+  ci.resize(c2[N]);
+  std::vector<int64_t> f(c2.begin(), c2.end() - 1);
+  for (int j = 0; j < N; j++)
+    for (int64_t q = K.p[j]; q < K.p[j + 1]; q++) {
+      int a = pv[K.i[q]], b = pv[j];
+      if (a != b) ci[f[std::max(a, b)]++] = std::min(a, b);
+    }
+}
+void etree_of(int N, const std::vector<int64_t> &cp, const std::vector<int> &ci, std::vector<int> &parent) {
+  parent.assign(N, -1);
+  std::vector<int> anc(N, -1);
+  for (int k = 0; k < N; k++)
+    for (int64_t q = cp[k]; q < cp[k + 1]; q++) {
+      int i = ci[q];
+      while (i != -1 && i < k) {  // path compression towards k
+        int nx = anc[i];
+        anc[i] = k;
+        if (nx == -1) { parent[i] = k; break; }
+        i = nx;
+      }
+    }
+}
+
+// ---- 4. pattern of L in the final numbering: row patterns by climbing the tree from each entry of the row ----
+// The rows are independent: blocks of consecutive rows go to host threads (own mark array), each block keeps its rows'
+// patterns and counts its entries per column; a block's first position inside column i is Lp[i] + the counts of the blocks
+// before it, so the second pass (finish_pattern) writes the CSC row lists (ascending: blocks and rows in order), and the CSR
+// view with the CSC position of every entry (row k: columns ascending after a sort of its small buffer), without any two
+// threads touching the same slot.
+void full_pattern(Symbolic &S, const Upper &K, int64_t nnzL_limit, int64_t nnzP, int64_t nnzA, const std::function<void(const char *)> &stage) {
+  const int N = S.N;
+  std::vector<int64_t> cp;
+  std::vector<int> ci;
+  build_cols(K, S.pinv, cp, ci);
+  const std::vector<int> &parent = S.parent;
+  const int nt4 = host_threads(cp[N] * 8);
+  // more blocks than threads, dealt through a counter: the rows of a factor with a dense block differ in length by orders of
+  // magnitude (a block holds one count per column: N ints, which bounds how many a long problem can afford)
+  const int nblk = std::max(1, std::min(std::max(N, 1), nt4 == 1 ? 1 : std::max(2 * nt4, std::min(8 * nt4, (int)(((int64_t)1 << 27) / std::max(1, N))))));
+  std::vector<std::vector<int>> blk_cols(nblk), blk_cnt(nblk);
+  std::vector<int> rowlen(N, 0);
+  std::vector<std::vector<int>> marks(nt4);
+  std::atomic<int64_t> total{0};
+  std::atomic<bool> over{false};
+  parallel_blocks(N, nblk, nt4, [&](int b, int k0, int k1, int t) {
+    if (marks[t].empty()) marks[t].assign(N, -1);
+    std::vector<int> &mark = marks[t], &cols = blk_cols[b], &cnt = blk_cnt[b];
+    cnt.assign(N, 0);
+    for (int k = k0; k < k1 && !over.load(std::memory_order_relaxed); k++) {
+      mark[k] = k;
+      const size_t c0 = cols.size();
+      for (int64_t q = cp[k]; q < cp[k + 1]; q++)
+        for (int i = ci[q]; mark[i] != k; i = parent[i]) { mark[i] = k; cols.push_back(i); cnt[i]++; }
+      rowlen[k] = (int)(cols.size() - c0);
+      if (total.fetch_add(rowlen[k]) + rowlen[k] > nnzL_limit) over = true;
+    }
+  });
+  if (over) { S.too_large = true; S.nnzL = total; return; }
+  S.nnzL = total;
+  finish_pattern(S, K, blk_cols, blk_cnt, rowlen, nblk, nt4, nnzP, nnzA, stage);
+}
+}  // namespace
 
 namespace {
 void finish_pattern(Symbolic &S, const Upper &K, std::vector<std::vector<int>> &blk_cols, std::vector<std::vector<int>> &blk_cnt,

@@ -15,11 +15,12 @@ namespace oq {
 
 struct HostCsc;
 
-// The rows of the pattern of L as a lean analysis leaves them: block b = rows [first[b], first[b + 1]), the columns of
-// every row in the order the tree walk met them (unsorted), rows back to back.
+// The rows of the pattern of L as a lean analysis leaves them, in the order its tree walk took them (the numbering of the
+// ordering, not the final one): the r-th row of the walk is row rowid[r] of L; block b holds the rows [first[b], first[b + 1])
+// of the walk back to back, the columns of every row (final ids) in the order they were met (unsorted).
 struct LeanRows {
-  std::vector<int> first;
-  std::vector<const std::vector<int> *> cols;
+  std::vector<int> first, rowid;
+  std::vector<std::vector<int>> cols;
 };
 
 struct Symbolic {
