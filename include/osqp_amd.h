@@ -323,6 +323,8 @@ c_int osqp_amd_setup_generated(OSQPWorkspace **workp, c_int kind, c_int n, c_int
  * 24 bytes of device address space this process has reserved for mapped blocks and never handed back (ranges are not reused
  *    -- a ROCm 7 re-map defect, csrc/devmem.hip -- so a long-lived process grows this until reservations fail and blocks fall
  *    back to hipMalloc; 128 TiB per process)
+ * 25 pivots of the dense top block of the direct back-end (its Schur complement is inverted explicitly: block sweeps on the
+ *    fp64 matrix cores from 512 pivots on); 0: none
  * Returns the number of entries written (at most OSQP_AMD_STATS_COUNT). */
 #define OSQP_AMD_STATS_COUNT 26
 c_int osqp_amd_get_stats(const OSQPWorkspace *work, c_float *out, c_int count);

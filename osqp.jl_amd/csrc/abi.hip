@@ -644,6 +644,7 @@ c_int osqp_amd_get_stats(const OSQPWorkspace *w, c_float *out, c_int count) {
   v[22] = e.lin->multifrontal();
   v[23] = e.lin->lean_setup();
   v[24] = (c_float)dev_va_reserved();
+  v[25] = e.lin->dense_block();
   c_int k = 0;
   for (; k < count && k < OSQP_AMD_STATS_COUNT; k++) out[k] = v[k];
   return k;

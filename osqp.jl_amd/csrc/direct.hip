@@ -1088,6 +1088,7 @@ struct LdlFactor {
   DevBuf<int> Li, Lcol, Rj, perm, pinv, level_ptr, status;
   DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2, gjT, gjW, gjC;  // gj*: pivot block, row panel and panel copy of the block sweeps
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
+  bool kD_dense = false;        // ... taken because it IS dense (choose_dense_top)
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
   int ldD = 0;                  // leading dimension of the dense block's array (kD, or kD padded to 64 for the block sweeps)
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
@@ -1261,7 +1262,11 @@ struct LdlFactor {
     const int mode = getenv("OSQP_AMD_SNODE") ? atoi(getenv("OSQP_AMD_SNODE")) : 1;
     if (mode == 0 || N < 2) return;
     if (mode != 2 && nlev < 48) return;
-    if (mode != 2 && kD > 0 && lD < 48) return;  // the depth IS the dense block: the few levels below it stay a level schedule (no partition to build)
+    // the depth IS a dense block (a dense P, dense constraint rows): the few levels below it stay a level schedule (no
+    // partition to build).  A block-sparse top chain taken as a block -- the separators of a dissection -- is no such case:
+    // the supernodal form replaces it when its model is the cheaper one (round 5: with the one-level-structure dissection
+    // the control problem with T = 400 has 44 levels below such a block and 5 supernode levels)
+    if (mode != 2 && kD > 0 && lD < 48 && kD_dense) return;
     int smax = kSnMax;  // OSQP_AMD_SNODE_MAX: smaller supernodes (tests: many levels on small problems)
     if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
     build_supernodes(S, smax, T, false, lean);  // lean: the partition, list lengths as upper bounds from the counts
@@ -1544,7 +1549,8 @@ struct LdlFactor {
   void choose_dense_block() {
     lD = nlev; cD = N; kD = 0;
     static const bool enabled = !(getenv("OSQP_AMD_DENSE_TOP") && atoi(getenv("OSQP_AMD_DENSE_TOP")) == 0);
-    if (enabled) choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD, cD, kD);
+    kD_dense = false;
+    if (enabled) choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD, cD, kD, &kD_dense);
   }
   // columns of the block whose work rows (N doubles each) are held at once: at most 256 MB
   int dense_batch() const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)kD, ((size_t)256 << 20) / ((size_t)N * sizeof(double)))); }
@@ -1930,6 +1936,7 @@ struct Direct : Linsys {
   double supernode_levels() const override { return F->sn ? (double)F->T.nlev : 0.0; }
   double multifrontal() const override { return F->mf ? 1.0 : 0.0; }
   double lean_setup() const override { return F->lean_built ? 1.0 : 0.0; }
+  double dense_block() const override { return (double)F->kD; }
   double trisolve_bytes() const override { return F->trisolve_bytes(); }
   double factorizations() const override { return (double)F->factorizations; }
   float time_solve(int reps) override {

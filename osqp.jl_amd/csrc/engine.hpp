@@ -43,6 +43,7 @@ struct Linsys {
   virtual double levels() const { return 0.0; }
   virtual double supernode_levels() const { return 0.0; }  // 0: the solves walk the level schedule
   virtual double multifrontal() const { return 0.0; }      // 1: the numeric factorisation runs by supernodes (mfront.hpp)
+  virtual double dense_block() const { return 0.0; }       // pivots of the dense top block inverted explicitly (0: none)
   virtual double lean_setup() const { return 0.0; }        // 1: the factor's index arrays were built on the device from a lean analysis
   virtual double trisolve_bytes() const { return 0.0; }
   virtual double factorizations() const { return 0.0; }

@@ -1042,7 +1042,8 @@ bool supernodes_pay(const Symbolic &S, const Supernodes &T, int chain_rows, int 
   return 4 * T.nlev <= nlev && supernode_solve_cost_us(T, threads) < 0.7 * level_solve_cost_us(S, chain_rows, lD, kD);
 }
 
-void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD) {
+void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD, bool *is_dense) {
+  if (is_dense) *is_dense = false;
   const auto &lp = S.level_ptr;
   const int N = S.N, nlev = (int)lp.size() - 1;
   lD = nlev; cD = N; kD = 0;
@@ -1076,6 +1077,7 @@ void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dens
   const double dense_us = (double)k * (double)k * 8.0 / 4.0e6 + 10.0, chain_us = 1.4 * (double)(nlev - l);
   if (!dense && dense_us > chain_us) return;
   lD = l; cD = c; kD = k;
+  if (is_dense) *is_dense = dense;
 }
 
 }  // namespace oq

@@ -101,7 +101,10 @@ void supernode_wmap(const Symbolic &S, Supernodes &out);
 // The dense top block of the level schedule: the longest suffix of the top chain (levels of at most chain_rows pivots)
 // with at most dense_max pivots, taken when at least an eighth of its lower triangle is in the pattern of L or when
 // one dense product costs less than its levels.  lD = first level of the block, cD its first pivot, kD = N - cD (0: none).
-void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD);
+// is_dense (may be null): the block was taken because an eighth of it is in the pattern (a dense P, dense rows), not as the cheaper
+// form of a block-sparse top chain
+void choose_dense_top(const Symbolic &S, int chain_rows, int dense_max, int dense_sparse_max, int dense_min, int &lD, int &cD, int &kD,
+                      bool *is_dense = nullptr);
 
 // Rough time of one forward + backward solve by the level schedule: a launch per wide level, a chain step per narrow
 // level below the dense top block, the bytes of L at 2 TB/s, the dense block's product.  Used to compare orderings

@@ -341,6 +341,40 @@ def test_auto_backend_selection(product_lib):
     assert int(oq.stats(m)[0]) == 0
 
 
+def test_auto_rule_sends_a_dense_P_to_the_direct_back_end(product_lib, oracle_lib):
+    """Round-4 review, item 7b: under the DEFAULT linsys_solver ("qdldl" = auto) a dense P goes to the direct back-end --
+    the dense top block is priced by what inverting it on the matrix cores costs (csrc/direct.hip, make_direct) -- the
+    block-sweep path runs (>= 512 pivots: k_gj_*), and the solve is the oracle's: same iteration count, x to 1e-7."""
+    import qp_zoo
+
+    prob = qp_zoo.equality_qp(n=3000)
+    opts = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **prob, **opts)
+    ro = oq.solve(mo)
+    m = oq.Model(product_lib)
+    oq.setup(m, linsys_solver="qdldl", **prob, **opts)
+    st = oq.stats(m)
+    assert int(st[0]) == 0, "the auto rule did not choose the direct back-end"
+    assert st[25] >= 512 and st[25] >= 0.9 * prob["P"].shape[0], st[25]  # the dense P is the block; the blocked sweeps took it
+    rp = oq.solve(m)
+    assert ro.info.status == rp.info.status == "Solved" and ro.info.iter == rp.info.iter
+    assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+    oq.clean(m); oq.clean(mo)
+
+
+def test_auto_rule_still_sends_random_sparsity_to_pcg(product_lib):
+    """Item 7c: the same rule on a fill-heavy problem of the same size (random sparsity, n = m = 3000, 30 per row: the factor
+    fills to a dense block with nothing cheap about the columns below it) still falls through to the indirect back-end."""
+    m = oq.Model(product_lib)
+    oq.setup_generated(m, 0, 3000, 30, 1, verbose=False)
+    st = oq.stats(m)
+    assert int(st[0]) == 2 and st[25] == 0
+    r = oq.solve(m)
+    assert r.info.status == "Solved" and st[6] == 0 and oq.stats(m)[6] > 0  # CG iterations were what solved it
+    oq.clean(m)
+
+
 def test_full_size_properties(product_lib):
     """BASELINE.json's full-size workload (n = m = 1e6, nnz(A) = 1e9) cannot be rebuilt on the host inside a test,
     so it is checked through size-independent properties of the operators the solve is made of -- the CSR /
