@@ -390,6 +390,11 @@ c_int osqp_amd_get_iterate(OSQPWorkspace *work, c_float *x_out, c_float *y_out);
  *  op 3: y = K^{-1} x through the linear-system back-end (n+m -> n+m)        */
 c_int osqp_amd_apply(OSQPWorkspace *work, c_int op, const c_float *in, c_float *out);
 
+/* Which kernel the last batched solve of this process ran (tests, benchmarks): -1 the 512-thread kernel (one QP per eight
+ * wavefronts, the factorisation through an n x n scratch in global memory), k >= 0 entry k of the table of instantiations of
+ * the four-wavefront kernel (csrc/batch.hip DevicePattern::kQuadCfg; 0 = the MPC family with its shape compiled in), -2 none yet. */
+c_int osqp_amd_batch_last_kernel(void);
+
 /* Batched path: `count` independent QPs that
  * share one sparsity pattern.  P (upper triangle) and A are given once as
  * patterns; values are [count x nnz] row-major; q,l,u are [count x n|m].

@@ -41,6 +41,7 @@ namespace {
 #define OQ_BATCH_NT 512
 #endif
 constexpr int NT = OQ_BATCH_NT;  // threads per workgroup = per QP
+int g_batch_last_kernel = -2;  // what launch_batch launched last: -1 the 512-thread kernel, >= 0 the entry of DevicePattern::kQuadCfg
 inline bool batch_quad_enabled() {  // OSQP_AMD_BATCH_QUAD=0: the MPC family on the 512-thread kernel (A/B runs, tests)
   const char *e = getenv("OSQP_AMD_BATCH_QUAD");
   return !e || atoi(e) != 0;
@@ -1142,13 +1143,39 @@ struct DevicePattern {
   }
 
   // ---- schedule of the four-wavefront kernel ------------------------------------------------------------------------
-  // Compile-time bounds of the one instantiation (the MPC family of BASELINE.json config 5; see launch_batch)
-  static constexpr int kNH = 50, kKC = 9, kKE = 11, kCH = 16;
+  // The instantiations of the kernel (launch_batch holds the same table): quadrant size NH (n <= 2 NH), compile-time bounds
+  // KC / KE of the longest column / row of A, CH rows per assembly window.  Entry 0 is the MPC family of BASELINE.json config
+  // 5 with its shape compiled in (every LDS offset an immediate); the others take the shape at run time.  A pattern takes the
+  // first entry it fits (round 5: up to round 4 entry 0 was the only one, every other pattern ran the 512-thread kernel with
+  // its n x n global scratch).
+  struct QuadCfg { int NH, KC, KE, CH; bool mpc; };
+  static constexpr int kQuadCfgs = 9;
+  static constexpr QuadCfg kQuadCfg[kQuadCfgs] = {{50, 9, 11, 16, true},   {16, 16, 16, 16, false}, {32, 16, 16, 16, false},
+                                                  {48, 16, 16, 16, false}, {64, 16, 16, 16, false}, {16, 32, 32, 16, false},
+                                                  {32, 32, 32, 16, false}, {48, 32, 32, 16, false}, {64, 32, 32, 16, false}};
+  int quad_cfg = -1;
+  int kNH = 50, kKC = 9, kKE = 11, kCH = 16;  // of the entry taken
   void build_quad(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
                   const std::vector<int> &rc, const std::vector<int> &rmap, const std::vector<int> &fp, const std::vector<int> &fc,
                   const std::vector<int> &tp, const std::vector<unsigned short> &ti, const std::vector<unsigned short> &tj,
                   const std::vector<unsigned short> &tr, const std::vector<unsigned short> &ta, const std::vector<unsigned short> &tb,
                   hipStream_t s) {
+    quad_ok = false; quad_cfg = -1;
+    const int only = getenv("OSQP_AMD_BATCH_QUAD_CFG") ? atoi(getenv("OSQP_AMD_BATCH_QUAD_CFG")) : -1;  // experiments: one entry by number
+    for (int c = 0; c < kQuadCfgs && !quad_ok; c++) {
+      if (only >= 0 && c != only) continue;
+      const QuadCfg &q = kQuadCfg[c];
+      if (q.mpc && !(n == MPC_N && m == MPC_M && hAp[n] == kMpcNnzA && (int)fc.size() == MPC_N)) continue;
+      kNH = q.NH; kKC = q.KC; kKE = q.KE; kCH = q.CH;
+      build_quad_with(n, m, hAp, hAi, rp, rc, rmap, fp, fc, tp, ti, tj, tr, ta, tb, s);
+      if (quad_ok) quad_cfg = c;
+    }
+  }
+  void build_quad_with(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
+                       const std::vector<int> &rc, const std::vector<int> &rmap, const std::vector<int> &fp, const std::vector<int> &fc,
+                       const std::vector<int> &tp, const std::vector<unsigned short> &ti, const std::vector<unsigned short> &tj,
+                       const std::vector<unsigned short> &tr, const std::vector<unsigned short> &ta, const std::vector<unsigned short> &tb,
+                       hipStream_t s) {
     using namespace quad;
     quad_ok = false;
     const int nnzA = hAp[n], nnzF = (int)fc.size();
@@ -1263,7 +1290,7 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
   size_t bytes = lds_bytes(P.n, P.m, P.nnzA, P.nnzF, sparse_fits(P));
   if (P.n > 128 || P.m > 65535 || P.nnzA > 65535 || P.nnzF > 65535) throw Error(1, "the batched path supports n <= 128 and fewer than 65536 rows / non-zeros");
   if (bytes > 160 * 1024) throw Error(1, "instance too large for the LDS-resident batched path (needs " + std::to_string(bytes) + " bytes of LDS)");
-  const bool quad_path = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N && dp.quad_ok && batch_quad_enabled();
+  const bool quad_path = dp.quad_ok && dp.quad_cfg >= 0 && batch_quad_enabled();
   const size_t need = quad_path ? 0 : (size_t)count * P.n * P.n;  // the four-wavefront kernel has no global scratch
   if (dp.scratch.n < need) { HIP_CHECK(hipStreamSynchronize(s)); dp.scratch.alloc(need); }
   const int nc = (P.n + PARTS - 1) / PARTS;  // columns of the inverse per thread: the register tile is sized at compile time
@@ -1276,15 +1303,33 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
   // shapes compiled in (same source, constants folded): the MPC family of BASELINE.json config 5
   const bool mpc = P.n == MPC_N && P.m == MPC_M && P.nnzA == kMpcNnzA && P.nnzF == MPC_N;
   const bool use_quad = batch_quad_enabled();
-  if (mpc && dp.quad_ok && use_quad) {
-    // one QP per four wavefronts, three QPs per compute unit, the factorisation on chip (batch_quad.hpp)
-    auto kern = quad::k_batch_quad<DevicePattern::kNH, DevicePattern::kKC, DevicePattern::kKE, DevicePattern::kCH, MPC_N, MPC_M, kMpcNnzA, MPC_N>;
-    const quad::Layout L = quad::make_layout(P.n, P.m, P.nnzA, P.nnzF, DevicePattern::kNH, DevicePattern::kKC, DevicePattern::kKE, DevicePattern::kCH);
-    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    OQ_LAUNCH(kern, dim3(count), dim3(quad::QT), (size_t)L.total, s, dp.QS, st, count, Px, Ax, q, l, u, x, y, info, x_stride, y_stride,
-              info_stride, info_cols);
+  if (quad_path && use_quad) {
+    // one QP per four wavefronts, three (two from 64-column quadrants on) QPs per compute unit, the factorisation on chip
+    // (batch_quad.hpp); the instantiation the pattern's schedule was built for (DevicePattern::kQuadCfg)
+    const quad::Layout L = quad::make_layout(P.n, P.m, P.nnzA, P.nnzF, dp.kNH, dp.kKC, dp.kKE, dp.kCH);
+#define OQ_QUAD_LAUNCH(KERN, ...)                                                                                                      \
+  do {                                                                                                                                 \
+    auto kern = quad::KERN<__VA_ARGS__>;                                                                                               \
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total));                           \
+    OQ_LAUNCH(kern, dim3(count), dim3(quad::QT), (size_t)L.total, s, dp.QS, st, count, Px, Ax, q, l, u, x, y, info, x_stride, y_stride, \
+              info_stride, info_cols);                                                                                                 \
+  } while (0)
+    g_batch_last_kernel = dp.quad_cfg;
+    switch (dp.quad_cfg) {
+    case 0: OQ_QUAD_LAUNCH(k_batch_quad, 50, 9, 11, 16, MPC_N, MPC_M, kMpcNnzA, MPC_N); break;
+    case 1: OQ_QUAD_LAUNCH(k_batch_quad, 16, 16, 16, 16, 0, 0, 0, 0); break;
+    case 2: OQ_QUAD_LAUNCH(k_batch_quad, 32, 16, 16, 16, 0, 0, 0, 0); break;
+    case 3: OQ_QUAD_LAUNCH(k_batch_quad, 48, 16, 16, 16, 0, 0, 0, 0); break;
+    case 4: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 16, 16, 16, 0, 0, 0, 0); break;
+    case 5: OQ_QUAD_LAUNCH(k_batch_quad, 16, 32, 32, 16, 0, 0, 0, 0); break;
+    case 6: OQ_QUAD_LAUNCH(k_batch_quad, 32, 32, 32, 16, 0, 0, 0, 0); break;
+    case 7: OQ_QUAD_LAUNCH(k_batch_quad2, 48, 32, 32, 16, 0, 0, 0, 0); break;
+    default: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 32, 32, 16, 0, 0, 0, 0); break;
+    }
+#undef OQ_QUAD_LAUNCH
     return;
   }
+  g_batch_last_kernel = -1;
   if (mpc) OQ_BATCH_LAUNCH(25, MPC_N, MPC_M, kMpcNnzA, MPC_N);
   else if (nc <= 16) OQ_BATCH_LAUNCH(16, 0, 0, 0, 0);
   else if (nc <= 25) OQ_BATCH_LAUNCH(25, 0, 0, 0, 0);
@@ -1311,6 +1356,8 @@ struct BatchPlan {
 using namespace oq;
 
 extern "C" {
+
+c_int osqp_amd_batch_last_kernel(void) { return g_batch_last_kernel; }
 
 c_int osqp_amd_batch_solve(c_int count, c_int n, c_int m, const c_int *Pp, const c_int *Pi, const c_float *Px_all, const c_int *Ap,
                            const c_int *Ai, const c_float *Ax_all, const c_float *q_all, const c_float *l_all, const c_float *u_all,

@@ -289,8 +289,8 @@ __device__ __forceinline__ Me make_me(int n, int wvs) {  // wvs: the wavefront's
 }
 
 template <int NH, int KC, int KE, int CH, int CN, int CM, int CA, int CF>
-__global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batch_quad(
-    Sched S, OSQPSettings st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
+__device__ __forceinline__ void quad_body(
+    const Sched &S, const OSQPSettings &st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
     const double *__restrict__ q_all, const double *__restrict__ l_all, const double *__restrict__ u_all,
     double *__restrict__ x_out, double *__restrict__ y_out, double *__restrict__ info_out, int x_stride, int y_stride,
     int info_stride, int info_cols) {
@@ -884,6 +884,27 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
   }
 #undef ME
+}
+
+// Two occupancies: quadrants of at most 50 columns keep three QPs per compute unit (168 vector registers a lane), larger
+// ones (NH = 64: 128 registers of inverse alone) two.
+template <int NH, int KC, int KE, int CH, int CN, int CM, int CA, int CF>
+__global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batch_quad(
+    Sched S, OSQPSettings st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
+    const double *__restrict__ q_all, const double *__restrict__ l_all, const double *__restrict__ u_all,
+    double *__restrict__ x_out, double *__restrict__ y_out, double *__restrict__ info_out, int x_stride, int y_stride,
+    int info_stride, int info_cols) {
+  quad_body<NH, KC, KE, CH, CN, CM, CA, CF>(S, st, count, Px_all, Ax_all, q_all, l_all, u_all, x_out, y_out, info_out, x_stride, y_stride,
+                                            info_stride, info_cols);
+}
+template <int NH, int KC, int KE, int CH, int CN, int CM, int CA, int CF>
+__global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_batch_quad2(
+    Sched S, OSQPSettings st, int count, const double *__restrict__ Px_all, const double *__restrict__ Ax_all,
+    const double *__restrict__ q_all, const double *__restrict__ l_all, const double *__restrict__ u_all,
+    double *__restrict__ x_out, double *__restrict__ y_out, double *__restrict__ info_out, int x_stride, int y_stride,
+    int info_stride, int info_cols) {
+  quad_body<NH, KC, KE, CH, CN, CM, CA, CF>(S, st, count, Px_all, Ax_all, q_all, l_all, u_all, x_out, y_out, info_out, x_stride, y_stride,
+                                            info_stride, info_cols);
 }
 
 }  // namespace quad

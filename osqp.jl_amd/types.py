@@ -202,6 +202,7 @@ EXT_SYMBOLS = {
     "osqp_amd_batch_mpc_create": (c_int, [C.POINTER(C.c_void_p), c_int, C.c_ulonglong, C.POINTER(Settings), C.c_void_p, c_int]),
     "osqp_amd_batch_mpc_solve": (c_int, [C.c_void_p, C.c_void_p]),
     "osqp_amd_batch_destroy": (c_int, [C.c_void_p]),
+    "osqp_amd_batch_last_kernel": (c_int, []),
     "osqp_amd_device_alloc": (C.c_void_p, [c_int, c_int]),
     "osqp_amd_device_free": (c_int, [C.c_void_p, c_int]),
     "osqp_amd_device_copy": (c_int, [C.c_void_p, C.c_void_p, c_int, c_int, c_int]),

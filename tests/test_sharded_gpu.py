@@ -189,7 +189,7 @@ def test_update_matrices_is_refused_cleanly_on_a_compact_row_block(tmp_path, mon
     the other ranks hanging in the next collective.  The workspace stays usable: the next solve returns the first one's answer."""
     monkeypatch.setenv("OSQP_AMD_PANEL", "2")  # sliced copies whatever the size (they are what a compact block keeps)
     monkeypatch.setenv("OSQP_AMD_COMPACT_NNZ", "0")
-    recs = run_ranks(tmp_path, 2, "host", "updaterefused:0:3000:12:7", SETTINGS)
+    recs = run_ranks(tmp_path, 2, "host", "updaterefused:0:40000:24:7", SETTINGS)
     for rec in recs:
         assert rec["compact"] == 1.0 and rec["raised"] and "compact" in rec["message"], rec["message"]
         assert rec["status1"] == rec["status2"] == "Solved"
