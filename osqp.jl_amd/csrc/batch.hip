@@ -1179,7 +1179,12 @@ struct DevicePattern {
     using namespace quad;
     quad_ok = false;
     const int nnzA = hAp[n], nnzF = (int)fc.size();
-    if (n > 2 * kNH || m > QT || m == 0 || nnzA == 0) return;
+    static const bool trace = getenv("OSQP_AMD_BATCH_TRACE") && atoi(getenv("OSQP_AMD_BATCH_TRACE")) == 1;
+    auto refuse = [&](const char *why, int a, int b) {
+      if (trace) fprintf(stderr, "[batch] quadrants of %d (columns <= %d, rows <= %d): not taken, %s (%d > %d)\n", kNH, kKC, kKE, why, a, b);
+    };
+    if (n > 2 * kNH) { refuse("n", n, 2 * kNH); return; }
+    if (m > QT || m == 0 || nnzA == 0) { refuse("rows", m, QT); return; }
     int kc = 0;
     for (int j = 0; j < n; j++) kc = std::max(kc, hAp[j + 1] - hAp[j]);
     // rows by length, longest first (stable): lane L holds row order[L], so the long rows share wavefronts
@@ -1187,9 +1192,13 @@ struct DevicePattern {
     for (int i = 0; i < m; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rp[a + 1] - rp[a] > rp[b + 1] - rp[b]; });
     const int ke = rp[order[0] + 1] - rp[order[0]];
-    if (kc > kKC || ke > kKE) return;
+    if (kc > kKC) { refuse("longest column", kc, kKC); return; }
+    if (ke > kKE) { refuse("longest row", ke, kKE); return; }
     const Layout L = make_layout(n, m, nnzA, nnzF, kNH, kKC, kKE, kCH);
-    if (L.total > 65535 || (size_t)(nnzA + 1) * 8 > 65535) return;
+    // the term words and row words carry 16-bit LDS offsets of values, row records and operands: everything up to the
+    // pattern tables (colstart, collist, meta, row words -- addressed with 32-bit arithmetic) must lie below 64 KB
+    if (L.colstart > 65535 || (size_t)(nnzA + 1) * 8 > 65535) { refuse("LDS bytes below the pattern tables (16-bit offsets)", L.colstart, 65535); return; }
+    if (L.total > 80 * 1024) { refuse("LDS bytes (two QPs per compute unit)", L.total, 80 * 1024); return; }
     const int kch = L.kch, kep = L.kep;
     std::vector<unsigned short> colstart(QT), collist((size_t)QT * kch);
     for (int t = 0; t < QT; t++) {
@@ -1254,7 +1263,8 @@ struct DevicePattern {
       for (int t = 0; t < QT; t++) ns = std::max(ns, load[t]);
     }
     ns = std::max(4, (ns + 3) & ~3);
-    if (ns > 12) return;  // NSM of k_batch_quad
+    if (ns > 64) { refuse("assembly terms per thread and window", ns, 64); return; }  // (the kernel prefetches 12 slots -- its NSM -- and reads further ones in place)
+    if (trace) fprintf(stderr, "[batch] quadrants of %d (columns <= %d, rows <= %d): taken, %d bytes of LDS, %d term slots\n", kNH, kKC, kKE, L.total, ns);
     const unsigned long long pad = (unsigned long long)(kCH * n) | 0x8000ull | ((unsigned long long)(L.rec + m * RECB + F_RHO) << 16) |
                                    ((unsigned long long)L.cst << 32) | ((unsigned long long)L.cst << 48);  // 0 * 1 * 1 into the spare position
     std::vector<unsigned long long> stream((size_t)nwin * ns * QT, pad);

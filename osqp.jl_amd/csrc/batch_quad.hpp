@@ -550,22 +550,27 @@ __device__ __forceinline__ void quad_body(
         constexpr int K = decltype(k_tag)::value;
         {
           double acc = 0.0;
+          auto four = [&](unsigned long long w0, unsigned long long w1, unsigned long long w2, unsigned long long w3) {
+            const unsigned long long w[4] = {w0, w1, w2, w3};
+            double r[4], a[4], bq[4];
 #pragma unroll
-          for (int sl = 0; sl < NSM; sl += 4) {
-            if (sl < NS) {
-              double r[4], a[4], bq[4];
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                const unsigned long long w = tw[sl + k];
-                r[k] = ld(lds, (unsigned)(w >> 16) & 0xFFFFu); a[k] = ld(lds, (unsigned)(w >> 32) & 0xFFFFu); bq[k] = ld(lds, (unsigned)(w >> 48));
-              }
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                const unsigned long long w = tw[sl + k];
-                acc += r[k] * a[k] * bq[k];
-                if (w & 0x8000u) { sd(lds, L.roww + 8 * ((unsigned)w & 0x7FFFu), acc); acc = 0.0; }
-              }
+            for (int k = 0; k < 4; k++) {
+              r[k] = ld(lds, (unsigned)(w[k] >> 16) & 0xFFFFu); a[k] = ld(lds, (unsigned)(w[k] >> 32) & 0xFFFFu); bq[k] = ld(lds, (unsigned)(w[k] >> 48));
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              acc += r[k] * a[k] * bq[k];
+              if (w[k] & 0x8000u) { sd(lds, L.roww + 8 * ((unsigned)w[k] & 0x7FFFu), acc); acc = 0.0; }
+            }
+          };
+#pragma unroll
+          for (int sl = 0; sl < NSM; sl += 4)
+            if (sl < NS) four(tw[sl], tw[sl + 1], tw[sl + 2], tw[sl + 3]);
+          // patterns whose longest sums exceed the prefetched slots (a column of 16 entries is a diagonal position of 18
+          // terms): the words of the further slots straight from L2, four at a time
+          if (NS > NSM) {
+            const unsigned long long *sp = S.stream + (size_t)K * NS * QT + tid();
+            for (int sl = NSM; sl < NS; sl += 4) four(sp[(size_t)sl * QT], sp[(size_t)(sl + 1) * QT], sp[(size_t)(sl + 2) * QT], sp[(size_t)(sl + 3) * QT]);
           }
         }
         if constexpr (K + 1 < NCH) fetch_words(K + 1);

@@ -725,13 +725,12 @@ std::unique_ptr<Linsys> make_pcg(Engine &e) { return std::unique_ptr<Linsys>(new
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_polish_sets(int m, double delta, const double *__restrict__ z, const double *__restrict__ y,
                                                         const double *__restrict__ l, const double *__restrict__ u, double *__restrict__ rho,
-                                                        double *__restrict__ bound, int *__restrict__ count) {
+                                                        double *__restrict__ bound) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
   const bool low = z[i] - l[i] < -y[i], upp = u[i] - z[i] < y[i];
   rho[i] = (low || upp) ? 1.0 / delta : 0.0;
   bound[i] = low ? l[i] : (upp ? u[i] : 0.0);  // a row active on both sides keeps its lower bound, as the reduced matrix of polish_run does
-  if (low || upp) atomicAdd(count, 1);
 }
 // y = mask .* (Ax - r2) / delta  (mask = rho > 0)
 __global__ __launch_bounds__(kBlock) void k_polish_dual(int m, double delta, const double *__restrict__ rho, const double *__restrict__ Ax,
@@ -765,12 +764,9 @@ int polish_run_pcg(Engine &e) {
   OSQPInfo *info = e.ws->info;
   const double delta = e.st.delta;
   DevBuf<double> rho_keep(m ? m : 1), rho_pol(m ? m : 1), bound(m ? m : 1), xz(n + m), px(n), py(m ? m : 1), pz(m ? m : 1), tmp(n), r2(m ? m : 1);
-  DevBuf<int> count(1);
-  count.zero(s);
   if (m > 0) {
     vec_copy(rho_keep.get(), e.rho.get(), m, s);
-    OQ_LAUNCH(k_polish_sets, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.z.get(), e.y.get(), e.l.get(), e.u.get(), rho_pol.get(), bound.get(),
-              count.get());
+    OQ_LAUNCH(k_polish_sets, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta, e.z.get(), e.y.get(), e.l.get(), e.u.get(), rho_pol.get(), bound.get());
     vec_copy(e.rho.get(), rho_pol.get(), m, s);
   }
   // Conjugate gradients cannot work on the operator at the reference's delta = 1e-6 (P + delta I + A_act' A_act / delta:
@@ -804,6 +800,10 @@ int polish_run_pcg(Engine &e) {
   px.zero(s);
   if (m > 0) py.zero(s);
   double first_norm = -1.0;
+  // whatever ends the refinement -- convergence, a refused solve, an exception out of a launch or a collective -- the workspace
+  // gets its rho, sigma, preconditioner and CG settings back (advisor, round 4: a throw left the polish values behind and
+  // later solves silently ran with rho = mask / delta, sigma = delta, rel_tol = 1e-6)
+  try {
   for (int it = 0; it < kPolishRefine; it++) {
     // residual of the unregularised system at (x, y): r1 = -q - (P x + A' y), r2 = bound - A x on the active rows
     vec_copy(xz.get(), e.q.get(), n, s);
@@ -829,6 +829,10 @@ int polish_run_pcg(Engine &e) {
     if (m > 0) OQ_LAUNCH(k_polish_dual, dim3(blocks_for(m)), dim3(kBlock), 0, s, m, delta_in, e.rho.get(), xz.get() + n, r2.get(), py.get(), 1);
     if (first_norm < 0.0) first_norm = rn;
     if (it >= e.st.polish_refine_iter && rn <= 1e-10 * first_norm) break;
+  }
+  } catch (...) {
+    try { restore(); } catch (...) {}
+    throw;
   }
   restore();
   // polished (x, z, y) and its residuals, as in polish_run

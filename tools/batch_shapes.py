@@ -27,7 +27,7 @@ OPTS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, adaptive_rho_interval=50,
 
 def family(n, m, seed, tridiag=False, pat_A=None):
     from test_batch_gpu import _family
-    return _family(n, m, 8, seed, tridiagonal_P=tridiag, pat_A=pat_A)
+    return _family(n, m, 8, seed, tridiagonal_P=tridiag, pat_A=pat_A, equalities=False)
 
 
 def tile(args, count):
