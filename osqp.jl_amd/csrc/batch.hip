@@ -1149,10 +1149,11 @@ struct DevicePattern {
   // first entry it fits (round 5: up to round 4 entry 0 was the only one, every other pattern ran the 512-thread kernel with
   // its n x n global scratch).
   struct QuadCfg { int NH, KC, KE, CH; bool mpc; };
-  static constexpr int kQuadCfgs = 9;
+  static constexpr int kQuadCfgs = 10;
   static constexpr QuadCfg kQuadCfg[kQuadCfgs] = {{50, 9, 11, 16, true},   {16, 16, 16, 16, false}, {32, 16, 16, 16, false},
-                                                  {48, 16, 16, 16, false}, {64, 16, 16, 16, false}, {16, 32, 32, 16, false},
-                                                  {32, 32, 32, 16, false}, {48, 32, 32, 16, false}, {64, 32, 32, 16, false}};
+                                                  {48, 16, 16, 16, false}, {50, 16, 16, 16, false}, {64, 16, 16, 16, false},
+                                                  {16, 32, 32, 16, false}, {32, 32, 32, 16, false}, {48, 32, 32, 16, false},
+                                                  {64, 32, 32, 16, false}};
   int quad_cfg = -1;
   int kNH = 50, kKC = 9, kKE = 11, kCH = 16;  // of the entry taken
   void build_quad(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
@@ -1330,10 +1331,11 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
     case 1: OQ_QUAD_LAUNCH(k_batch_quad, 16, 16, 16, 16, 0, 0, 0, 0); break;
     case 2: OQ_QUAD_LAUNCH(k_batch_quad, 32, 16, 16, 16, 0, 0, 0, 0); break;
     case 3: OQ_QUAD_LAUNCH(k_batch_quad, 48, 16, 16, 16, 0, 0, 0, 0); break;
-    case 4: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 16, 16, 16, 0, 0, 0, 0); break;
-    case 5: OQ_QUAD_LAUNCH(k_batch_quad, 16, 32, 32, 16, 0, 0, 0, 0); break;
-    case 6: OQ_QUAD_LAUNCH(k_batch_quad, 32, 32, 32, 16, 0, 0, 0, 0); break;
-    case 7: OQ_QUAD_LAUNCH(k_batch_quad2, 48, 32, 32, 16, 0, 0, 0, 0); break;
+    case 4: OQ_QUAD_LAUNCH(k_batch_quad, 50, 16, 16, 16, 0, 0, 0, 0); break;   // the MPC sizes with another pattern (a non-diagonal P ...): no padding of the quadrants
+    case 5: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 16, 16, 16, 0, 0, 0, 0); break;
+    case 6: OQ_QUAD_LAUNCH(k_batch_quad, 16, 32, 32, 16, 0, 0, 0, 0); break;
+    case 7: OQ_QUAD_LAUNCH(k_batch_quad, 32, 32, 32, 16, 0, 0, 0, 0); break;
+    case 8: OQ_QUAD_LAUNCH(k_batch_quad2, 48, 32, 32, 16, 0, 0, 0, 0); break;
     default: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 32, 32, 16, 0, 0, 0, 0); break;
     }
 #undef OQ_QUAD_LAUNCH

@@ -880,6 +880,24 @@ __global__ __launch_bounds__(kBlock) void k_sn_gather(int64_t nf, const int64_t 
   if (i < N) Dinv_s[i] = Dinv[piv[i]];
 }
 
+// sum over j = j0, j0 + dj, ... < s of W(a, j) t[j] (forward: the packed columns, j <= a) or W(j, a) t[j] (backward: the packed
+// rows, j >= a) for row a of an s x s block; j is uniform over the lanes that call it together, four loads in flight
+template <bool kForward>
+__device__ __forceinline__ double sn_block_row(const double *__restrict__ Wj, const double *t, int s, int a, int j0, int dj) {
+  auto w = [&](int j) -> double {
+    if (kForward) return (a < s && j <= a) ? Wj[j * s - j * (j - 1) / 2 + (a - j)] : 0.0;
+    return (a < s && j >= a) ? Wj[j * (j + 1) / 2 + a] : 0.0;
+  };
+  double acc = 0.0;
+  int j = j0;
+  for (; j + 3 * dj < s; j += 4 * dj) {
+    const double w0 = w(j), w1 = w(j + dj), w2 = w(j + 2 * dj), w3 = w(j + 3 * dj);
+    acc += w0 * t[j]; acc += w1 * t[j + dj]; acc += w2 * t[j + 2 * dj]; acc += w3 * t[j + 3 * dj];
+  }
+  for (; j < s; j += dj) acc += w(j) * t[j];
+  return acc;
+}
+
 // LA lanes per row for the entries outside the block, 4 lanes per row for the block product
 template <int LA, bool kForward>
 __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
@@ -887,6 +905,7 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
                                                          const double *__restrict__ Ex, const double *__restrict__ W,
                                                          const double *__restrict__ Dinv_s, double *__restrict__ b) {
   __shared__ double t[kSnMax];
+  __shared__ double part[kSnThreads / 64][kSnMax];
   const int J = J0 + blockIdx.x, q0 = ptr[J], s = ptr[J + 1] - q0;
   {
     const int lane = threadIdx.x % LA;
@@ -899,16 +918,15 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__re
     }
   }
   __syncthreads();
+  // The block product, round 5: lane = row a, the step index j is wavefront-uniform, so every load of the block is ONE
+  // contiguous piece (column j of the packed columns forward, row j of the packed rows backward) instead of 64 scattered
+  // doubles (four lanes per row, each walking its own row); the four wavefronts take every fourth j, their partial sums meet
+  // in LDS in a fixed order.
   const double *Wj = W + woff[J];
-  const int part = threadIdx.x & 3;
-  for (int a = threadIdx.x >> 2; a < s; a += kSnThreads / 4) {
-    double acc = 0.0;
-    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s - j * (j - 1) / 2 + (a - j)] * t[j]; }  // W(a, j), packed columns
-    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * (j + 1) / 2 + a] * t[j]; }                       // W(j, a), packed rows
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (part == 0) b[q0 + a] = acc;
-  }
+  const int wv = threadIdx.x >> 6, a = threadIdx.x & 63;
+  part[wv][a] = sn_block_row<kForward>(Wj, t, s, a, wv, kSnThreads / 64);
+  __syncthreads();
+  if (wv == 0 && a < s) b[q0 + a] = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
 }
 
 // The same step with a WAVEFRONT per supernode (four per workgroup), for levels of many small supernodes: level 0 of a
@@ -943,15 +961,9 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's LDS writes are done before any of its lanes reads them
   __builtin_amdgcn_wave_barrier();
   const double *Wj = W + (live ? woff[J] : 0);
-  const int part = gl & 3;
-  for (int a = gl >> 2; a < s; a += GS / 4) {
-    double acc = 0.0;
-    if (kForward) { for (int j = part; j <= a; j += 4) acc += Wj[j * s - j * (j - 1) / 2 + (a - j)] * t[j]; }  // W(a, j), packed columns
-    else { for (int j = a + part; j < s; j += 4) acc += Wj[j * (j + 1) / 2 + a] * t[j]; }                       // W(j, a), packed rows
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (part == 0) b[q0 + a] = acc;
-  }
+  // lane = row, the step index uniform over the lanes of the supernode: contiguous loads of the block (see k_sn_level)
+  const double acc = sn_block_row<kForward>(Wj, t, s, gl, 0, 1);
+  if (gl < s) b[q0 + gl] = acc;
 }
 
 // The supernodes of level >= 1 in ONE launch per direction: workgroup = supernode, started in level order, each
