@@ -906,10 +906,33 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   // wavefront each (direct.hip k_sn_level_w), the rest with a whole one
   std::vector<int> newid(count);
   out.lvl_small.assign(nlev, 0);
+  // ... and inside each of the two classes the supernodes stand in the order of the supernode that holds their tree parent
+  // (round 5): the rows of a supernode gather the solution at the slots of its children -- with the children of one parent
+  // side by side those gathers fall into a few cache lines shared by the whole workgroup (and its neighbours) instead of
+  // lines all over the level.  OSQP_AMD_SNODE_ORDER=0: the order of discovery, as up to round 4.
   {
-    std::vector<int> f(out.lvl_ptr.begin(), out.lvl_ptr.end() - 1);
-    for (int J = 0; J < count; J++) if (members[J] <= Supernodes::kSmall) { newid[J] = f[level[J]]++; out.lvl_small[level[J]]++; }
-    for (int J = 0; J < count; J++) if (members[J] > Supernodes::kSmall) newid[J] = f[level[J]]++;
+    static const bool by_parent = !(getenv("OSQP_AMD_SNODE_ORDER") && atoi(getenv("OSQP_AMD_SNODE_ORDER")) == 0);
+    std::vector<int> up_old(count, -1);
+    for (int v = 0; v < N; v++) {
+      const int p = parent[v];
+      if (p >= 0 && sn[p] != sn[v]) up_old[sn[v]] = sn[p];
+    }
+    std::vector<std::vector<int>> by_level(nlev);
+    for (int L = 0; L < nlev; L++) by_level[L].reserve(out.lvl_ptr[L + 1] - out.lvl_ptr[L]);
+    for (int J = 0; J < count; J++) by_level[level[J]].push_back(J);
+    for (int L = nlev - 1; L >= 0; L--) {  // parents (higher levels) are numbered before their children look at them
+      std::vector<int> &v = by_level[L];
+      auto small = [&](int J) { return members[J] <= Supernodes::kSmall; };
+      if (by_parent)
+        std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+          if (small(a) != small(b)) return small(a);
+          const int pa = up_old[a] >= 0 ? newid[up_old[a]] : -1, pb = up_old[b] >= 0 ? newid[up_old[b]] : -1;
+          return pa < pb;
+        });
+      else
+        std::stable_partition(v.begin(), v.end(), small);
+      for (size_t k = 0; k < v.size(); k++) { newid[v[k]] = out.lvl_ptr[L] + (int)k; out.lvl_small[L] += small(v[k]); }
+    }
   }
   out.ptr.assign(count + 1, 0);
   for (int J = 0; J < count; J++) out.ptr[newid[J] + 1] = members[J];
