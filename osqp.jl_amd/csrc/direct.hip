@@ -1172,12 +1172,17 @@ struct LdlFactor {
     // host.  Any other outcome completes the analysis on the host (symbolic_complete: the same arrays as a full analysis).
     // OSQP_AMD_LEAN = 0 never, 1 whenever the row map is the identity (tests: the path on small problems).
     const int lean_mode = getenv("OSQP_AMD_LEAN") ? atoi(getenv("OSQP_AMD_LEAN")) : -1;
-    bool lean_try = lean_mode != 0 && (lean_mode == 1 || nd_by_depth) && mr_ == e.m;
-    for (int i = 0; lean_try && i < mr_; i++) lean_try = row_map[i] == i;
+    bool identity = mr_ == e.m;
+    for (int i = 0; identity && i < mr_; i++) identity = row_map[i] == i;
+    const bool lean_try = lean_mode != 0 && (lean_mode == 1 || nd_by_depth) && identity;
+    // the scatter maps of the whole KKT system (every row of A in it) are built on the device from the CSC arrays of L
+    const bool device_maps = identity && !(getenv("OSQP_AMD_DEVICE_MAPS") && atoi(getenv("OSQP_AMD_DEVICE_MAPS")) == 0);
+    S.no_host_maps = device_maps;
     symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S, lean_try);
     if (nd_by_depth && (S.too_large || (int)S.level_ptr.size() - 1 > level_limit())) {  // the dissection did not deliver: as before
       first_ordering = 0;
       S = Symbolic();
+      S.no_host_maps = device_maps;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 0, S);
     }
     if (S.lean && !S.too_large) {  // the decision a full analysis takes in choose_supernodes, from the counts
@@ -1198,6 +1203,7 @@ struct LdlFactor {
     if (!S.lean) choose_dense_top(S, kChainRows, dense_max(), kDenseSparseMax, kDenseMin, lD0, cD0, kD0);
     if (!S.lean && try_nd && first_ordering != 1 && (kD0 ? lD0 : (int)S.level_ptr.size() - 1) > 400) {
       Symbolic S2;
+      S2.no_host_maps = device_maps;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 1, S2);
       if (!S2.too_large && solve_cost_us(S2) < 0.7 * solve_cost_us(S)) S = std::move(S2);
     }
@@ -1206,6 +1212,7 @@ struct LdlFactor {
     const bool try_fifo = !(getenv("OSQP_AMD_MD_FIFO") && atoi(getenv("OSQP_AMD_MD_FIFO")) == 0);
     if (!S.lean && try_fifo && (int)S.level_ptr.size() - 1 >= 3 && (int)S.level_ptr.size() - 1 <= 400) {
       Symbolic S3;
+      S3.no_host_maps = device_maps;
       symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, 2, S3);
       if (!S3.too_large && S3.nnzL <= S.nnzL + S.nnzL / 10 && solve_cost_us(S3) < 0.9 * solve_cost_us(S)) S = std::move(S3);
     }
@@ -1219,8 +1226,10 @@ struct LdlFactor {
     lean_built = lean;
     if (lean) { lean_device_pattern(); e.setup_mark("    scatter maps"); }
     else {
-      up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap); up64(PtoL, S.PtoL); up64(AtoL, S.AtoL);
+      up64(Lp, S.Lp); up64(Rp, S.Rp); up64(Rmap, S.Rmap);
       up32(Li, S.Li); up32(Rj, S.Rj);
+      if (S.no_host_maps) device_scatter_maps();
+      else { up64(PtoL, S.PtoL); up64(AtoL, S.AtoL); }
     }
     Lcol.alloc(std::max<size_t>(1, (size_t)S.nnzL));  // the column of every entry of L: what the entry kernels of the factorisation start from
     expand_colptr(N, Lp.get(), S.nnzL, Lcol.get(), s);
@@ -1397,6 +1406,11 @@ struct LdlFactor {
     if (Lc.nnz != nnzL) throw Error(6, "internal: the transposed pattern of L lost entries");
     Lc.val.release(); src.release(); ecol.release(); erow.release();
     Lp = std::move(Lc.rowptr); Li = std::move(Lc.col);
+    device_scatter_maps();
+  }
+  // where every entry of triu(P) and of A sits in L: one bisection per entry in its column of the CSC arrays (identity row map)
+  void device_scatter_maps() {
+    hipStream_t s = e.stream;
     PtoL.alloc(std::max<int64_t>(1, e.nnzPtriu)); AtoL.alloc(std::max<int64_t>(1, e.nnzA));
     if (e.nnzPtriu > 0) {
       DevBuf<int> pcol((size_t)e.nnzPtriu);

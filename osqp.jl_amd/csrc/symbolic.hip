@@ -774,6 +774,7 @@ void finish_pattern(Symbolic &S, const Upper &K, std::vector<std::vector<int>> &
   }
   stage("CSR view of L");
   // ---- 5. scatter maps from the caller's nnz order into Lx / D ------------------------
+  if (S.no_host_maps) { S.PtoL.clear(); S.AtoL.clear(); stage("(scatter maps left to the device)"); return; }
   S.PtoL.assign(nnzP, 0);
   S.AtoL.assign(nnzA, INT64_MIN);
   // every entry of K on its own (a binary search in its column of L; distinct targets): columns dealt to host threads --
@@ -906,12 +907,12 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   // wavefront each (direct.hip k_sn_level_w), the rest with a whole one
   std::vector<int> newid(count);
   out.lvl_small.assign(nlev, 0);
-  // ... and inside each of the two classes the supernodes stand in the order of the supernode that holds their tree parent
-  // (round 5): the rows of a supernode gather the solution at the slots of its children -- with the children of one parent
-  // side by side those gathers fall into a few cache lines shared by the whole workgroup (and its neighbours) instead of
-  // lines all over the level.  OSQP_AMD_SNODE_ORDER=0: the order of discovery, as up to round 4.
+  // ... inside each of the two classes in the order of discovery.  (Measured and dropped in round 5, OSQP_AMD_SNODE_ORDER=1:
+  // the supernodes of a level in the order of the supernode that holds their tree parent, so that the rows of a parent gather
+  // the solution from neighbouring slots -- control-1e6 1118 -> 1090 it/s: the order of discovery follows the pivot numbering,
+  // which is what the streams of the entries and of the blocks are laid out by.)
   {
-    static const bool by_parent = !(getenv("OSQP_AMD_SNODE_ORDER") && atoi(getenv("OSQP_AMD_SNODE_ORDER")) == 0);
+    static const bool by_parent = getenv("OSQP_AMD_SNODE_ORDER") && atoi(getenv("OSQP_AMD_SNODE_ORDER")) == 1;
     std::vector<int> up_old(count, -1);
     for (int v = 0; v < N; v++) {
       const int p = parent[v];

@@ -45,6 +45,9 @@ struct Symbolic {
   // the unsorted rows of the pattern are known: Li, Rj, Rmap, PtoL, AtoL stay empty -- a supernodal factor builds them on
   // the device from the rows (direct.hip LdlFactor::lean_device) -- until symbolic_complete fills them in on the host.
   bool lean = false;
+  bool no_host_maps = false;         // set by the caller BEFORE the analysis: leave PtoL / AtoL empty (the device builds them by one
+                                     // bisection per entry of K, direct.hip device_scatter_maps -- 16e6 cache-missing searches on the
+                                     // host were the largest piece of the setup of a dense-P problem)
   std::shared_ptr<LeanRows> lean_rows;
   std::shared_ptr<void> lean_state;
 };
