@@ -337,17 +337,20 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, int ld, const do
 // and a copy C of S_B: as it was; (3) the update of the tiles on and below the diagonal, each written to both triangles
 // through an LDS transposition, so that the array stays bit-symmetric.  The array is padded to a multiple of 64 (identity
 // on the padding: its sweeps change nothing).
-constexpr int kGjK = 32;
-__global__ __launch_bounds__(256) void k_gj_pivot(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
-                                                  int *__restrict__ status) {
-  __shared__ double buf[2][kGjK][kGjK + 1];
+// Round 5: blocks of 64 pivots (32 before): half the passes over the array, twice the matrix-core work per tile load; the
+// pivot block -- the one serial piece of a step, a single workgroup -- is swept by 1024 threads (four elements each per pivot).
+constexpr int kGjK = 64, kGjPivotThreads = 1024;
+__global__ __launch_bounds__(kGjPivotThreads) void k_gj_pivot(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
+                                                              int *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double gj_lds[];
+  double (*buf)[kGjK][kGjK + 1] = (double (*)[kGjK][kGjK + 1])gj_lds;  // [2][kGjK][kGjK + 1]
   const int t = threadIdx.x;
-  for (int e = t; e < kGjK * kGjK; e += 256) { const int i = e % kGjK, j = e / kGjK; buf[0][i][j] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
+  for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) { const int i = e % kGjK, j = e / kGjK; buf[0][i][j] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
   __syncthreads();
   int cur = 0, pos = 0, bad = 0;
   for (int p = 0; p < kGjK; p++) {
     const double piv = buf[cur][p][p], ip = 1.0 / piv;
-    for (int e = t; e < kGjK * kGjK; e += 256) {
+    for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) {
       const int i = e % kGjK, j = e / kGjK;
       buf[cur ^ 1][i][j] = sweep_value(i == p, j == p, buf[cur][i][j], buf[cur][i][p], buf[cur][p][j], ip);
     }
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_gj_pivot(int kD, int ld, int p0, const 
     cur ^= 1;
     __syncthreads();
   }
-  for (int e = t; e < kGjK * kGjK; e += 256) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = buf[cur][i][j]; }
+  for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = buf[cur][i][j]; }
   if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
 }
 // thread per column j of the array: W[k][j] = sum_l G[k][l] S[p0 + l][j], C[k][j] = S[p0 + k][j]  (G = -T)
@@ -364,18 +367,20 @@ __global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *
   __shared__ double G[kGjK][kGjK];
   for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e % kGjK][e / kGjK] = -T[e];
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  // 64 columns per workgroup, its four wavefronts a quarter of the panel's rows each (round 5: a thread per column and all
+  // kGjK rows left the 6000-column panel of equality_qp on 24 compute units, 86 us per step)
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
   if (j >= ld) return;
   double s[kGjK];
 #pragma unroll
   for (int l = 0; l < kGjK; l++) s[l] = S[(size_t)(p0 + l) + (size_t)j * ld];
 #pragma unroll 4
-  for (int k = 0; k < kGjK; k++) {
+  for (int k = kq * (kGjK / 4); k < (kq + 1) * (kGjK / 4); k++) {
     double w = 0.0;
 #pragma unroll
     for (int l = 0; l < kGjK; l++) w = __builtin_fma(G[k][l], s[l], w);
     Wp[(size_t)k * ld + j] = w;
-    Cp[(size_t)k * ld + j] = s[k];
+    Cp[(size_t)k * ld + j] = S[(size_t)(p0 + k) + (size_t)j * ld];  // (from the cache: s[k] with a run-time k would be a scratch access)
   }
 }
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__res
   if (I == J && wi < wj) return;  // the upper quadrant of a diagonal tile is the mirror of the lower one
   const int lr = lane >> 4, lc = lane & 15;
   const int r0 = I * 64 + wi * 32, c0 = J * 64 + wj * 32;  // rows r0 .. r0 + 32, columns c0 .. c0 + 32
-  const bool rowsB = r0 == p0, colsB = c0 == p0;           // the pivot block is 32 wide and 32-aligned
+  const bool rowsB = I * 64 == p0, colsB = J * 64 == p0;   // the pivot block is one 64 x 64 tile (64 pivots, 64-aligned)
 #pragma unroll
   for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -1740,9 +1745,14 @@ struct LdlFactor {
     if (factorizations == 0) e.setup_mark("  numeric: Schur complement of the block");
     if (kD >= kDenseBlocked) {  // block sweeps of kGjK pivots on the matrix cores, in place
       if (ldD > kD) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - kD)), dim3(kBlock), 0, s, kD, ldD, S0a.get());
-      const dim3 gp(blocks_for(ldD, 256)), gu(ldD / 64, ldD / 64);
+      const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
+      static bool lds_set = false;
+      if (!lds_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
+        lds_set = true;
+      }
       for (int p0 = 0; p0 < ldD; p0 += kGjK) {
-        OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(256), 0, s, kD, ldD, p0, S0a.get(), gjT.get(), status.get());
+        OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, kD, ldD, p0, S0a.get(), gjT.get(), status.get());
         OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
         OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
       }

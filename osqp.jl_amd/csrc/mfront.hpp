@@ -85,8 +85,14 @@ __global__ __launch_bounds__(kMfBlock) void k_mf_front(MfArgs a) {
     for (int64_t t = a.Lp[k] + tid % G; t < a.Lp[k + 1]; t += G) F[cc + a.loc[t]] = a.Lx[t];
   }
   mf_sync<TF>();
-  // 2. extend-add of the children's update matrices, one child after the other (its entries go to distinct places)
+  // 2. extend-add of the children's update matrices.  No barrier between children: a target column belongs to ONE wavefront
+  //    (column mod 4 of the front for the workgroup form; the only wavefront otherwise), and the LDS operations of a wavefront
+  //    run in program order, so every entry of the front receives its children's terms in ascending order of the children --
+  //    a fixed order of sums without the child-after-child barriers that made a front with 58 children ~100 us of latency.
   {
+    constexpr int NWV = TF >= 64 ? TF / 64 : 1;                 // wavefronts of the front
+    constexpr int LW = TF >= 64 ? 64 : TF;                      // lanes that share the rows of one child column
+    const int wvf = TF >= 64 ? tid / 64 : 0, ln = tid % LW;
     const int c0 = live ? a.chp[J] : 0, c1 = live ? a.chp[J + 1] : 0;
     int cn = c0 < c1 ? a.chl[c0] : 0;
     int bn = c0 < c1 ? a.bsz[cn] : 0;
@@ -96,12 +102,14 @@ __global__ __launch_bounds__(kMfBlock) void k_mf_front(MfArgs a) {
       const double *Uc = a.U + un;
       const uint16_t *rl = a.rel + rn;
       if (ci + 1 < c1) { cn = a.chl[ci + 1]; bn = a.bsz[cn]; un = a.uoff[cn]; rn = a.reloff[cn]; }  // the next child's header rides along
-      for (int bb = tb; bb < bc; bb += CW) {
-        const int cb = cs(rl[bb]), ub = bb * (2 * bc - bb - 1) / 2;
-        for (int r = bb + ta; r < bc; r += RW) F[cb + rl[r]] += Uc[ub + r];
+      for (int bb = 0; bb < bc; bb++) {
+        const int tc = rl[bb];
+        if (NWV > 1 && (tc & (NWV - 1)) != wvf) continue;
+        const int cb = cs(tc), ub = bb * (2 * bc - bb - 1) / 2;
+        for (int r = bb + ln; r < bc; r += LW) F[cb + rl[r]] += Uc[ub + r];
       }
-      mf_sync<TF>();
     }
+    mf_sync<TF>();
   }
   // 3. the pivots of the supernode: right-looking over the columns of the panel
   int bad = 0;
