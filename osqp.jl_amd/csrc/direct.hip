@@ -436,6 +436,42 @@ __global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__res
       __builtin_amdgcn_s_waitcnt(0xc07f);
     }
 }
+// ---- the Schur complement of a LARGE dense block on the matrix cores (round 5) ---------------------------------------------
+// S0 = K22 - L21 D1 L21' entry by entry is a sparse dot product per entry of the block (k_dense_entries: 3.6e7 wavefronts for
+// the 6000-pivot block of equality_qp, 22 ms -- as much as the whole inversion).  When L21 is not very sparse the same sum is
+// a symmetric rank-k update: 64 columns of L at a time are spread out as dense 64 x ld panels (W = the column times its pivot,
+// C = the column) and k_gj_update -- the rank-64 matrix-core update of the block sweeps, with no pivot block (p0 = -64) --
+// subtracts W' C from the array; S0 starts as K22.  The zeros it multiplies are cheaper than the gathers they replace.
+__global__ __launch_bounds__(kBlock) void k_dense_init(int cD, int N, int ld, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                       const int *__restrict__ Lcol, const double *__restrict__ Lx,
+                                                       const double *__restrict__ D, double *__restrict__ S0) {
+  const int64_t e = Lp[cD] + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e < Lp[N]) {
+    const int k = Lcol[e] - cD, i = Li[e] - cD;
+    const double v = Lx[e];
+    S0[(size_t)i + (size_t)k * ld] = v;
+    S0[(size_t)k + (size_t)i * ld] = v;
+  }
+  const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (d < N - cD) S0[(size_t)d * (ld + 1)] = D[cD + d];
+}
+// wavefront w of the launch: column cols[c0 + w] of L, its entries in the rows of the block into row w of the two panels
+__global__ __launch_bounds__(kBlock) void k_dense_chunk(int c0, int ncols, int cD, int ld, const int *__restrict__ cols,
+                                                        const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                        const double *__restrict__ Lx, const double *__restrict__ D,
+                                                        double *__restrict__ Wp, double *__restrict__ Cp) {
+  const int lane = threadIdx.x & 63, w = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  if (w >= kGjK || c0 + w >= ncols) return;
+  const int j = cols[c0 + w];
+  const double dj = D[j];
+  for (int64_t e = Lp[j] + lane; e < Lp[j + 1]; e += 64) {
+    const int i = Li[e];
+    if (i < cD) continue;
+    const double v = Lx[e];
+    Wp[(size_t)w * ld + (i - cD)] = v * dj;
+    Cp[(size_t)w * ld + (i - cD)] = v;
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_gj_pad(int kD, int ld, double *__restrict__ S) {
   const int i = kD + blockIdx.x * kBlock + threadIdx.x;
   if (i < ld) S[(size_t)i * (ld + 1)] = 1.0;
@@ -1106,6 +1142,8 @@ struct LdlFactor {
   DevBuf<double> Lx, Rx, D, Dinv, bp, W, S0a, S0b, x2, gjT, gjW, gjC;  // gj*: pivot block, row panel and panel copy of the block sweeps
   int lD = 0, cD = 0, kD = 0;   // dense top block: levels [lD, nlev), pivots [cD, N), kD = N - cD (0: none)
   bool kD_dense = false;        // ... taken because it IS dense (choose_dense_top)
+  DevBuf<int> schur_cols;       // the columns below the block with entries in its rows (k_dense_chunk); empty: the Schur complement entry by entry
+  int schur_ncols = 0;
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
   int ldD = 0;                  // leading dimension of the dense block's array (kD, or kD padded to 64 for the block sweeps)
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
@@ -1268,6 +1306,23 @@ struct LdlFactor {
         S0a.alloc((size_t)ldD * ldD);
         if (blocked) { gjT.alloc(kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD); }
         else S0b.alloc((size_t)kD * kD);
+        schur_ncols = 0;
+        if (blocked && !S.Li.empty() && !(getenv("OSQP_AMD_SCHUR_DENSE") && atoi(getenv("OSQP_AMD_SCHUR_DENSE")) == 0)) {
+          // the rank-64 form of the Schur complement when L21 is not very sparse: a rank-64 update costs (ld / 64)^2 / 2 tiles
+          // whatever its columns hold; entry by entry costs a 64-lane gather round per 64 entries of a row of L21
+          std::vector<int> cols;
+          int64_t entries = 0;
+          for (int j = 0; j < cD; j++) {
+            const int *beg = S.Li.data() + S.Lp[j], *end = S.Li.data() + S.Lp[j + 1];
+            const int64_t in_block = end - std::lower_bound(beg, end, cD);
+            if (in_block > 0) { cols.push_back(j); entries += in_block; }
+          }
+          if (!cols.empty() && (double)entries >= 0.005 * (double)cols.size() * (double)kD) {
+            schur_ncols = (int)cols.size();
+            schur_cols.alloc(cols.size());
+            schur_cols.upload(cols.data(), cols.size(), s);
+          }
+        }
         x2.alloc(kD);
       }
     }
@@ -1521,6 +1576,7 @@ struct LdlFactor {
   }
   // size classes of the fronts: rows at most 16 / 48 (16 lanes / a wavefront each, fixed slabs), then workgroups with the
   // slab of the launch's largest front -- cut at 96 so that a few large fronts do not take the occupancy of many mid-size ones
+  static constexpr int kMfWideCount = 192;  // launches of at most this many workgroup-class fronts give each 1024 threads (the device is not full either way)
   static constexpr int kMfClasses = 4;
   static constexpr int kMfClassCap[kMfClasses] = {16, 48, 96, kMfMaxFront};
   void build_mf() {
@@ -1546,6 +1602,7 @@ struct LdlFactor {
     if (err) throw Error(6, "internal: the fronts of the supernodes do not cover the pattern of L (code " + std::to_string(err) + ")");
     const int lds = (int)(mf_slab_doubles(mf_fmax) * sizeof(double));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     if (getenv("OSQP_AMD_SETUP_TRACE"))
       for (const MfLaunch &l : mf_launches) fprintf(stderr, "[fronts] class %d: %d fronts, slab for %d rows\n", l.cls, l.count, l.fcap);
     std::vector<int>().swap(mfh_snof); std::vector<int>().swap(mfh_list); std::vector<int>().swap(mfh_chl);
@@ -1558,6 +1615,7 @@ struct LdlFactor {
                sn_Wc.get(), sn_Wr.get(), sn_woff.get()};
       if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else if (l.cls == 1) OQ_LAUNCH(k_mf_front<64>, dim3((l.count + 3) / 4), dim3(kMfBlock), 4 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+      else if (l.count <= kMfWideCount) OQ_LAUNCH(k_mf_front<1024>, dim3(l.count), dim3(1024), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else OQ_LAUNCH(k_mf_front<256>, dim3(l.count), dim3(kMfBlock), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
     }
   }
@@ -1731,7 +1789,19 @@ struct LdlFactor {
     hipStream_t s = e.stream;
     S0a.zero(s);
     const int bw = dense_batch();
-    for (int b0 = cD; b0 < N; b0 += bw) {
+    if (schur_ncols > 0) {
+      const int64_t inside = S.Lp[N] - S.Lp[cD];
+      OQ_LAUNCH(k_dense_init, dim3(blocks_for(std::max<int64_t>(inside, kD))), dim3(kBlock), 0, s, cD, N, ldD, Lp.get(), Li.get(), (const int *)Lcol.get(),
+                Lx.get(), D.get(), S0a.get());
+      const dim3 gu(ldD / 64, ldD / 64);
+      for (int c0 = 0; c0 < schur_ncols; c0 += kGjK) {
+        gjW.zero(s); gjC.zero(s);
+        OQ_LAUNCH(k_dense_chunk, dim3(blocks_for((int64_t)kGjK * 64)), dim3(kBlock), 0, s, c0, schur_ncols, cD, ldD, (const int *)schur_cols.get(), Lp.get(),
+                  Li.get(), Lx.get(), D.get(), gjW.get(), gjC.get());
+        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, -kGjK, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+      }
+    }
+    for (int b0 = cD; b0 < N && schur_ncols == 0; b0 += bw) {
       const int b1 = std::min(N, b0 + bw);
       const dim3 gw(blocks_for((int64_t)(b1 - b0) * 64));
       OQ_LAUNCH(k_ldl_wrow, gw, dim3(kBlock), 0, s, b0, b1, N, Lx.get(), Rp.get(), Rj.get(), Rmap.get(), D.get(), W.get(), 1);

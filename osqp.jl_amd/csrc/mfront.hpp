@@ -58,10 +58,11 @@ constexpr int kMfBlock = 256;
 __host__ __device__ inline size_t mf_slab_doubles(int fcap) { return (size_t)fcap * (fcap + 1) / 2 + (size_t)(fcap < 64 ? fcap : 64); }
 
 template <int TF>
-__global__ __launch_bounds__(kMfBlock) void k_mf_front(MfArgs a) {
+__global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mf_lds[];
   __shared__ int blk_pos;
-  constexpr int NFB = kMfBlock / TF;         // fronts per workgroup
+  constexpr int NFB = TF > kMfBlock ? 1 : kMfBlock / TF;  // fronts per workgroup (TF = 1024: a level of few large fronts, where
+                                                          // the latency of ONE front is the level's time)
   constexpr int RW = TF >= 256 ? 32 : 16;    // lanes along the rows of a tile of work, CW along its columns
   constexpr int CW = TF / RW;
   constexpr int G = TF >= 64 ? 16 : 1;       // lanes per column when the columns of L are read / written
