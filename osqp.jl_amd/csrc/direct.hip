@@ -372,15 +372,18 @@ __global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
   if (j >= ld) return;
   double s[kGjK];
+  // element (p0 + l, j) from the LOWER triangle (round 5: the sweeps keep only that one current, the mirror is written once at
+  // the end): its own place for j <= p0 + l, the place of (j, p0 + l) otherwise -- which is also the contiguous read
+  auto at = [&](int r) -> double { return j <= r ? S[(size_t)r + (size_t)j * ld] : S[(size_t)j + (size_t)r * ld]; };
 #pragma unroll
-  for (int l = 0; l < kGjK; l++) s[l] = S[(size_t)(p0 + l) + (size_t)j * ld];
+  for (int l = 0; l < kGjK; l++) s[l] = at(p0 + l);
 #pragma unroll 4
   for (int k = kq * (kGjK / 4); k < (kq + 1) * (kGjK / 4); k++) {
     double w = 0.0;
 #pragma unroll
     for (int l = 0; l < kGjK; l++) w = __builtin_fma(G[k][l], s[l], w);
     Wp[(size_t)k * ld + j] = w;
-    Cp[(size_t)k * ld + j] = S[(size_t)(p0 + k) + (size_t)j * ld];  // (from the cache: s[k] with a run-time k would be a scratch access)
+    Cp[(size_t)k * ld + j] = at(p0 + k);  // (from the cache: s[k] with a run-time k would be a scratch access)
   }
 }
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
@@ -429,7 +432,8 @@ __global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__res
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) S[(size_t)(ri + lc) + (size_t)(cj + lr + 4 * r) * ld] = nv[r];
-      if (ri != cj) {
+      if (ri != cj && I == J) {  // the mirror only inside a diagonal 64 x 64 tile (the pivot kernel reads those whole); the rest of
+                                 // the upper triangle is written once, when the sweeps are done (k_gj_mirror)
 #pragma unroll
         for (int r = 0; r < 4; r++) S[(size_t)(cj + lc) + (size_t)(ri + lr + 4 * r) * ld] = tr[w][lc][lr + 4 * r];  // S[j][i] = value of (i, j)
       }
@@ -471,6 +475,15 @@ __global__ __launch_bounds__(kBlock) void k_dense_chunk(int c0, int ncols, int c
     Wp[(size_t)w * ld + (i - cD)] = v * dj;
     Cp[(size_t)w * ld + (i - cD)] = v;
   }
+}
+// upper triangle := transpose of the lower one, tile by tile through LDS (both sides contiguous)
+__global__ __launch_bounds__(256) void k_gj_mirror(int ld, double *__restrict__ S) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J >= I) return;
+  __shared__ double tile[64][65];
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) { const int r = e & 63, c = e >> 6; tile[c][r] = S[(size_t)(I * 64 + r) + (size_t)(J * 64 + c) * ld]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) { const int r = e & 63, c = e >> 6; S[(size_t)(J * 64 + r) + (size_t)(I * 64 + c) * ld] = tile[r][c]; }
 }
 __global__ __launch_bounds__(kBlock) void k_gj_pad(int kD, int ld, double *__restrict__ S) {
   const int i = kD + blockIdx.x * kBlock + threadIdx.x;
@@ -1826,6 +1839,7 @@ struct LdlFactor {
         OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
         OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
       }
+      OQ_LAUNCH(k_gj_mirror, gu, dim3(256), 0, s, ldD, S0a.get());
       Sinv = S0a.get();
       return;
     }
