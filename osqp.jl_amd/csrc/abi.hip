@@ -197,10 +197,11 @@ static c_int setup_from_host_once(OSQPWorkspace **workp, const OSQPData *data, c
 // ascending (what SparseMatrixCSC always hands over).  A caller whose columns are not sorted gets the same behaviour as from
 // libosqp at the price of one sorted host copy: the setup is repeated on it and osqp_update_A translates nnz indices.
 static c_int setup_from_host(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings *settings, Comm *comm) {
+  g_unsorted_columns = false;
   c_int rc = setup_from_host_once(workp, data, settings, comm);
-  if (rc != 1 || !data || !data->A) return rc;
-  const char *why = last_error_cstr();
-  if (!why || !strstr(why, "must ascend")) return rc;
+  const bool unsorted = g_unsorted_columns;  // raised with the UnsortedColumns error (engine.hip), not read off the message text
+  g_unsorted_columns = false;
+  if (rc != 1 || !unsorted || !data || !data->A) return rc;
   std::vector<c_int> rows;
   std::vector<c_float> vals;
   std::vector<int64_t> to_sorted;

@@ -1149,11 +1149,14 @@ struct DevicePattern {
   // first entry it fits (round 5: up to round 4 entry 0 was the only one, every other pattern ran the 512-thread kernel with
   // its n x n global scratch).
   struct QuadCfg { int NH, KC, KE, CH; bool mpc; };
-  static constexpr int kQuadCfgs = 10;
+  static constexpr int kQuadCfgs = 11;
   static constexpr QuadCfg kQuadCfg[kQuadCfgs] = {{50, 9, 11, 16, true},   {16, 16, 16, 16, false}, {32, 16, 16, 16, false},
                                                   {48, 16, 16, 16, false}, {50, 16, 16, 16, false}, {64, 16, 16, 16, false},
                                                   {16, 32, 32, 16, false}, {32, 32, 32, 16, false}, {48, 32, 32, 16, false},
-                                                  {64, 32, 32, 16, false}};
+                                                  {64, 32, 32, 16, false}, {50, 12, 12, 16, false}};
+  // the order patterns try the entries in: the MPC sizes with short columns / rows first look at the entry whose LDS layout
+  // still holds THREE QPs per compute unit (bounds 12 / 12: 53 KB; 16 / 16 is 59 KB, two per unit)
+  static constexpr int kQuadOrder[kQuadCfgs] = {0, 1, 2, 3, 10, 4, 5, 6, 7, 8, 9};
   int quad_cfg = -1;
   int kNH = 50, kKC = 9, kKE = 11, kCH = 16;  // of the entry taken
   void build_quad(int n, int m, const std::vector<int> &hAp, const std::vector<int> &hAi, const std::vector<int> &rp,
@@ -1163,7 +1166,8 @@ struct DevicePattern {
                   hipStream_t s) {
     quad_ok = false; quad_cfg = -1;
     const int only = getenv("OSQP_AMD_BATCH_QUAD_CFG") ? atoi(getenv("OSQP_AMD_BATCH_QUAD_CFG")) : -1;  // experiments: one entry by number
-    for (int c = 0; c < kQuadCfgs && !quad_ok; c++) {
+    for (int oi = 0; oi < kQuadCfgs && !quad_ok; oi++) {
+      const int c = kQuadOrder[oi];
       if (only >= 0 && c != only) continue;
       const QuadCfg &q = kQuadCfg[c];
       if (q.mpc && !(n == MPC_N && m == MPC_M && hAp[n] == kMpcNnzA && (int)fc.size() == MPC_N)) continue;
@@ -1336,7 +1340,8 @@ void launch_batch(const DevicePattern &dp, const OSQPSettings &st, int count, co
     case 6: OQ_QUAD_LAUNCH(k_batch_quad, 16, 32, 32, 16, 0, 0, 0, 0); break;
     case 7: OQ_QUAD_LAUNCH(k_batch_quad, 32, 32, 32, 16, 0, 0, 0, 0); break;
     case 8: OQ_QUAD_LAUNCH(k_batch_quad2, 48, 32, 32, 16, 0, 0, 0, 0); break;
-    default: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 32, 32, 16, 0, 0, 0, 0); break;
+    case 9: OQ_QUAD_LAUNCH(k_batch_quad2, 64, 32, 32, 16, 0, 0, 0, 0); break;
+    default: OQ_QUAD_LAUNCH(k_batch_quad, 50, 12, 12, 16, 0, 0, 0, 0); break;
     }
 #undef OQ_QUAD_LAUNCH
     return;

@@ -29,6 +29,12 @@ struct PanelRefused : Error {
 };
 // a wait inside k_sn_tree timed out (direct.hip): the iterations since the last residual evaluation cannot be trusted.
 // Engine::solve catches it, cold-starts and runs the solve again on the per-level form of the triangular solves.
+// the columns of A handed to osqp_setup do not list their rows in ascending order (or repeat one): the ABI's setup entry point
+// catches exactly this type and repeats the setup on a sorted host copy, as libosqp accepts such columns (abi.hip setup_from_host)
+struct UnsortedColumns : Error {
+  UnsortedColumns() : Error(1, "the row indices inside a column of A must ascend (and not repeat)") {}
+};
+extern thread_local bool g_unsorted_columns;  // set where UnsortedColumns is thrown, read (and cleared) by setup_from_host
 struct TreeFault : Error {
   TreeFault() : Error(6, "internal: a supernode of the triangular solve waited 200 ms for its children (the solves fall back to one launch per level)") {}
 };

@@ -12,6 +12,7 @@
 
 namespace oq {
 
+thread_local bool g_unsorted_columns = false;
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &m) { g_last_error = m; }
 const char *last_error_cstr() { return g_last_error.c_str(); }
@@ -258,6 +259,15 @@ __global__ __launch_bounds__(kBlock) void k_shard_pick_P(int64_t E, int j0, cons
   if (fill && ku) { pr[p] = i - n0; pc[p] = j; pv[p] = v; if (po) po[p] = (int)(base + e); }
 }
 
+// flag = 1 when two neighbouring entries of a (sorted) row share their column
+__global__ __launch_bounds__(kBlock) void k_csr_repeats(int64_t nnz, int rows, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+                                                        int *__restrict__ flag) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < 1 || k >= nnz || col[k] != col[k - 1]) return;
+  int lo = 0, hi = rows;  // same column: a repeat unless k opens a row
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowptr[mid] <= k) lo = mid; else hi = mid; }
+  if (rowptr[lo] != k) *flag = 1;
+}
 __global__ __launch_bounds__(kBlock) void k_gather_ints(int64_t n, const int *__restrict__ src, const int *__restrict__ in, int *__restrict__ out) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k < n) out[k] = in[src[k]];
@@ -331,6 +341,15 @@ void Engine::setup_sharded(ColumnSource &src, const OSQPSettings &s) {
                    DevBuf<int> &org) {
     DevBuf<int> order;
     csr_from_coo(rows, cols, (int64_t)E, er.get(), ec.get(), M, order, stream);
+    if (M.nnz > 1) {  // the same (row, column) twice: refused, as on one device (the sort accepts any order of the caller's entries)
+      flag.zero(stream);
+      OQ_LAUNCH(k_csr_repeats, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, stream, M.nnz, rows, M.rowptr.get(), M.col.get(), flag.get());
+      int rep = 0;
+      flag.download(&rep, 1, stream);
+      sync();
+      flag.zero(stream);
+      if (rep) throw Error(1, "a matrix of the problem holds the same entry twice");
+    }
     gather_values(M.nnz, order.get(), ev.get(), M.val.get(), 0, stream);
     if (keep_org) org.alloc(std::max<size_t>(1, (size_t)M.nnz));
     if (keep_org && M.nnz > 0) OQ_LAUNCH(k_gather_ints, dim3(blocks_for(M.nnz)), dim3(kBlock), 0, stream, (int64_t)M.nnz, order.get(), eo.get(), org.get());
@@ -467,7 +486,7 @@ void Engine::setup_device(int n_, int m_, DevBuf<int64_t> &Pp, DevBuf<int> &Pi, 
     flag.download(&bad, 1, stream);
     sync();
     flag.zero(stream);
-    if (bad) throw Error(1, "the row indices inside a column of A must ascend (and not repeat)");
+    if (bad) { g_unsorted_columns = true; throw UnsortedColumns(); }
   }
   // A problem that is certain to run the indirect back-end at a size where the workspace goes compact: every matrix gets
   // its sliced-ELL copy and gives up its CSR arrays NOW, one after the other (Ruiz scaling then runs over the slices:

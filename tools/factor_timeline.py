@@ -23,7 +23,10 @@ for st, en, name in rows:
         busy += (en - st) / 1e3
         prev_end = max(prev_end, en)
         n += 1
-        if "k_gather_csr" in name or "k_sn_invert" in name:
+        # the last kernel of a factorisation: the CSR copy of the values (level-scheduled solves), the block inversion
+        # (supernodal solves, level-by-level factorisation) or the gather of the supernodes' lists (supernodal solves after a
+        # multifrontal factorisation: the fronts invert their blocks themselves)
+        if "k_gather_csr" in name or "k_sn_invert" in name or ("k_sn_gather" in name and any("k_mf_front" in q for q in by)):
             span = (en - t0) / 1e3
             print("factorisation: %d launches, span %.1f ms, kernels %.1f ms, idle %.1f ms" % (n, span / 1e3, busy / 1e3, (span - busy) / 1e3))
             for kk, (cnt, dur, idle) in sorted(by.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:8]:
