@@ -7,7 +7,8 @@
 // Host (symbolic.hip): ordering, elimination tree, pattern of L, level schedule.
 // Pivots are numbered level by level (level = height in the elimination tree), so
 // that level l is the contiguous index range [level_ptr[l], level_ptr[l+1]):
-//   * numeric factorisation: left-looking, one wavefront per column, levels in
+//   * numeric factorisation: by supernodes where the solves run by supernodes (multifrontal, fronts in LDS, one launch
+//     per supernode level and size class: mfront.hpp, round 5); otherwise in dot-product form level by level, levels in
 //     ascending order (a column only needs columns of lower levels);
 //   * forward solve  L v = b: row-oriented over the CSR copy of L, ascending levels;
 //   * backward solve L' w = D^-1 v: row-oriented over the CSC arrays, descending levels.
@@ -1579,6 +1580,18 @@ struct LdlFactor {
         cls[c].push_back(J);
         cap[c] = std::max(cap[c], f);
       }
+      // a workgroup class of few fronts joins the next larger one of its level: a launch costs the latency of one front
+      // whatever its size (~90 us), the finer slabs only pay where thousands of fronts share the device
+      for (int c = 2; c + 1 < kMfClasses; c++) {
+        if (cls[c].empty() || cls[c].size() >= 1024) continue;
+        int up = c + 1;
+        while (up + 1 < kMfClasses && cls[up].empty()) up++;
+        if (cls[up].empty()) continue;
+        cls[up].insert(cls[up].end(), cls[c].begin(), cls[c].end());
+        std::sort(cls[up].begin(), cls[up].end());
+        cap[up] = std::max(cap[up], cap[c]);
+        cls[c].clear();
+      }
       for (int c = 0; c < kMfClasses; c++) {
         if (cls[c].empty()) continue;
         mf_launches.push_back({c, (int)mfh_list.size(), (int)cls[c].size(), c < 2 ? kMfClassCap[c] : cap[c]});
@@ -1588,10 +1601,11 @@ struct LdlFactor {
     return true;
   }
   // size classes of the fronts: rows at most 16 / 48 (16 lanes / a wavefront each, fixed slabs), then workgroups with the
-  // slab of the launch's largest front -- cut at 96 so that a few large fronts do not take the occupancy of many mid-size ones
+  // slab of the launch's largest front -- cut at 64 / 80 / 96 / 128 rows so that a few large fronts do not take the occupancy
+  // of many mid-size ones (the fronts of a compute unit are as many as their slabs fit its 160 KB of LDS)
   static constexpr int kMfWideCount = 192;  // launches of at most this many workgroup-class fronts give each 1024 threads (the device is not full either way)
-  static constexpr int kMfClasses = 4;
-  static constexpr int kMfClassCap[kMfClasses] = {16, 48, 96, kMfMaxFront};
+  static constexpr int kMfClasses = 7;
+  static constexpr int kMfClassCap[kMfClasses] = {16, 48, 64, 80, 96, 128, kMfMaxFront};
   void build_mf() {
     mf = false;
     if (!sn || !mf_ok) return;

@@ -122,7 +122,20 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
     for (int j = p + 1 + tb; j < s; j += CW) {
       const double w = F[cp + j] * dinv;
       const int cj = cs(j);
-      for (int i = j + ta; i < f; i += RW) F[cj + i] -= F[cp + i] * w;
+      int i = j + ta;
+      // four rows of the strip at a time, every LDS read issued before the first write (one read-modify-write per loop step
+      // is one LDS round trip of latency per step: the pivot loop of a 96-row front was ~2 us per pivot)
+      for (; i + 3 * RW < f; i += 4 * RW) {
+        const double a0 = F[cp + i], a1 = F[cp + i + RW], a2 = F[cp + i + 2 * RW], a3 = F[cp + i + 3 * RW];
+        const double c0 = F[cj + i], c1 = F[cj + i + RW], c2 = F[cj + i + 2 * RW], c3 = F[cj + i + 3 * RW];
+        F[cj + i] = c0 - a0 * w; F[cj + i + RW] = c1 - a1 * w; F[cj + i + 2 * RW] = c2 - a2 * w; F[cj + i + 3 * RW] = c3 - a3 * w;
+      }
+      if (i + RW < f) {
+        const double a0 = F[cp + i], a1 = F[cp + i + RW], c0 = F[cj + i], c1 = F[cj + i + RW];
+        F[cj + i] = c0 - a0 * w; F[cj + i + RW] = c1 - a1 * w;
+        i += 2 * RW;
+      }
+      if (i < f) F[cj + i] -= F[cp + i] * w;
     }
     mf_sync<TF>();
   }
@@ -133,7 +146,14 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
       const int cc = cs(s + c), uc = c * (2 * b - c - 1) / 2;
       for (int r = c + ta; r < b; r += RW) {
         double acc = F[cc + s + r];
-        for (int p = 0; p < s; p++) { const int cp = cs(p); acc -= F[cp + s + r] * (F[cp + s + c] * dv[p]); }
+        int p = 0;
+        for (; p + 3 < s; p += 4) {  // the twelve reads of four pivots in flight together, the sum in the order of the plain loop
+          const int c0 = cs(p), c1 = cs(p + 1), c2 = cs(p + 2), c3 = cs(p + 3);
+          const double x0 = F[c0 + s + r], x1 = F[c1 + s + r], x2 = F[c2 + s + r], x3 = F[c3 + s + r];
+          const double y0 = F[c0 + s + c] * dv[p], y1 = F[c1 + s + c] * dv[p + 1], y2 = F[c2 + s + c] * dv[p + 2], y3 = F[c3 + s + c] * dv[p + 3];
+          acc -= x0 * y0; acc -= x1 * y1; acc -= x2 * y2; acc -= x3 * y3;
+        }
+        for (; p < s; p++) { const int cp = cs(p); acc -= F[cp + s + r] * (F[cp + s + c] * dv[p]); }
         Uj[uc + r] = acc;
       }
     }
@@ -162,7 +182,13 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
       for (int c = tb; c < p; c += CW) {
         const int cc = cs(c);
         const double w = F[cc + p];
-        for (int i = p + 1 + ta; i < s; i += RW) F[cc + i] -= F[cp + i] * w;
+        int i = p + 1 + ta;
+        if (i + RW < s) {  // (s <= 64: at most two rows per lane with 32 lanes along the rows, four with 16)
+          const double a0 = F[cp + i], a1 = F[cp + i + RW], c0 = F[cc + i], c1 = F[cc + i + RW];
+          F[cc + i] = c0 - a0 * w; F[cc + i + RW] = c1 - a1 * w;
+          i += 2 * RW;
+        }
+        for (; i < s; i += RW) F[cc + i] -= F[cp + i] * w;
       }
       mf_sync<TF>();
     }

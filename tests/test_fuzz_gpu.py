@@ -87,12 +87,16 @@ def test_random_small_problems_follow_the_oracle(product_lib, oracle_lib, block)
     assert solved > 0
 
 
+@pytest.mark.parametrize("lean", ["0", "1"])
 @pytest.mark.parametrize("smax", [3, 64])
-def test_supernodal_solves_follow_the_oracle(product_lib, oracle_lib, smax, monkeypatch):
+def test_supernodal_solves_follow_the_oracle(product_lib, oracle_lib, smax, lean, monkeypatch):
     """The same comparison with the triangular solves forced through supernodes (csrc/direct.hip k_sn_*; blocks of at
-    most `smax` pivots inverted once per factorisation): subtree and path supernodes, many levels at smax = 3."""
+    most `smax` pivots inverted once per factorisation): subtree and path supernodes, many levels at smax = 3.  Round 5: the
+    numeric factorisation behind them is the multifrontal one (csrc/mfront.hpp), and with lean = 1 the factor's index arrays
+    are built on the device from a lean host analysis (polish included: its reduced KKT system takes the host path)."""
     monkeypatch.setenv("OSQP_AMD_SNODE", "2")
     monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    monkeypatch.setenv("OSQP_AMD_LEAN", lean)
     rng = np.random.default_rng(3000 + smax)
     tally = {"exact": 0, "close": 0, "borderline": 0, "different": 0}
     notes = []
@@ -109,6 +113,7 @@ def test_supernodal_solves_follow_the_oracle(product_lib, oracle_lib, smax, monk
             if lib is product_lib:
                 st = oq.stats(m)
                 assert st[19] >= 1  # the supernodal path is what ran
+                assert st[22] == 1.0 and st[23] == float(lean == "1")  # ... behind a multifrontal factorisation, device-built when lean
                 deepest = max(deepest, int(st[19]))
             oq.clean(m)
         verdict = compare(res[0], res[1], 1e-5)
