@@ -1582,7 +1582,7 @@ struct LdlFactor {
       }
       // a workgroup class of few fronts joins the next larger one of its level: a launch costs the latency of one front
       // whatever its size (~90 us), the finer slabs only pay where thousands of fronts share the device
-      for (int c = 2; c + 1 < kMfClasses; c++) {
+      for (int c = 0; c + 1 < kMfClasses; c++) {
         if (cls[c].empty() || cls[c].size() >= 1024) continue;
         int up = c + 1;
         while (up + 1 < kMfClasses && cls[up].empty()) up++;
