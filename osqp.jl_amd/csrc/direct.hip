@@ -1053,20 +1053,34 @@ __device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, in
   return acc;
 }
 constexpr int kSnCap = 16;  // entries per lane whose index and value are in registers before the wait
-template <bool kForward>
-__global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+template <bool kForward, int NT>  // NT threads per supernode: 1024, or 512 when that lets the launch take one more level (twice the resident workgroups)
+__global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                             const int64_t *__restrict__ Ep, const int64_t *__restrict__ Es,
                                                             const int *__restrict__ Ej, const double *__restrict__ Ex,
                                                             const double *__restrict__ W, const double *__restrict__ Dinv_s,
                                                             const int *__restrict__ up, const int *__restrict__ waits,
-                                                            int *__restrict__ sync, int *__restrict__ fault, double *b) {
+                                                            int *__restrict__ sync, int *__restrict__ fault, double *b, int *ticket) {
   __shared__ double t[kSnMax];
   __shared__ double Wl[kSnMax * kSnMax];
-  const int J = kForward ? J0 + (int)blockIdx.x : count - 1 - (int)blockIdx.x;
+  __shared__ int Js;
+  // ticket != nullptr (round 5): PERSISTENT workgroups -- as many as the device holds -- take the supernodes of the launch in
+  // level order from a counter.  A workgroup that waits (forward: for children, backward: for its parent) waits on a
+  // supernode with an earlier ticket, i.e. one that some resident workgroup is working on or has finished: progress whatever
+  // the count, so the launch can take EVERY level above level 0 (control-1e6: 19 000 supernodes in 10 levels instead of the
+  // top 841 that fit the device at once; the plain launches of levels 1 - 3 were 6 x ~55 us of a 0.85 ms iteration).
+  for (int k = ticket ? -1 : (int)blockIdx.x;;) {
+  if (ticket) {
+    __syncthreads();  // everybody is past the previous supernode: t, Wl and Js are free
+    if (threadIdx.x == 0) Js = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    k = Js;
+    if (k >= count - J0) break;
+  }
+  const int J = kForward ? J0 + k : count - 1 - k;
   const int P = up[J];
   const int q0 = ptr[J], s = ptr[J + 1] - q0;
-  // all rows of the supernode at once: 64 / 32 / 16 lanes per row
-  const int la = s <= 16 ? 64 : (s <= 32 ? 32 : 16);
+  // all rows of the supernode at once: 64 / 32 / 16 (/ 8 with 512 threads) lanes per row
+  const int la = s <= NT / 64 ? 64 : (s <= NT / 32 ? 32 : (s <= NT / 16 ? 16 : NT / 64));
   const int lane = threadIdx.x & (la - 1), a = threadIdx.x / la;
   const bool mine = a < s;
   const int q = q0 + (mine ? a : 0);
@@ -1089,7 +1103,7 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
   }
   {
     const double *Wj = W + woff[J];
-    for (int e = threadIdx.x; e < s * (s + 1) / 2; e += kSnTreeThreads) Wl[e] = Wj[e];
+    for (int e = threadIdx.x; e < s * (s + 1) / 2; e += NT) Wl[e] = Wj[e];
   }
   const double own = mine ? (kForward ? b[q] : b[q] * Dinv_s[q]) : 0.0;
   if (threadIdx.x == 0) {
@@ -1123,14 +1137,15 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
   }
   __syncthreads();
   {
-    const int part = threadIdx.x & 15, r = threadIdx.x >> 4;  // 64 rows x 16 lanes
+    constexpr int LP = NT / 64;  // 64 rows x LP lanes
+    const int part = threadIdx.x & (LP - 1), r = threadIdx.x / LP;
     double acc = 0.0;
     if (r < s) {
-      if (kForward) { for (int j = part; j <= r; j += 16) acc += Wl[j * s - j * (j - 1) / 2 + (r - j)] * t[j]; }
-      else { for (int j = r + part; j < s; j += 16) acc += Wl[j * (j + 1) / 2 + r] * t[j]; }
+      if (kForward) { for (int j = part; j <= r; j += LP) acc += Wl[j * s - j * (j - 1) / 2 + (r - j)] * t[j]; }
+      else { for (int j = r + part; j < s; j += LP) acc += Wl[j * (j + 1) / 2 + r] * t[j]; }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    for (int o = LP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (part == 0 && r < s) __hip_atomic_store(&b[q0 + r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
@@ -1138,6 +1153,8 @@ __global__ __launch_bounds__(kSnTreeThreads) void k_sn_tree(int J0, int count, c
   if (threadIdx.x == 0) {
     if (kForward) { if (P >= 0) __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     else if (waits[J] > 0) __hip_atomic_store(&sync[J], waits[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!ticket) break;
   }
 }
 
@@ -1177,6 +1194,9 @@ struct LdlFactor {
   }
   mutable bool inject_fault = getenv("OSQP_AMD_SNODE_FAULT_TEST") && atoi(getenv("OSQP_AMD_SNODE_FAULT_TEST")) == 1;
   bool sn_tree = false;     // the levels from sn_tree_L0 on in one launch per direction (k_sn_tree) instead of one per level
+  int sn_tree_threads = 1024;  // threads per supernode of that launch (512: twice the resident workgroups, one more level fits)
+  int sn_tree_grid = 0;        // persistent form: workgroups of the launch (0: one per supernode, all resident)
+  DevBuf<int> sn_ticket;       // [forward, backward] counters of the persistent form
   int sn_tree_L0 = 1;       // first level of that launch: the lowest one from which all supernodes above fit the device at once
   DevBuf<int64_t> sn_woff, sn_wmap, sn_Fp, sn_Fpos, sn_Gp, sn_Gpos, sn_Fsplit;
   DevBuf<double> sn_Wc, sn_Wr, sn_Fx, sn_Gx, sn_Dinv;
@@ -1392,10 +1412,40 @@ struct LdlFactor {
       int per_cu_f = 0, per_cu_b = 0, cus = 0, dev = 0;
       HIP_CHECK(hipGetDevice(&dev));
       HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true>, kSnTreeThreads, 0));
-      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false>, kSnTreeThreads, 0));
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true, 1024>, 1024, 0));
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false, 1024>, 1024, 0));
       const long long cap = (long long)std::min(per_cu_f, per_cu_b) * cus;
       while (sn_tree_L0 < T.nlev && (long long)(T.count - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
+      // round 5: with 512 threads per supernode twice as many workgroups are resident; taken when that brings one more level
+      // (or more) into the launch -- a plain launch per level and direction is ~50 us on control-1e6, a level inside the
+      // launch a hand-over of a few microseconds
+      sn_tree_threads = 1024;
+      if (sn_tree_L0 > 1 && !(getenv("OSQP_AMD_SNODE_TREE_512") && atoi(getenv("OSQP_AMD_SNODE_TREE_512")) == 0)) {
+        int pf = 0, pb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, (const void *)k_sn_tree<true, 512>, 512, 0));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, (const void *)k_sn_tree<false, 512>, 512, 0));
+        const long long cap2 = (long long)std::min(pf, pb) * cus;
+        int L2 = 1;
+        while (L2 < T.nlev && (long long)(T.count - T.lvl_ptr[L2]) > cap2) L2++;
+        if (L2 < sn_tree_L0) { sn_tree_L0 = L2; sn_tree_threads = 512; }
+        // persistent workgroups: every level above level 0 in the launch, whatever the count (k_sn_tree, ticket)
+        // (measured on control-1e6: from level 1 on 1 165 -> 858 it/s -- the wide levels are throughput work that the plain
+        // level kernels do better than 512-thread workgroups with device-scope loads; OSQP_AMD_SNODE_TREE_PERSIST=k takes the
+        // levels from k on, default: off)
+        sn_tree_grid = 0;
+        int persist_from = 0;
+        if (getenv("OSQP_AMD_SNODE_TREE_PERSIST")) persist_from = atoi(getenv("OSQP_AMD_SNODE_TREE_PERSIST"));
+        else {  // default: the lowest level from which the supernodes above are at most three device-fuls (control-1e6: level 3,
+                // 2 674 supernodes on 1 024 resident workgroups: 1 169 -> 1 192 it/s; level 2 -- 7 700 -- is slower: 1 068)
+          persist_from = 1;
+          while (persist_from < T.nlev && (long long)(T.count - T.lvl_ptr[persist_from]) > 3 * cap2) persist_from++;
+        }
+        if (persist_from >= 1 && persist_from < sn_tree_L0) {
+          sn_tree_L0 = persist_from; sn_tree_threads = 512;
+          sn_tree_grid = (int)std::min<long long>(cap2, (long long)(T.count - T.lvl_ptr[sn_tree_L0]));
+          sn_ticket.alloc(2);
+        }
+      }
       if (T.nlev - sn_tree_L0 < 2) sn_tree = false;  // a single level (or none) left: nothing to fuse
     }
     // the split of the forward rows: where the entries that point at the first level of the one-launch tree (level 1
@@ -1914,10 +1964,12 @@ struct LdlFactor {
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
   } while (0)
 #define OQ_SN_TREE(FWD)                                                                                                           \
-  OQ_LAUNCH((k_sn_tree<FWD>), dim3(T.count - T.lvl_ptr[sn_tree_L0]), dim3(kSnTreeThreads), 0, s, T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
+  if (sn_tree_threads == 512) OQ_SN_TREE_N(FWD, 512); else OQ_SN_TREE_N(FWD, 1024)
+#define OQ_SN_TREE_N(FWD, NT_)                                                                                                    \
+  OQ_LAUNCH((k_sn_tree<FWD, NT_>), dim3(sn_tree_grid ? sn_tree_grid : T.count - T.lvl_ptr[sn_tree_L0]), dim3(NT_), 0, s, T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
-            FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get())
+            FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
   // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
   void run_supernodes() {
@@ -1929,6 +1981,7 @@ struct LdlFactor {
       case 16: OQ_SN_LEVEL(16, true, L); break;
       default: OQ_SN_LEVEL(64, true, L); break;
     }
+    if (sn_tree && sn_tree_grid) HIP_CHECK(hipMemsetAsync(sn_ticket.get(), 0, 2 * sizeof(int), s));
     if (sn_tree) { OQ_SN_TREE(true); OQ_SN_TREE(false); }
     for (int L = plain - 1; L >= 0; L--) switch (sn_lanes_b[L]) {
       case 1: OQ_SN_LEVEL(1, false, L); break;
@@ -1940,6 +1993,7 @@ struct LdlFactor {
 #undef OQ_SN_LEVEL
 #undef OQ_SN_LEVEL_W
 #undef OQ_SN_TREE
+#undef OQ_SN_TREE_N
 
   void run_steps(bool skip_first_fwd = false, bool skip_last_bwd = false) {
     hipStream_t s = e.stream;
