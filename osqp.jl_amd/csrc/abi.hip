@@ -458,6 +458,25 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
           smax_l = std::max(smax_l, T.ptr[J + 1] - T.ptr[J]);
           for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) { rows++; pre += T.Fsplit[q] - T.Fp[q]; post += T.Fp[q + 1] - T.Fsplit[q]; back += T.Gp[q + 1] - T.Gp[q]; }
         }
+        {
+          int64_t cnt[3] = {0, 0, 0}, rw[3] = {0, 0, 0}, ef[3] = {0, 0, 0}, eb[3] = {0, 0, 0}, mxb[3] = {0, 0, 0};
+          for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+            const int64_t sz = T.ptr[J + 1] - T.ptr[J];
+            const int c = sz == 1 ? 0 : (sz <= Supernodes::kSmall ? 1 : 2);
+            cnt[c]++; rw[c] += sz;
+            for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) { ef[c] += T.Fp[q + 1] - T.Fp[q]; eb[c] += T.Gp[q + 1] - T.Gp[q]; mxb[c] = std::max<int64_t>(mxb[c], T.Gp[q + 1] - T.Gp[q]); }
+          }
+          for (int c = 0; c < 3; c++)
+            fprintf(stderr, "level %d class %d (1 / <= small / larger): %lld supernodes, %lld rows, forward entries %lld, backward entries %lld (longest row %lld)\n", L, c,
+                    (long long)cnt[c], (long long)rw[c], (long long)ef[c], (long long)eb[c], (long long)mxb[c]);
+          int64_t wsm = 0, wbg = 0, rsm = 0, rbg = 0;
+          for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
+            const int64_t sz = T.ptr[J + 1] - T.ptr[J];
+            if (J < T.lvl_ptr[L] + T.lvl_small[L]) { wsm += sz * (sz + 1) / 2; rsm += sz; } else { wbg += sz * (sz + 1) / 2; rbg += sz; }
+          }
+          fprintf(stderr, "level %d: %d small supernodes (%lld rows, %lld block doubles), %d larger (%lld rows, %lld block doubles)\n", L, T.lvl_small[L],
+                  (long long)rsm, (long long)wsm, T.lvl_ptr[L + 1] - T.lvl_ptr[L] - T.lvl_small[L], (long long)rbg, (long long)wbg);
+        }
         fprintf(stderr, "level %d: %d supernodes, %lld rows (largest %d), per row: %.1f entries at level 0, %.1f above, %.1f backward\n", L,
                 T.lvl_ptr[L + 1] - T.lvl_ptr[L], (long long)rows, smax_l, (double)pre / rows, (double)post / rows, (double)back / rows);
         // fronts: border = pattern of the top node's column

@@ -1021,6 +1021,20 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const
   if (gl < s) b[q0 + gl] = acc;
 }
 
+// Backward step of the supernodes of ONE pivot that a level starts with (symbolic.hpp lvl_single; control-1e6: 388 258 of the
+// 496 738 leaves, one entry each): the block is the number 1, so x_q = D_q^-1 y_q - G_q x with a lane per pivot over
+// consecutive slots -- in k_sn_level_w they were a quarter wavefront each, 15 of 16 lanes idle.  (Forward they are skipped
+// at level 0 altogether: no entries outside the block, y_q = b_q.)
+__global__ __launch_bounds__(kBlock) void k_sn_single_bwd(int q0, int count, const int64_t *__restrict__ Gp, const int *__restrict__ Gi,
+                                                          const double *__restrict__ Gx, const double *__restrict__ Dinv_s,
+                                                          double *__restrict__ b) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const int q = q0 + i;
+  const double acc = gather_dot(Gp[q], Gp[q + 1], 1, Gi, Gx, b);
+  b[q] = b[q] * Dinv_s[q] - acc;
+}
+
 // The supernodes of level >= 1 in ONE launch per direction: workgroup = supernode, started in level order, each
 // waiting on a counter for the supernodes below it (forward: `pending[J]` children still running; backward: the
 // supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
@@ -1951,8 +1965,13 @@ struct LdlFactor {
     const int cnt_ = T.lvl_ptr[L + 1] - T.lvl_ptr[L];                                                                             \
     if (cnt_ >= sn_wave_min()) {                                                                                                  \
       const int mid_ = T.lvl_ptr[L] + T.lvl_small[L];                                                                             \
+      /* the single pivots the level starts with: forward nothing to do at level 0, backward a lane each */                       \
+      const int ones_ = sn_singles ? T.lvl_single[L] : 0, first_ = T.lvl_ptr[L] + ((FWD && L > 0) ? 0 : ones_);                   \
+      if (!FWD && ones_ > 0)                                                                                                      \
+        OQ_LAUNCH(k_sn_single_bwd, dim3(blocks_for(ones_)), dim3(kBlock), 0, s, T.ptr[T.lvl_ptr[L]], ones_, sn_Gp.get(),          \
+                  sn_Gi.get(), sn_Gx.get(), sn_Dinv.get(), bp.get());                                                             \
       /* a wide level is bound by rows in flight x latency, not by the latency of one row: a notch fewer lanes per row */         \
-      if (mid_ > T.lvl_ptr[L]) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 16, T.lvl_ptr[L], mid_);                  \
+      if (mid_ > first_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 16, first_, mid_);                             \
       if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);          \
     } else if (cnt_ >= kSnBusyLevel)  /* more workgroups than the device holds at once: rows in flight count, as above */         \
       OQ_LAUNCH((k_sn_level<(LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), \
@@ -1971,6 +1990,7 @@ struct LdlFactor {
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
   // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
+  const bool sn_singles = !(getenv("OSQP_AMD_SNODE_SINGLE") && atoi(getenv("OSQP_AMD_SNODE_SINGLE")) == 0);
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
   void run_supernodes() {
     hipStream_t s = e.stream;

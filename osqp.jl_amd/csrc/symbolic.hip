@@ -907,6 +907,7 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   // wavefront each (direct.hip k_sn_level_w), the rest with a whole one
   std::vector<int> newid(count);
   out.lvl_small.assign(nlev, 0);
+  out.lvl_single.assign(nlev, 0);
   // ... inside each of the two classes in the order of discovery.  (Measured and dropped in round 5, OSQP_AMD_SNODE_ORDER=1:
   // the supernodes of a level in the order of the supernode that holds their tree parent, so that the rows of a parent gather
   // the solution from neighbouring slots -- control-1e6 1118 -> 1090 it/s: the order of discovery follows the pivot numbering,
@@ -930,9 +931,14 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
           const int pa = up_old[a] >= 0 ? newid[up_old[a]] : -1, pb = up_old[b] >= 0 ? newid[up_old[b]] : -1;
           return pa < pb;
         });
-      else
-        std::stable_partition(v.begin(), v.end(), small);
+      else {
+        // ... and the single pivots first among the small ones: a leaf of one pivot has nothing to do in the forward sweep
+        // (no entries outside, a 1 x 1 unit block) and one lane's work in the backward one (direct.hip k_sn_single_bwd)
+        auto mid = std::stable_partition(v.begin(), v.end(), small);
+        std::stable_partition(v.begin(), mid, [&](int J) { return members[J] == 1; });
+      }
       for (size_t k = 0; k < v.size(); k++) { newid[v[k]] = out.lvl_ptr[L] + (int)k; out.lvl_small[L] += small(v[k]); }
+      if (!by_parent) for (size_t k = 0; k < v.size() && members[v[k]] == 1; k++) out.lvl_single[L]++;
     }
   }
   out.ptr.assign(count + 1, 0);

@@ -1,5 +1,7 @@
 """Standard QP classes (tests/qp_zoo.py): the CPU oracle against an independent evaluation of the stopping criteria
 (CPU), and the HIP engine against the oracle and the same evaluation (GPU)."""
+import ctypes as C
+
 import numpy as np
 import scipy.sparse as sp
 import pytest
@@ -88,6 +90,42 @@ def test_nested_dissection_ordering_on_a_long_horizon(product_lib, oracle_lib):
     assert ro.info.iter == rp.info.iter
     assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
     assert np.max(np.abs(ro.y - rp.y)) <= 1e-7 * max(1.0, np.max(np.abs(ro.y)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smax", ["64", "3", "1"])
+def test_single_pivot_supernodes_of_a_wide_level(product_lib, oracle_lib, monkeypatch, smax):
+    """Round 5 (control-1e6: 388 258 of the 496 738 leaves are supernodes of ONE pivot): a wide level numbers them first;
+    the forward sweep skips them at level 0 (nothing outside the block, a 1 x 1 unit block) and the backward sweep gives
+    them a lane each (csrc/direct.hip k_sn_single_bwd) instead of a quarter wavefront.  Forced onto a small problem with
+    three partitions (largest supernode 64 / 3 / 1 -- the last: every supernode of every level takes that path backward):
+    the same KKT solves as with the path switched off, and the oracle's trajectory."""
+    prob = qp_zoo.control(nx=8, nu=4, T=400)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **opts, **prob)
+    ro = oq.solve(mo)
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", smax)
+    monkeypatch.setenv("OSQP_AMD_SNODE_WAVE_MIN", "1")
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(3).standard_normal(n + mm)
+    sols = []
+    for single in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_SNODE_SINGLE", single)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", **opts, **prob)
+        assert oq.stats(m)[19] > 2
+        out = np.empty_like(rhs)
+        assert m.lib.osqp_amd_apply(m.workspace, 3, rhs.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        rp = oq.solve(m)
+        assert rp.info.status == ro.info.status == "Solved" and rp.info.iter == ro.info.iter
+        assert np.max(np.abs(ro.x - rp.x)) <= 1e-7 * max(1.0, np.max(np.abs(ro.x)))
+        sols.append(out)
+        oq.clean(m)
+    assert np.all(np.isfinite(sols[1]))
+    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-10 * max(1.0, np.max(np.abs(sols[0])))
+    oq.clean(mo)
 
 
 @pytest.mark.gpu
