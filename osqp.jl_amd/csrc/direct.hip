@@ -1021,6 +1021,121 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const
   if (gl < s) b[q0 + gl] = acc;
 }
 
+// The same two steps with the entries outside the block taken FLAT (round 5).  The forms above give every row LA lanes and
+// walk the rows of a supernode LA-th by LA-th: a level-3 supernode of control-1e6 (54 rows of 94 entries) is fourteen rounds of
+// {row pointers -> entries -> gathered solution -> shuffle sum} behind each other, 42 memory latencies for 60 KB -- the levels
+// are bound by that chain, not by bytes (3 TB/s).  The entries of the rows of a supernode are ONE contiguous stretch of the
+// lists (its rows are consecutive slots), so: every thread takes kSnFlatU entries of the stretch whatever their row -- full
+// wavefront loads of the index and value streams, kSnFlatU gathers in flight per lane -- and leaves the products in LDS; then
+// the rows add up their own piece of the chunk in entry order (four lanes per row taking every fourth entry, met in a fixed
+// order: the same sum on every run).  Two latencies per chunk of 2048 entries.
+constexpr int kSnFlatU = 8;
+template <bool kForward>
+__global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                           const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
+                                                           const double *__restrict__ Ex, const double *__restrict__ W,
+                                                           const double *__restrict__ Dinv_s, double *__restrict__ b) {
+  constexpr int C = kSnThreads * kSnFlatU;
+  __shared__ double prod[C];
+  __shared__ double t[kSnMax];
+  __shared__ double part[kSnThreads / 64][kSnMax];
+  const int J = J0 + blockIdx.x, q0 = ptr[J], s = ptr[J + 1] - q0;
+  const int tid = threadIdx.x, ra = tid >> 2, rk = tid & 3;  // row ra (kSnThreads / 4 = kSnMax of them), lane rk of its four
+  const int64_t E0 = Ep[q0], E1 = Ep[q0 + s];
+  int64_t r1 = 0, pos = 0;
+  double rhs = 0.0;
+  if (ra < s) {
+    pos = Ep[q0 + ra] + rk; r1 = Ep[q0 + ra + 1];
+    if (rk == 0) rhs = kForward ? b[q0 + ra] : b[q0 + ra] * Dinv_s[q0 + ra];
+  }
+  double acc = 0.0;
+  for (int64_t base = E0; base < E1; base += C) {
+    int idx[kSnFlatU];
+    double val[kSnFlatU], bv[kSnFlatU];
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) {
+      const int64_t e = base + u * kSnThreads + tid;
+      const bool ok = e < E1;
+      idx[u] = ok ? Ej[e] : -1;
+      val[u] = ok ? Ex[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) bv[u] = idx[u] >= 0 ? b[idx[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) prod[u * kSnThreads + tid] = val[u] * bv[u];
+    __syncthreads();
+    const int64_t end = r1 < base + C ? r1 : base + C;
+    for (; pos < end; pos += 4) acc += prod[pos - base];
+    __syncthreads();
+  }
+  {
+    const double a1 = __shfl_xor(acc, 1);
+    const double pair = (rk & 1) ? a1 + acc : acc + a1;  // (lane 0 + lane 1), (lane 2 + lane 3) -- the same operands in the same order on both lanes
+    const double other = __shfl_xor(pair, 2);
+    const double sum = (rk & 2) ? other + pair : pair + other;
+    if (rk == 0 && ra < s) t[ra] = rhs - sum;
+  }
+  __syncthreads();
+  const double *Wj = W + woff[J];
+  const int wv = tid >> 6, a = tid & 63;
+  part[wv][a] = sn_block_row<kForward>(Wj, t, s, a, wv, kSnThreads / 64);
+  __syncthreads();
+  if (wv == 0 && a < s) b[q0 + a] = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
+}
+// ... and with a wavefront per supernode (k_sn_level_w, GS = 64): lane = row for the sums, chunks of 64 x kSnFlatU entries in
+// the wavefront's own slab of LDS, no workgroup barrier (LDS operations of a wavefront complete in order)
+template <bool kForward>
+__global__ __launch_bounds__(kSnThreads) void k_sn_level_wf(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+                                                            const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
+                                                            const double *__restrict__ Ex, const double *__restrict__ W,
+                                                            const double *__restrict__ Dinv_s, double *__restrict__ b) {
+  constexpr int C = 64 * kSnFlatU;
+  __shared__ double prod_all[kSnThreads / 64][C];
+  __shared__ double tt[kSnThreads / 64][kSnMax];
+  const int wv = threadIdx.x >> 6, gl = threadIdx.x & 63;
+  const int J = J0 + blockIdx.x * (kSnThreads / 64) + wv;
+  if (J >= J1) return;  // no workgroup barrier below
+  double *prod = prod_all[wv], *t = tt[wv];
+  const int q0 = ptr[J], s = ptr[J + 1] - q0;
+  const int64_t E0 = Ep[q0], E1 = Ep[q0 + s];
+  int64_t r1 = 0, pos = 0;
+  double rhs = 0.0;
+  if (gl < s) {
+    pos = Ep[q0 + gl]; r1 = Ep[q0 + gl + 1];
+    rhs = kForward ? b[q0 + gl] : b[q0 + gl] * Dinv_s[q0 + gl];
+  }
+  double acc = 0.0;
+  for (int64_t base = E0; base < E1; base += C) {
+    int idx[kSnFlatU];
+    double val[kSnFlatU], bv[kSnFlatU];
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) {
+      const int64_t e = base + u * 64 + gl;
+      const bool ok = e < E1;
+      idx[u] = ok ? Ej[e] : -1;
+      val[u] = ok ? Ex[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) bv[u] = idx[u] >= 0 ? b[idx[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kSnFlatU; u++) prod[u * 64 + gl] = val[u] * bv[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const int64_t end = r1 < base + C ? r1 : base + C;
+    for (; pos < end; pos++) acc += prod[pos - base];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (gl < s) t[gl] = rhs - acc;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const double *Wj = W + woff[J];
+  const double out = sn_block_row<kForward>(Wj, t, s, gl, 0, 1);
+  if (gl < s) b[q0 + gl] = out;
+}
+
 // Backward step of the supernodes of ONE pivot that a level starts with (symbolic.hpp lvl_single; control-1e6: 388 258 of the
 // 496 738 leaves, one entry each): the block is the number 1, so x_q = D_q^-1 y_q - G_q x with a lane per pivot over
 // consecutive slots -- in k_sn_level_w they were a quarter wavefront each, 15 of 16 lanes idle.  (Forward they are skipped
@@ -1972,8 +2087,16 @@ struct LdlFactor {
                   sn_Gi.get(), sn_Gx.get(), sn_Dinv.get(), bp.get());                                                             \
       /* a wide level is bound by rows in flight x latency, not by the latency of one row: a notch fewer lanes per row */         \
       if (mid_ > first_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 16, first_, mid_);                             \
-      if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);          \
-    } else if (cnt_ >= kSnBusyLevel)  /* more workgroups than the device holds at once: rows in flight count, as above */         \
+      if (T.lvl_ptr[L + 1] > mid_ && sn_flat && !(FWD && L == 0))                                                                 \
+        OQ_LAUNCH((k_sn_level_wf<FWD>), dim3((T.lvl_ptr[L + 1] - mid_ + 3) / 4), dim3(kSnThreads), 0, s, mid_, T.lvl_ptr[L + 1],   \
+                  sn_ptr.get(), sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),                    \
+                  FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                      \
+      else if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);     \
+    } else if (sn_flat)                                                                                                            \
+      OQ_LAUNCH((k_sn_level_f<FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), sn_woff.get(),                \
+                FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),                  \
+                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
+    else if (cnt_ >= kSnBusyLevel)  /* more workgroups than the device holds at once: rows in flight count, as above */         \
       OQ_LAUNCH((k_sn_level<(LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), \
                 sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),  \
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
@@ -1990,6 +2113,7 @@ struct LdlFactor {
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
   // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
+  const bool sn_flat = !(getenv("OSQP_AMD_SNODE_FLAT") && atoi(getenv("OSQP_AMD_SNODE_FLAT")) == 0);  // k_sn_level_f / _wf
   const bool sn_singles = !(getenv("OSQP_AMD_SNODE_SINGLE") && atoi(getenv("OSQP_AMD_SNODE_SINGLE")) == 0);
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
   void run_supernodes() {
