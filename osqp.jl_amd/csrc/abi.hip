@@ -445,7 +445,7 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
              S2.AtoL == S.AtoL;
       out[14] = same ? 1.0 : 0.0;
     }
-    out[5] = (double)T.Fp[S.N]; out[6] = (double)T.woff[T.count]; out[7] = largest; out[8] = ok ? 1.0 : 0.0; out[9] = (double)inside;
+    out[5] = (double)T.Fp[S.N]; out[6] = (double)T.wdoubles; out[7] = largest; out[8] = ok ? 1.0 : 0.0; out[9] = (double)inside;
     int lD, cD, kD;
     choose_dense_top(S, 512, getenv("OSQP_AMD_DENSE_MAX") ? atoi(getenv("OSQP_AMD_DENSE_MAX")) : 12288, 1024, 32, lD, cD, kD);
     out[10] = level_solve_cost_us(S, 512, lD, kD); out[11] = supernode_solve_cost_us(T, 256);

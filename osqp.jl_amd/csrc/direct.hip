@@ -1084,7 +1084,37 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__
 }
 // ... and with a wavefront per supernode (k_sn_level_w, GS = 64): lane = row for the sums, chunks of 64 x kSnFlatU entries in
 // the wavefront's own slab of LDS, no workgroup barrier (LDS operations of a wavefront complete in order)
+// kFold: the block is stored FOLDED (k_sn_fold below).  Reading the packed triangle piece by piece leaves half the lanes of
+// every load masked off and the memory system at 3.3 TB/s (tools/micro/block_stream.hip: 4.9 TB/s for 64 rows, 2.6 for 24;
+// folded 6.2 / 4.3).  Folded, lane a < h = ceil(s / 2) owns the TWO rows a and s - 1 - a (forward; columns backward): a + 1
+// and s - a entries, s + 1 together for every lane, stored step by step (entry k of lane a at k h + a).  The lanes 32..63
+// take the odd steps, so a wavefront load is steps k and k + 1: 2 h contiguous doubles, no lane masked (s = 64), and the block
+// is over in (s + 1) / 2 loads instead of s.  The two halves meet through one lane exchange, even steps + odd steps.
 template <bool kForward>
+__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, double &lo, double &hi) {
+  const int h = (s + 1) >> 1, a = gl & 31, par = gl >> 5;
+  lo = 0.0; hi = 0.0;
+  if (a < h) {
+    auto idx = [&](int k) { return kForward ? (k <= a ? k : k - a - 1) : (k <= a ? s - 1 - a + k : k - 1); };
+    int k = par;
+    for (; k + 6 <= s; k += 8) {
+      const double w0 = Wj[k * h + a], w1 = Wj[(k + 2) * h + a], w2 = Wj[(k + 4) * h + a], w3 = Wj[(k + 6) * h + a];
+      const double p0 = w0 * t[idx(k)], p1 = w1 * t[idx(k + 2)], p2 = w2 * t[idx(k + 4)], p3 = w3 * t[idx(k + 6)];
+      if (k <= a) lo += p0; else hi += p0;
+      if (k + 2 <= a) lo += p1; else hi += p1;
+      if (k + 4 <= a) lo += p2; else hi += p2;
+      if (k + 6 <= a) lo += p3; else hi += p3;
+    }
+    for (; k <= s; k += 2) {
+      const double p0 = Wj[k * h + a] * t[idx(k)];
+      if (k <= a) lo += p0; else hi += p0;
+    }
+  }
+  const double lo2 = __shfl_xor(lo, 32), hi2 = __shfl_xor(hi, 32);
+  lo = par ? lo2 + lo : lo + lo2;
+  hi = par ? hi2 + hi : hi + hi2;
+}
+template <bool kForward, bool kFold>
 __global__ __launch_bounds__(kSnThreads) void k_sn_level_wf(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                             const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
                                                             const double *__restrict__ Ex, const double *__restrict__ W,
@@ -1132,8 +1162,39 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_wf(int J0, int J1, cons
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   const double *Wj = W + woff[J];
+  if (kFold) {
+    double lo, hi;
+    sn_block_fold<kForward>(Wj, t, s, gl, lo, hi);
+    const int a = gl & 31, h = (s + 1) >> 1;
+    if (gl < h) {  // forward: lo is row a, hi row s - 1 - a; backward: lo is column s - 1 - a, hi column a
+      b[q0 + (kForward ? a : s - 1 - a)] = lo;
+      if (a != s - 1 - a) b[q0 + (kForward ? s - 1 - a : a)] = hi;
+    }
+    return;
+  }
   const double out = sn_block_row<kForward>(Wj, t, s, gl, 0, 1);
   if (gl < s) b[q0 + gl] = out;
+}
+// A packed block to its folded form, in place through LDS (after every numeric factorisation, for the supernodes the
+// wavefront form solves: LdlFactor::fold_blocks).  kForward: the block is packed by columns (Wc), else by rows (Wr).
+template <bool kForward>
+__global__ __launch_bounds__(64) void k_sn_fold(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff, double *__restrict__ W) {
+  __shared__ double tri[kSnMax * (kSnMax + 1) / 2];
+  const int J = J0 + blockIdx.x, s = ptr[J + 1] - ptr[J], gl = threadIdx.x;
+  double *Wj = W + woff[J];
+  const int nel = s * (s + 1) / 2, h = (s + 1) >> 1;
+  for (int e = gl; e < nel; e += 64) tri[e] = Wj[e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  auto at = [&](int r, int c) { return kForward ? tri[c * s - c * (c - 1) / 2 + (r - c)] : tri[r * (r + 1) / 2 + c]; };  // W(r, c), r >= c
+  for (int e = gl; e < (s + 1) * h; e += 64) {
+    const int k = e / h, a = e - k * h;
+    double v;
+    if (kForward) v = k <= a ? at(a, k) : (a != s - 1 - a ? at(s - 1 - a, k - a - 1) : 0.0);
+    else v = k <= a ? at(s - 1 - a + k, s - 1 - a) : (a != s - 1 - a ? at(k - 1, a) : 0.0);
+    Wj[e] = v;
+  }
 }
 
 // Backward step of the supernodes of ONE pivot that a level starts with (symbolic.hpp lvl_single; control-1e6: 388 258 of the
@@ -1979,6 +2040,7 @@ struct LdlFactor {
                 sn_piv.get(), Dinv.get(), sn_Dinv.get(), Lx.get());
       if (!mf)  // (the fronts leave the inverted blocks behind themselves)
         OQ_LAUNCH(k_sn_invert, dim3(T.count), dim3(kSnThreads), 0, s, sn_ptr.get(), sn_woff.get(), sn_wmap.get(), Lx.get(), sn_Wc.get(), sn_Wr.get());
+      fold_blocks(s);
     }
     // (the CSR copy of the values serves the level-scheduled solves only)
     if (S.nnzL > 0 && !sn) OQ_LAUNCH(k_gather_csr, dim3(blocks_for(S.nnzL)), dim3(kBlock), 0, s, S.nnzL, Rmap.get(), Lx.get(), Rx.get());
@@ -2078,7 +2140,7 @@ struct LdlFactor {
 #define OQ_SN_LEVEL(LA, FWD, L)                                                                                                   \
   do {                                                                                                                            \
     const int cnt_ = T.lvl_ptr[L + 1] - T.lvl_ptr[L];                                                                             \
-    if (cnt_ >= sn_wave_min()) {                                                                                                  \
+    if (cnt_ >= sn_wave_min_fixed) {                                                                                                \
       const int mid_ = T.lvl_ptr[L] + T.lvl_small[L];                                                                             \
       /* the single pivots the level starts with: forward nothing to do at level 0, backward a lane each */                       \
       const int ones_ = sn_singles ? T.lvl_single[L] : 0, first_ = T.lvl_ptr[L] + ((FWD && L > 0) ? 0 : ones_);                   \
@@ -2087,9 +2149,13 @@ struct LdlFactor {
                   sn_Gi.get(), sn_Gx.get(), sn_Dinv.get(), bp.get());                                                             \
       /* a wide level is bound by rows in flight x latency, not by the latency of one row: a notch fewer lanes per row */         \
       if (mid_ > first_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 16, first_, mid_);                             \
-      if (T.lvl_ptr[L + 1] > mid_ && sn_flat && !(FWD && L == 0))                                                                 \
-        OQ_LAUNCH((k_sn_level_wf<FWD>), dim3((T.lvl_ptr[L + 1] - mid_ + 3) / 4), dim3(kSnThreads), 0, s, mid_, T.lvl_ptr[L + 1],   \
-                  sn_ptr.get(), sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),                    \
+      if (T.lvl_ptr[L + 1] > mid_ && !lvl_fold.empty() && lvl_fold[L])                                                            \
+        OQ_LAUNCH((k_sn_level_wf<FWD, true>), dim3((T.lvl_ptr[L + 1] - mid_ + 3) / 4), dim3(kSnThreads), 0, s, mid_,               \
+                  T.lvl_ptr[L + 1], sn_ptr.get(), sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),  \
+                  FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                      \
+      else if (T.lvl_ptr[L + 1] > mid_ && sn_flat && !(FWD && L == 0))                                                            \
+        OQ_LAUNCH((k_sn_level_wf<FWD, false>), dim3((T.lvl_ptr[L + 1] - mid_ + 3) / 4), dim3(kSnThreads), 0, s, mid_,              \
+                  T.lvl_ptr[L + 1], sn_ptr.get(), sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),  \
                   FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                      \
       else if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);     \
     } else if (sn_flat)                                                                                                            \
@@ -2113,6 +2179,30 @@ struct LdlFactor {
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
   // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
+  // the blocks of the supernodes that the wavefront form solves are kept folded (k_sn_fold / sn_block_fold); fixed at setup:
+  // the levels are chosen by the same count the launches look at
+  const bool sn_fold = !(getenv("OSQP_AMD_SNODE_FOLD") && atoi(getenv("OSQP_AMD_SNODE_FOLD")) == 0) &&
+                       !(getenv("OSQP_AMD_SNODE_FLAT") && atoi(getenv("OSQP_AMD_SNODE_FLAT")) == 0);
+  const int sn_wave_min_fixed = sn_wave_min();
+  std::vector<char> lvl_fold;  // per level: the blocks of its larger supernodes are folded (decided once: a factor that falls
+                               // back from k_sn_tree to one launch per level keeps reading them the way they are stored)
+  void fold_blocks(hipStream_t s) {
+    if (!sn || !sn_fold) return;
+    if (lvl_fold.empty()) {
+      lvl_fold.assign(T.nlev, 0);
+      for (int L = 0; L < T.nlev; L++) {
+        const int cnt = T.lvl_ptr[L + 1] - T.lvl_ptr[L], mid = T.lvl_ptr[L] + T.lvl_small[L];
+        // (the levels from sn_tree_L0 on are solved by k_sn_tree whatever their count)
+        lvl_fold[L] = cnt >= sn_wave_min_fixed && T.lvl_ptr[L + 1] > mid && !(sn_tree && L >= sn_tree_L0);
+      }
+    }
+    for (int L = 0; L < T.nlev; L++) {
+      const int mid = T.lvl_ptr[L] + T.lvl_small[L];
+      if (!lvl_fold[L]) continue;
+      OQ_LAUNCH(k_sn_fold<true>, dim3(T.lvl_ptr[L + 1] - mid), dim3(64), 0, s, mid, sn_ptr.get(), sn_woff.get(), sn_Wc.get());
+      OQ_LAUNCH(k_sn_fold<false>, dim3(T.lvl_ptr[L + 1] - mid), dim3(64), 0, s, mid, sn_ptr.get(), sn_woff.get(), sn_Wr.get());
+    }
+  }
   const bool sn_flat = !(getenv("OSQP_AMD_SNODE_FLAT") && atoi(getenv("OSQP_AMD_SNODE_FLAT")) == 0);  // k_sn_level_f / _wf
   const bool sn_singles = !(getenv("OSQP_AMD_SNODE_SINGLE") && atoi(getenv("OSQP_AMD_SNODE_SINGLE")) == 0);
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
@@ -2209,7 +2299,7 @@ struct LdlFactor {
   }
 
   double trisolve_bytes() const {
-    if (sn) return 2.0 * (12.0 * (double)T.Fp[N] + 8.0 * (double)T.woff[T.count] + 8.0 * ((double)N + 1.0)) + 40.0 * (double)N;
+    if (sn) return 2.0 * (12.0 * (double)T.Fp[N] + 8.0 * (double)T.wdoubles + 8.0 * ((double)N + 1.0)) + 40.0 * (double)N;
     return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N;
   }
 };

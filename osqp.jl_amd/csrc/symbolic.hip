@@ -957,9 +957,13 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   for (int J = out.lvl_ptr[std::min(1, nlev)]; J < count; J++)
     if (out.up[J] >= 0) out.waits[out.up[J]]++;
   out.woff.assign(count + 1, 0);
+  out.wdoubles = 0;
   for (int J = 0; J < count; J++) {
     const int64_t s = out.ptr[J + 1] - out.ptr[J];
-    out.woff[J + 1] = out.woff[J] + s * (s + 1) / 2;  // the lower triangle, packed (round 4: the dense s x s blocks were 45 % zeros)
+    // the lower triangle, packed (round 4: the dense s x s blocks were 45 % zeros); room for its folded form (round 5,
+    // direct.hip k_sn_fold: s + 1 steps of ceil(s / 2) lanes -- the triangle itself for even s, half a row more for odd s)
+    out.woff[J + 1] = out.woff[J] + (s + 1) * ((s + 1) / 2);
+    out.wdoubles += s * (s + 1) / 2;
     out.flops += (double)(s * s);
   }
   stage("partition, levels, slots");

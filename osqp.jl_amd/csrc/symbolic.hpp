@@ -86,6 +86,7 @@ struct Supernodes {
   static constexpr int kSmall = 16;  // supernodes of at most this many pivots are numbered first inside their level
   std::vector<int> lvl_small;        // per level: how many of its supernodes are that small
   std::vector<int> lvl_single;       // per level: how many of those have ONE pivot (they come first of all)
+  int64_t wdoubles = 0;        // entries of all blocks together (woff[count] includes the room the folded form of an odd triangle needs)
   std::vector<int64_t> woff;  // offset of the block of supernode J in the W arrays: its lower triangle, packed, s (s + 1) / 2 entries (count + 1 offsets)
   std::vector<int64_t> wmap;  // per block entry a (a + 1) / 2 + b, b <= a: position in Lx of L(slot a, slot b) for a > b, -1 if not in the pattern (and on the diagonal)
   // the entries of L outside the diagonal blocks, by row (forward solve) and by column (backward solve), rows and
