@@ -160,3 +160,47 @@ def test_lean_setup_builds_the_same_factor_on_the_device(product_lib, monkeypatc
         assert np.array_equal(sols["0"][k], sols["1"][k]), (case, k, np.max(np.abs(sols["0"][k] - sols["1"][k])))
     assert sols["0"][4:] == sols["1"][4:]  # iterations, nnz(L), levels, supernode levels, bytes of a solve
     assert np.max(np.abs(sols["1"][0] - sols["1"][1])) > 1e-9
+
+
+FORM_CASES = {
+    "control-400": (lambda: qp_zoo.control(nx=8, nu=4, T=400), 64),
+    "control-300-odd-blocks": (lambda: qp_zoo.control(nx=12, nu=6, T=300), 23),
+    "portfolio": (lambda: qp_zoo.portfolio(n=300, k=10), 40),
+    "random-200": (lambda: _random_problem(np.random.default_rng(6), 200, 150, 0.02), 33),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave_min", ["1", "1000000000"])
+@pytest.mark.parametrize("case", sorted(FORM_CASES))
+def test_forms_of_the_supernode_level_kernels_agree(product_lib, monkeypatch, case, wave_min):
+    """Round 5, second pass over the level kernels (csrc/direct.hip): entries outside the blocks taken flat through LDS
+    (k_sn_level_f / _wf), inverted blocks of the wavefront-form supernodes folded in place after every factorisation
+    (k_sn_fold / sn_block_fold), single pivots a lane each.  Each switched off in turn against all on -- the same KKT solves
+    (the order of a row's sum differs between forms, not its terms) before and after a refactorisation (the blocks are folded
+    again), with every level in the wavefront form (OSQP_AMD_SNODE_WAVE_MIN=1) and with none; odd and even block sizes."""
+    make, smax = FORM_CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    monkeypatch.setenv("OSQP_AMD_SNODE_WAVE_MIN", wave_min)
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(13).standard_normal(n + mm)
+    sols = {}
+    for off in ("", "OSQP_AMD_SNODE_FLAT", "OSQP_AMD_SNODE_FOLD", "OSQP_AMD_SNODE_SINGLE"):
+        for name in ("OSQP_AMD_SNODE_FLAT", "OSQP_AMD_SNODE_FOLD", "OSQP_AMD_SNODE_SINGLE"):
+            monkeypatch.setenv(name, "0" if name == off else "1")
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        assert oq.stats(m)[19] >= 1
+        first = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.413)
+        second = _kkt_solve(m, rhs)
+        sols[off] = (first, second)
+        oq.clean(m)
+    for off, (first, second) in sols.items():
+        for k, v in enumerate((first, second)):
+            ref = sols[""][k]
+            assert np.all(np.isfinite(v))
+            assert np.max(np.abs(v - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref))), (case, off, k, np.max(np.abs(v - ref)))
+    assert np.max(np.abs(sols[""][0] - sols[""][1])) > 1e-6
