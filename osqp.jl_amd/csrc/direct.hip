@@ -2178,7 +2178,6 @@ struct LdlFactor {
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
-  // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
   // the blocks of the supernodes that the wavefront form solves are kept folded (k_sn_fold / sn_block_fold); fixed at setup:
   // the levels are chosen by the same count the launches look at
   const bool sn_fold = !(getenv("OSQP_AMD_SNODE_FOLD") && atoi(getenv("OSQP_AMD_SNODE_FOLD")) == 0) &&
@@ -2205,6 +2204,7 @@ struct LdlFactor {
   }
   const bool sn_flat = !(getenv("OSQP_AMD_SNODE_FLAT") && atoi(getenv("OSQP_AMD_SNODE_FLAT")) == 0);  // k_sn_level_f / _wf
   const bool sn_singles = !(getenv("OSQP_AMD_SNODE_SINGLE") && atoi(getenv("OSQP_AMD_SNODE_SINGLE")) == 0);
+  // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
   void run_supernodes() {
     hipStream_t s = e.stream;
