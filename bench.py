@@ -358,9 +358,9 @@ def replica_bench(ctx):
         abytes = st[11] + 8.0 * (6 * n + 12 * int(oq.dimensions(model)[1]))  # trisolve bytes + the vector updates
         pmc_names = ["k_direct2_fwd", "k_direct2_bwd_update"]  # the two-launch iteration of a two-level factor
         if int(st[19]) > 0:  # supernodal solves: right-hand side | level 0 | tree (forward, backward) | level 0 | update
-            kname = ("direct ADMM iteration on a supernodal factor: k_direct_rhs | k_sn_level (level 0) | k_sn_tree forward | k_sn_tree backward | "
-                     "k_sn_level | k_direct_update")
-            pmc_names = {"sum": ["k_direct_rhs", "k_sn_level", "k_sn_tree", "k_direct_update"], "per": "k_direct_rhs"}
+            kname = ("direct ADMM iteration on a supernodal factor: k_direct_rhs | k_sn_level_w / _wf / _f forward (levels below the tree launch) | "
+                     "k_sn_tree forward | k_sn_tree backward | k_sn_level_f / _wf / _w + k_sn_single_bwd backward | k_direct_update")
+            pmc_names = {"sum": ["k_direct_rhs", "k_sn_level", "k_sn_single", "k_sn_tree", "k_direct_update"], "per": "k_direct_rhs"}
     ms = float(lib.osqp_amd_time_kernel(ws, which, 20))
     achieved = abytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -850,8 +850,18 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   };
   out = Supernodes();
   out.smax = smax;
+  // Lone leaves (round 5): a tree leaf whose column holds ONE entry (a box-constraint row hanging off its variable: 7.8e5 of
+  // the 2.67e6 pivots of control-1e6) stays out of its parent's subtree supernode.  Inside, it adds a row and a column to an
+  // inverted block (a leaf subtree of 40 pivots holds 11 of them: half the triangle); outside, it is a supernode of one
+  // pivot -- nothing to do forward, one lane's work backward (direct.hip k_sn_single_bwd) -- and one entry in its parent's
+  // forward row.  OSQP_AMD_SNODE_LEAF=0: off; 2: they do not count towards the size of a subtree either.
+  static const int leaf_mode = getenv("OSQP_AMD_SNODE_LEAF") ? atoi(getenv("OSQP_AMD_SNODE_LEAF")) : 1;
+  auto lone = [&](int v) {
+    return leaf_mode > 0 && smax > 1 && parent[v] >= 0 && S.Rp[v + 1] == S.Rp[v] && S.Lp[v + 1] - S.Lp[v] == 1;
+  };
   // subtree sizes (parents have larger indices than their children)
   std::vector<int> size(N, 1), big_children(N, 0);
+  if (leaf_mode == 2) for (int v = 0; v < N; v++) if (lone(v)) size[v] = 0;
   for (int v = 0; v < N; v++)
     if (parent[v] >= 0) size[parent[v]] += size[v];
   auto big = [&](int v) { return size[v] > smax; };
@@ -870,7 +880,7 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   for (int v = N - 1; v >= 0; v--) {
     const int p = parent[v];
     if (!big(v)) {
-      if (p >= 0 && !big(p)) sn[v] = sn[p];
+      if (p >= 0 && !big(p) && !lone(v)) sn[v] = sn[p];
     } else if (p >= 0) {
       if (big_children[p] == 1 && (members[sn[p]] < reserved[sn[p]])) sn[v] = sn[p];              // the path goes on
       else if (reserved[sn[p]] + plen[v] <= smax) { sn[v] = sn[p]; reserved[sn[p]] += plen[v]; }  // a new path joins
