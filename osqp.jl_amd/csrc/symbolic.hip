@@ -854,11 +854,19 @@ void build_supernodes(const Symbolic &S, int smax, Supernodes &out, bool with_wm
   // the 2.67e6 pivots of control-1e6) stays out of its parent's subtree supernode.  Inside, it adds a row and a column to an
   // inverted block (a leaf subtree of 40 pivots holds 11 of them: half the triangle); outside, it is a supernode of one
   // pivot -- nothing to do forward, one lane's work backward (direct.hip k_sn_single_bwd) -- and one entry in its parent's
-  // forward row.  OSQP_AMD_SNODE_LEAF=0: off; 2: they do not count towards the size of a subtree either.
-  static const int leaf_mode = getenv("OSQP_AMD_SNODE_LEAF") ? atoi(getenv("OSQP_AMD_SNODE_LEAF")) : 1;
-  auto lone = [&](int v) {
-    return leaf_mode > 0 && smax > 1 && parent[v] >= 0 && S.Rp[v + 1] == S.Rp[v] && S.Lp[v + 1] - S.Lp[v] == 1;
-  };
+  // forward row.  The price is one more level of the supernode graph (~10 us per iteration: control T = 800 10.5 -> 8.8 k
+  // it/s, T = 8000 5.0 -> 4.5 k, T = 30000 2.41 -> 2.47 k, control-1e6 1 647 -> 1 714 it/s and 0.058 -> 0.055 s to eps), so
+  // by default only from 400 000 such leaves on.  OSQP_AMD_SNODE_LEAF=0: never; 1: always; 2: always, and they do not
+  // count towards the size of a subtree either (larger blocks: 1 721 it/s, but no gain in the factorisation).
+  const int leaf_env = getenv("OSQP_AMD_SNODE_LEAF") ? atoi(getenv("OSQP_AMD_SNODE_LEAF")) : -1;
+  auto is_lone = [&](int v) { return parent[v] >= 0 && S.Rp[v + 1] == S.Rp[v] && S.Lp[v + 1] - S.Lp[v] == 1; };
+  int leaf_mode = leaf_env;
+  if (leaf_env < 0) {
+    int64_t lones = 0;
+    for (int v = 0; v < N; v++) lones += is_lone(v);
+    leaf_mode = lones >= 400000 ? 1 : 0;
+  }
+  auto lone = [&](int v) { return leaf_mode > 0 && smax > 1 && is_lone(v); };
   // subtree sizes (parents have larger indices than their children)
   std::vector<int> size(N, 1), big_children(N, 0);
   if (leaf_mode == 2) for (int v = 0; v < N; v++) if (lone(v)) size[v] = 0;

@@ -204,3 +204,38 @@ def test_forms_of_the_supernode_level_kernels_agree(product_lib, monkeypatch, ca
             assert np.all(np.isfinite(v))
             assert np.max(np.abs(v - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref))), (case, off, k, np.max(np.abs(v - ref)))
     assert np.max(np.abs(sols[""][0] - sols[""][1])) > 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["control-400", "portfolio"])
+def test_lone_leaves_outside_the_blocks(product_lib, monkeypatch, case):
+    """Round 5: tree leaves whose column holds one entry (box-constraint rows) stay out of their parent's subtree supernode --
+    supernodes of one pivot instead of a row and a column of an inverted block (csrc/symbolic.hip build_supernodes; by
+    default only from 400 000 of them on, forced here).  Same KKT solves with the rule off (0), on (1) and on with the
+    leaves not counted towards the subtree size (2), through the multifrontal factorisation and a refactorisation."""
+    make, smax = FORM_CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    monkeypatch.setenv("OSQP_AMD_SNODE_WAVE_MIN", "1")
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(14).standard_normal(n + mm)
+    sols, levels = {}, {}
+    for leaf in ("0", "1", "2"):
+        monkeypatch.setenv("OSQP_AMD_SNODE_LEAF", leaf)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        st = oq.stats(m)
+        assert st[19] >= 1 and st[22] == 1.0
+        levels[leaf] = st[19]
+        first = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.29)
+        sols[leaf] = (first, _kkt_solve(m, rhs))
+        oq.clean(m)
+    for leaf in ("1", "2"):
+        for k in range(2):
+            ref, v = sols["0"][k], sols[leaf][k]
+            assert np.all(np.isfinite(v))
+            assert np.max(np.abs(v - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (case, leaf, k, np.max(np.abs(v - ref)))
+    if case == "control-400":
+        assert levels["1"] >= levels["0"]  # (the leaves are a level of their own below the subtrees)

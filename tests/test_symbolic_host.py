@@ -43,6 +43,19 @@ def test_supernode_partition_invariants(product_lib, name, ordering, smax):
         assert r["inside"] == 0 and r["supernodes"] == r["N"] and r["sn_levels"] == r["levels"]
 
 
+@pytest.mark.parametrize("leaf", ["1", "2"])
+@pytest.mark.parametrize("name", sorted(qp_zoo.ZOO))
+def test_lone_leaves_keep_the_partition_invariants(product_lib, monkeypatch, name, leaf):
+    """OSQP_AMD_SNODE_LEAF: leaves with a one-entry column as supernodes of their own (by default from 400 000 on)."""
+    monkeypatch.setenv("OSQP_AMD_SNODE_LEAF", "0")
+    off = probe(product_lib, qp_zoo.ZOO[name](), 0, 16)
+    monkeypatch.setenv("OSQP_AMD_SNODE_LEAF", leaf)
+    on = probe(product_lib, qp_zoo.ZOO[name](), 0, 16)
+    assert on["ok"] and on["lean_same"] and on["nnzL"] == off["nnzL"] and on["supernodes"] >= off["supernodes"]
+    if leaf == "1":
+        assert on["block_doubles"] <= off["block_doubles"]
+
+
 def test_supernodes_on_random_patterns(product_lib):
     rng = np.random.default_rng(7)
     for _ in range(30):
