@@ -1625,11 +1625,10 @@ struct LdlFactor {
         sn_tree_grid = 0;
         int persist_from = 0;
         if (getenv("OSQP_AMD_SNODE_TREE_PERSIST")) persist_from = atoi(getenv("OSQP_AMD_SNODE_TREE_PERSIST"));
-        else {  // default: the lowest level from which the supernodes above are at most three device-fuls (control-1e6: level 3,
-                // 2 674 supernodes on 1 024 resident workgroups: 1 169 -> 1 192 it/s; level 2 -- 7 700 -- is slower: 1 068)
-          persist_from = 1;
-          while (persist_from < T.nlev && (long long)(T.count - T.lvl_ptr[persist_from]) > 3 * cap2) persist_from++;
-        }
+        // (It was the default for a while -- from the lowest level with at most three device-fuls of supernodes above, control-1e6
+        // 1 169 -> 1 192 it/s -- until the level kernels took their entries flat (k_sn_level_f): a level of a thousand
+        // supernodes is now cheaper as a plain launch than inside the launch.  Without it: control-1e6 1 704 -> 1 737 it/s,
+        // control T = 8000 5.09 -> 5.56 k, T = 30 000 2.50 -> 2.67 k, T = 800 unchanged.)
         if (persist_from >= 1 && persist_from < sn_tree_L0) {
           sn_tree_L0 = persist_from; sn_tree_threads = 512;
           sn_tree_grid = (int)std::min<long long>(cap2, (long long)(T.count - T.lvl_ptr[sn_tree_L0]));

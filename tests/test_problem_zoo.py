@@ -157,6 +157,41 @@ def test_wavefront_forms_of_the_supernode_levels(product_lib, oracle_lib, monkey
 
 
 @pytest.mark.gpu
+def test_persistent_form_of_the_tree_kernels(product_lib, oracle_lib, monkeypatch):
+    """Round 5: k_sn_tree with as many workgroups as the device holds taking the supernodes of the launch in level order from
+    a ticket counter (opt-in since the level kernels take their entries flat: OSQP_AMD_SNODE_TREE_PERSIST=k, the levels from k
+    on).  A horizon long enough that the levels above level 0 do not all fit the device (the plain form starts higher up):
+    the trajectory of the plain form -- same iteration count, same solution -- twice on one workspace (the counters are back
+    at rest after a solve), and the oracle's solution (its count may differ by one check interval at this tolerance: the
+    supernodal and the oracle's factor round differently)."""
+    prob = qp_zoo.control(nx=8, nu=4, T=6000)
+    opts = dict(verbose=False, eps_abs=1e-5, eps_rel=1e-5, max_iter=4000, adaptive_rho_interval=25)
+    mo = oq.Model(oracle_lib)
+    oq.setup(mo, linsys_solver="qdldl", **opts, **prob)
+    ro = oq.solve(mo)
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", "8")  # many supernodes: thousands above level 0
+    res = {}
+    for persist in ("0", "1", "2"):
+        monkeypatch.setenv("OSQP_AMD_SNODE_TREE_PERSIST", persist)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", **opts, **prob)
+        assert oq.stats(m)[19] > 2
+        for _ in range(2):
+            rp = oq.solve(m)
+            assert rp.info.status == ro.info.status == "Solved" and abs(rp.info.iter - ro.info.iter) <= 25
+            assert np.max(np.abs(ro.x - rp.x)) <= 1e-4 * max(1.0, np.max(np.abs(ro.x)))
+            res.setdefault(persist, []).append((rp.info.iter, rp.x.copy()))
+            oq.warm_start(m, x=np.zeros_like(ro.x), y=np.zeros_like(ro.y))
+        oq.clean(m)
+    for persist in ("1", "2"):
+        for k in range(2):
+            assert res[persist][k][0] == res["0"][k][0]
+            assert np.max(np.abs(res[persist][k][1] - res["0"][k][1])) <= 1e-9 * max(1.0, np.max(np.abs(res["0"][k][1])))
+    oq.clean(mo)
+
+
+@pytest.mark.gpu
 def test_a_timed_out_wait_in_the_tree_kernels_restarts_the_solve_on_the_level_path(product_lib, oracle_lib, monkeypatch):
     """k_sn_tree waits inside a kernel (csrc/direct.hip); a wait that times out raises a flag in mapped host memory.
     The host side of that: the factor goes back to one launch per level and the solve in progress starts again from a
