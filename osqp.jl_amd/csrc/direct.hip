@@ -1614,7 +1614,8 @@ struct LdlFactor {
         int pf = 0, pb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, (const void *)k_sn_tree<true, 512>, 512, 0));
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, (const void *)k_sn_tree<false, 512>, 512, 0));
-        const long long cap2 = (long long)std::min(pf, pb) * cus;
+        long long cap2 = (long long)std::min(pf, pb) * cus;
+        if (getenv("OSQP_AMD_SNODE_TREE_CAP")) cap2 = std::min<long long>(cap2, atoll(getenv("OSQP_AMD_SNODE_TREE_CAP")));  // (experiments: a later start)
         int L2 = 1;
         while (L2 < T.nlev && (long long)(T.count - T.lvl_ptr[L2]) > cap2) L2++;
         if (L2 < sn_tree_L0) { sn_tree_L0 = L2; sn_tree_threads = 512; }

@@ -1,14 +1,13 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_try; mkdir -p $O
-for v in "OSQP_AMD_SNODE_TREE_PERSIST=99" "OSQP_AMD_SNODE_TREE_PERSIST=99 OSQP_AMD_SNODE_TREE_512=0" "OSQP_AMD_SNODE_TREE=0" "OSQP_AMD_SNODE_TREE_PERSIST=99"; do
-  env $v timeout 600 python bench.py --workload control-1e6 --steps 100 --warmup 25 --no-cpu --traffic off > $O/b.json 2>/dev/null
-  python - $O/b.json "$v" <<'PY'
+for c in 1024 400 150 50; do
+  OSQP_AMD_SNODE_TREE_CAP=$c timeout 600 python bench.py --workload control-1e6 --steps 100 --warmup 25 --no-cpu --traffic off > $O/b.json 2>/dev/null
+  python - $O/b.json "$c" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d.get("roofline") or {}
-print(sys.argv[2], "it/s", d.get("value"), "ms", d.get("ms_per_step"), "frac", r.get("frac"), "to_eps", d.get("time_to_eps_s"), "iters", d.get("iters_to_eps"), d.get("status"))
+print("cap", sys.argv[2], "it/s", d.get("value"), "ms", d.get("ms_per_step"), "frac", r.get("frac"), "to_eps", d.get("time_to_eps_s"), "iters", d.get("iters_to_eps"), d.get("status"))
 PY
-done
-for v in "X=1" "OSQP_AMD_SNODE_TREE_PERSIST=99"; do env $v python - <<'PY'
+  OSQP_AMD_SNODE_TREE_CAP=$c python - <<'PY'
 import sys, os, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, osqp_jl_amd as oq, qp_zoo
@@ -23,7 +22,7 @@ for T in (800, 8000, 30000):
         oq.warm_start(m, x=np.zeros(prob["P"].shape[0]), y=np.zeros(prob["A"].shape[0]))
         r = oq.solve(m)
         best = min(best, r.info.solve_time)
-    print(os.environ.get("OSQP_AMD_SNODE_TREE_PERSIST", "default"), "T", T, r.info.status, r.info.iter, "it/s %.0f" % (r.info.iter / best), "sn_levels", oq.stats(m)[19])
+    print("cap", os.environ.get("OSQP_AMD_SNODE_TREE_CAP"), "T", T, r.info.status, r.info.iter, "it/s %.0f" % (r.info.iter / best))
     oq.clean(m)
 PY
 done
