@@ -497,7 +497,7 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
       }
     if (getenv("OSQP_AMD_PROBE_VERBOSE")) fprintf(stderr, "sum colcount^2 = %.4g\n", S.flops);
     if (getenv("OSQP_AMD_PROBE_VERBOSE")) {  // what the inverted blocks would weigh without the leaf pivots (no row entries, one column entry)
-      int64_t leaves = 0, w_now = 0, w_without = 0, rows0 = 0;
+      int64_t leaves = 0, w_now = 0, w_without = 0;
       for (int J = 0; J < T.count; J++) {
         int lv = 0;
         const int64_t sz = T.ptr[J + 1] - T.ptr[J];
@@ -508,7 +508,6 @@ c_int osqp_amd_symbolic_probe(c_int n, c_int m, const c_int *Pp, const c_int *Pi
         leaves += lv;
         w_now += sz * (sz + 1) / 2;
         w_without += (sz - lv) * (sz - lv + 1) / 2;
-        if (J < T.lvl_ptr[1]) rows0 += sz;
       }
       fprintf(stderr, "leaf pivots %lld of %d; packed block doubles %lld, without the leaves %lld\n", (long long)leaves, S.N, (long long)w_now, (long long)w_without);
     }

@@ -1222,7 +1222,6 @@ __global__ __launch_bounds__(kBlock) void k_sn_single_bwd(int q0, int count, con
 // memory) and carries on: the host sees the flag at the next residual evaluation -- tested again once the read-back has
 // drained the stream -- and at the end of osqp_solve, switches the factor to one launch per level and runs the solve
 // again from a cold start (Engine::solve), so a broken assumption costs time, never a wrong or missing answer.
-constexpr int kSnTreeThreads = 1024;
 constexpr long long kSnWaitTicks = 20000000LL;  // 200 ms of the 100 MHz wall clock (a legitimate wait is microseconds; a workgroup
                                                  // pre-empted on a shared device can look like milliseconds)
 __device__ __forceinline__ int sn_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
