@@ -1030,7 +1030,9 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const
 // the rows add up their own piece of the chunk in entry order (four lanes per row taking every fourth entry, met in a fixed
 // order: the same sum on every run).  Two latencies per chunk of 2048 entries.
 constexpr int kSnFlatU = 8;
-template <bool kForward>
+template <bool kForward, int DK>
+__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, int k0, double &lo, double &hi);  // below
+template <bool kForward, bool kFold>
 __global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                            const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
                                                            const double *__restrict__ Ex, const double *__restrict__ W,
@@ -1078,6 +1080,20 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__
   __syncthreads();
   const double *Wj = W + woff[J];
   const int wv = tid >> 6, a = tid & 63;
+  if (kFold) {  // the block is stored folded (sn_block_fold): the eight half-wavefronts take every eighth step
+    double lo, hi;
+    sn_block_fold<kForward, 8>(Wj, t, s, a, 2 * wv + (a >> 5), lo, hi);
+    if (a < 32) { part[wv][a] = lo; part[wv][32 + a] = hi; }
+    __syncthreads();
+    const int h = (s + 1) >> 1;
+    if (wv == 0 && a < h) {
+      const double slo = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
+      const double shi = (part[0][32 + a] + part[1][32 + a]) + (part[2][32 + a] + part[3][32 + a]);
+      b[q0 + (kForward ? a : s - 1 - a)] = slo;
+      if (a != s - 1 - a) b[q0 + (kForward ? s - 1 - a : a)] = shi;
+    }
+    return;
+  }
   part[wv][a] = sn_block_row<kForward>(Wj, t, s, a, wv, kSnThreads / 64);
   __syncthreads();
   if (wv == 0 && a < s) b[q0 + a] = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
@@ -1090,22 +1106,24 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__
 // and s - a entries, s + 1 together for every lane, stored step by step (entry k of lane a at k h + a).  The lanes 32..63
 // take the odd steps, so a wavefront load is steps k and k + 1: 2 h contiguous doubles, no lane masked (s = 64), and the block
 // is over in (s + 1) / 2 loads instead of s.  The two halves meet through one lane exchange, even steps + odd steps.
-template <bool kForward>
-__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, double &lo, double &hi) {
+// (DK: the steps are dealt to DK half-wavefronts -- 2: the two halves of one wavefront; 8: of the four wavefronts of a workgroup,
+// whose sums the caller adds up; k0: this half-wavefront's first step)
+template <bool kForward, int DK>
+__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, int k0, double &lo, double &hi) {
   const int h = (s + 1) >> 1, a = gl & 31, par = gl >> 5;
   lo = 0.0; hi = 0.0;
   if (a < h) {
     auto idx = [&](int k) { return kForward ? (k <= a ? k : k - a - 1) : (k <= a ? s - 1 - a + k : k - 1); };
-    int k = par;
-    for (; k + 6 <= s; k += 8) {
-      const double w0 = Wj[k * h + a], w1 = Wj[(k + 2) * h + a], w2 = Wj[(k + 4) * h + a], w3 = Wj[(k + 6) * h + a];
-      const double p0 = w0 * t[idx(k)], p1 = w1 * t[idx(k + 2)], p2 = w2 * t[idx(k + 4)], p3 = w3 * t[idx(k + 6)];
+    int k = k0;
+    for (; k + 3 * DK <= s; k += 4 * DK) {
+      const double w0 = Wj[k * h + a], w1 = Wj[(k + DK) * h + a], w2 = Wj[(k + 2 * DK) * h + a], w3 = Wj[(k + 3 * DK) * h + a];
+      const double p0 = w0 * t[idx(k)], p1 = w1 * t[idx(k + DK)], p2 = w2 * t[idx(k + 2 * DK)], p3 = w3 * t[idx(k + 3 * DK)];
       if (k <= a) lo += p0; else hi += p0;
-      if (k + 2 <= a) lo += p1; else hi += p1;
-      if (k + 4 <= a) lo += p2; else hi += p2;
-      if (k + 6 <= a) lo += p3; else hi += p3;
+      if (k + DK <= a) lo += p1; else hi += p1;
+      if (k + 2 * DK <= a) lo += p2; else hi += p2;
+      if (k + 3 * DK <= a) lo += p3; else hi += p3;
     }
-    for (; k <= s; k += 2) {
+    for (; k <= s; k += DK) {
       const double p0 = Wj[k * h + a] * t[idx(k)];
       if (k <= a) lo += p0; else hi += p0;
     }
@@ -1164,7 +1182,7 @@ __global__ __launch_bounds__(kSnThreads) void k_sn_level_wf(int J0, int J1, cons
   const double *Wj = W + woff[J];
   if (kFold) {
     double lo, hi;
-    sn_block_fold<kForward>(Wj, t, s, gl, lo, hi);
+    sn_block_fold<kForward, 2>(Wj, t, s, gl, gl >> 5, lo, hi);
     const int a = gl & 31, h = (s + 1) >> 1;
     if (gl < h) {  // forward: lo is row a, hi row s - 1 - a; backward: lo is column s - 1 - a, hi column a
       b[q0 + (kForward ? a : s - 1 - a)] = lo;
@@ -2157,8 +2175,12 @@ struct LdlFactor {
                   T.lvl_ptr[L + 1], sn_ptr.get(), sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),  \
                   FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                      \
       else if (T.lvl_ptr[L + 1] > mid_) OQ_SN_LEVEL_W((LA == 64 ? 16 : (LA == 16 ? 4 : LA)), FWD, 64, mid_, T.lvl_ptr[L + 1]);     \
-    } else if (sn_flat)                                                                                                            \
-      OQ_LAUNCH((k_sn_level_f<FWD>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), sn_woff.get(),                \
+    } else if (sn_flat && !lvl_fold.empty() && lvl_fold[L])                                                                       \
+      OQ_LAUNCH((k_sn_level_f<FWD, true>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), sn_woff.get(),          \
+                FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),                  \
+                FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
+    else if (sn_flat)                                                                                                             \
+      OQ_LAUNCH((k_sn_level_f<FWD, false>), dim3(cnt_), dim3(kSnThreads), 0, s, T.lvl_ptr[L], sn_ptr.get(), sn_woff.get(),         \
                 FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(), FWD ? sn_Fx.get() : sn_Gx.get(),                  \
                 FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), bp.get());                                                        \
     else if (cnt_ >= kSnBusyLevel)  /* more workgroups than the device holds at once: rows in flight count, as above */         \
@@ -2182,6 +2204,7 @@ struct LdlFactor {
   const bool sn_fold = !(getenv("OSQP_AMD_SNODE_FOLD") && atoi(getenv("OSQP_AMD_SNODE_FOLD")) == 0) &&
                        !(getenv("OSQP_AMD_SNODE_FLAT") && atoi(getenv("OSQP_AMD_SNODE_FLAT")) == 0);
   const int sn_wave_min_fixed = sn_wave_min();
+  const bool sn_fold_wg = !(getenv("OSQP_AMD_SNODE_FOLD") && atoi(getenv("OSQP_AMD_SNODE_FOLD")) == 2);  // 2: wavefront-form levels only
   std::vector<char> lvl_fold;  // per level: the blocks of its larger supernodes are folded (decided once: a factor that falls
                                // back from k_sn_tree to one launch per level keeps reading them the way they are stored)
   void fold_blocks(hipStream_t s) {
@@ -2190,12 +2213,14 @@ struct LdlFactor {
       lvl_fold.assign(T.nlev, 0);
       for (int L = 0; L < T.nlev; L++) {
         const int cnt = T.lvl_ptr[L + 1] - T.lvl_ptr[L], mid = T.lvl_ptr[L] + T.lvl_small[L];
-        // (the levels from sn_tree_L0 on are solved by k_sn_tree whatever their count)
-        lvl_fold[L] = cnt >= sn_wave_min_fixed && T.lvl_ptr[L + 1] > mid && !(sn_tree && L >= sn_tree_L0);
+        // the larger supernodes of a level in the wavefront form, every supernode of a level in the workgroup form
+        // (k_sn_level_f); the levels from sn_tree_L0 on are solved by k_sn_tree whatever their count: packed triangles
+        lvl_fold[L] = (cnt >= sn_wave_min_fixed ? T.lvl_ptr[L + 1] > mid : sn_fold_wg) && !(sn_tree && L >= sn_tree_L0);
       }
     }
     for (int L = 0; L < T.nlev; L++) {
-      const int mid = T.lvl_ptr[L] + T.lvl_small[L];
+      const int cnt = T.lvl_ptr[L + 1] - T.lvl_ptr[L];
+      const int mid = cnt >= sn_wave_min_fixed ? T.lvl_ptr[L] + T.lvl_small[L] : T.lvl_ptr[L];
       if (!lvl_fold[L]) continue;
       OQ_LAUNCH(k_sn_fold<true>, dim3(T.lvl_ptr[L + 1] - mid), dim3(64), 0, s, mid, sn_ptr.get(), sn_woff.get(), sn_Wc.get());
       OQ_LAUNCH(k_sn_fold<false>, dim3(T.lvl_ptr[L + 1] - mid), dim3(64), 0, s, mid, sn_ptr.get(), sn_woff.get(), sn_Wr.get());
