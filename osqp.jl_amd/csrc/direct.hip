@@ -313,6 +313,72 @@ __global__ __launch_bounds__(kBlock) void k_dense_sweep2(int kD, int p, const do
   }
 }
 // x2 = -(S v) with S = -S0^-1 as the sweeps leave it (symmetric: row a is read as column a, contiguous); wave per row
+// The same product from the LOWER triangle of the (symmetric) array alone: half the bytes of what is the iteration of a dense-P
+// problem (6000 pivots: 288 MB per product, 60 us of a 106 us iteration).  A workgroup per 64 x 64 tile (rb, cb), rb >= cb,
+// brought to LDS with full-width loads (lane = row: 512 contiguous bytes per wavefront load, 16 in flight per lane); from LDS
+// thread c adds up S(b, c) v[b] over the tile's rows (its share of out[column block cb]) and thread b adds up S(b, c) v[c] over
+// the tile's columns (the mirrored entries: its share of out[row block rb]; not for a diagonal tile, whose both halves are in
+// the tile).  The shares go to two [blocks x blocks x 64] buffers and k_dense_sym_reduce adds them up in a fixed order.
+constexpr int kDsT = 64;
+__global__ __launch_bounds__(256) void k_dense_apply_sym(int kD, int ld, int nb, const double *__restrict__ S, const double *__restrict__ v,
+                                                         double *__restrict__ P1, double *__restrict__ P2) {
+  __shared__ double tile[kDsT][kDsT + 1];
+  __shared__ double vr[kDsT], vc[kDsT], part[4][kDsT];
+  // tile t of the lower triangle, row by row: rb (rb + 1) / 2 + cb
+  const int t = blockIdx.x;
+  int rb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((rb + 1) * (rb + 2) / 2 <= t) rb++;
+  while (rb * (rb + 1) / 2 > t) rb--;
+  const int cb = t - rb * (rb + 1) / 2;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  {
+    const double *base = S + (size_t)(cb * kDsT) * ld + (size_t)rb * kDsT + lane;
+    double w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = base[(size_t)(wv * 16 + i) * ld];
+    if (wv == 0) { const int g = rb * kDsT + lane; vr[lane] = g < kD ? v[g] : 0.0; }
+    if (wv == 1) { const int g = cb * kDsT + lane; vc[lane] = g < kD ? v[g] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) tile[wv * 16 + i][lane] = w[i];  // tile[c][b] = S(row rb*64 + b, column cb*64 + c)
+  }
+  __syncthreads();
+  const int half = (tid >> 6) & 1;
+  double acc = 0.0;
+  if (tid < 128) {  // column sums: thread c over the rows b of its half
+    for (int b = 32 * half; b < 32 * half + 32; b++) acc += tile[lane][b] * vr[b];
+  } else {          // row sums: thread b over the columns c of its half
+    for (int c = 32 * half; c < 32 * half + 32; c++) acc += tile[c][lane] * vc[c];
+  }
+  part[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0) P1[((size_t)cb * nb + rb) * kDsT + lane] = part[0][lane] + part[1][lane];
+  else if (wv == 2 && rb != cb) P2[((size_t)rb * nb + cb) * kDsT + lane] = part[2][lane] + part[3][lane];
+}
+// out[a] = -(sum over the tiles below and on the diagonal of a's column block + sum over the tiles left of the diagonal of a's
+// row block), the four wavefronts of a workgroup taking every fourth term, met in a fixed order
+__global__ __launch_bounds__(256) void k_dense_sym_reduce(int kD, int nb, const double *__restrict__ P1, const double *__restrict__ P2,
+                                                          double *__restrict__ out) {
+  __shared__ double part[4][kDsT];
+  const int B = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double acc = 0.0;
+  // terms 0 .. nb - B - 1: P1[B][B + j]; then B terms P2[B][j]
+  const int n1 = nb - B, n = n1 + B;
+  int j = wv;
+  for (; j + 12 < n; j += 16) {
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int jj = j + 4 * u;
+      x[u] = jj < n1 ? P1[((size_t)B * nb + B + jj) * kDsT + lane] : P2[((size_t)B * nb + (jj - n1)) * kDsT + lane];
+    }
+    acc += x[0]; acc += x[1]; acc += x[2]; acc += x[3];
+  }
+  for (; j < n; j += 4) acc += j < n1 ? P1[((size_t)B * nb + B + j) * kDsT + lane] : P2[((size_t)B * nb + (j - n1)) * kDsT + lane];
+  part[wv][lane] = acc;
+  __syncthreads();
+  const int a = B * kDsT + lane;
+  if (wv == 0 && a < kD) out[a] = -((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, int ld, const double *__restrict__ S, const double *__restrict__ v,
                                                         double *__restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -1382,6 +1448,7 @@ struct LdlFactor {
   bool kD_dense = false;        // ... taken because it IS dense (choose_dense_top)
   DevBuf<int> schur_cols;       // the columns below the block with entries in its rows (k_dense_chunk); empty: the Schur complement entry by entry
   int schur_ncols = 0;
+  DevBuf<double> dsP1, dsP2;    // shares of the symmetric dense product, per tile (k_dense_apply_sym)
   double *Sinv = nullptr;       // which of S0a / S0b holds -S0^-1 after the last factorisation
   int ldD = 0;                  // leading dimension of the dense block's array (kD, or kD padded to 64 for the block sweeps)
   std::vector<char> long_rows;  // per level: phase 2 of the factorisation through dense work rows (k_ldl_entries_w)
@@ -1565,6 +1632,11 @@ struct LdlFactor {
           }
         }
         x2.alloc(kD);
+        // the symmetric form of the product (k_dense_apply_sym) for the blocked inverse; OSQP_AMD_DENSE_SYM=0: the full one
+        if (kD >= kDenseBlocked && ldD % kDsT == 0 && !(getenv("OSQP_AMD_DENSE_SYM") && atoi(getenv("OSQP_AMD_DENSE_SYM")) == 0)) {
+          const size_t nb = (size_t)ldD / kDsT;
+          dsP1.alloc(nb * nb * kDsT); dsP2.alloc(nb * nb * kDsT);
+        }
       }
     }
     e.sync();
@@ -2277,7 +2349,12 @@ struct LdlFactor {
     if (kD) {  // x2 = S0^-1 (b2 - L21 y1)
       // the reduced right-hand side goes to x2, the product straight back into the block's slots of the solution
       OQ_LAUNCH(k_fwd_far<kBlock>, dim3(kD), dim3(kBlock), 0, s, cD, N, Rp.get(), Rsplit.get(), Rj.get(), Rx.get(), bp.get(), x2.get());
-      OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, ldD, Sinv, x2.get(), bp.get() + cD);
+      if (dsP1.n) {  // the blocked inverse: symmetric, padded to whole tiles -- the product reads its lower triangle only
+        const int nb = ldD / kDsT;
+        OQ_LAUNCH(k_dense_apply_sym, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, kD, ldD, nb, (const double *)Sinv, (const double *)x2.get(), dsP1.get(), dsP2.get());
+        OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, kD, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + cD);
+      } else
+        OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, ldD, Sinv, x2.get(), bp.get() + cD);
     }
     for (size_t si = 0; si < bwd.size(); si++) {
       const Step &t = bwd[si];

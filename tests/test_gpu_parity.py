@@ -363,6 +363,42 @@ def test_auto_rule_sends_a_dense_P_to_the_direct_back_end(product_lib, oracle_li
     oq.clean(m); oq.clean(mo)
 
 
+@pytest.mark.parametrize("n", [1100, 1984])
+def test_dense_block_product_from_the_lower_triangle(product_lib, monkeypatch, n):
+    """Round 5: the product with the inverted dense top block reads the lower triangle of the symmetric array alone
+    (csrc/direct.hip k_dense_apply_sym + k_dense_sym_reduce: a workgroup per 64 x 64 tile, the mirrored half from the same tile
+    through LDS, shares added up in a fixed order) -- half the bytes of the iteration of a dense-P problem.  Against the product
+    over the full array (OSQP_AMD_DENSE_SYM=0): the same KKT solves, before and after a refactorisation, on a block whose size
+    is not a multiple of the tile (padded) and on one that is."""
+    import ctypes as C
+
+    import qp_zoo
+
+    prob = qp_zoo.equality_qp(n=n)
+    rhs = np.random.default_rng(21).standard_normal(n + n // 2)
+    sols = {}
+    for sym in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_DENSE_SYM", sym)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        assert oq.stats(m)[25] >= 512
+        out = []
+        for rho in (None, 0.37):
+            if rho is not None:
+                oq.update_settings(m, rho=rho)
+            o = np.empty_like(rhs)
+            assert m.lib.osqp_amd_apply(m.workspace, 3, rhs.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            out.append(o)
+        r = oq.solve(m)
+        assert r.info.status == "Solved"
+        sols[sym] = out + [r.x.copy()]
+        oq.clean(m)
+    for k in range(3):
+        a, b = sols["0"][k], sols["1"][k]
+        assert np.all(np.isfinite(b))
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (n, k, np.max(np.abs(a - b)))
+
+
 def test_auto_rule_still_sends_random_sparsity_to_pcg(product_lib):
     """Item 7c: the same rule on a fill-heavy problem of the same size (random sparsity, n = m = 3000, 30 per row: the factor
     fills to a dense block with nothing cheap about the columns below it) still falls through to the indirect back-end."""
