@@ -1,8 +1,9 @@
-cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_problem_zoo.py -m gpu -x -q 2>&1 | tail -3
-for c in 1 0 1 0; do OSQP_AMD_DENSE_SYM=$c timeout 600 python tools/zoo_rates.py 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); g = d['gpu_direct']
-    if d['problem'] in ('equality_qp',): print('sym $c', d['problem'], g['status'], g['iter'], g['it_per_s'], 'setup', g['setup_s'])
-"; done
+# per-kernel stats of one zoo class through the direct back-end
+cd /tmp; export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r05_zooprof; mkdir -p $O
+for name in portfolio svm control; do
+  ZOO_LABELS=gpu_direct rocprofv3 --kernel-trace --stats -d $O/p_$name -o p -- python $GRAFT_REPO_ROOT/tools/zoo_rates.py $name > $O/rate_$name.json 2>/dev/null
+  python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $(find $O/p_$name -name '*_results.db' | head -1) > $O/kernel_stats_zoo_$name.md
+  rm -rf $O/p_$name
+  echo "== $name"; cat $O/rate_$name.json | cut -c1-300; head -14 $O/kernel_stats_zoo_$name.md | cut -c1-150
+done
