@@ -2405,6 +2405,39 @@ struct LdlFactor {
   }
 };
 
+// k_direct_update that also leaves the right-hand side of the NEXT iteration behind (k_direct_rhs's arithmetic on the values it
+// has just formed, into the slot it has just read): inside a chunk graph iteration k + 1 follows iteration k with nothing in
+// between, and its own pass over x, q, z, y for the right-hand side -- one launch, 64 MB on control-1e6 -- is not needed
+__global__ __launch_bounds__(kBlock) void k_direct_update_rhs(int n, int m, double alpha, double sigma, const int *__restrict__ pinv,
+                                                              double *__restrict__ bp, const double *__restrict__ q,
+                                                              const double *__restrict__ rho, const double *__restrict__ rho_inv,
+                                                              const double *__restrict__ l, const double *__restrict__ u,
+                                                              double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
+                                                              double *__restrict__ delta_x, double *__restrict__ delta_y) {
+  int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o < n) {
+    const int slot = pinv[o];
+    double xp = x[o];
+    double xn = alpha * bp[slot] + (1.0 - alpha) * xp;
+    x[o] = xn;
+    delta_x[o] = xn - xp;
+    bp[slot] = sigma * xn - q[o];
+  } else if (o < n + m) {
+    int j = o - n;
+    const int slot = pinv[o];
+    double zp = z[j], yj = y[j], ri = rho_inv[j];
+    double zt = (zp - ri * yj) + ri * bp[slot];
+    double zh = alpha * zt + (1.0 - alpha) * zp;
+    double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
+    z[j] = zn;
+    double dy = rho[j] * (zh - zn);
+    delta_y[j] = dy;
+    const double yn = yj + dy;
+    y[j] = yn;
+    bp[slot] = zn - ri * yn;
+  }
+}
+
 struct Direct : Linsys {
   Engine &e;
   std::unique_ptr<LdlFactor> F;
@@ -2430,19 +2463,26 @@ struct Direct : Linsys {
       OQ_LAUNCH(k_direct_rhs_fwd1, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->pinv.get(), F->perm.get(),
                 F->S.level_ptr[1], F->S.level_ptr[2], F->Rp.get(), F->Rj.get(), F->Rx.get(), e.x.get(), e.q.get(), e.z.get(),
                 e.rho_inv.get(), e.y.get(), F->bp.get());
-    else
+    else if (!rhs_left)
       OQ_LAUNCH(k_direct_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.sigma, F->vec_pinv(), e.x.get(), e.q.get(),
                 e.z.get(), e.rho_inv.get(), e.y.get(), F->bp.get());
+    rhs_left = false;
     F->run_steps(f1, b0);
     if (b0)
       OQ_LAUNCH(k_direct_bwd0_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->pinv.get(), F->S.level_ptr[1],
                 F->Lp.get(), F->Li.get(), F->Lx.get(), F->Dinv.get(), F->bp.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(),
                 e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
-    else
+    else if (next_follows && !f1 && leave_rhs) {
+      OQ_LAUNCH(k_direct_update_rhs, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, e.st.sigma, F->vec_pinv(), F->bp.get(),
+                e.q.get(), e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
+      rhs_left = true;  // (only ever true between two steps of one capture: the last step of a chunk has next_follows = false)
+    } else
       OQ_LAUNCH(k_direct_update, dim3(blocks_for(N)), dim3(kBlock), 0, s, e.n, e.m, e.st.alpha, F->vec_pinv(), F->bp.get(),
                 e.rho.get(), e.rho_inv.get(), e.l.get(), e.u.get(), e.x.get(), e.z.get(), e.y.get(), e.dx.get(), e.dy.get());
     return 0;
   }
+  bool rhs_left = false;  // the previous step of this capture left this step's right-hand side in the factor's vector
+  const bool leave_rhs = !(getenv("OSQP_AMD_DIRECT_LEAVE_RHS") && atoi(getenv("OSQP_AMD_DIRECT_LEAVE_RHS")) == 0);
   // a supernode waited 200 ms for its children: the factor goes back to one launch per level (no waiting inside a
   // kernel); 6 tells the engine that the iterations since the last test cannot be trusted (TreeFault: the solve restarts)
   int flush() override {

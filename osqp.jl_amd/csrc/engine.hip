@@ -910,7 +910,8 @@ void Engine::run_chunk() {
   if (!chunk_exec) {
     hipGraph_t graph = nullptr;
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < k; i++) admm_step();
+    for (int i = 0; i < k; i++) { lin->next_follows = i + 1 < k; admm_step(); }
+    lin->next_follows = false;
     HIP_CHECK(hipStreamEndCapture(stream, &graph));
     HIP_CHECK(hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);

@@ -35,6 +35,9 @@ struct Linsys {
   // one whole ADMM iteration with back-end specific fusion; -1 = not provided (generic path runs), 0 done, 5 negative
   // curvature met (problem non-convex)
   virtual int fused_step() { return -1; }
+  // set by the engine around a fused_step that is captured into a chunk graph: another iteration follows this one inside the
+  // same graph with nothing in between, so the step may leave that iteration's right-hand side behind (direct.hip)
+  bool next_follows = false;
   // back-ends that enqueue work ahead of the host (pcg.hip): wait for it; 0, or 5 when negative curvature was met
   virtual int flush() { return 0; }
   // a scalar the enqueued / captured work holds by value changed (alpha, sigma)
