@@ -157,6 +157,30 @@ def test_wavefront_forms_of_the_supernode_levels(product_lib, oracle_lib, monkey
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["control", "portfolio"])
+def test_update_that_leaves_the_next_right_hand_side_is_bit_identical(product_lib, monkeypatch, name):
+    """Round 5: inside a chunk graph the update of iteration k writes the right-hand side of iteration k + 1 into the factor's
+    vector (csrc/direct.hip k_direct_update_rhs) and that iteration skips its own right-hand-side launch.  Same arithmetic on
+    the same values: the solve with the fusion off (OSQP_AMD_DIRECT_LEAVE_RHS=0) bit for bit, through a rho update and a second
+    solve on the workspace (the chunk graph is captured again after the refactorisation)."""
+    prob = qp_zoo.control(nx=8, nu=4, T=400) if name == "control" else qp_zoo.portfolio(n=300, k=10)
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=25)
+    res = {}
+    for leave in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_DIRECT_LEAVE_RHS", leave)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", **opts, **prob)
+        r1 = oq.solve(m)
+        oq.update_q(m, 1.1 * prob["q"])
+        r2 = oq.solve(m)
+        res[leave] = (r1.info.iter, r1.x.copy(), r1.y.copy(), r2.info.iter, r2.x.copy(), r2.y.copy())
+        assert r1.info.status == r2.info.status == "Solved"
+        oq.clean(m)
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_persistent_form_of_the_tree_kernels(product_lib, oracle_lib, monkeypatch):
     """Round 5: k_sn_tree with as many workgroups as the device holds taking the supernodes of the launch in level order from
     a ticket counter (opt-in since the level kernels take their entries flat: OSQP_AMD_SNODE_TREE_PERSIST=k, the levels from k
