@@ -224,6 +224,83 @@ __global__ __launch_bounds__(kBlock) void k_pcg_next(int n, const double *__rest
   if (!(pw > 0.0) || rn != rn) { ctl[C_ERR] = 1; ctl[C_STALL] = 1; ctl[1 - cur] = 1; return; }  // M is not positive definite
   ctl[1 - cur] = rn <= *tol_p ? 1 : 0;
 }
+// ---------------------------------------------------------------------------------------------------------
+// Single-reduction recurrence (Chronopoulos & Gear), OPT-IN: OSQP_AMD_PCG_SR=1, fused single-device host loop only.  The product
+// of an iteration is taken of z = M^-1-preconditioned r (not of p): u = A z, w = M z, delta = z'w from the epilogue of the A'
+// product; with gamma = r'z carried from the previous update, beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old)
+// and p = z + beta p, q = w + beta q (= M p), s = u + beta s (= A p) every vector of the iteration is updated in ONE kernel,
+// whose last workgroup to finish adds up the block partials of the new gamma and ||r||inf and hands them to the host -- instead of
+// k_pcg_step + k_pcg_next.  The partials cross workgroups inside a launch: stored and loaded at device scope (past the per-XCD
+// L2s, as the counters of k_sn_tree in direct.hip), the ticket counter is back at zero when the launch ends (graph-safe).
+// CPU statement: oracle/pcg.c with OSQP_ORACLE_PCG_SINGLE_REDUCTION=1 (tests/test_gpu_parity.py holds the two together).
+constexpr int S_ALPHA = S_T5 + 1;  // alpha of the previous iteration (a free scratch slot)
+__device__ __forceinline__ double sum_partials_dev(const double *partials) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < kReduceBlocks; i += kBlock) v += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return block_sum(v);
+}
+__device__ __forceinline__ double max_partials_dev(const double *partials) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < kReduceBlocks; i += kBlock) v = nanmax(v, __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return block_max(v);
+}
+__global__ __launch_bounds__(kBlock) void k_pcg_sr(int n, int m, int first, int cur, double *__restrict__ slots, double *partials,
+                                                   double *__restrict__ xs, double *__restrict__ p, double *__restrict__ qv,
+                                                   double *__restrict__ r, const double *__restrict__ w, const double *__restrict__ dinv,
+                                                   double *__restrict__ zz, double *__restrict__ Mxs, double *__restrict__ Axs,
+                                                   const double *__restrict__ u, double *__restrict__ sA, int *counter, Publish pub,
+                                                   const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ int is_last;
+  const double delta = sum_partials(partials + R_DOT);
+  const double gamma = slots[S_T0 + 2 * cur], gamma_old = slots[S_T0 + 2 * (1 - cur)], alpha_old = slots[S_ALPHA];
+  const double beta = first ? 0.0 : gamma / gamma_old;
+  const double denom = first ? delta : delta - beta * gamma / alpha_old;
+  const double alpha = gamma / denom;
+  double rz = 0.0, mx = 0.0;
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double zi = zz[i], wi = w[i];
+    const double pi = first ? zi : zi + beta * p[i];
+    const double qi = first ? wi : wi + beta * qv[i];
+    p[i] = pi; qv[i] = qi;
+    Mxs[i] += alpha * qi;
+    xs[i] += alpha * pi;
+    const double ri = r[i] - alpha * qi, zn = dinv[i] * ri;
+    r[i] = ri; zz[i] = zn;
+    rz += ri * zn;
+    mx = nanmax(mx, fabs(ri));
+  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < m; j += stride) {
+    const double sj = first ? u[j] : u[j] + beta * sA[j];
+    sA[j] = sj;
+    Axs[j] += alpha * sj;
+  }
+  rz = block_sum(rz);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[R_RZ + blockIdx.x], rz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[R_RN + blockIdx.x], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two stores have reached the device-coherent level
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = ticket == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // every other workgroup has stored its partials (and read the slots it needs) before its ticket
+  const double rz_new = sum_partials_dev(partials + R_RZ), rn = max_partials_dev(partials + R_RN);
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  slots[S_T0 + 2 * (1 - cur)] = rz_new; slots[S_T1 + 2 * (1 - cur)] = rn;
+  slots[S_T4] = denom; slots[S_ALPHA] = alpha;
+  if (pub.host_slots) {
+    pub.host_slots[S_T0 + 2 * (1 - cur)] = rz_new; pub.host_slots[S_T1 + 2 * (1 - cur)] = rn; pub.host_slots[S_T4] = denom;
+    __threadfence_system();
+    *pub.host_seq = pub.seq;
+    __threadfence_system();
+  }
+}
+
 // first stage of the extrapolation dot products alone (the consumer recombines the partials)
 __global__ __launch_bounds__(kBlock) void k_extrap_partials(int n, const double *__restrict__ x1, const double *__restrict__ x0,
                                                             const double *__restrict__ Mx1, const double *__restrict__ Mx0,
@@ -244,6 +321,9 @@ __global__ __launch_bounds__(kBlock) void k_extrap_partials(int n, const double 
 struct Pcg : Linsys {
   Engine &e;
   DevBuf<double> xs, r, zz, p, w, t, u, b1, dinv, Axs, Mxs, xs0, Axs0, Mxs0;
+  DevBuf<double> qv, sA;            // single-reduction recurrence: M p and A p carried
+  DevBuf<int> sr_counter;
+  bool sr_on = false, sr_first = true;
   bool extrapolate = true, have_prev = false;
   long long total_iters = 0;
   int max_iter = 20000;
@@ -274,6 +354,9 @@ struct Pcg : Linsys {
       const char *fv = getenv("OSQP_AMD_PCG_FUSED");
       fused_on = !e.comm && e.m > 0 && e.A.panel.active && e.At.panel.active && e.Pf.panel.active && !(fv && atoi(fv) == 0);
       pair_on = fused_on && spmv_pair_ok(e.A, e.Pf);
+      const char *sv = getenv("OSQP_AMD_PCG_SR");
+      sr_on = fused_on && extrapolate && sv && atoi(sv) == 1;
+      if (sr_on) { qv.alloc(n); sA.alloc(std::max<size_t>(1, m)); sr_counter.alloc(1); sr_counter.zero(e.stream); }
     }
     const char *ev = getenv("OSQP_AMD_PCG_ASYNC");
     // opt-in (OSQP_AMD_PCG_ASYNC=1): measured on rand-1e5 the empty kernels of the iterations enqueued beyond convergence
@@ -406,6 +489,7 @@ struct Pcg : Linsys {
     const int n = e.n, m = e.m;
     double *slots = e.slots.get(), *xz = e.xz.get(), *part = e.partials.get();
     int *flags = async ? ctl.get() : nullptr;
+    sr_first = true;
     if (fused_on) {
       if (!(rhs_ready && !async))
         OQ_LAUNCH(k_pcg_rhs, dim3(blocks_for((int64_t)n + m)), dim3(kBlock), 0, s, n, m, e.st.sigma, e.x.get(), e.q.get(), e.z.get(),
@@ -466,6 +550,23 @@ struct Pcg : Linsys {
     double *slots = e.slots.get(), *part = e.partials.get();
     double *rz = slots + S_T0 + 2 * cur, *rz_new = slots + S_T0 + 2 * (1 - cur), *pw = slots + S_T4;
     int *flags = async ? ctl.get() : nullptr;
+    if (fused_on && sr_on && !async) {  // single-reduction recurrence (k_pcg_sr): the product is taken of zz
+      SpmvExtra exA;
+      exA.y2 = t.get(); exA.s2 = e.rho.get();
+      if (pair_on) spmv_pair(e.A, e.Pf, zz.get(), u.get(), &exA, w.get(), e.st.sigma, zz.get(), s);
+      else {
+        spmv(e.A, zz.get(), u.get(), nullptr, 0.0, 0.0, nullptr, s, &exA);
+        spmv(e.Pf, zz.get(), w.get(), nullptr, 0.0, e.st.sigma, zz.get(), s);
+      }
+      SpmvExtra exT;
+      exT.dotv = zz.get(); exT.dot_partials = part + R_DOT;
+      spmv(e.At, t.get(), w.get(), nullptr, 1.0, 0.0, nullptr, s, &exT);
+      OQ_LAUNCH(k_pcg_sr, dim3(kReduceBlocks), dim3(kBlock), 0, s, n, m, sr_first ? 1 : 0, cur, slots, part, xs.get(), p.get(), qv.get(), r.get(),
+                (const double *)w.get(), (const double *)dinv.get(), zz.get(), Mxs.get(), Axs.get(), (const double *)u.get(), sA.get(),
+                sr_counter.get(), pub_next, g_skip);
+      sr_first = false;
+      return;
+    }
     if (fused_on) {
       SpmvExtra exA;
       exA.y2 = t.get(); exA.s2 = e.rho.get();                        // t = rho .* (A p) next to u = A p

@@ -289,6 +289,36 @@ def test_pcg_forms_are_one_arithmetic(product_lib, monkeypatch, kind, n, k):
         assert ref[2] == out[key][2], key  # the same number of CG iterations in total
 
 
+def test_single_reduction_cg_follows_the_oracles_statement(product_lib, oracle_lib, monkeypatch):
+    """Round 5, opt-in (OSQP_AMD_PCG_SR=1): the single-reduction CG recurrence on the device (csrc/pcg.hip k_pcg_sr: every vector
+    of a CG iteration updated in one kernel, the last workgroup adds up the partials) against its CPU statement (oracle/pcg.c
+    with OSQP_ORACLE_PCG_SINGLE_REDUCTION=1): the same ADMM iteration count, the same number of CG iterations in total, the
+    solution to 1e-9, through a second solve with a new q on the same workspace -- and the classic recurrence's solution to
+    the solve's own tolerance (a different rounding path to the same point)."""
+    monkeypatch.setenv("OSQP_AMD_PANEL", "2")  # the fused kernels (which the recurrence is built on) need the panel products
+    n, k = 20000, 40
+    opts = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=25, linsys_solver="pcg")
+    q2 = np.random.default_rng(1).standard_normal(n)
+    res = {}
+    for name, lib, sr in (("oracle", oracle_lib, "1"), ("engine", product_lib, "1"), ("classic", product_lib, "0")):
+        monkeypatch.setenv("OSQP_ORACLE_PCG_SINGLE_REDUCTION", sr)
+        monkeypatch.setenv("OSQP_AMD_PCG_SR", sr)
+        m = oq.Model(lib); oq.setup_generated(m, 0, n, k, 5, **opts)
+        r1 = oq.solve(m)
+        oq.update_q(m, q2)
+        r2 = oq.solve(m)
+        res[name] = (r1, r2, oq.stats(m)[6])
+        oq.clean(m)
+    for a, b in zip(res["oracle"][:2], res["engine"][:2]):
+        assert a.info.status == b.info.status == "Solved" and a.info.iter == b.info.iter
+        assert np.max(np.abs(a.x - b.x)) <= 1e-9 * max(1.0, np.max(np.abs(a.x)))
+        assert np.max(np.abs(a.y - b.y)) <= 1e-9 * max(1.0, np.max(np.abs(a.y)))
+    assert res["oracle"][2] == res["engine"][2]
+    for a, b in zip(res["classic"][:2], res["engine"][:2]):
+        assert b.info.status == "Solved" and abs(a.info.iter - b.info.iter) <= 25
+        assert np.max(np.abs(a.x - b.x)) <= 1e-4 * max(1.0, np.max(np.abs(a.x)))
+
+
 def test_dense_row_and_arrow_P(product_lib, oracle_lib):
     """Rows longer than the LDS sort tile (4096): a dense budget row sum(x) = 1 in A and an arrow-shaped P (dense
     first row / column) go through the global-memory row sort of the CSR build; products against scipy, 30 ADMM iterations
