@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_try; mkdir -p $O
-for sr in 1 0; do
+for sr in 0 1 0 1 0 1; do
   OSQP_AMD_PCG_SR=$sr timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu --traffic off > $O/b.json 2>/dev/null
   python - $O/b.json "$sr rand-1e6 k20w5" <<'PY'
 import json, sys
