@@ -1,6 +1,6 @@
 # end state of round 5 for the pieces that changed after gpu_round5_final.sh: control-1e6 (bench line with live PMC + CPU oracle, kernel stats, timeline), zoo, refactor times, the suite
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r05_end4; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r05_end5; mkdir -p $O
 export TMPDIR=/tmp
 timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
