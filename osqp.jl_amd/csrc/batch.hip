@@ -1091,6 +1091,9 @@ struct DevicePattern {
   DevBuf<unsigned short> qs_colstart, qs_collist;
   DevBuf<unsigned> qs_roww, qs_meta;
   DevBuf<unsigned long long> qs_stream;
+  DevBuf<int> qs_Fp, qs_Fc, qs_Fmap;   // the full symmetric P in the kernel's numbering of the variables
+  DevBuf<unsigned short> qs_perm;
+  std::vector<int> hFmap;
   void build(int n, int m, const std::vector<int> &hPp, const std::vector<int> &hPi, const std::vector<int> &hAp,
              const std::vector<int> &hAi, hipStream_t s) {
     const int nnzA = hAp[n], nnzP = hPp[n];
@@ -1139,6 +1142,7 @@ struct DevicePattern {
     for (int i = 0; i < m; i++) max_row = std::max(max_row, rp[i + 1] - rp[i]);
     P = Pattern{n, m, nnzA, nnzP, (int)fc.size(), Ap.get(), Ai.get(), Rp.get(), Rc.get(), Rmap.get(), Fp.get(), Fc.get(), Fmap.get(),
                 (int)ti.size(), Tp.get(), Ti.get(), Tj.get(), Tr.get(), Ta.get(), Tb.get(), max_col, max_row};
+    hFmap = fmap;
     build_quad(n, m, hAp, hAi, rp, rc, rmap, fp, fc, tp, ti, tj, tr, ta, tb, s);
   }
 
@@ -1205,10 +1209,56 @@ struct DevicePattern {
     if (L.colstart > 65535 || (size_t)(nnzA + 1) * 8 > 65535) { refuse("LDS bytes below the pattern tables (16-bit offsets)", L.colstart, 65535); return; }
     if (L.total > 80 * 1024) { refuse("LDS bytes (two QPs per compute unit)", L.total, 80 * 1024); return; }
     const int kch = L.kch, kep = L.kep;
+    // ---- the pattern of M = P + sigma I + A' rho A and the kernel's numbering of the variables ---------------------------
+    // perm[j]: the caller's index of the kernel's variable j.  Row half 1 is numbered in reverse when that lets the first
+    // phase of the sweeps (batch_quad.hpp: two-ended) take pivots from both ends of a banded pattern: the kernel's pivots
+    // 0, 1, ... of half 0 stay inside the quadrant (0, 0), its pivots kNH, kNH + 1, ... of half 1 -- the caller's n - 1,
+    // n - 2, ... -- inside (1, 1).  Counted by symbolic elimination: a pivot reaches at most what the pivots before it reached.
+    std::vector<std::vector<int>> pair_of(n, std::vector<int>(n, -1)), pent0(n, std::vector<int>(n, -1));
+    for (size_t t = 0; t < ti.size(); t++) { pair_of[ti[t]][tj[t]] = (int)t; pair_of[tj[t]][ti[t]] = (int)t; }
+    for (int r = 0; r < n; r++) for (int q = fp[r]; q < fp[r + 1]; q++) pent0[r][fc[q]] = q;
+    auto mnz = [&](int i, int j) { return i == j || pair_of[i][j] >= 0 || pent0[i][j] >= 0; };
+    std::vector<int> perm(n), inv(n);
+    int p1_top = 0, p1_bot = 0, bw = 0;
+    {
+      for (int i = 0; i < n; i++) perm[i] = i < kNH ? i : n - 1 - (i - kNH);
+      auto count = [&](int first, int last, int &reach_over) {  // pivots first, first + 1, ... whose reach stays in [.., last]
+        int reach = -1, cnt = 0;
+        for (int a = first; a <= last; a++) {
+          for (int j = last + 1; j < n; j++) if (mnz(perm[a], perm[j])) return cnt;      // (half 0 only: a column of half 1)
+          for (int j = 0; j < first; j++) if (mnz(perm[a], perm[j])) return cnt;         // (half 1 only: a column of half 0)
+          for (int j = a; j <= last; j++) if (mnz(perm[a], perm[j])) { reach = std::max(reach, j); reach_over = std::max(reach_over, j - a); }
+          cnt = a - first + 1;
+        }
+        return cnt;
+      };
+      int over = 0;
+      p1_top = count(0, std::min(n, kNH) - 1, over);
+      if (n > kNH) p1_bot = count(kNH, n - 1, over);
+      bw = over;  // the furthest a first-phase pivot reaches beyond itself
+      const int nb = (kNH + 15) / 16, cap = nb > 1 ? (nb - 1) * 16 : kNH;  // the kernel compiles the phase for its first nb - 1 pivot blocks
+      p1_top = std::min(p1_top, cap); p1_bot = std::min(p1_bot, cap);
+      static const bool off = getenv("OSQP_AMD_BATCH_TWO_ENDED") && atoi(getenv("OSQP_AMD_BATCH_TWO_ENDED")) == 0;  // A/B runs
+      const bool entry0 = kNH == kQuadCfg[0].NH && kKC == kQuadCfg[0].KC && kKE == kQuadCfg[0].KE;  // compiles the reach in: 19
+      if (off || p1_top + p1_bot < 8 || (entry0 && bw > 19)) {
+        p1_top = p1_bot = 0;
+        for (int i = 0; i < n; i++) perm[i] = i;
+      }
+      for (int i = 0; i < n; i++) inv[perm[i]] = i;
+      if (trace) fprintf(stderr, "[batch] pattern of M: first-phase pivots %d + %d of %d (reach %d)\n", p1_top, p1_bot, n, bw);
+    }
+    // the full symmetric P in the kernel's numbering (entries of a row in the caller's order)
+    std::vector<int> fp2(n + 1, 0), fc2(nnzF), fmap2(nnzF);
+    std::vector<std::vector<int>> pent(n, std::vector<int>(n, -1));
+    for (int i = 0, k = 0; i < n; i++) {
+      for (int q = fp[perm[i]]; q < fp[perm[i] + 1]; q++, k++) { fc2[k] = inv[fc[q]]; fmap2[k] = hFmap[q]; pent[i][fc2[k]] = k; }
+      fp2[i + 1] = k;
+    }
     std::vector<unsigned short> colstart(QT), collist((size_t)QT * kch);
     for (int t = 0; t < QT; t++) {
-      const int wv = t >> 6, cbk = wv & 1, hb = wv >> 1, cl = t & 63, j = cbk * kNH + cl;
-      const bool col = cl < kNH && j < n;
+      const int wv = t >> 6, cbk = wv & 1, hb = wv >> 1, cl = t & 63, jk = cbk * kNH + cl;
+      const bool col = cl < kNH && jk < n;
+      const int j = col ? perm[jk] : 0;
       colstart[t] = (unsigned short)(col ? hAp[j] : nnzA);
       for (int e = 0; e < kch; e++) {
         const bool real = col && hAp[j] + 2 * e + hb < hAp[j + 1];
@@ -1222,7 +1272,7 @@ struct DevicePattern {
       const int row = order[k];
       meta[k] = (unsigned)row * RECB;
       kew[k >> 6] = std::max(kew[k >> 6], rp[row + 1] - rp[row]);
-      for (int q = rp[row], e = 0; q < rp[row + 1]; q++, e++) roww[(size_t)k * kep + e] = ((unsigned)(rmap[q] * 8) << 16) | (unsigned)(rc[q] * 16);  // operands: 16 bytes per column
+      for (int q = rp[row], e = 0; q < rp[row + 1]; q++, e++) roww[(size_t)k * kep + e] = ((unsigned)(rmap[q] * 8) << 16) | (unsigned)(inv[rc[q]] * 16);  // operands: 16 bytes per column
     }
     // terms of M, grouped by position (i, j) of a window (rows k kCH / 2 + r of either row half), the groups of a window
     // dealt to the threads (longest first)
@@ -1231,16 +1281,13 @@ struct DevicePattern {
     std::vector<std::vector<std::vector<Term>>> groups(nwin);
     std::vector<std::vector<unsigned short>> targets(nwin);
     {
-      std::vector<std::vector<int>> pair_of(n, std::vector<int>(n, -1));
-      for (size_t t = 0; t < ti.size(); t++) { pair_of[ti[t]][tj[t]] = (int)t; pair_of[tj[t]][ti[t]] = (int)t; }
-      std::vector<std::vector<int>> pent(n, std::vector<int>(n, -1));
-      for (int r = 0; r < n; r++) for (int q = fp[r]; q < fp[r + 1]; q++) pent[r][fc[q]] = q;
       for (int i = 0; i < n; i++) {
         const int wh = i / kNH, il = i - wh * kNH, cw = il / ch2, wrow = wh * ch2 + il % ch2;
         for (int j = 0; j < n; j++) {
           std::vector<Term> g;
-          if (pair_of[i][j] >= 0) {
-            const int t = pair_of[i][j];
+          const int io = perm[i], jo = perm[j];
+          if (pair_of[io][jo] >= 0) {
+            const int t = pair_of[io][jo];
             for (int q = tp[t]; q < tp[t + 1]; q++)
               g.push_back(Term{(unsigned short)(L.rec + tr[q] * RECB + F_RHO), (unsigned short)(L.Av + 8 * ta[q]), (unsigned short)(L.Av + 8 * tb[q])});
           }
@@ -1291,8 +1338,13 @@ struct DevicePattern {
     up16(qs_colstart, colstart); up16(qs_collist, collist); up32(qs_roww, roww); up32(qs_meta, meta);
     qs_stream.alloc(stream.size()); qs_stream.upload(stream.data(), stream.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
-    QS = Sched{n, m, nnzA, P.nnzP, nnzF, {kew[0], kew[1], kew[2], kew[3]}, ns, qs_colstart.get(), qs_collist.get(), qs_roww.get(),
-               qs_meta.get(), qs_stream.get(), Fp.get(), Fc.get(), Fmap.get()};
+    std::vector<unsigned short> perm16(perm.begin(), perm.end());
+    up16(qs_perm, perm16);
+    auto upi = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+    upi(qs_Fp, fp2); upi(qs_Fc, fc2); upi(qs_Fmap, fmap2);
+    HIP_CHECK(hipStreamSynchronize(s));
+    QS = Sched{n, m, nnzA, P.nnzP, nnzF, {kew[0], kew[1], kew[2], kew[3]}, ns, p1_top, p1_bot, bw, qs_perm.get(), qs_colstart.get(),
+               qs_collist.get(), qs_roww.get(), qs_meta.get(), qs_stream.get(), qs_Fp.get(), qs_Fc.get(), qs_Fmap.get()};
     quad_ok = true;
   }
 };

@@ -54,6 +54,11 @@ struct Sched {  // device pointers, shared by all instances (built on the host f
   int n, m, nnzA, nnzP, nnzF;
   int kew[4];                       // longest row held by each wavefront
   int ns;                           // term slots per thread and window (a multiple of 4)
+  // two-ended sweeps (round 6): the first p1_top pivots (0, 1, ...) fill in only inside the quadrant (0, 0), the last p1_bot
+  // (n - 1, n - 2, ...) only inside (1, 1) -- found on the host by symbolic elimination of the pattern of M; bw: its half
+  // bandwidth (the MPC family: 19, two stages)
+  int p1_top, p1_bot, bw;
+  const unsigned short *perm;       // [n]: the caller's index of the kernel's variable j (identity, or row half 1 reversed)
   const unsigned short *colstart;   // [QT]: first value of the lane's column (lanes without a column: nnzA)
   const unsigned short *collist;    // [QT][kch]: byte offset of the row record of entries hb, hb + 2, ... of the lane's column;
                                     // padding: the zero record (m)
@@ -187,6 +192,14 @@ __device__ __forceinline__ void quad_reduce2(double *v, lchar *lds, int redoff, 
 }
 
 #define OQ_FENCE() asm volatile("" ::: "memory")
+// a zero of its own: as a literal the second half of a 16-byte store shares ONE loop-invariant register tuple with every other
+// zero of the kernel (the base of the 16-bit offset extractions among them), and under pressure that tuple is spilled and
+// reloaded from scratch memory in every phase that needs a zero
+__device__ __forceinline__ double fresh_zero() {
+  double z;
+  asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+  return z;
+}
 
 // register file of the lane's column: U[p] for a wave-uniform p, through a tree of scalar branches (a select chain would be
 // two v_cndmask per register and access).  The asm at the END of a leaf keeps the optimiser from sinking the leaves' loads /
@@ -251,6 +264,15 @@ __device__ __forceinline__ void rank1_all(double (&U)[NR], const double (&B)[NB]
   if constexpr (K < NB) {
     rank1_16<K * 16, (K * 16 + 16 < NR ? K * 16 + 16 : NR), NR>(U, B[K], g);
     rank1_all<K + 1, NB, NR>(U, B, g);
+  }
+}
+// U[i] += b(i) * g over i in [R0, R1) only (the rows a pivot of a banded array reaches)
+template <int K, int R0, int R1, int NB, int NR>
+__device__ __forceinline__ void rank1_range(double (&U)[NR], const double (&B)[NB], double g) {
+  if constexpr (K < NB) {
+    constexpr int A0 = K * 16 > R0 ? K * 16 : R0, A1 = K * 16 + 16 < R1 ? K * 16 + 16 : R1;
+    if constexpr (A0 < A1) rank1_16<A0, A1, NR>(U, B[K], g);
+    rank1_range<K + 1, R0, R1, NB, NR>(U, B, g);
   }
 }
 template <int K, int NB, int NR, int NACC>
@@ -338,7 +360,7 @@ __device__ __forceinline__ void quad_body(
     }
     // x_j, q_j, D_j, delta_x_j live in LDS, not in registers of the column's owner: they are touched once or twice per
     // iteration, and every register next to the inverse counts
-    if (me.owner) { sd(lds, L.cx + me.j * 8, 0.0); sd(lds, L.cq + me.j * 8, q_all[(size_t)inst * n + me.j]); sd(lds, L.cD + me.j * 8, 1.0); sd(lds, L.cdx + me.j * 8, 0.0); }
+    if (me.owner) { sd(lds, L.cx + me.j * 8, 0.0); sd(lds, L.cq + me.j * 8, q_all[(size_t)inst * n + S.perm[me.j]]); sd(lds, L.cD + me.j * 8, 1.0); sd(lds, L.cdx + me.j * 8, 0.0); }
   }
   auto stage_words = [&]() {
     const int t = tid();
@@ -598,6 +620,76 @@ __device__ __forceinline__ void quad_body(
       // unscaled one (entries at the positions cb NHP + c of the padded halves), d and the pivot behind them.
       double sc = 1.0;
       bool pd = true;
+      // ---- first phase, two-ended (round 6): while the pivots taken from the top of row half 0 (0, 1, ...) reach no row or
+      // column beyond the quadrant (0, 0), and the pivots taken from the top of row half 1 (NH, NH + 1, ... -- the host numbers
+      // the variables of that half in REVERSE, S.perm, so that these are the LAST variables of a banded pattern) none outside
+      // (1, 1), the two sweeps touch disjoint registers of ONE wavefront each (pivots of a sweep commute; the swept array of
+      // a banded M -- the MPC family: two stages, half bandwidth 19 -- stays zero outside the reach of the pivots taken so
+      // far).  Wavefront 0 takes the pivots of half 0, wavefront 3 those of half 1, at the same time and through the same
+      // code, each with its own pivot-row buffer and WITHOUT a workgroup barrier (the LDS operations of one wavefront
+      // complete in order); the other two wait at the hand-over.  With the half bandwidth compiled in (BWC) a step also skips
+      // the registers its pivot cannot reach.  S.p1_top / p1_bot: counted on the host by symbolic elimination of the
+      // pattern of M (0: a pattern without such pivots, the phase is skipped).
+      const int T1 = uni(S.p1_top), B1 = uni(S.p1_bot);
+      if (T1 + B1 > 0) {
+        constexpr int BWC = CN ? 19 : 0;  // the half bandwidth compiled in (the host leaves the phase out when the pattern's is larger)
+        ME;
+        const unsigned slot8 = (me.cb * NHP + me.cl) * 8, brow8 = (me.hb * NHP + me.lane16) * 8;
+        const bool inpad = NHP == 64 || me.cl < NHP;
+        // (the same shape as the four-wavefront step below -- publish under `hb == PH`, read back, update, put -- minus the
+        // barrier: other arrangements of the same step left the allocator with copies of the sixteen candidate pivot
+        // registers in every trip; the host caps the counts at the pivots of the first NB - 1 sixteen-pivot blocks)
+        auto solo16 = [&](auto ph_tag, auto pb_tag) {
+          constexpr int PH = decltype(ph_tag)::value, PB = decltype(pb_tag)::value, P1 = (PB + 1) * 16 < NH ? (PB + 1) * 16 : NH;
+          constexpr int R1 = BWC > 0 && P1 + BWC < NH ? P1 + BWC : NH;
+          const int cnt = me.wv == (PH ? 3 : 0) ? (PH ? B1 : T1) : 0;
+          const unsigned pbw = L.vec + PH * 2 * L.pbstride * 8;
+#pragma unroll 1
+          for (int pr = PB * 16; pr < P1 && pr < cnt; pr++) {
+            if (me.hb == PH) {
+              const double up = reg_get<PB * 16, P1, NH>(U, pr);
+              const double pv = sc * up;
+              if (inpad) { sd(lds, pbw + slot8, pv); sd(lds, pbw + L.pbstride * 8 + slot8, up); }
+              if (me.cl == pr) {
+                double d = __builtin_amdgcn_rcp(pv);
+                d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+                d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+                st2at(lds, pbw + L.nh2 * 8, d, pv);
+              }
+            }
+            OQ_FENCE();
+            double B[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) B[k] = (k * 16 < R1) ? ld(lds, pbw + brow8 + 128 * k) : 0.0;
+            const double up = inpad ? ld(lds, pbw + L.pbstride * 8 + slot8) : 0.0;
+            const d2_t dp = ld2at(lds, pbw + L.nh2 * 8);
+            OQ_FENCE();
+            const double d = dp.x;
+            if (!(dp.y > 0.0)) pd = false;
+            const bool mine = me.cl == pr;
+            const double g = mine ? 0.0 : -d * up;
+            rank1_range<0, 0, R1, NB, NH>(U, B, g);
+            if (me.hb == PH) reg_put<PB * 16, P1, NH>(U, pr, mine ? -1.0 : -g);
+            sc = mine ? d : sc;
+          }
+        };
+        [&]<int... IS>(std::integer_sequence<int, IS...>) {
+          (solo16(std::integral_constant<int, IS / (NB > 1 ? NB - 1 : 1)>{}, std::integral_constant<int, IS % (NB > 1 ? NB - 1 : 1)>{}), ...);
+        }(std::make_integer_sequence<int, 2 * (NB > 1 ? NB - 1 : 1)>{});
+        const unsigned pbw = L.vec + (me.wv == 3 ? 2 * L.pbstride * 8 : 0);
+        // the column factors and the definiteness flags of the two sweeps, to the wavefronts that share their columns
+        if (me.wv == 0 || me.wv == 3) {
+          if (inpad) sd(lds, pbw + L.pbstride * 8 + slot8, sc);
+          if (me.cl == 0) sd(lds, pbw + L.nh2 * 8, pd ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (me.wv == 1 || me.wv == 2) {
+          const unsigned pbo = L.vec + (me.wv == 1 ? 2 * L.pbstride * 8 : 0);
+          if (inpad) sc = ld(lds, pbo + L.pbstride * 8 + slot8);
+        }
+        pd = ld(lds, L.vec + L.nh2 * 8) != 0.0 && ld(lds, L.vec + 2 * L.pbstride * 8 + L.nh2 * 8) != 0.0;
+        __syncthreads();
+      }
       auto sweep16 = [&](auto ph_tag, auto pb_tag) {
         constexpr int PH = decltype(ph_tag)::value, PB = decltype(pb_tag)::value;
         constexpr int P1 = (PB + 1) * 16 < NH ? (PB + 1) * 16 : NH;
@@ -606,7 +698,7 @@ __device__ __forceinline__ void quad_body(
         const unsigned brow8 = (me.hb * NHP + me.lane16) * 8;   // the lane's element of the row half's broadcast registers
         const bool inpad = NHP == 64 || me.cl < NHP;
 #pragma unroll 1
-        for (int pr = PB * 16; pr < P1 && PH * NH + pr < n; pr++) {
+        for (int pr = (PH ? B1 : T1) > PB * 16 ? (PH ? B1 : T1) : PB * 16; pr < P1 && PH * NH + pr < n; pr++) {  // what the first phase left
           const int p = PH * NH + pr;
           const unsigned pb = L.vec + (p & 1) * 2 * L.pbstride * 8;
           if (me.hb == PH) {  // the wavefronts that hold row p publish it
@@ -719,7 +811,7 @@ __device__ __forceinline__ void quad_body(
       const int t = me.t, j = me.j;
       const unsigned myrec = my_rec(me);
       const bool hasrow = myrec != 0xFFFFFFFFu, owner = me.owner;
-      if (owner) { const double xv = ld(lds, L.cx + j * 8); sd(lds, L.xs + j * 8, xv); st2at(lds, L.xp + j * 16, xv, 0.0); }
+      if (owner) { const double xv = ld(lds, L.cx + j * 8); sd(lds, L.xs + j * 8, xv); st2at(lds, L.xp + j * 16, xv, fresh_zero()); }
       __syncthreads();
       {
         double v[6] = {0, 0, 0, 0, 0, 0};
@@ -829,7 +921,7 @@ __device__ __forceinline__ void quad_body(
         const double cs = uns ? c : 1.0;
         if (uni((int)(nv > edi && qdx < -cs * edi * nv))) {
           __syncthreads();
-          if (owner) { sd(lds, L.xs + j * 8, dxj); st2at(lds, L.xp + j * 16, dxj, 0.0); }
+          if (owner) { sd(lds, L.xs + j * 8, dxj); st2at(lds, L.xp + j * 16, dxj, fresh_zero()); }
           __syncthreads();
           const double pdx = p_row_dot(me, L.xs);
           double w1[1] = {owner ? fabs(uns ? pdx / Dj : pdx) : 0.0};
@@ -877,7 +969,7 @@ __device__ __forceinline__ void quad_body(
   {
     ME;
     const bool has_sol = status == OSQP_SOLVED || status == OSQP_SOLVED_INACCURATE || status == OSQP_MAX_ITER_REACHED;
-    if (me.owner) x_out[(size_t)inst * x_stride + me.j] = has_sol ? ld(lds, L.cD + me.j * 8) * ld(lds, L.cx + me.j * 8) : NAN;
+    if (me.owner) x_out[(size_t)inst * x_stride + S.perm[me.j]] = has_sol ? ld(lds, L.cD + me.j * 8) * ld(lds, L.cx + me.j * 8) : NAN;
     for (int i = me.t; i < m; i += QT) {
       const unsigned r = (unsigned)i * RECB;
       y_out[(size_t)inst * y_stride + i] = has_sol ? cinv * ld(lds, L.rec + r + F_E) * ld(lds, L.rec + r + F_Y) : NAN;
