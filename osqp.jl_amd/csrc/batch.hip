@@ -1343,7 +1343,7 @@ struct DevicePattern {
     auto upi = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
     upi(qs_Fp, fp2); upi(qs_Fc, fc2); upi(qs_Fmap, fmap2);
     HIP_CHECK(hipStreamSynchronize(s));
-    QS = Sched{n, m, nnzA, P.nnzP, nnzF, {kew[0], kew[1], kew[2], kew[3]}, ns, p1_top, p1_bot, bw, qs_perm.get(), qs_colstart.get(),
+    QS = Sched{n, m, nnzA, P.nnzP, nnzF, {kew[0], kew[1], kew[2], kew[3]}, ns, p1_top, p1_bot, bw, getenv("OSQP_AMD_BATCH_ROT") ? atoi(getenv("OSQP_AMD_BATCH_ROT")) : 0, qs_perm.get(), qs_colstart.get(),
                qs_collist.get(), qs_roww.get(), qs_meta.get(), qs_stream.get(), qs_Fp.get(), qs_Fc.get(), qs_Fmap.get()};
     quad_ok = true;
   }

@@ -58,6 +58,7 @@ struct Sched {  // device pointers, shared by all instances (built on the host f
   // (n - 1, n - 2, ...) only inside (1, 1) -- found on the host by symbolic elimination of the pattern of M; bw: its half
   // bandwidth (the MPC family: 19, two stages)
   int p1_top, p1_bot, bw;
+  int rot;                          // > 0: the roles of the four wavefronts rotate with (workgroup id >> rot) & 3 (which SIMD carries the one-wavefront sweeps)
   const unsigned short *perm;       // [n]: the caller's index of the kernel's variable j (identity, or row half 1 reversed)
   const unsigned short *colstart;   // [QT]: first value of the lane's column (lanes without a column: nnzA)
   const unsigned short *collist;    // [QT][kch]: byte offset of the row record of entries hb, hb + 2, ... of the lane's column;
@@ -283,6 +284,24 @@ __device__ __forceinline__ void dot_all(const double (&U)[NR], const double (&B)
   }
 }
 
+// v of lane 16 k + (l & 15) in every lane l: one pass through the LDS crossbar (ds_bpermute, no memory), where a write and a
+// read back are two
+__device__ __forceinline__ double row16_of(double v, int addr4) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_ds_bpermute(addr4, a.i[0]);
+  r.i[1] = __builtin_amdgcn_ds_bpermute(addr4, a.i[1]);
+  return r.d;
+}
+template <int LN>
+__device__ __forceinline__ double lane_of(double v) {  // v of lane LN, wave-uniform
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_readlane(a.i[0], LN);
+  r.i[1] = __builtin_amdgcn_readlane(a.i[1], LN);
+  return r.d;
+}
+
 // One QP per 256-thread workgroup.  NH: rows / columns per quadrant (n <= 2 NH); KC, KE: compile-time bounds of the longest
 // column / row of A; CH: rows per assembly window; CN > 0: the shape is compiled in (the MPC family), every LDS offset an
 // immediate.
@@ -328,7 +347,7 @@ __device__ __forceinline__ void quad_body(
   constexpr int NCH = (NH + CH / 2 - 1) / (CH / 2);  // assembly windows: CH / 2 rows of either row half each
   constexpr bool FULL = CN == 2 * NH;      // every lane below NH of a quadrant has a column
   lchar *lds = (lchar *)lds_raw;
-  const int wvs = uni((int)threadIdx.x >> 6);
+  const int wvs = uni(((int)threadIdx.x >> 6) ^ (S.rot > 0 ? ((int)blockIdx.x >> S.rot) & 3 : 0));
   auto tid = [&]() { return (wvs << 6) | lane_now(); };
 #define ME const Me me = make_me<NH, FULL>(n, wvs)
   const unsigned ZREC = (unsigned)m * RECB;  // the zero record
@@ -639,6 +658,36 @@ __device__ __forceinline__ void quad_body(
         // (the same shape as the four-wavefront step below -- publish under `hb == PH`, read back, update, put -- minus the
         // barrier: other arrangements of the same step left the allocator with copies of the sixteen candidate pivot
         // registers in every trip; the host caps the counts at the pivots of the first NB - 1 sixteen-pivot blocks)
+        if constexpr (CN > 0) {
+          // the compiled-in family: the steps unrolled, the pivot a compile-time register and lane.  No register-selection
+          // trees (two per step, ~600 of its ~1200 cycles), no LDS: the pivot comes through v_readlane, the pivot row through
+          // ds_bpermute (the crossbar alone), and a step stops at the last register its pivot can reach.  One code path for
+          // both wavefronts (wavefront 0: pivots of half 0, wavefront 3: of half 1).
+          const int cnt = me.wv == 0 ? T1 : (me.wv == 3 ? B1 : 0);
+          const int a4 = me.lane16 * 4;
+          constexpr int CAP = (NB > 1 ? NB - 1 : 1) * 16 < NH ? (NB > 1 ? NB - 1 : 1) * 16 : NH;
+          auto step = [&](auto k_tag) {
+            constexpr int K = decltype(k_tag)::value;
+            constexpr int R1 = K + BWC + 1 < NH ? K + BWC + 1 : NH, NBK = (R1 + 15) / 16;
+            if (K < cnt) {
+              const double up = U[K], pv = sc * up;
+              double B[NB];
+#pragma unroll
+              for (int k = 0; k < NB; k++) B[k] = k < NBK ? row16_of(pv, a4 + 64 * k) : 0.0;
+              const double pvp = lane_of<K>(pv);
+              double d = __builtin_amdgcn_rcp(pvp);
+              d = __builtin_fma(__builtin_fma(-pvp, d, 1.0), d, d);
+              d = __builtin_fma(__builtin_fma(-pvp, d, 1.0), d, d);
+              if (!(pvp > 0.0)) pd = false;
+              const bool mine = me.cl == K;
+              const double g = mine ? 0.0 : -d * up;
+              rank1_range<0, 0, R1, NB, NH>(U, B, g);
+              U[K] = mine ? -1.0 : -g;
+              sc = mine ? d : sc;
+            }
+          };
+          [&]<int... IS>(std::integer_sequence<int, IS...>) { (step(std::integral_constant<int, IS>{}), ...); }(std::make_integer_sequence<int, CAP>{});
+        } else {
         auto solo16 = [&](auto ph_tag, auto pb_tag) {
           constexpr int PH = decltype(ph_tag)::value, PB = decltype(pb_tag)::value, P1 = (PB + 1) * 16 < NH ? (PB + 1) * 16 : NH;
           constexpr int R1 = BWC > 0 && P1 + BWC < NH ? P1 + BWC : NH;
@@ -676,6 +725,7 @@ __device__ __forceinline__ void quad_body(
         [&]<int... IS>(std::integer_sequence<int, IS...>) {
           (solo16(std::integral_constant<int, IS / (NB > 1 ? NB - 1 : 1)>{}, std::integral_constant<int, IS % (NB > 1 ? NB - 1 : 1)>{}), ...);
         }(std::make_integer_sequence<int, 2 * (NB > 1 ? NB - 1 : 1)>{});
+        }
         const unsigned pbw = L.vec + (me.wv == 3 ? 2 * L.pbstride * 8 : 0);
         // the column factors and the definiteness flags of the two sweeps, to the wavefronts that share their columns
         if (me.wv == 0 || me.wv == 3) {
