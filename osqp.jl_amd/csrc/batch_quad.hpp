@@ -776,9 +776,53 @@ __device__ __forceinline__ void quad_body(
           sc = (me.jp == p) ? d : sc;
         }
       };
-      [&]<int... IS>(std::integer_sequence<int, IS...>) {
-        (sweep16(std::integral_constant<int, IS / NB>{}, std::integral_constant<int, IS % NB>{}), ...);
-      }(std::make_integer_sequence<int, 2 * NB>{});
+      // the compiled-in family: the four-wavefront steps of the last two sixteen-pivot blocks of a row half unrolled as well
+      // (the pivot a compile-time register: no selection trees; what the first phase leaves of the MPC pattern -- ten pivots
+      // per half -- lies there); UB: the first unrolled block
+      constexpr int UB = CN > 0 && NB > 2 ? NB - 2 : NB;
+      auto joint = [&](auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        if constexpr (UB < NB) {
+          ME;
+          const unsigned slot8 = (me.cb * NHP + me.cl) * 8, brow8 = (me.hb * NHP + me.lane16) * 8;
+          const bool inpad = NHP == 64 || me.cl < NHP;
+          const int lo = PH ? B1 : T1;
+          auto step = [&](auto k_tag) {
+            constexpr int K = UB * 16 + decltype(k_tag)::value, p = PH * NH + K;
+            constexpr unsigned pbo = (p & 1) * 2;
+            if (K >= lo && p < n) {
+              const unsigned pb = L.vec + pbo * L.pbstride * 8;
+              if (me.hb == PH) {
+                const double up = U[K], pv = sc * up;
+                if (inpad) { sd(lds, pb + slot8, pv); sd(lds, pb + L.pbstride * 8 + slot8, up); }
+                if (me.jp == p) {
+                  double d = __builtin_amdgcn_rcp(pv);
+                  d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+                  d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+                  st2at(lds, pb + L.nh2 * 8, d, pv);
+                }
+              }
+              __syncthreads();
+              double B[NB];
+#pragma unroll
+              for (int k = 0; k < NB; k++) B[k] = ld(lds, pb + brow8 + 128 * k);
+              const double up = inpad ? ld(lds, pb + L.pbstride * 8 + slot8) : 0.0;
+              const d2_t dp = ld2at(lds, pb + L.nh2 * 8);
+              const double d = dp.x;
+              if (!(dp.y > 0.0)) pd = false;
+              const double g = (me.jp == p) ? 0.0 : -d * up;
+              rank1_all<0, NB, NH>(U, B, g);
+              if (me.hb == PH) U[K] = (me.jp == p) ? -1.0 : -g;
+              sc = (me.jp == p) ? d : sc;
+            }
+          };
+          [&]<int... IS>(std::integer_sequence<int, IS...>) { (step(std::integral_constant<int, IS>{}), ...); }(std::make_integer_sequence<int, NH - UB * 16>{});
+        }
+      };
+      [&]<int... IS>(std::integer_sequence<int, IS...>) { (sweep16(std::integral_constant<int, 0>{}, std::integral_constant<int, IS>{}), ...); }(std::make_integer_sequence<int, UB>{});
+      joint(std::integral_constant<int, 0>{});
+      [&]<int... IS>(std::integer_sequence<int, IS...>) { (sweep16(std::integral_constant<int, 1>{}, std::integral_constant<int, IS>{}), ...); }(std::make_integer_sequence<int, UB>{});
+      joint(std::integral_constant<int, 1>{});
       nsc = -sc;  // the registers stay as the sweeps left them: column j of M^-1 is nsc U, applied to the sum of the product
       __syncthreads();  // the pivot buffers are the partial b / x~ and the copy of x again
       for (int k = tid(); k < 2 * L.nh2 + 4 * n; k += QT) sd(lds, L.vec + k * 8, 0.0);
