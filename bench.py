@@ -63,6 +63,8 @@ SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25,
                 polish=False, max_iter=4000)
 
 BATCH_TOTAL = 4096
+# the other BASELINE.json configurations, reported beside the headline line (`other_workloads`)
+OTHER_WORKLOADS = ("rand-1e5", "lasso-5e5", "mpc-batch", "control-1e6")
 CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r04_cpu_rand1e6.json")}
 CPU_RECORD_WINDOW = (5, 20)  # W, K of the committed CPU record (the driver's protocol)
 
@@ -223,7 +225,9 @@ def main():
     if args.workload == "mpc-batch":
         rec = batch_leg(ctx, want_cpu=(not args.no_cpu and world == 1))
         if rank == 0:
-            print(json.dumps(batch_line(args, world, rec)))
+            line = batch_line(args, world, rec)
+            line["device"] = device_identity(torch, local_rank)
+            print(json.dumps(line))
             sys.stdout.flush()
         if world > 1:
             dist.destroy_process_group()
@@ -408,6 +412,11 @@ def replica_bench(ctx):
     oq.clean(model)  # the replica's memory goes before any other leg is built
     del model
 
+    if rank == 0:
+        out["device"] = device_identity(torch, ctx["local_rank"])
+    if rank == 0 and world == 1 and args.child is None and args.workload == "rand-1e6" and os.environ.get("OSQP_AMD_BENCH_OTHERS", "1") != "0":
+        out["other_workloads"] = other_workloads(ctx)
+
     if rank == 0 and world == 1 and args.traffic != "off" and pmc_names:
         tr, src = (None, None)
         if args.traffic == "live":
@@ -446,6 +455,92 @@ def replica_bench(ctx):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_roofline(oq, lib, model, n, st):
+    """(kernel label, algorithmic bytes per launch, ms per launch) of the dominant kernel of the model's back-end, timed with HIP
+    events on the engine's stream (osqp_amd_time_kernel)."""
+    if st[0] == 2:
+        which, abytes, label = 0, st[10], "spmv y = A x"
+    else:
+        which, label = 5, "direct ADMM iteration (rhs | triangular solves | update)"
+        abytes = st[11] + 8.0 * (6 * n + 12 * int(oq.dimensions(model)[1]))
+    ms = float(lib.osqp_amd_time_kernel(model.workspace, which, 20))
+    return label, abytes, ms
+
+
+def other_workload(ctx, name):
+    """One of the other single-QP configurations of BASELINE.json through the same protocol as the headline (W untimed
+    iterations from the cold start, K timed, then a full cold solve to eps): a compact record for the `other_workloads` block."""
+    args, oq, lib, torch = (ctx[k] for k in ("args", "oq", "lib", "torch"))
+    model, n, setup_s = build_model(oq, lib, name, 1)
+    ws = model.workspace
+    if args.warmup > 0:
+        assert lib.osqp_amd_iterate(ws, args.warmup) == 0
+    st0 = oq.stats(model)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert lib.osqp_amd_iterate(ws, args.steps) == 0
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st1 = oq.stats(model)
+    cg = (st1[6] - st0[6]) / max(args.steps, 1)
+    oq.update_settings(model, warm_start=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = oq.solve(model)
+    torch.cuda.synchronize()
+    solve_s = time.perf_counter() - t0
+    st = oq.stats(model)
+    m = int(oq.dimensions(model)[1])
+    label, abytes, ms = kernel_roofline(oq, lib, model, n, st)
+    step_bytes = step_algorithmic_bytes(st, n, m, cg)
+    rec = {"value": round(args.steps / elapsed, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+           "time_to_eps_s": round(solve_s, 4), "iters_to_eps": int(res.info.iter), "status": res.info.status,
+           "n": n, "m": m, "backend": "pcg" if st[0] == 2 else "direct-ldl", "cg_iters_per_admm_iter": round(cg, 3), "setup_s": round(setup_s, 3),
+           "roofline": {"kernel": label, "frac": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None, "ms_per_launch": round(ms, 4),
+                        "step_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+    oq.clean(model)
+    return rec
+
+
+def other_workloads(ctx):
+    """The BASELINE.json configurations next to the headline one, measured in the same process (about 20 s of GPU time):
+    rand-1e5, lasso-5e5, control-1e6 (and grid2d-1e6, the direct back-end on a structure it was not tuned on) as single
+    QPs, mpc-batch through the batched kernel.  A workload that fails reports its error and the others go on."""
+    out = {}
+    for name in OTHER_WORKLOADS:
+        if name == ctx["args"].workload:
+            continue
+        try:
+            if name == "mpc-batch":
+                rec = batch_leg(ctx, want_cpu=False, traffic=False)
+                out[name] = {k: rec[k] for k in ("value", "unit", "ms_per_step", "instances", "instances_per_s", "mean_iters_per_instance", "solved")}
+                out[name]["roofline"] = {"bound": "lds", "frac": rec["roofline"]["frac"], "fp64_tflops": rec["roofline"]["fp64"]["achieved_tflops"]}
+            else:
+                out[name] = other_workload(ctx, name)
+        except Exception as e:  # noqa: BLE001 -- the headline line must not depend on the side block
+            out[name] = {"error": str(e)[:200]}
+    return out
+
+
+def device_identity(torch, local_rank):
+    """Which device the bench ran on (the driver's own busy sampler has read 0 % on card0 in several rounds)."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        ident = {"index": local_rank, "name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+                 "memory_gb": round(p.total_memory / 1e9, 1)}
+        for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+            if hasattr(p, k):
+                ident[k] = int(getattr(p, k))
+        if "pci_bus_id" in ident:
+            ident["pci"] = "%04x:%02x:%02x.0" % (ident.get("pci_domain_id", 0), ident["pci_bus_id"], ident.get("pci_device_id", 0))
+        for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            if k in os.environ:
+                ident[k] = os.environ[k]
+        return ident
+    except Exception as e:  # noqa: BLE001
+        return {"index": local_rank, "error": str(e)[:100]}
 
 
 def step_algorithmic_bytes(st, n, m, cg_per_admm, k=25):
@@ -672,7 +767,7 @@ def sharded_leg(ctx, kind, n, per_row, one_gpu_its):
     return rec
 
 
-def batch_leg(ctx, want_cpu):
+def batch_leg(ctx, want_cpu, traffic=True):
     """BASELINE.json config 5: 4096 independent MPC QPs (n = 100, m = 200) cut into contiguous blocks over the ranks
     (instance i -> rank floor(i / (4096 / N))), resident in HBM; a step = one solve of the whole batch: every rank its
     block, one workgroup per QP, then ONE in-place all-gather of the packed [x | y | info] rows on the library's own
@@ -745,7 +840,7 @@ def batch_leg(ctx, want_cpu):
     if want_cpu:
         rec["cpu_baseline"] = batch_cpu_leg(oq, args)
     b.close()
-    if rank == 0 and world == 1 and args.child is None and args.traffic == "live":  # HBM bytes of one launch, two --pmc passes over a child
+    if traffic and rank == 0 and world == 1 and args.child is None and args.traffic == "live":  # HBM bytes of one launch, two --pmc passes over a child
         tr, src = live_traffic(args, ["k_batch_solve" if os.environ.get("OSQP_AMD_BATCH_QUAD") == "0" else "k_batch_quad"])
         rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = tr, src
     if comm is not None:

@@ -16,6 +16,7 @@
 #include <string.h>
 #include <math.h>
 #include <time.h>
+#include <signal.h>
 
 /* ---------------------------------------------------------------- private */
 typedef struct {
@@ -724,8 +725,22 @@ c_int osqp_setup(OSQPWorkspace **workp, const OSQPData *data, const OSQPSettings
 
 /* ---------------------------------------------------------------- solve
  * [REF src/interface.jl:171]; loop of SURVEY.md A.2-A.5. */
+/* ---------------------------------------------------------------- Ctrl-C
+ * The published library listens for SIGINT while osqp_solve runs (its CTRLC build, the one the reference ships): the
+ * handler only sets a flag, the loop tests it at the top of every iteration, the status becomes OSQP_SIGINT (-5)
+ * [REF src/constants.jl:17 :Interrupted], osqp_solve returns 1 without storing a solution, and the handler that was
+ * installed before the call is put back. */
+static volatile sig_atomic_t oracle_sigint = 0;
+static void oracle_on_sigint(int sig) { (void)sig; oracle_sigint = 1; }
+
 c_int osqp_solve(OSQPWorkspace *w) {
   if (!w) return 7;
+  struct sigaction sa_new, sa_old;
+  memset(&sa_new, 0, sizeof sa_new);
+  sa_new.sa_handler = oracle_on_sigint;
+  sigemptyset(&sa_new.sa_mask);
+  oracle_sigint = 0;
+  sigaction(SIGINT, &sa_new, &sa_old);
   c_int iter, max_iter = w->settings->max_iter;
   int can_check_termination = 0, can_print = (int)w->settings->verbose;
   int compute_cost_function = (int)w->settings->verbose;
@@ -747,6 +762,15 @@ c_int osqp_solve(OSQPWorkspace *w) {
   }
 
   for (iter = 1; iter <= max_iter; iter++) {
+    if (oracle_sigint) { /* no solution is stored, the iterate stays as it is (a later solve warm-starts from it) */
+      update_status(w->info, OSQP_SIGINT);
+      w->info->solve_time = toc(w);
+      PRIV(w)->rho_update_from_solve = 0;
+      sigaction(SIGINT, &sa_old, NULL);
+      for (c_int k = 0; k < w->data->n; k++) w->solution->x[k] = ORACLE_NAN;
+      for (c_int k = 0; k < w->data->m; k++) w->solution->y[k] = ORACLE_NAN;
+      return 1;
+    }
     /* time limit (A.3 last bullet) */
     if (w->first_run) temp_run_time = w->info->setup_time + toc(w);
     else temp_run_time = w->info->update_time + toc(w);
@@ -810,6 +834,7 @@ c_int osqp_solve(OSQPWorkspace *w) {
     printf("status: %s, iterations: %lld, objective: %.6e, run time: %.3es\n", w->info->status,
            (long long)w->info->iter, w->info->obj_val, w->info->run_time);
   store_solution(w);
+  sigaction(SIGINT, &sa_old, NULL);
   return 0;
 }
 

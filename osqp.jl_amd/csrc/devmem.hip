@@ -45,9 +45,12 @@ int g_vm_state = (getenv("OSQP_AMD_VMM") && atoi(getenv("OSQP_AMD_VMM")) == 0) ?
 const bool g_va_free_at_once = getenv("OSQP_AMD_VMM_VA") && atoi(getenv("OSQP_AMD_VMM_VA")) == 0;
 
 size_t g_va_reserved = 0;  // address space taken so far (never returned: see above); OSQP_AMD_ALLOC_TRACE prints it
+// test hook: the reservation "fails" once this many MiB of address space have been taken (tests/test_devmem_gpu.py drives the
+// allocator into its hipMalloc fallback in the middle of a setup and compares the results bit for bit)
+const size_t g_va_limit = getenv("OSQP_AMD_VMM_VA_LIMIT_MB") ? (size_t)atol(getenv("OSQP_AMD_VMM_VA_LIMIT_MB")) << 20 : ~size_t(0);
 void *va_get(size_t size) {
   void *va = nullptr;
-  if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) {
+  if (g_va_reserved + size > g_va_limit || hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess) {
     (void)hipGetLastError();
     // Said once, loudly: from here on large blocks come from hipMalloc again -- correct, but with the driver's 1-5 s stalls
     // this allocator exists to avoid.  A long-lived process that sets up thousands of large workspaces gets here.

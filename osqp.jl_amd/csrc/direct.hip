@@ -1541,7 +1541,8 @@ struct LdlFactor {
       lD = nlev; cD = N; kD = 0;
       e.setup_mark("  lean analysis");
       decide_supernodes(true);
-      if (!(sn && mf_ok)) { sn = false; mf_ok = false; T = Supernodes(); symbolic_complete(S); }
+      // (the device build of the index arrays sorts 32-bit positions: a factor beyond 2^31 entries completes on the host, int64 throughout)
+      if (!(sn && mf_ok) || S.nnzL >= (int64_t)2147483646) { sn = false; mf_ok = false; T = Supernodes(); symbolic_complete(S); }
     }
     e.setup_mark("  symbolic analysis");
     if (S.too_large) return;
@@ -2173,11 +2174,8 @@ struct LdlFactor {
     if (kD >= kDenseBlocked) {  // block sweeps of kGjK pivots on the matrix cores, in place
       if (ldD > kD) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - kD)), dim3(kBlock), 0, s, kD, ldD, S0a.get());
       const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
-      static bool lds_set = false;
-      if (!lds_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
-        lds_set = true;
-      }
+      // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
       for (int p0 = 0; p0 < ldD; p0 += kGjK) {
         OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, kD, ldD, p0, S0a.get(), gjT.get(), status.get());
         OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
@@ -2485,7 +2483,9 @@ struct Direct : Linsys {
   const bool leave_rhs = !(getenv("OSQP_AMD_DIRECT_LEAVE_RHS") && atoi(getenv("OSQP_AMD_DIRECT_LEAVE_RHS")) == 0);
   // a supernode waited 200 ms for its children: the factor goes back to one launch per level (no waiting inside a
   // kernel); 6 tells the engine that the iterations since the last test cannot be trusted (TreeFault: the solve restarts)
+  void invalidate() override { rhs_left = false; }
   int flush() override {
+    rhs_left = false;
     if (!F->faulted()) return 0;
     *F->sn_fault_host = 0;
     F->sn_tree = false;

@@ -6,6 +6,8 @@
 // the host only sequences launches and reads back a handful of scalars every
 // `check_termination` iterations.
 #include "engine.hpp"
+#include <csignal>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -910,8 +912,22 @@ void Engine::run_chunk() {
   if (!chunk_exec) {
     hipGraph_t graph = nullptr;
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    // a launch that throws inside the capture must not leave the stream capturing, nor the back-end believing that a
+    // next step follows (its right-hand side `left` in the factor's vector): the next chunk would solve with a stale one
+    struct CaptureGuard {
+      Engine &e; bool armed = true;
+      ~CaptureGuard() {
+        if (!armed) return;
+        e.lin->next_follows = false;
+        e.lin->invalidate();
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(e.stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+      }
+    } guard{*this};
     for (int i = 0; i < k; i++) { lin->next_follows = i + 1 < k; admm_step(); }
     lin->next_follows = false;
+    guard.armed = false;
     HIP_CHECK(hipStreamEndCapture(stream, &graph));
     HIP_CHECK(hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
@@ -1141,7 +1157,37 @@ void Engine::store_solution() {
 // A timed-out wait inside k_sn_tree (direct back-end, supernodal solves in one launch per direction) leaves an iterate
 // that cannot be trusted: the factor has gone back to one launch per level (Direct::flush), the solve starts again from
 // a cold start.  A second fault cannot happen (nothing waits inside a kernel any more); if it does it is error 6.
+// Ctrl-C [REF src/constants.jl:17 :Interrupted = -5]: for the duration of osqp_solve a SIGINT handler that only sets a flag
+// (never calls back into the host runtime: the caller may be a Julia task or a Python thread); the loop tests it at the top
+// of an iteration -- between chunks when iterations run as captured graphs -- and the handler found at entry is put back on
+// every way out.  Nested / concurrent solves (distinct workspaces on different threads) share one installation.
+namespace {
+volatile std::sig_atomic_t g_sigint = 0;
+std::mutex g_sigint_mutex;
+int g_sigint_depth = 0;
+struct sigaction g_sigint_prev;
+void on_sigint(int) { g_sigint = 1; }
+struct InterruptListener {
+  InterruptListener() {
+    std::lock_guard<std::mutex> lock(g_sigint_mutex);
+    if (g_sigint_depth++ == 0) {
+      g_sigint = 0;
+      struct sigaction sa;
+      memset(&sa, 0, sizeof sa);
+      sa.sa_handler = on_sigint;
+      sigemptyset(&sa.sa_mask);
+      sigaction(SIGINT, &sa, &g_sigint_prev);
+    }
+  }
+  ~InterruptListener() {
+    std::lock_guard<std::mutex> lock(g_sigint_mutex);
+    if (--g_sigint_depth == 0) sigaction(SIGINT, &g_sigint_prev, nullptr);
+  }
+};
+}  // namespace
+
 int Engine::solve() {
+  InterruptListener listener;
   // what an abandoned attempt may have changed besides the iterate: rho (adaptive updates) and the interval it settled on
   const double rho_at_entry = st.rho;
   const c_int interval_at_entry = st.adaptive_rho_interval;
@@ -1183,6 +1229,23 @@ int Engine::solve_attempt(bool restarted) {
   }
 
   for (iter = 1; iter <= max_iter; iter++) {
+    {
+      bool interrupted = g_sigint != 0;
+      if (comm) {  // one decision for all ranks, taken where they meet anyway: right after a termination test
+        const long long cadence = st.check_termination ? st.check_termination : 25;
+        interrupted = (iter % cadence == 1 || cadence == 1) ? agree_max(interrupted ? 1.0 : 0.0) > 0.0 : false;
+      }
+      if (interrupted) {  // as the published library: no solution stored, the iterate stays (a later solve warm-starts from it)
+        update_status(info, OSQP_SIGINT);
+        sync();
+        info->solve_time = toc();
+        rho_update_from_solve = false;
+        std::fill(h_x.begin(), h_x.end(), NAN);
+        std::fill(h_y.begin(), h_y.end(), NAN);
+        *ws->settings = st;
+        return 1;
+      }
+    }
     if (ws->first_run) temp_run_time = info->setup_time + toc();
     else temp_run_time = info->update_time + toc();
     bool out_of_time = st.time_limit && temp_run_time >= st.time_limit;

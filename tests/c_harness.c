@@ -17,7 +17,10 @@
  *   ./c_harness <path of libosqp_amd.so | libosqp_oracle.so>
  * Prints one JSON line per step; exit status 0 iff every check passed.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <dlfcn.h>
+#include <signal.h>
+#include <sys/time.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +34,13 @@ typedef c_int (*fn_w)(OSQPWorkspace *);
 typedef c_int (*fn_wv)(OSQPWorkspace *, const c_float *);
 typedef c_int (*fn_wf)(OSQPWorkspace *, c_float);
 typedef const char *(*fn_ver)(void);
+typedef c_int (*fn_wi)(OSQPWorkspace *, c_int);
+
+/* Ctrl-C during a solve [REF src/constants.jl:17 :Interrupted]: the harness's own SIGINT handler (what a host runtime
+ * has installed), and a timer that raises SIGINT at this process while osqp_solve runs */
+static volatile sig_atomic_t harness_sigint = 0;
+static void harness_on_sigint(int sig) { (void)sig; harness_sigint = 1; }
+static void harness_on_alarm(int sig) { (void)sig; raise(SIGINT); }
 
 static void *must(void *h, const char *name) {
   void *p = dlsym(h, name);
@@ -144,6 +154,37 @@ int main(int argc, char **argv) {
     aty0 = aty1 = 0.0;
     for (int i = 0; i < 5; i++) { mx = fmax(mx, fabs(cert[i])); ub += u3[i] * fmax(cert[i], 0.0); aty0 += Ad[i][0] * cert[i]; aty1 += Ad[i][1] * cert[i]; }
     check(fabs(mx - 1.0) < 1e-9 && ub < 0.0 && fabs(aty0) < 1e-3 && fabs(aty1) < 1e-3, "delta_y is a primal-infeasibility certificate");
+  }
+  /* --- interrupted solve: a solve that cannot end on its own (no termination test, 2e9 iterations) gets a SIGINT 30 ms
+   *     in; status_val -5 "interrupted", osqp_solve comes back, and the handler installed before the call is in place
+   *     again afterwards (the library must neither keep its own nor reset to the default) --- */
+  {
+    fn_wi update_max_iter = (fn_wi)must(h, "osqp_update_max_iter"), update_check = (fn_wi)must(h, "osqp_update_check_termination");
+    c_float u4[5] = {0.0, 0.0, -15.0, 100.0, 80.0};
+    check(update_u(work, u4) == 0 && update_max_iter(work, 2000000000) == 0 && update_check(work, 0) == 0, "settings of the endless solve");
+    struct sigaction sa, sa_alarm;
+    memset(&sa, 0, sizeof sa); sa.sa_handler = harness_on_sigint; sigemptyset(&sa.sa_mask);
+    memset(&sa_alarm, 0, sizeof sa_alarm); sa_alarm.sa_handler = harness_on_alarm; sigemptyset(&sa_alarm.sa_mask);
+    sigaction(SIGINT, &sa, NULL);
+    sigaction(SIGALRM, &sa_alarm, NULL);
+    struct itimerval tv = {{0, 0}, {0, 30000}};
+    setitimer(ITIMER_REAL, &tv, NULL);
+    c_int rc = solve(work);
+    info = hop(work, 208);
+    memcpy(status, (const char *)info + 8, 32); status[32] = 0;
+    x = (const c_float *)hop(hop(work, 200), 0);
+    printf("{\"step\": \"interrupt\", \"status\": \"%s\", \"status_val\": %lld, \"exitflag\": %lld, \"harness_handler_ran_during_solve\": %d}\n", status,
+           (long long)rd_int(info, 40), (long long)rc, (int)harness_sigint);
+    check(rd_int(info, 40) == OSQP_SIGINT && strcmp(status, "interrupted") == 0, "status of the interrupted solve [REF src/constants.jl:17]");
+    check(harness_sigint == 0, "the library's handler, not the caller's, took the SIGINT raised during the solve");
+    check(x[0] != x[0], "no solution is stored by an interrupted solve");
+    raise(SIGINT);
+    check(harness_sigint == 1, "the caller's SIGINT handler is back after osqp_solve");
+    signal(SIGINT, SIG_DFL); signal(SIGALRM, SIG_DFL);
+    /* and the workspace is still usable: back to a terminating configuration, solved from the interrupted iterate */
+    check(update_max_iter(work, 4000) == 0 && update_check(work, 1) == 0, "settings back");
+    solve(work);
+    check(rd_int(hop(work, 208), 40) == OSQP_SOLVED, "a solve after the interrupted one");
   }
   check(cleanup(work) == 0, "osqp_cleanup [REF src/interface.jl:223-233]");
   printf("{\"step\": \"done\", \"failures\": %d}\n", failures);

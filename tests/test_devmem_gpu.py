@@ -67,6 +67,24 @@ def test_mapped_chunk_blocks_give_the_results_of_plain_hipmalloc():
     assert default == plain
 
 
+def test_exhausted_address_space_falls_back_to_hipmalloc_with_the_same_results():
+    """The allocator never reuses a reserved address range (a ROCm re-map defect): a process
+    that sets up large workspaces for long enough runs out of ranges, and from then on large blocks come from hipMalloc.
+    Driven there on purpose -- every buffer >= 1 MiB mapped, the reservation refused after 24 MiB of ranges, i.e. in the
+    middle of the first setup -- the whole setup / solve / update / solve sequence has to give the plain path's bits,
+    and say (once) on stderr that it fell back."""
+    plain = _run({"OSQP_AMD_VMM": "0"})
+    env = dict(os.environ)
+    for key in ("OSQP_AMD_VMM", "OSQP_AMD_VMM_MIN_MB", "OSQP_AMD_POISON", "OSQP_AMD_VMM_VA"):
+        env.pop(key, None)
+    env.update({"OSQP_AMD_VMM_MIN_MB": "1", "OSQP_AMD_POISON": "1", "OSQP_AMD_VMM_VA_LIMIT_MB": "24"})
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ":" in ln]
+    assert lines == plain
+    assert "fall back to hipMalloc" in r.stderr, r.stderr[-500:]
+
+
 CYCLES = r"""
 import sys, os, hashlib
 sys.path.insert(0, sys.argv[1])
