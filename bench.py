@@ -689,9 +689,11 @@ def make_comm(ctx):
 
     if ctx["world"] == 1:
         return None, "none (one rank)"
-    if ctx["backend"] == "gloo":
+    # test hooks: the library's transport chosen apart from torch's backend, and the collective library by path
+    transport = os.environ.get("OSQP_AMD_BENCH_TRANSPORT") or ("host" if ctx["backend"] == "gloo" else "rccl")
+    if transport == "host":
         return sharded.HostComm(lib=ctx["lib"]), "host/gloo"
-    return sharded.RcclComm(lib=ctx["lib"]), "rccl"
+    return sharded.RcclComm(lib=ctx["lib"], librccl_path=os.environ.get("OSQP_AMD_BENCH_RCCL_LIB")), "rccl"
 
 
 def comm_ranks_seen(ctx, comm):
@@ -800,6 +802,8 @@ def batch_leg(ctx, want_cpu, traffic=True):
         elapsed = float(tt.item())
     x, y, info = batch.split_packed(packed.numpy())  # the packed array is the library's own allocation (no torch on this path)
     iters = float(info[:, 0].sum())
+    import hashlib
+    packed_sha16 = hashlib.sha256(packed.numpy().tobytes()).hexdigest()[:16]  # the gathered batch, bit for bit (equal for every world size)
     # every rank must hold the whole batch after the gather: a checksum of checksums over the ranks
     check = torch.tensor([float(x.sum()), float(y.sum()), float(iters)], dtype=torch.float64, device="cuda")
     same = True
@@ -819,6 +823,7 @@ def batch_leg(ctx, want_cpu, traffic=True):
         "instances": BATCH_TOTAL, "instances_per_rank": BATCH_TOTAL // world, "instances_per_s": round(BATCH_TOTAL * steps / elapsed, 1),
         "mean_iters_per_instance": round(iters / BATCH_TOTAL, 2), "solved": int((info[:, 1] == 1).sum()),
         "transport": transport, "comm_ranks_seen": seen, "transport_ranks": transport_ranks(comm), "every_rank_holds_the_whole_batch": bool(same),
+        "packed_sha16": packed_sha16,
         "gather_bytes_per_rank": (BATCH_TOTAL // world) * 304 * 8 * (world - 1),
         "sharding": f"{BATCH_TOTAL // world} instances per GPU (contiguous blocks), one in-place all-gather of [x|y|info] at the end of each solve",
         "roofline": {"bound": "lds", "kernel": "k_batch_quad (one QP per four wavefronts, three per compute unit; the inverse in registers, "
@@ -854,7 +859,7 @@ def batch_line(args, world, rec):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "mpc-batch", "instances": BATCH_TOTAL, "n": 100, "m": 200, "eps_abs": 1e-4, "eps_rel": 1e-4,
                       "sharding": rec["sharding"]}}
-    for k in ("instances_per_s", "mean_iters_per_instance", "solved", "transport", "comm_ranks_seen", "transport_ranks", "every_rank_holds_the_whole_batch", "roofline"):
+    for k in ("instances_per_s", "mean_iters_per_instance", "solved", "transport", "comm_ranks_seen", "transport_ranks", "every_rank_holds_the_whole_batch", "packed_sha16", "roofline"):
         out[k] = rec[k]
     out["cpu_baseline"] = rec.get("cpu_baseline")
     return out

@@ -52,6 +52,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
 }
 
 ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank) {
+  if (getenv("STUB_RCCL_FAIL_INIT")) return ncclSystemError; /* a node whose collective library cannot connect its ranks */
   if (!out || nranks < 1 || rank < 0 || rank >= nranks || id.internal[0] != '/') return ncclInvalidArgument;
   stub_comm *c = (stub_comm *)calloc(1, sizeof(stub_comm));
   c->rank = rank; c->world = nranks;
