@@ -21,6 +21,7 @@
 #include "engine.hpp"
 #include "symbolic.hpp"
 #include "mfront.hpp"
+#include "mfront_big.hpp"
 
 namespace oq {
 
@@ -1482,8 +1483,14 @@ struct LdlFactor {
   DevBuf<int64_t> mf_uoff, mf_reloff;
   DevBuf<uint16_t> mf_rel, mf_loc;
   DevBuf<double> mf_U;
-  struct MfLaunch { int cls, off, count, fcap; };
+  struct MfLaunch { int cls, off, count, fcap; int tile_off = 0, tile_count = 0; };  // cls kMfBig: the fronts beyond LDS (mfront_big.hpp)
   std::vector<MfLaunch> mf_launches;  // in level order
+  DevBuf<int64_t> mf_poff;            // panel scratch of the big fronts
+  DevBuf<double> mf_panel;
+  DevBuf<int> mf_tiles;
+  std::vector<int64_t> mfh_poff;
+  std::vector<int> mfh_tiles;
+  int mf_big_count = 0, mf_big_fmax = 0;
   int mf_fmax = 0;
   bool mf_ok = false;                 // the host plan exists (mf_plan): every front fits LDS
   bool lean_built = false;            // the index arrays of the factor were built on the device (lean_device_*)
@@ -1876,19 +1883,36 @@ struct LdlFactor {
     if (mode == 0) return false;
     const int count = T.count;
     mfh_bsz.assign(count, 0); mfh_snof.assign(N, 0);
-    mfh_uoff.assign(count + 1, 0); mfh_reloff.assign(count + 1, 0);
-    mf_fmax = 0;
+    mfh_uoff.assign(count + 1, 0); mfh_reloff.assign(count + 1, 0); mfh_poff.assign(count + 1, 0);
+    mf_fmax = 0; mf_big_count = 0; mf_big_fmax = 0;
+    mfh_tiles.clear();
+    // tests: OSQP_AMD_MF_MAX_FRONT sends smaller fronts through the global-memory kernels too (the zoo at test sizes has none beyond 192 rows)
+    const int max_front = getenv("OSQP_AMD_MF_MAX_FRONT") ? std::min(kMfMaxFront, std::max(1, atoi(getenv("OSQP_AMD_MF_MAX_FRONT")))) : kMfMaxFront;
+    const bool big_ok = !(getenv("OSQP_AMD_MF_BIG") && atoi(getenv("OSQP_AMD_MF_BIG")) == 0);  // 0: the round-5 behaviour (A/B runs)
     for (int J = 0; J < count; J++) {
       const int top = T.piv[T.ptr[J + 1] - 1], s_ = T.ptr[J + 1] - T.ptr[J];
       const int64_t b = S.Lp[top + 1] - S.Lp[top];
-      if (s_ + b > kMfMaxFront) return false;
+      // (round 6) a front beyond one workgroup's LDS is factorised out of global memory (mfront_big.hpp) instead of sending
+      // the whole matrix back to the level-by-level factorisation; what still does: a front beyond the 16-bit row indices of
+      // `rel` / `loc`, or a supernode of more pivots than the pivot block of that kernel holds
+      if (s_ + b > max_front) {
+        if (s_ + b > 65000 || s_ > kMfbSmax || !big_ok) return false;
+        mf_big_count++;
+        mf_big_fmax = std::max(mf_big_fmax, s_ + (int)b);
+        mfh_poff[J + 1] = (int64_t)(s_ + b) * s_;
+      } else mf_fmax = std::max(mf_fmax, s_ + (int)b);
       mfh_bsz[J] = (int)b;
-      mf_fmax = std::max(mf_fmax, s_ + (int)b);
       mfh_uoff[J + 1] = mfh_uoff[J] + b * (b + 1) / 2;
       mfh_reloff[J + 1] = mfh_reloff[J] + b;
       for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) mfh_snof[T.piv[q]] = J;
     }
-    if (mfh_uoff[count] > ((int64_t)1 << 30)) return false;
+    for (int J = 0; J < count; J++) mfh_poff[J + 1] += mfh_poff[J];
+    {  // the update matrices of all supernodes are resident at once, beside the factor: they have to fit what the device has free
+      size_t free_b = 0, total_b = 0;
+      const int64_t need = 8 * (mfh_uoff[count] + mfh_poff[count]);
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+      if (mfh_uoff[count] > ((int64_t)1 << 32) || (free_b && (double)need > 0.5 * (double)free_b)) return false;
+    }
     mfh_chp.assign(count + 1, 0);
     for (int J = 0; J < count; J++) if (T.up[J] >= 0) mfh_chp[T.up[J] + 1]++;
     for (int J = 0; J < count; J++) mfh_chp[J + 1] += mfh_chp[J];
@@ -1903,8 +1927,11 @@ struct LdlFactor {
     for (int L = 0; L < T.nlev; L++) {
       std::vector<int> cls[kMfClasses];
       int cap[kMfClasses] = {0};
+      std::vector<int> bigs;
+      int bigcap = 0;
       for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
         const int f = T.ptr[J + 1] - T.ptr[J] + mfh_bsz[J];
+        if (f > max_front) { bigs.push_back(J); bigcap = std::max(bigcap, f); continue; }
         int c = 0;
         while (f > kMfClassCap[c]) c++;
         cls[c].push_back(J);
@@ -1927,6 +1954,18 @@ struct LdlFactor {
         mf_launches.push_back({c, (int)mfh_list.size(), (int)cls[c].size(), c < 2 ? kMfClassCap[c] : cap[c]});
         mfh_list.insert(mfh_list.end(), cls[c].begin(), cls[c].end());
       }
+      if (!bigs.empty()) {  // the level's fronts beyond LDS: one panel launch, one launch over the tiles of their update matrices
+        MfLaunch l{kMfBig, (int)mfh_list.size(), (int)bigs.size(), bigcap};
+        l.tile_off = (int)(mfh_tiles.size() / 3);
+        for (int i = 0; i < (int)bigs.size(); i++) {
+          const int nt = (mfh_bsz[bigs[i]] + kMfbTile - 1) / kMfbTile;
+          for (int ti = 0; ti < nt; ti++)
+            for (int tj = 0; tj <= ti; tj++) { mfh_tiles.push_back(i); mfh_tiles.push_back(ti); mfh_tiles.push_back(tj); }
+        }
+        l.tile_count = (int)(mfh_tiles.size() / 3) - l.tile_off;
+        mf_launches.push_back(l);
+        mfh_list.insert(mfh_list.end(), bigs.begin(), bigs.end());
+      }
     }
     return true;
   }
@@ -1934,7 +1973,7 @@ struct LdlFactor {
   // slab of the launch's largest front -- cut at 64 / 80 / 96 / 128 rows so that a few large fronts do not take the occupancy
   // of many mid-size ones (the fronts of a compute unit are as many as their slabs fit its 160 KB of LDS)
   static constexpr int kMfWideCount = 192;  // launches of at most this many workgroup-class fronts give each 1024 threads (the device is not full either way)
-  static constexpr int kMfClasses = 7;
+  static constexpr int kMfClasses = 7, kMfBig = 100;
   static constexpr int kMfClassCap[kMfClasses] = {16, 48, 64, 80, 96, 128, kMfMaxFront};
   void build_mf() {
     mf = false;
@@ -1947,6 +1986,8 @@ struct LdlFactor {
     up32(mf_bsz, mfh_bsz); up32(mf_chp, mfh_chp); up32(mf_chl, mfh_chl); up32(mf_list, mfh_list);
     up64(mf_uoff, mfh_uoff); up64(mf_reloff, mfh_reloff);
     mf_rel.alloc(std::max<int64_t>(1, mfh_reloff[count])); mf_loc.alloc(std::max<int64_t>(1, S.nnzL)); mf_U.alloc(std::max<int64_t>(1, mfh_uoff[count]));
+    up64(mf_poff, mfh_poff); up32(mf_tiles, mfh_tiles);
+    mf_panel.alloc(std::max<int64_t>(1, mfh_poff[count]));
     mf_err.alloc(1); mf_err.zero(s);
     OQ_LAUNCH(k_mf_rel, dim3(blocks_for(count)), dim3(kBlock), 0, s, count, sn_ptr.get(), sn_piv.get(), sn_up.get(), mf_snof.get(), mf_slot.get(),
               Lp.get(), Li.get(), mf_reloff.get(), mf_rel.get(), mf_err.get());
@@ -1960,8 +2001,13 @@ struct LdlFactor {
     const int lds = (int)(mf_slab_doubles(mf_fmax) * sizeof(double));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
-    if (getenv("OSQP_AMD_SETUP_TRACE"))
+    if (mf_big_count)
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_mfb_panel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((int)mfb_panel_lds(mf_big_fmax), 65536)));
+    if (getenv("OSQP_AMD_SETUP_TRACE")) {
       for (const MfLaunch &l : mf_launches) fprintf(stderr, "[fronts] class %d: %d fronts, slab for %d rows\n", l.cls, l.count, l.fcap);
+      fprintf(stderr, "[fronts] beyond LDS: %d fronts (largest %d rows), %.1f MB of panels, update matrices of all fronts %.1f MB\n", mf_big_count,
+              mf_big_fmax, 8e-6 * (double)mfh_poff[count], 8e-6 * (double)mfh_uoff[count]);
+    }
     std::vector<int>().swap(mfh_snof); std::vector<int>().swap(mfh_list); std::vector<int>().swap(mfh_chl);
     mf = true;
   }
@@ -1970,7 +2016,11 @@ struct LdlFactor {
       MfArgs a{mf_list.get() + l.off, l.count, l.fcap, sn_ptr.get(), sn_piv.get(), mf_bsz.get(), mf_uoff.get(), mf_reloff.get(), mf_rel.get(),
                mf_chp.get(), mf_chl.get(), Lp.get(), mf_loc.get(), Lx.get(), D.get(), Dinv.get(), mf_U.get(), status.get(),
                sn_Wc.get(), sn_Wr.get(), sn_woff.get()};
-      if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+      if (l.cls == kMfBig) {
+        MfbArgs g{a, mf_poff.get(), mf_panel.get(), mf_tiles.get() + 3 * (size_t)l.tile_off};
+        OQ_LAUNCH(k_mfb_panel, dim3(l.count), dim3(kMfbPanelThreads), mfb_panel_lds(l.fcap), s, g);
+        if (l.tile_count) OQ_LAUNCH(k_mfb_update, dim3(l.tile_count), dim3(256), 0, s, g);
+      } else if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else if (l.cls == 1) OQ_LAUNCH(k_mf_front<64>, dim3((l.count + 3) / 4), dim3(kMfBlock), 4 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else if (l.count <= kMfWideCount) OQ_LAUNCH(k_mf_front<1024>, dim3(l.count), dim3(1024), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else OQ_LAUNCH(k_mf_front<256>, dim3(l.count), dim3(kMfBlock), mf_slab_doubles(l.fcap) * sizeof(double), s, a);

@@ -174,13 +174,27 @@ struct NestedDissection {
   // tag: the piece a node currently belongs to; dist: the stamp of the last search that reached it (or its local index
   // inside a leaf).  Pieces handled by different threads are disjoint node sets: a thread writes only its own nodes and
   // reads a foreign node's tag at most (never equal to its own: tags are unique), through relaxed atomics.
-  std::vector<int> tag, dist, order;
-  std::atomic<int> next_tag{0}, stamp{0}, spare_threads{0};
+  std::vector<int> tag, dist, order, mark;
+  std::atomic<int> next_tag{0}, stamp{0}, spare_threads{0}, mark_stamp{0};
   int leaf_size;
   size_t parallel_min = (size_t)1 << 62;  // pieces from this size on put their two sides on two threads
 
   NestedDissection(int n, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf)
-      : N(n), xadj(xa), adj(ad), tag(n, -1), dist(n, -1), leaf_size(leaf) {}
+      : N(n), xadj(xa), adj(ad), tag(n, -1), dist(n, -1), mark(n, 0), leaf_size(leaf) {}
+
+  // A level of a level structure separates what lies before it from what lies after it -- but only its nodes that HAVE a
+  // neighbour in the next level are needed for that (George & Liu): the others (on a KKT graph: the constraint rows that
+  // hang off a variable of the level before, pendant nodes among them) join the side before it.  Without this a separator
+  // of a grid QP carried one pendant row per variable, ordered last with it: twice the fill of minimum degree.
+  void trim(const std::vector<int> &level, const std::vector<int> &next_level, std::vector<int> &sep, std::vector<int> &before) {
+    const int st = ++mark_stamp;
+    for (int w : next_level) mark[w] = st;
+    for (int v : level) {
+      bool needed = false;
+      for (int64_t q = xadj[v]; q < xadj[v + 1] && !needed; q++) needed = mark[adj[q]] == st;
+      (needed ? sep : before).push_back(v);
+    }
+  }
 
   int tag_of(int w) const { return __atomic_load_n(&tag[w], __ATOMIC_RELAXED); }
   void set_tag(int v, int t) { __atomic_store_n(&tag[v], t, __ATOMIC_RELAXED); }
@@ -331,8 +345,9 @@ struct NestedDissection {
       before += levels[l].size();
     }
     if (best < 0) best = median;
-    std::vector<int> A, B, Sep = levels[best];
+    std::vector<int> A, B, Sep;
     for (int l = 0; l < best; l++) A.insert(A.end(), levels[l].begin(), levels[l].end());
+    trim(levels[best], levels[best + 1], Sep, A);
     for (int l = best + 1; l < nl; l++) B.insert(B.end(), levels[l].begin(), levels[l].end());
     std::vector<std::vector<int>>().swap(levels);
     std::vector<int>().swap(V);

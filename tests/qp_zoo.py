@@ -116,7 +116,21 @@ def control(nx=8, nu=4, T=30, seed=6):
     return dict(P=P, q=q, A=A, l=np.concatenate([leq, lo]), u=np.concatenate([leq, -lo]))
 
 
-ZOO = {"control": control, "portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
+def grid2d(g=24, seed=7, diag=0.1):
+    """A QP on a g x g grid (a structure the direct back-end was not tuned on: a 2-D graph, no chain to unroll, separators of
+    ~g nodes): P = the 5-point Laplacian + diag * I (a discretised Dirichlet energy), box constraints on every variable
+    (A = I, n = m = g^2), a random load q.  The KKT graph is the grid with one pendant node per variable."""
+    rng = np.random.default_rng(seed)
+    n = g * g
+    T = sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+    P = (sp.kron(sp.eye(g), T) + sp.kron(T, sp.eye(g)) + diag * sp.eye(n)).tocsc()
+    q = rng.standard_normal(n)
+    A = sp.eye(n, format="csc")
+    b = 0.5 + rng.random(n)
+    return dict(P=P, q=q, A=A, l=-b, u=b)
+
+
+ZOO = {"grid2d": grid2d, "control": control, "portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
 
 
 def kkt_check(prob, x, y, eps):

@@ -41,6 +41,7 @@ CASES = {
     "svm": (lambda: qp_zoo.svm(n=20, m=150), 64),
     "random-60": (lambda: _random_problem(np.random.default_rng(5), 60, 90, 0.08), 64),
     "random-200": (lambda: _random_problem(np.random.default_rng(6), 200, 150, 0.02), 24),
+    "grid2d-40": (lambda: qp_zoo.grid2d(40), 64),
 }
 
 
@@ -71,6 +72,41 @@ def test_multifrontal_factor_is_the_level_factor(product_lib, monkeypatch, case)
         assert np.all(np.isfinite(b))
         assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (case, k, np.max(np.abs(a - b)), np.max(np.abs(a)))
     assert np.max(np.abs(sols["1"][0] - sols["1"][1])) > 1e-6  # the rho update did change the factor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_front", [8, 40])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_fronts_beyond_lds_give_the_level_factor(product_lib, monkeypatch, case, max_front):
+    """Round 6: fronts of more rows than one workgroup's LDS holds are factorised out of global memory (csrc/mfront_big.hpp:
+    pivot block in LDS, panel and update matrix in global tiles) instead of sending the whole matrix back to the level-by-level
+    factorisation.  The zoo at test sizes has no front beyond 192 rows, so the threshold is lowered (OSQP_AMD_MF_MAX_FRONT): every
+    front above `max_front` rows -- parents and children of LDS fronts among them -- takes the global-memory path, and the KKT
+    solves must be those of the level-by-level factor, before and after a rho update."""
+    make, smax = CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(12).standard_normal(n + mm)
+    sols = {}
+    for mf in ("0", "1"):
+        monkeypatch.setenv("OSQP_AMD_MF", mf)
+        if mf == "1":
+            monkeypatch.setenv("OSQP_AMD_MF_MAX_FRONT", str(max_front))
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        st = oq.stats(m)
+        assert st[19] >= 1 and st[22] == float(mf == "1"), (st[19], st[22])
+        first = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.731)
+        second = _kkt_solve(m, rhs)
+        sols[mf] = (first, second)
+        oq.clean(m)
+    for k in range(2):
+        a, b = sols["0"][k], sols["1"][k]
+        assert np.all(np.isfinite(b))
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (case, k, np.max(np.abs(a - b)), np.max(np.abs(a)))
 
 
 @pytest.mark.gpu
