@@ -57,6 +57,11 @@ WORKLOADS = {
     # m = 1 666 674): nested dissection + supernodal triangular solves -- the trisolve path on a factor with real fill
     # (nnz(L) = 6.7e7, 519 pivot levels, 11 supernode levels).  Built on the host and handed to osqp_setup as CSC arrays.
     "control-1e6": ("control", 55_555, 0, "direct"),
+    # a 2-D structure the direct back-end was NOT tuned on (tests/qp_zoo.py `grid2d`): P = 5-point Laplacian + 0.1 I on a
+    # 1000 x 1000 grid, box constraints on every variable (A = I): n = m = 1e6.  Separators of ~1000 nodes: fronts of up to
+    # ~2000 rows, far beyond one workgroup's LDS (csrc/mfront_big.hpp).  Built on the host, handed to osqp_setup as CSC arrays.
+    "grid2d-1e6": ("grid", 1000, 0, "direct"),
+    "grid2d-5e5": ("grid", 700, 0, "direct"),
 }
 
 SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25, adaptive_rho_interval=50,
@@ -64,7 +69,7 @@ SETTINGS = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, check_termination=25,
 
 BATCH_TOTAL = 4096
 # the other BASELINE.json configurations, reported beside the headline line (`other_workloads`)
-OTHER_WORKLOADS = ("rand-1e5", "lasso-5e5", "mpc-batch", "control-1e6")
+OTHER_WORKLOADS = ("rand-1e5", "lasso-5e5", "mpc-batch", "control-1e6", "grid2d-1e6")
 CPU_RECORDS = {"rand-1e6": os.path.join(ROOT, "profiles", "r04_cpu_rand1e6.json")}
 CPU_RECORD_WINDOW = (5, 20)  # W, K of the committed CPU record (the driver's protocol)
 
@@ -268,6 +273,14 @@ def build_model(oq, lib, workload, seed, oracle=False):
     if kind == "control":
         # no hint: the library finds the long KKT graph itself and sends nested dissection first (csrc/direct.hip)
         prob = control_problem(n)
+        t0 = time.time()
+        oq.setup(model, linsys_solver="qdldl" if oracle else linsys, **prob, **SETTINGS)
+        return model, int(prob["P"].shape[0]), time.time() - t0
+    if kind == "grid":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import qp_zoo
+
+        prob = qp_zoo.grid2d(n)
         t0 = time.time()
         oq.setup(model, linsys_solver="qdldl" if oracle else linsys, **prob, **SETTINGS)
         return model, int(prob["P"].shape[0]), time.time() - t0

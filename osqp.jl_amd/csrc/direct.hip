@@ -1537,7 +1537,10 @@ struct LdlFactor {
     const bool device_maps = identity && !(getenv("OSQP_AMD_DEVICE_MAPS") && atoi(getenv("OSQP_AMD_DEVICE_MAPS")) == 0);
     S.no_host_maps = device_maps;
     symbolic_analyse(e.hP, e.hA, row_map, mr_, limit, flops_limit, first_ordering == 1 ? 1 : 0, S, lean_try);
-    if (nd_by_depth && (S.too_large || (int)S.level_ptr.size() - 1 > level_limit())) {  // the dissection did not deliver: as before
+    // (the depth that counts for a supernodal factor is that of the SUPERNODE graph -- up to 64 pivots a step -- which is not
+    // known yet: a dissection is only given up here when even that bound is hopeless; grid 1000 x 1000: 3 500 pivot levels, 60
+    // supernode levels)
+    if (nd_by_depth && (S.too_large || (int)S.level_ptr.size() - 1 > 16 * level_limit())) {  // the dissection did not deliver: as before
       first_ordering = 0;
       S = Symbolic();
       S.no_host_maps = device_maps;

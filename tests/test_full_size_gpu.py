@@ -74,6 +74,44 @@ def test_control_1e6_matches_oracle_at_full_size(product_lib, oracle_lib, monkey
     assert np.all((rp.y > -tol) | (Ax - prob["l"] < 20 * eps_pri)) and np.all((rp.y < tol) | (prob["u"] - Ax < 20 * eps_pri))
 
 
+def test_grid2d_700_matches_oracle_at_full_size(product_lib, oracle_lib, monkeypatch):
+    """Round 6: the direct back-end on a structure it was NOT tuned on -- a 700 x 700 grid QP (bench.py `grid2d-5e5`,
+    tests/qp_zoo.py grid2d: n = m = 490 000, a 2-D KKT graph with separators of ~700 nodes).  Up to round 5 one front above
+    192 rows sent the whole factorisation back to two launches per pivot level, and the level-structure dissection carried a
+    pendant constraint row per separator node (twice the fill of minimum degree).  Now: the dissection is the ordering taken
+    (by the graph's depth), its fill is below minimum degree's 1.96e7 entries, the factorisation is the multifrontal one with
+    its large fronts out of global memory (stats[22]), the index arrays are built on the device from a lean host analysis
+    (stats[23]) -- and the solve is the CPU oracle's: same status, the SAME iteration count, x / y to 2e-4 of scale, objective,
+    OSQP's stopping criteria re-evaluated in numpy on the unscaled data."""
+    import qp_zoo
+
+    monkeypatch.delenv("OSQP_AMD_FIRST_ORDERING", raising=False)
+    prob = qp_zoo.grid2d(bench.WORKLOADS["grid2d-5e5"][1])
+    res = []
+    for lib, ls in ((product_lib, "direct"), (oracle_lib, "qdldl")):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver=ls, **prob, **bench.SETTINGS)
+        if lib is product_lib:
+            st = oq.stats(m)
+            assert st[0] == 0 and st[19] > 2  # direct back-end, supernodal solves
+            assert st[22] == 1.0 and st[23] == 1.0, (st[22], st[23])  # multifrontal factorisation, device-built index arrays
+            assert st[4] <= 1.96e7, st[4]  # nnz(L) of the ordering taken: not above minimum degree's
+        res.append(oq.solve(m))
+        if lib is product_lib:  # a rho update refactors [REF src/interface.jl:539-550]: the second solve must still be the oracle's answer
+            oq.update_settings(m, rho=0.3)
+            res.append(oq.solve(m))
+        oq.clean(m)
+    rp, rp2, ro = res
+    assert rp.info.status == ro.info.status == rp2.info.status == "Solved"
+    assert rp.info.iter == ro.info.iter, (rp.info.iter, ro.info.iter)
+    for r in (rp, rp2):
+        assert np.max(np.abs(r.x - ro.x)) <= 2e-4 * max(1.0, np.max(np.abs(ro.x)))
+        assert np.max(np.abs(r.y - ro.y)) <= 2e-4 * max(1.0, np.max(np.abs(ro.y)))
+    assert abs(ro.info.obj_val - rp.info.obj_val) <= 1e-4 * max(1.0, abs(ro.info.obj_val))
+    pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, rp.x, rp.y, 1e-4)
+    assert pri <= 2.0 * eps_pri and dua <= 2.0 * eps_dua, (pri, eps_pri, dua, eps_dua)
+
+
 @pytest.mark.parametrize("name", ["rand-1e5", "lasso-5e5"])
 def test_bench_config_matches_oracle_at_full_size(product_lib, oracle_lib, name):
     kind, n, k, linsys = bench.WORKLOADS[name]
