@@ -7,7 +7,8 @@
 //
 //   k_mfb_panel   one workgroup per front.  The s x s pivot block lives in LDS (assembled, factorised and inverted there
 //                 exactly as mfront.hpp does for a small front); the rows below it -- the b x s panel F21 -- are assembled
-//                 in a global scratch (row-major, s doubles per row) by OWNER-COMPUTES gathers from the children's update
+//                 in a global scratch (column-major: a column of the panel is what the entries of L, the children's columns and the
+//                 lanes of a wavefront walk) by OWNER-COMPUTES gathers from the children's update
 //                 matrices (a per-child inverse map  row of this front -> row of the child  in LDS: every entry is summed
 //                 by one thread, children in ascending order: a fixed order of sums, no atomics), then turned into
 //                 Y = F21 L11^-T = L21 D with the inverted block, written back to the scratch, and scattered to Lx as L21.
@@ -17,17 +18,29 @@
 // Update matrices, `rel` and `loc` are the arrays of mfront.hpp (a big front's parent or child may be a small one).
 #pragma once
 #include "mfront.hpp"
+#include <utility>
 
 namespace oq {
 namespace {
 
+#ifdef OQ_MFB_PROFILE  // experiment build: wall-clock stamps (100 MHz) per phase of k_mfb_panel, printed by launches of one front
+#define MFB_T0 long long mt0 = wall_clock64(), macc[12] = {0};
+#define MFB_T(k) { __syncthreads(); long long mt1 = wall_clock64(); macc[k] += mt1 - mt0; mt0 = mt1; }
+#define MFB_PRINT if (a.count == 1 && tid == 0) printf("mfb f %d s %d children %d: zero %lld scatter %lld narrow %lld wide %lld ldl %lld lx %lld inv %lld w %lld y %lld lxp %lld (x10 ns)\n", f, s, c1 - c0, macc[0], macc[1], macc[2], macc[3], macc[4], macc[5], macc[6], macc[7], macc[8], macc[9]);
+#else
+#define MFB_T0
+#define MFB_T(k)
+#define MFB_PRINT
+#endif
 constexpr int kMfbPanelThreads = 512;
 constexpr int kMfbTile = 64;
 constexpr int kMfbSmax = 64;  // pivots of a big front (the LDS block and the slabs of the update are sized for it)
+constexpr int kMfbRows = 4;   // rows of the panel a wavefront turns into rows of Y at a time
+constexpr int kMfbNarrow = 8, kMfbNarrowU = kMfbNarrow * (kMfbNarrow + 1) / 2;  // children of at most this many border rows are staged in LDS
 
 struct MfbArgs {
   MfArgs a;                   // the arrays of mfront.hpp; a.list / a.count: the big fronts of this launch
-  const int64_t *poff;        // panel scratch of supernode J: panel + poff[J], (s + b) rows of s doubles (rows 0..s-1 unused)
+  const int64_t *poff;        // panel scratch of supernode J: panel + poff[J], s columns of (s + b) doubles (rows 0..s-1 of a column unused)
   double *panel;
   const int *tiles;           // k_mfb_update: (index into a.list, tile row, tile column) per workgroup
 };
@@ -35,12 +48,15 @@ struct MfbArgs {
 // LDS of k_mfb_panel: the pivot block (packed lower triangle of order <= 64, column-major), reciprocal pivots, one row of
 // the panel per wavefront, the inverse maps (16 bits per row of the front)
 __host__ __device__ inline size_t mfb_panel_lds(int fcap) {
-  return sizeof(double) * (kMfbSmax * (kMfbSmax + 1) / 2 + kMfbSmax + (kMfbPanelThreads / 64) * kMfbSmax) + sizeof(uint16_t) * ((size_t)fcap + 8);
+  return sizeof(double) * (kMfbSmax * (kMfbSmax + 1) / 2 + kMfbSmax + (kMfbPanelThreads / 64) * kMfbRows * kMfbSmax + 64 * kMfbNarrowU) + sizeof(uint16_t) * ((size_t)fcap + 8 + 64 * kMfbNarrow);
 }
 
 __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
   extern __shared__ __attribute__((aligned(16))) double mfb_lds[];
   __shared__ int blk_pos, blk_bad;
+  __shared__ int h_bc[64], h_first[64], h_last[64];  // headers of up to 64 children at a time (a separator supernode has one pendant
+  __shared__ long long h_uoff[64], h_roff[64];       // constraint row per pivot among its children: 66 dependent trips to memory otherwise)
+  __shared__ double h_val[64];
   const MfArgs &a = g.a;
   constexpr int TF = kMfbPanelThreads, NWV = TF / 64, RW = 32, CW = TF / RW;
   const int tid = threadIdx.x, wv = tid / 64, ln = tid % 64, ta = tid % RW, tb = tid / RW;
@@ -48,58 +64,137 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
   const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0, b = a.bsz[J], f = s + b;
   double *F = mfb_lds;                                   // pivot block, packed lower triangle of order s
   double *dv = F + kMfbSmax * (kMfbSmax + 1) / 2;        // reciprocal pivots
-  double *xrow = dv + kMfbSmax + wv * kMfbSmax;          // this wavefront's row of the panel
-  uint16_t *inv = (uint16_t *)(dv + kMfbSmax + NWV * kMfbSmax);  // row of this front -> row of the child's border (0xFFFF: none)
+  double *stU = dv + kMfbSmax + NWV * kMfbRows * kMfbSmax;  // [64][kMfbNarrowU]: update matrices of the staged children
+  uint16_t *stR = (uint16_t *)(stU + 64 * kMfbNarrowU);      // [64][kMfbNarrow]: their rows in this front
+  uint16_t *inv = stR + 64 * kMfbNarrow;                      // row of this front -> row of the child's border (0xFFFF: none)
   double *Pn = g.panel + g.poff[J];
   auto cs = [&](int j) { return j * (2 * s - j - 1) / 2; };
+  MFB_T0
   if (tid == 0) { blk_pos = 0; blk_bad = 0; }
   for (int e = tid; e < s * (s + 1) / 2; e += TF) F[e] = 0.0;
-  for (int64_t e = (int64_t)s * s + tid; e < (int64_t)f * s; e += TF) Pn[e] = 0.0;
+  for (int64_t e = tid; e < (int64_t)f * s; e += TF) Pn[e] = 0.0;
   __syncthreads();
+  MFB_T(0)
   // 1. the entries of K in the columns of the supernode: pivot block to LDS, the rest to the panel
-  for (int c = tid / 16; c < s; c += TF / 16) {
+  for (int c = tid / 32; c < s; c += TF / 32) {
     const int k = a.piv[q0 + c], cc = cs(c);
-    if (tid % 16 == 0) F[cc + c] = a.D[k];
-    for (int64_t t = a.Lp[k] + tid % 16; t < a.Lp[k + 1]; t += 16) {
+    if (tid % 32 == 0) F[cc + c] = a.D[k];
+    const int64_t t1 = a.Lp[k + 1];
+    int64_t t = a.Lp[k] + tid % 32;
+    for (; t + 96 < t1; t += 128) {  // four entries of the column in flight per lane
+      const int r0 = a.loc[t], r1 = a.loc[t + 32], r2 = a.loc[t + 64], r3 = a.loc[t + 96];
+      const double v0 = a.Lx[t], v1 = a.Lx[t + 32], v2 = a.Lx[t + 64], v3 = a.Lx[t + 96];
+      if (r0 < s) F[cc + r0] = v0; else Pn[(int64_t)c * f + r0] = v0;
+      if (r1 < s) F[cc + r1] = v1; else Pn[(int64_t)c * f + r1] = v1;
+      if (r2 < s) F[cc + r2] = v2; else Pn[(int64_t)c * f + r2] = v2;
+      if (r3 < s) F[cc + r3] = v3; else Pn[(int64_t)c * f + r3] = v3;
+    }
+    for (; t < t1; t += 32) {
       const int r = a.loc[t];
       if (r < s) F[cc + r] = a.Lx[t];
-      else Pn[(int64_t)r * s + c] = a.Lx[t];
+      else Pn[(int64_t)c * f + r] = a.Lx[t];
     }
   }
   __syncthreads();
+  MFB_T(1)
   // 2. extend-add of the children.  Pivot block: as mfront.hpp (a target column belongs to one wavefront, whose LDS operations
   //    run in program order).  Panel: every entry (row R >= s, column C < s) belongs to one thread, which looks the two rows up
   //    in the child's inverse map.
   const int c0 = a.chp[J], c1 = a.chp[J + 1];
-  for (int ci = c0; ci < c1; ci++) {
-    const int cn = a.chl[ci], bc = a.bsz[cn];
-    const double *Uc = a.U + a.uoff[cn];
-    const uint16_t *rl = a.rel + a.reloff[cn];
-    if (bc == 0) continue;
-    const bool wide = rl[bc - 1] >= s;  // the child reaches rows below the pivot block (rel ascends)
-    if (wide) {
-      for (int R = tid; R < f; R += TF) inv[R] = 0xFFFF;
-      __syncthreads();
-      for (int i = tid; i < bc; i += TF) inv[rl[i]] = (uint16_t)i;
-      __syncthreads();
+  for (int cbase = c0; cbase < c1; cbase += 64) {
+    const int nc = c1 - cbase < 64 ? c1 - cbase : 64;
+    __syncthreads();
+    if (tid < nc) {
+      const int cn = a.chl[cbase + tid], bc = a.bsz[cn];
+      const long long uo = a.uoff[cn], ro = a.reloff[cn];
+      h_bc[tid] = bc; h_uoff[tid] = uo; h_roff[tid] = ro;
+      h_first[tid] = bc ? a.rel[ro] : 0; h_last[tid] = bc ? a.rel[ro + bc - 1] : 0;
+      h_val[tid] = bc == 1 ? a.U[uo] : 0.0;
     }
-    for (int bb = 0; bb < bc; bb++) {
-      const int tc = rl[bb];
-      if (tc >= s) break;
-      if ((tc & (NWV - 1)) != wv) continue;
-      const int cb = cs(tc), ub = bb * (2 * bc - bb - 1) / 2;
-      for (int r = bb + ln; r < bc; r += 64) { const int tr = rl[r]; if (tr < s) F[cb + tr] += Uc[ub + r]; }
-    }
-    if (wide) {
-      for (int64_t e = tid; e < (int64_t)b * s; e += TF) {
-        const int R = s + (int)(e / s), C = (int)(e % s);
-        const unsigned i = inv[R], j = inv[C];
-        if (i != 0xFFFFu && j != 0xFFFFu) Pn[(int64_t)R * s + C] += Uc[(int64_t)j * (2 * bc - j - 1) / 2 + i];
+    __syncthreads();
+    // children of a few border rows, all of them pivots of this front (the leaf subtrees along a separator: ~100 per front, each
+    // 2 - 3 dependent trips to memory when walked from global arrays): rows and update matrices staged in LDS, eight lanes a child
+    {
+      const int k = tid / 8, l = tid % 8;
+      if (k < nc) {
+        const int bc = h_bc[k];
+        if (bc >= 2 && bc <= kMfbNarrow && h_last[k] < s) {
+          if (l < bc) stR[k * kMfbNarrow + l] = a.rel[h_roff[k] + l];
+          for (int e = l; e < bc * (bc + 1) / 2; e += 8) stU[k * kMfbNarrowU + e] = a.U[h_uoff[k] + e];
+        }
       }
-      __syncthreads();  // the map is rewritten for the next child
+    }
+    __syncthreads();
+    // children of ONE border row (a pendant constraint row of a pivot): their single entry goes to the diagonal of their pivot,
+    // summed by the pivot's thread in the order of the children
+    if (tid < s) {
+      double d = F[cs(tid) + tid];
+      for (int k = 0; k < nc; k++) if (h_bc[k] == 1 && h_first[k] == tid) d += h_val[k];
+      F[cs(tid) + tid] = d;
+    }
+    __syncthreads();  // (the diagonal sums)
+    for (int k = 0; k < nc; k++) {  // the staged children: a target column belongs to one wavefront, children in order
+      const int bc = h_bc[k];
+      if (!(bc >= 2 && bc <= kMfbNarrow && h_last[k] < s)) continue;
+      const uint16_t *rl = stR + k * kMfbNarrow;
+      const double *Uc = stU + k * kMfbNarrowU;
+      for (int bb = 0; bb < bc; bb++) {
+        const int tc = rl[bb];
+        if ((tc & (NWV - 1)) != wv) continue;
+        const int r = bb + ln;
+        if (r < bc) F[cs(tc) + rl[r]] += Uc[bb * (2 * bc - bb - 1) / 2 + r];
+      }
+    }
+    MFB_T(2)
+    for (int k = 0; k < nc; k++) {
+      const int bc = h_bc[k];
+      if (bc <= 1 || (bc <= kMfbNarrow && h_last[k] < s)) continue;
+      const double *Uc = a.U + h_uoff[k];
+      const uint16_t *rl = a.rel + h_roff[k];
+      const bool wide = h_last[k] >= s;  // the child reaches rows below the pivot block (rel ascends)
+      __syncthreads();                   // (the diagonal sums above, the previous child's map)
+      if (wide) {
+        for (int R = tid; R < f; R += TF) inv[R] = 0xFFFF;
+        __syncthreads();
+        for (int i = tid; i < bc; i += TF) inv[rl[i]] = (uint16_t)i;
+        __syncthreads();
+      }
+      if (h_first[k] < s)
+        for (int bb = 0; bb < bc; bb++) {
+          const int tc = rl[bb];
+          if (tc >= s) break;
+          if ((tc & (NWV - 1)) != wv) continue;
+          const int cb = cs(tc), ub = bb * (2 * bc - bb - 1) / 2;
+          for (int r = bb + ln; r < bc; r += 64) { const int tr = rl[r]; if (tr < s) F[cb + tr] += Uc[ub + r]; }
+        }
+      if (wide) {  // a wavefront takes eight columns of the panel (their rows of the child looked up once), its lanes the rows: a row's
+                   // place in the child is looked up once per row, the eight gathers and the eight sums of a row are independent
+        unsigned jv[kMfbSmax / NWV];
+        const double *Ucj[kMfbSmax / NWV];
+#pragma unroll
+        for (int qq = 0; qq < kMfbSmax / NWV; qq++) {
+          const int C = wv + NWV * qq;
+          jv[qq] = C < s ? inv[C] : 0xFFFFu;
+          Ucj[qq] = Uc + (int64_t)jv[qq] * (2 * bc - (int64_t)jv[qq] - 1) / 2;
+        }
+        for (int R = s + ln; R < f; R += 64) {
+          const unsigned i = inv[R];
+          if (i == 0xFFFFu) continue;
+          double u[kMfbSmax / NWV], o[kMfbSmax / NWV];
+#pragma unroll
+          for (int qq = 0; qq < kMfbSmax / NWV; qq++) {
+            const bool on = jv[qq] != 0xFFFFu;
+            u[qq] = on ? Ucj[qq][i] : 0.0;
+            o[qq] = on ? Pn[(int64_t)(wv + NWV * qq) * f + R] : 0.0;
+          }
+#pragma unroll
+          for (int qq = 0; qq < kMfbSmax / NWV; qq++) if (jv[qq] != 0xFFFFu) Pn[(int64_t)(wv + NWV * qq) * f + R] = o[qq] + u[qq];
+        }
+      }
     }
   }
   __syncthreads();
+  MFB_T(3)
   // 3. the pivots, right-looking inside the block
   for (int p = 0; p < s; p++) {
     const int cp = cs(p);
@@ -113,6 +208,7 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
     }
     __syncthreads();
   }
+  MFB_T(4)
   // 4. pivots and the block's columns of L to D / Dinv / Lx
   int pos = 0;
   for (int c = tid / 16; c < s; c += TF / 16) {
@@ -122,6 +218,7 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
     for (int64_t t = a.Lp[k] + tid % 16; t < a.Lp[k + 1]; t += 16) { const int r = a.loc[t]; if (r < s) a.Lx[t] = F[cc + r] * dinv; }
   }
   __syncthreads();
+  MFB_T(5)
   // 5. W = L11^-1 in place (mfront.hpp step 6): B = -W below the diagonal
   for (int j = tb; j < s; j += CW) {
     const int cj = cs(j);
@@ -138,6 +235,7 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
     }
     __syncthreads();
   }
+  MFB_T(6)
   if (a.Wc) {
     double *Wc = a.Wc + a.woff[J], *Wr = a.Wr + a.woff[J];
     for (int j = tb; j < s; j += CW) {
@@ -149,31 +247,52 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
       }
     }
   }
+  MFB_T(7)
   // 6. Y = F21 L11^-T = L21 D: row R of the panel times W', one row per wavefront at a time, lane c = column c:
   //    Y(R, c) = x(c) + sum_{k < c} W(c, k) x(k),  W(c, k) = -F[cs(k) + c]
-  for (int R = s + wv; R < f; R += NWV) {
-    double *row = Pn + (int64_t)R * s;
-    if (ln < s) xrow[ln] = row[ln];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (ln < s) {
-      double acc = xrow[ln];
-      for (int k = 0; k < ln; k++) acc -= F[cs(k) + ln] * xrow[k];
-      row[ln] = acc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+  //    A lane keeps ONE row: its s sums in registers, x(k) read once per k (a coalesced read of column k of the panel), the
+  //    coefficients W(c, k) broadcast from LDS.
+  //    Both loops unrolled (k and c compile-time: the sums stay in registers, a coefficient is ONE ds_read at an immediate
+  //    offset from the column's base); columns c >= s of a narrower block are computed on garbage and never stored.
+  for (int R = s + tid; R < f; R += TF) {
+    double acc[kMfbSmax];
+    [&]<int... KS>(std::integer_sequence<int, KS...>) {
+      ([&] {
+        constexpr int K = KS;
+        if (K < s) {
+          const double xk = Pn[(int64_t)K * f + R];
+          const double *Fk = F + cs(K);
+          acc[K] = K == 0 ? xk : acc[K] + xk;
+          [&]<int... CS>(std::integer_sequence<int, CS...>) {
+            ((acc[K + 1 + CS] = K == 0 ? -Fk[K + 1 + CS] * xk : __builtin_fma(-Fk[K + 1 + CS], xk, acc[K + 1 + CS])), ...);
+          }(std::make_integer_sequence<int, kMfbSmax - 1 - K>{});
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, kMfbSmax>{});
+    [&]<int... CS>(std::integer_sequence<int, CS...>) { ((CS < s ? (void)(Pn[(int64_t)CS * f + R] = acc[CS]) : (void)0), ...); }(std::make_integer_sequence<int, kMfbSmax>{});
   }
   __threadfence_block();
   __syncthreads();
+  MFB_T(8)
   // 7. the panel's part of the columns of L
-  for (int c = tid / 16; c < s; c += TF / 16) {
+  for (int c = tid / 32; c < s; c += TF / 32) {
     const int k = a.piv[q0 + c];
     const double dinv = dv[c];
-    for (int64_t t = a.Lp[k] + tid % 16; t < a.Lp[k + 1]; t += 16) { const int r = a.loc[t]; if (r >= s) a.Lx[t] = Pn[(int64_t)r * s + c] * dinv; }
+    const int64_t t1 = a.Lp[k + 1];
+    int64_t t = a.Lp[k] + tid % 32;
+    for (; t + 96 < t1; t += 128) {
+      const int r0 = a.loc[t], r1 = a.loc[t + 32], r2 = a.loc[t + 64], r3 = a.loc[t + 96];
+      const double v0 = r0 >= s ? Pn[(int64_t)c * f + r0] : 0.0, v1 = r1 >= s ? Pn[(int64_t)c * f + r1] : 0.0;
+      const double v2 = r2 >= s ? Pn[(int64_t)c * f + r2] : 0.0, v3 = r3 >= s ? Pn[(int64_t)c * f + r3] : 0.0;
+      if (r0 >= s) a.Lx[t] = v0 * dinv;
+      if (r1 >= s) a.Lx[t + 32] = v1 * dinv;
+      if (r2 >= s) a.Lx[t + 64] = v2 * dinv;
+      if (r3 >= s) a.Lx[t + 96] = v3 * dinv;
+    }
+    for (; t < t1; t += 32) { const int r = a.loc[t]; if (r >= s) a.Lx[t] = Pn[(int64_t)c * f + r] * dinv; }
   }
+  MFB_T(9)
+  MFB_PRINT
   if (pos) atomicAdd(&blk_pos, pos);
   __syncthreads();
   if (tid == 0) {
@@ -198,7 +317,7 @@ __global__ __launch_bounds__(256) void k_mfb_update(MfbArgs g) {
   const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
   const int li = g.tiles[3 * blockIdx.x], ti = g.tiles[3 * blockIdx.x + 1], tj = g.tiles[3 * blockIdx.x + 2];
   const int J = a.list[li];
-  const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0, b = a.bsz[J];
+  const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0, b = a.bsz[J], f = s + b;
   const int r0 = ti * kMfbTile, cc0 = tj * kMfbTile;
   const double *Pn = g.panel + g.poff[J];
   double acc[4][4];
@@ -238,9 +357,9 @@ __global__ __launch_bounds__(256) void k_mfb_update(MfbArgs g) {
     const int np = s - p0 < kMfbPass ? s - p0 : kMfbPass;
     __syncthreads();
     for (int e = tid; e < kMfbTile * np; e += 256) {
-      const int r = e / np, p = e % np;
-      Yr[p][r] = r0 + r < b ? Pn[(int64_t)(s + r0 + r) * s + p0 + p] : 0.0;
-      Yc[p][r] = cc0 + r < b ? Pn[(int64_t)(s + cc0 + r) * s + p0 + p] * a.Dinv[a.piv[q0 + p0 + p]] : 0.0;
+      const int p = e / kMfbTile, r = e % kMfbTile;  // (lanes along the rows: a column of the panel is contiguous)
+      Yr[p][r] = r0 + r < b ? Pn[(int64_t)(p0 + p) * f + s + r0 + r] : 0.0;
+      Yc[p][r] = cc0 + r < b ? Pn[(int64_t)(p0 + p) * f + s + cc0 + r] * a.Dinv[a.piv[q0 + p0 + p]] : 0.0;
     }
     __syncthreads();
     for (int p = 0; p < np; p++) {

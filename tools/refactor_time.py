@@ -1,6 +1,8 @@
 """Wall time of one numeric refactorisation (osqp_update_rho: rho vector, KKT scatter, numeric LDL', inverted blocks) on
 the long-horizon control problem, multifrontal (default) against level by level (OSQP_AMD_MF=0).
-usage: python tools/refactor_time.py [T ...]"""
+usage: python tools/refactor_time.py [T ...]      (control problem of horizon T)
+       python tools/refactor_time.py grid g ...   (g x g grid QP, tests/qp_zoo.py grid2d; the second run of a pair is OSQP_AMD_MF_BIG=0:
+                                                    no fronts out of global memory, i.e. the level-by-level factorisation of round 5)"""
 import os
 import subprocess
 import sys
@@ -15,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import osqp_jl_amd as oq
     import qp_zoo
     T = int(sys.argv[2])
-    prob = qp_zoo.control(nx=12, nu=6, T=T)
+    prob = qp_zoo.grid2d(T) if os.environ.get("REFACTOR_GRID") == "1" else qp_zoo.control(nx=12, nu=6, T=T)
     m = oq.Model(oq.load_library())
     t0 = time.perf_counter()
     oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
@@ -32,6 +34,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         T, prob["P"].shape[0] + prob["A"].shape[0], st[4], st[5], st[19], st[22], setup, 1e3 * ts[len(ts) // 2], 1e3 * ts[0], r.info.status, r.info.iter))
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "grid":
+    for g in [int(a) for a in sys.argv[2:]] or [700]:
+        for big in ("1", "0"):
+            env = dict(os.environ, REFACTOR_GRID="1", OSQP_AMD_MF_BIG=big)
+            subprocess.call([sys.executable, os.path.abspath(__file__), "--child", str(g)], env=env)
+    sys.exit(0)
 for T in [int(a) for a in sys.argv[1:]] or [800, 8000]:
     for mf in ("1", "0"):
         env = dict(os.environ, OSQP_AMD_MF=mf)
