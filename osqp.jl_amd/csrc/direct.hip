@@ -30,1407 +30,16 @@ namespace {
 constexpr int kChainRows = 512;   // levels at most this wide are chained in one workgroup
 constexpr int kChainThreads = 1024;
 
-// ------------------------------------------------------------------ assembly
-__global__ __launch_bounds__(kBlock) void k_diag_init(int N, int n, double sigma, const int *__restrict__ pinv,
-                                                      const double *__restrict__ cdiag, double cconst, double *__restrict__ D) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o >= N) return;
-  D[pinv[o]] = o < n ? sigma : (cdiag ? -cdiag[o - n] : cconst);
-}
-__global__ __launch_bounds__(kBlock) void k_scatter_P(int64_t nnz, const int64_t *__restrict__ PtoL, const int *__restrict__ k2lo,
-                                                      const double *__restrict__ Pfval, double *__restrict__ Lx, double *__restrict__ D) {
-  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= nnz) return;
-  int64_t t = PtoL[k];
-  double v = Pfval[k2lo[k]];
-  if (t >= 0) Lx[t] = v; else D[-t - 1] += v;
-}
-__global__ __launch_bounds__(kBlock) void k_scatter_A(int64_t nnz, const int64_t *__restrict__ AtoL, const double *__restrict__ Atval,
-                                                      double *__restrict__ Lx) {
-  int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= nnz) return;
-  int64_t t = AtoL[k];
-  if (t != INT64_MIN) Lx[t] = Atval[k];
-}
+}  // namespace
+}  // namespace oq
 
-// ------------------------------------------------------------------ K2: numeric LDL'
-// Dot-product form, two launches per level (levels ascending; every column of a level only needs columns of
-// lower levels).  On entry Lx / D hold the entries of K (lower part), on exit L and the pivots.
-//   phase 1, one wavefront per column k:   d_k = K_kk - sum_j L_kj^2 d_j              (row k of L, CSR view; k_ldl_diag_w)
-//   phase 2, one thread per entry (i, k):  L_ik = (K_ik - sum_j L_ij L_kj d_j) / d_k   (merge of rows i and k,
-//            both sorted by column; only j < k can match because row k ends at k)
-// All entries of a column -- and all columns of a level -- are independent, so a dense trailing block
-// exposes (N - k) lanes per column instead of one wavefront walking k updates one after the other.
-__global__ __launch_bounds__(kBlock) void k_ldl_entries(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                        double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                        const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                        const double *__restrict__ D, const double *__restrict__ Dinv,
-                                                        const int *__restrict__ Lcol) {
-  const int64_t e = Lp[c0] + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= Lp[c1]) return;
-  const int k = Lcol[e], i = Li[e];  // the entry's column from a table built once (a bisection in Lp was ~8 dependent loads per entry)
-  int64_t a = Rp[i], ae = Rp[i + 1], b = Rp[k], be = Rp[k + 1];
-  double acc = 0.0;
-  while (a < ae && b < be) {
-    const int ja = Rj[a], jb = Rj[b];
-    if (ja == jb) { acc += Lx[Rmap[a]] * Lx[Rmap[b]] * D[ja]; a++; b++; }
-    else if (ja < jb) a++; else b++;
-  }
-  Lx[e] = (Lx[e] - acc) * Dinv[k];
-}
-// Phase 2 for levels whose rows are long (the dense trailing block behind a few dense constraint rows): the
-// thread-per-entry merge walks 10^4 entries serially.  Instead row k is scattered once into a dense work row
-// w_k[j] = L_kj d_j (k_ldl_wrow, one wavefront per column of the level; fill = 0 clears it again afterwards),
-// and one wavefront per entry (i, k) takes the sparse-times-dense product of row i with w_k: coalesced reads of
-// row i, gathers from a work row that stays in L2.  Only columns below the level contribute (two columns of one
-// level are independent in the elimination tree), which also keeps the waves of a level off each other's output.
-__global__ __launch_bounds__(kBlock) void k_ldl_wrow(int c0, int c1, int N, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                     const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                     const double *__restrict__ D, double *__restrict__ W, int fill) {
-  const int lane = threadIdx.x & 63;
-  const int k = c0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (k >= c1) return;
-  double *w = W + (size_t)(k - c0) * N;
-  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) { const int j = Rj[q]; w[j] = fill ? Lx[Rmap[q]] * D[j] : 0.0; }
-}
-// phase 1 of a level and the work rows of its phase 2 in one launch: one wavefront per column k of [c0, c1) walks row k
-// once for d_k and (Wfill != nullptr) for w_k = L_k,: o d; the wavefronts behind them clear the work rows of the previous
-// such level [p0, p1) in the other half of W (its phase 2 has run: stream order), so a level is two launches, not four.
-__global__ __launch_bounds__(kBlock) void k_ldl_diag_w(int c0, int c1, int N, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                       const int *__restrict__ Rj, const int64_t *__restrict__ Rmap, double *__restrict__ D,
-                                                       double *__restrict__ Dinv, int *__restrict__ status, double *__restrict__ Wfill, int p0,
-                                                       int p1, double *__restrict__ Wclear) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  if (wv < c1 - c0) {
-    const int k = c0 + (int)wv;
-    double *w = Wfill ? Wfill + (size_t)(k - c0) * N : nullptr;
-    double acc = 0.0;
-    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) {
-      const int j = Rj[q];
-      const double l = Lx[Rmap[q]], d = D[j];
-      acc += l * l * d;  // (l l) d, the order of the oracle's column update: pivots agree to the last bit on short rows
-      if (w) w[j] = l * d;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) {
-      const double dk = D[k] - acc;
-      const bool bad = (dk == 0.0) || (dk != dk);
-      D[k] = dk; Dinv[k] = 1.0 / dk;
-      if (bad) atomicOr(&status[0], 1);
-      else if (dk > 0.0) atomicAdd(&status[1], 1);
-    }
-  } else if (wv < (int64_t)(c1 - c0) + (p1 - p0)) {
-    const int k = p0 + (int)(wv - (c1 - c0));
-    double *w = Wclear + (size_t)(k - p0) * N;
-    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) w[Rj[q]] = 0.0;
-  }
-}
-// phase 1 for levels of SHORT rows (no work rows involved): G lanes per column instead of a wavefront -- a level of 10^6
-// columns with two entries each (the constraint rows of a lasso / box-constrained problem) is 10^6 wavefronts of which 62
-// lanes idle in k_ldl_diag_w: 2.9 ms per factorisation on lasso-5e5 where the whole ADMM iteration takes 31 us.  G = 1 adds
-// the terms in column order, the order of the oracle's update.
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_ldl_diag_g(int c0, int c1, const double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                       const int *__restrict__ Rj, const int64_t *__restrict__ Rmap, double *__restrict__ D,
-                                                       double *__restrict__ Dinv, int *__restrict__ status) {
-  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
-  const int lane = threadIdx.x & (G - 1);
-  const bool live = g < c1 - c0;
-  const int k = c0 + (int)(live ? g : 0);
-  double acc = 0.0;
-  if (live)
-    for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += G) {
-      const double l = Lx[Rmap[q]];
-      acc += l * l * D[Rj[q]];
-    }
-#pragma unroll
-  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (live && lane == 0) {
-    const double dk = D[k] - acc;
-    const bool bad = (dk == 0.0) || (dk != dk);
-    D[k] = dk; Dinv[k] = 1.0 / dk;
-    if (bad) atomicOr(&status[0], 1);
-    else if (dk > 0.0) atomicAdd(&status[1], 1);
-  }
-}
-// The same entries with a WAVEFRONT each and no work rows: the lanes take the entries of the shorter of the two rows and
-// look each column up in the longer one by bisection -- ~log2(length) dependent loads per lane where the thread-per-entry
-// merge walks both rows (2 x 300 dependent loads per entry on the separators of a nested-dissection tree).  For levels whose
-// rows are long but whose work rows (one dense N-vector per column) would not fit: control-1e6 has hundreds of separator
-// columns per level at N = 2.7e6 (0.47 ms per level with the merge).
-template <int G>  // lanes per entry: 64 on narrow levels (all latency), 16 on wide ones
-__global__ __launch_bounds__(kBlock) void k_ldl_entries_bs(int c0, int c1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                           double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                           const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                           const double *__restrict__ D, const double *__restrict__ Dinv,
-                                                           const int *__restrict__ Lcol) {
-  const int lane = threadIdx.x & (G - 1);
-  const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
-  const bool live = e < Lp[c1];  // all lanes of a group agree; dead groups still take part in the shuffles
-  double acc = 0.0;
-  int k = c0;
-  if (live) {
-    k = Lcol[e];
-    const int i = Li[e];
-    int64_t a0 = Rp[i], a1 = Rp[i + 1], b0 = Rp[k], b1 = Rp[k + 1];
-    if (a1 - a0 > b1 - b0) { int64_t t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }  // [a0, a1): the shorter row
-    for (int64_t q = a0 + lane; q < a1; q += G) {
-      const int j = Rj[q];
-      if (j >= k) break;  // row i holds columns up to i > k; only those below k meet row k
-      int64_t l = b0, h = b1;
-      while (l < h) { const int64_t mid = (l + h) >> 1; if (Rj[mid] < j) l = mid + 1; else h = mid; }
-      if (l < b1 && Rj[l] == j) acc += Lx[Rmap[q]] * Lx[Rmap[l]] * D[j];
-    }
-  }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (live && lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
-}
-__global__ __launch_bounds__(kBlock) void k_ldl_entries_w(int c0, int c1, int N, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                          double *__restrict__ Lx, const int64_t *__restrict__ Rp,
-                                                          const int *__restrict__ Rj, const int64_t *__restrict__ Rmap,
-                                                          const double *__restrict__ W, const double *__restrict__ Dinv,
-                                                          const int *__restrict__ Lcol) {
-  const int lane = threadIdx.x & 63;
-  const int64_t e = Lp[c0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (e >= Lp[c1]) return;
-  const int k = Lcol[e], i = Li[e];
-  const double *w = W + (size_t)(k - c0) * N;
-  double acc = 0.0;
-  for (int64_t q = Rp[i] + lane; q < Rp[i + 1]; q += 64) {
-    const int j = Rj[q];
-    if (j >= c0) break;  // columns ascending: nothing below the level is left (for any lane at or after this one)
-    acc += Lx[Rmap[q]] * w[j];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) Lx[e] = (Lx[e] - acc) * Dinv[k];
-}
-// ------------------------------------------------------------------ dense top block
-// The top of the elimination tree of a problem with a few dense rows / columns (a budget constraint, a factor
-// model, a data matrix) is a dense block: every pivot its own level, rows as long as the block.  Its triangular
-// solves are a chain of k dependent steps forward and k backward whatever the kernel.  So the last kD pivots are
-// not factorised at all: their Schur complement S0 = K22 - L21 D1 L21' is assembled as a dense kD x kD array,
-// inverted once per factorisation by kD Gauss-Jordan sweeps (two per launch, ping-pong buffers, the pivots
-// are the same Schur complements LDL' would meet, so the inertia count is unchanged), and a solve replaces both
-// chains by one dense product x2 = S0^-1 (b2 - L21 y1).
-// wave per entry (i, k) of columns [b0, b1) of L's pattern inside the block; the work rows w_k hold L_kj d_j (k_ldl_wrow)
-__global__ __launch_bounds__(kBlock) void k_dense_entries(int b0, int b1, int cD, int kD, int ld, int N, const int64_t *__restrict__ Lp,
-                                                          const int *__restrict__ Li, const double *__restrict__ Lx,
-                                                          const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                          const int64_t *__restrict__ Rmap, const double *__restrict__ W,
-                                                          double *__restrict__ S0) {
-  const int lane = threadIdx.x & 63;
-  const int64_t e = Lp[b0] + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (e >= Lp[b1]) return;
-  int lo = b0, hi = b1;
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (Lp[mid] <= e) lo = mid; else hi = mid; }
-  const int k = lo, i = Li[e];
-  const double *w = W + (size_t)(k - b0) * N;
-  double acc = 0.0;
-  for (int64_t q = Rp[i] + lane; q < Rp[i + 1]; q += 64) {
-    const int j = Rj[q];
-    if (j >= cD) break;
-    acc += Lx[Rmap[q]] * w[j];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) {
-    const double v = Lx[e] - acc;
-    S0[(size_t)(i - cD) + (size_t)(k - cD) * ld] = v;
-    S0[(size_t)(k - cD) + (size_t)(i - cD) * ld] = v;
-  }
-}
-// wave per column k of [b0, b1): diagonal of the Schur complement
-__global__ __launch_bounds__(kBlock) void k_dense_diag(int b0, int b1, int cD, int kD, int ld, int N, const double *__restrict__ Lx,
-                                                       const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                       const int64_t *__restrict__ Rmap, const double *__restrict__ D,
-                                                       const double *__restrict__ W, double *__restrict__ S0) {
-  const int lane = threadIdx.x & 63;
-  const int k = b0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (k >= b1) return;
-  const double *w = W + (size_t)(k - b0) * N;
-  double acc = 0.0;
-  for (int64_t q = Rp[k] + lane; q < Rp[k + 1]; q += 64) {
-    const int j = Rj[q];
-    if (j >= cD) break;
-    acc += Lx[Rmap[q]] * w[j];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) S0[(size_t)(k - cD) * (ld + 1)] = D[k] - acc;
-}
-// one Gauss-Jordan sweep on pivot p, out of place (no ordering between the threads of a launch is needed)
-__global__ __launch_bounds__(kBlock) void k_dense_sweep(int kD, int p, const double *__restrict__ Sold, double *__restrict__ Snew,
-                                                        int *__restrict__ status) {
-  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= (int64_t)kD * kD) return;
-  const int i = (int)(idx % kD), j = (int)(idx / kD);
-  const double piv = Sold[(size_t)p * (kD + 1)];
-  const double ip = 1.0 / piv;
-  const double aip = Sold[(size_t)i + (size_t)p * kD], apj = Sold[(size_t)p + (size_t)j * kD];
-  double v;
-  if (i == p && j == p) v = -ip;
-  else if (i == p) v = apj * ip;
-  else if (j == p) v = aip * ip;
-  else v = Sold[idx] - aip * apj * ip;
-  Snew[idx] = v;
-  if (idx == 0) {
-    if (piv == 0.0 || piv != piv) atomicOr(&status[0], 1);
-    else if (piv > 0.0) atomicAdd(&status[1], 1);
-  }
-}
-// Two consecutive sweeps (pivots p, then q = p + 1) in one pass over the array: every thread recomputes the four
-// once-swept values its element needs (S'_ij, S'_iq, S'_qj, S'_qq) with the very expressions of k_dense_sweep, so
-// the result is bit-identical to two launches at half the traffic.  (A block sweep through the inverse of the 2 x 2
-// pivot block is NOT: on the quasi-definite Schur complement that block can be badly conditioned -- sigma next to a
-// large off-diagonal -- and the feasibility test of the reference lost its accuracy with it.)
-__device__ __forceinline__ double sweep_value(bool row_p, bool col_p, double xij, double xip, double xpj, double ip) {
-  if (row_p && col_p) return -ip;
-  if (row_p) return xpj * ip;
-  if (col_p) return xip * ip;
-  return xij - xip * xpj * ip;
-}
-__global__ __launch_bounds__(kBlock) void k_dense_sweep2(int kD, int p, const double *__restrict__ Sold, double *__restrict__ Snew,
-                                                         int *__restrict__ status) {
-  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= (int64_t)kD * kD) return;
-  const int i = (int)(idx % kD), j = (int)(idx / kD), q = p + 1;
-  const size_t cp = (size_t)p * kD, cq = (size_t)q * kD, cj = (size_t)j * kD;
-  const double piv = Sold[cp + p], ip = 1.0 / piv;
-  const double sip = Sold[cp + i], spj = Sold[cj + p], siq = Sold[cq + i], sqj = Sold[cj + q];
-  const double spq = Sold[cq + p], sqp = Sold[cp + q], sqq = Sold[cq + q];
-  // after the first sweep
-  const double t_ij = sweep_value(i == p, j == p, Sold[idx], sip, spj, ip);
-  const double t_iq = sweep_value(i == p, false, siq, sip, spq, ip);
-  const double t_qj = sweep_value(false, j == p, sqj, sqp, spj, ip);
-  const double piv2 = sqq - sqp * spq * ip, ip2 = 1.0 / piv2;
-  Snew[idx] = sweep_value(i == q, j == q, t_ij, t_iq, t_qj, ip2);
-  if (idx == 0) {
-    if (piv == 0.0 || piv != piv || piv2 == 0.0 || piv2 != piv2) atomicOr(&status[0], 1);
-    else atomicAdd(&status[1], (piv > 0.0 ? 1 : 0) + (piv2 > 0.0 ? 1 : 0));
-  }
-}
-// x2 = -(S v) with S = -S0^-1 as the sweeps leave it (symmetric: row a is read as column a, contiguous); wave per row
-// The same product from the LOWER triangle of the (symmetric) array alone: half the bytes of what is the iteration of a dense-P
-// problem (6000 pivots: 288 MB per product, 60 us of a 106 us iteration).  A workgroup per 64 x 64 tile (rb, cb), rb >= cb,
-// brought to LDS with full-width loads (lane = row: 512 contiguous bytes per wavefront load, 16 in flight per lane); from LDS
-// thread c adds up S(b, c) v[b] over the tile's rows (its share of out[column block cb]) and thread b adds up S(b, c) v[c] over
-// the tile's columns (the mirrored entries: its share of out[row block rb]; not for a diagonal tile, whose both halves are in
-// the tile).  The shares go to two [blocks x blocks x 64] buffers and k_dense_sym_reduce adds them up in a fixed order.
-constexpr int kDsT = 64;
-__global__ __launch_bounds__(256) void k_dense_apply_sym(int kD, int ld, int nb, const double *__restrict__ S, const double *__restrict__ v,
-                                                         double *__restrict__ P1, double *__restrict__ P2) {
-  __shared__ double tile[kDsT][kDsT + 1];
-  __shared__ double vr[kDsT], vc[kDsT], part[4][kDsT];
-  // tile t of the lower triangle, row by row: rb (rb + 1) / 2 + cb
-  const int t = blockIdx.x;
-  int rb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((rb + 1) * (rb + 2) / 2 <= t) rb++;
-  while (rb * (rb + 1) / 2 > t) rb--;
-  const int cb = t - rb * (rb + 1) / 2;
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  {
-    const double *base = S + (size_t)(cb * kDsT) * ld + (size_t)rb * kDsT + lane;
-    double w[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = base[(size_t)(wv * 16 + i) * ld];
-    if (wv == 0) { const int g = rb * kDsT + lane; vr[lane] = g < kD ? v[g] : 0.0; }
-    if (wv == 1) { const int g = cb * kDsT + lane; vc[lane] = g < kD ? v[g] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < 16; i++) tile[wv * 16 + i][lane] = w[i];  // tile[c][b] = S(row rb*64 + b, column cb*64 + c)
-  }
-  __syncthreads();
-  const int half = (tid >> 6) & 1;
-  double acc = 0.0;
-  if (tid < 128) {  // column sums: thread c over the rows b of its half
-    for (int b = 32 * half; b < 32 * half + 32; b++) acc += tile[lane][b] * vr[b];
-  } else {          // row sums: thread b over the columns c of its half
-    for (int c = 32 * half; c < 32 * half + 32; c++) acc += tile[c][lane] * vc[c];
-  }
-  part[wv][lane] = acc;
-  __syncthreads();
-  if (wv == 0) P1[((size_t)cb * nb + rb) * kDsT + lane] = part[0][lane] + part[1][lane];
-  else if (wv == 2 && rb != cb) P2[((size_t)rb * nb + cb) * kDsT + lane] = part[2][lane] + part[3][lane];
-}
-// out[a] = -(sum over the tiles below and on the diagonal of a's column block + sum over the tiles left of the diagonal of a's
-// row block), the four wavefronts of a workgroup taking every fourth term, met in a fixed order
-__global__ __launch_bounds__(256) void k_dense_sym_reduce(int kD, int nb, const double *__restrict__ P1, const double *__restrict__ P2,
-                                                          double *__restrict__ out) {
-  __shared__ double part[4][kDsT];
-  const int B = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double acc = 0.0;
-  // terms 0 .. nb - B - 1: P1[B][B + j]; then B terms P2[B][j]
-  const int n1 = nb - B, n = n1 + B;
-  int j = wv;
-  for (; j + 12 < n; j += 16) {
-    double x[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int jj = j + 4 * u;
-      x[u] = jj < n1 ? P1[((size_t)B * nb + B + jj) * kDsT + lane] : P2[((size_t)B * nb + (jj - n1)) * kDsT + lane];
-    }
-    acc += x[0]; acc += x[1]; acc += x[2]; acc += x[3];
-  }
-  for (; j < n; j += 4) acc += j < n1 ? P1[((size_t)B * nb + B + j) * kDsT + lane] : P2[((size_t)B * nb + (j - n1)) * kDsT + lane];
-  part[wv][lane] = acc;
-  __syncthreads();
-  const int a = B * kDsT + lane;
-  if (wv == 0 && a < kD) out[a] = -((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-}
-__global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, int ld, const double *__restrict__ S, const double *__restrict__ v,
-                                                        double *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int a = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (a >= kD) return;
-  const double *col = S + (size_t)a * ld;
-  double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;  // four loads in flight per lane (a 6000-row block: 94 rounds of one)
-  int b = lane;
-  for (; b + 192 < kD; b += 256) { acc += col[b] * v[b]; acc1 += col[b + 64] * v[b + 64]; acc2 += col[b + 128] * v[b + 128]; acc3 += col[b + 192] * v[b + 192]; }
-  for (; b < kD; b += 64) acc += col[b] * v[b];
-  acc = (acc + acc1) + (acc2 + acc3);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) out[a] = -acc;
-}
-// ---- the same inverse by BLOCK sweeps on the fp64 matrix cores (blocks of kGjK pivots; large dense blocks) -----------
-// With B the pivot indices of a step, G = S_BB^-1, the kGjK single sweeps of the block amount to
-//   S_RR <- S_RR - S_RB G S_BR,   S_BR <- G S_BR (and its mirror),   S_BB <- -G
-// i.e. one rank-kGjK update of the whole array -- v_mfma_f64_16x16x4_f64 -- instead of kGjK passes over it: the array
-// (288 MB at 6000 pivots) is read and written once per 32 pivots, n^3 multiply-adds at matrix-core rate.  Three launches
-// per step: (1) one workgroup sweeps the pivot block by itself, pivot by pivot (the pivots are the ones the single sweeps
-// and LDL' would meet: inertia and zero-pivot checks unchanged), leaving T = -G; (2) the row panel W = G S_B: (kGjK x ld)
-// and a copy C of S_B: as it was; (3) the update of the tiles on and below the diagonal, each written to both triangles
-// through an LDS transposition, so that the array stays bit-symmetric.  The array is padded to a multiple of 64 (identity
-// on the padding: its sweeps change nothing).
-// Round 5: blocks of 64 pivots (32 before): half the passes over the array, twice the matrix-core work per tile load; the
-// pivot block -- the one serial piece of a step, a single workgroup -- is swept by 1024 threads (four elements each per pivot).
-constexpr int kGjK = 64, kGjPivotThreads = 1024;
-__global__ __launch_bounds__(kGjPivotThreads) void k_gj_pivot(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
-                                                              int *__restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) double gj_lds[];
-  double (*buf)[kGjK][kGjK + 1] = (double (*)[kGjK][kGjK + 1])gj_lds;  // [2][kGjK][kGjK + 1]
-  const int t = threadIdx.x;
-  for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) { const int i = e % kGjK, j = e / kGjK; buf[0][i][j] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
-  __syncthreads();
-  int cur = 0, pos = 0, bad = 0;
-  for (int p = 0; p < kGjK; p++) {
-    const double piv = buf[cur][p][p], ip = 1.0 / piv;
-    for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) {
-      const int i = e % kGjK, j = e / kGjK;
-      buf[cur ^ 1][i][j] = sweep_value(i == p, j == p, buf[cur][i][j], buf[cur][i][p], buf[cur][p][j], ip);
-    }
-    if (p0 + p < kD) { if (piv == 0.0 || piv != piv) bad = 1; else if (piv > 0.0) pos++; }
-    cur ^= 1;
-    __syncthreads();
-  }
-  for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = buf[cur][i][j]; }
-  if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
-}
-// thread per column j of the array: W[k][j] = sum_l G[k][l] S[p0 + l][j], C[k][j] = S[p0 + k][j]  (G = -T)
-__global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *__restrict__ S, const double *__restrict__ T,
-                                                  double *__restrict__ Wp, double *__restrict__ Cp) {
-  __shared__ double G[kGjK][kGjK];
-  for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e % kGjK][e / kGjK] = -T[e];
-  __syncthreads();
-  // 64 columns per workgroup, its four wavefronts a quarter of the panel's rows each (round 5: a thread per column and all
-  // kGjK rows left the 6000-column panel of equality_qp on 24 compute units, 86 us per step)
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
-  if (j >= ld) return;
-  double s[kGjK];
-  // element (p0 + l, j) from the LOWER triangle (round 5: the sweeps keep only that one current, the mirror is written once at
-  // the end): its own place for j <= p0 + l, the place of (j, p0 + l) otherwise -- which is also the contiguous read
-  auto at = [&](int r) -> double { return j <= r ? S[(size_t)r + (size_t)j * ld] : S[(size_t)j + (size_t)r * ld]; };
-#pragma unroll
-  for (int l = 0; l < kGjK; l++) s[l] = at(p0 + l);
-#pragma unroll 4
-  for (int k = kq * (kGjK / 4); k < (kq + 1) * (kGjK / 4); k++) {
-    double w = 0.0;
-#pragma unroll
-    for (int l = 0; l < kGjK; l++) w = __builtin_fma(G[k][l], s[l], w);
-    Wp[(size_t)k * ld + j] = w;
-    Cp[(size_t)k * ld + j] = at(p0 + k);  // (from the cache: s[k] with a run-time k would be a scratch access)
-  }
-}
-typedef double gj_d4 __attribute__((ext_vector_type(4)));
-// workgroup (I, J), I >= J: the 64 x 64 tile of rows I, columns J and its mirror; wavefront w its 32 x 32 quadrant
-__global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__restrict__ S, const double *__restrict__ T,
-                                                   const double *__restrict__ Wp, const double *__restrict__ Cp) {
-  const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
-  __shared__ double tr[4][16][17];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1;
-  if (I == J && wi < wj) return;  // the upper quadrant of a diagonal tile is the mirror of the lower one
-  const int lr = lane >> 4, lc = lane & 15;
-  const int r0 = I * 64 + wi * 32, c0 = J * 64 + wj * 32;  // rows r0 .. r0 + 32, columns c0 .. c0 + 32
-  const bool rowsB = I * 64 == p0, colsB = J * 64 == p0;   // the pivot block is one 64 x 64 tile (64 pivots, 64-aligned)
-#pragma unroll
-  for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-    for (int tj = 0; tj < 2; tj++) {
-      const int ri = r0 + ti * 16, cj = c0 + tj * 16;
-      if (ri < cj) continue;  // above the diagonal inside a diagonal quadrant: written by its mirror
-      gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
-      double nv[4];
-      if (!rowsB && !colsB) {
-#pragma unroll
-        for (int kk = 0; kk < kGjK / 4; kk++) {
-          const double aop = Wp[(size_t)(4 * kk + lr) * ld + cj + lc];  // A[m = lane & 15][k = lane >> 4] = W[k][cj + m]
-          const double bop = Cp[(size_t)(4 * kk + lr) * ld + ri + lc];  // B[k = lane >> 4][n = lane & 15] = C[ri + n][k]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) nv[r] = S[(size_t)(ri + lc) + (size_t)(cj + lr + 4 * r) * ld] - acc[r];  // D[m = lr + 4 r][n = lc]
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = ri + lc, j = cj + lr + 4 * r;
-          nv[r] = (rowsB && colsB) ? T[(i - p0) + (j - p0) * kGjK] : (rowsB ? Wp[(size_t)(i - p0) * ld + j] : Wp[(size_t)(j - p0) * ld + i]);
-        }
-      }
-      // both triangles: the tile as computed (rows contiguous across the lanes) and its transpose through LDS
-#pragma unroll
-      for (int r = 0; r < 4; r++) tr[w][lr + 4 * r][lc] = nv[r];  // tr[column offset][row offset]
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes before its reads (one wavefront per slab)
-      if (ri == cj) {  // a diagonal 16 x 16 tile: the lower triangle decides
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int m = lr + 4 * r; if (lc < m) nv[r] = tr[w][lc][m]; }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) S[(size_t)(ri + lc) + (size_t)(cj + lr + 4 * r) * ld] = nv[r];
-      if (ri != cj && I == J) {  // the mirror only inside a diagonal 64 x 64 tile (the pivot kernel reads those whole); the rest of
-                                 // the upper triangle is written once, when the sweeps are done (k_gj_mirror)
-#pragma unroll
-        for (int r = 0; r < 4; r++) S[(size_t)(cj + lc) + (size_t)(ri + lr + 4 * r) * ld] = tr[w][lc][lr + 4 * r];  // S[j][i] = value of (i, j)
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
-}
-// ---- the Schur complement of a LARGE dense block on the matrix cores (round 5) ---------------------------------------------
-// S0 = K22 - L21 D1 L21' entry by entry is a sparse dot product per entry of the block (k_dense_entries: 3.6e7 wavefronts for
-// the 6000-pivot block of equality_qp, 22 ms -- as much as the whole inversion).  When L21 is not very sparse the same sum is
-// a symmetric rank-k update: 64 columns of L at a time are spread out as dense 64 x ld panels (W = the column times its pivot,
-// C = the column) and k_gj_update -- the rank-64 matrix-core update of the block sweeps, with no pivot block (p0 = -64) --
-// subtracts W' C from the array; S0 starts as K22.  The zeros it multiplies are cheaper than the gathers they replace.
-__global__ __launch_bounds__(kBlock) void k_dense_init(int cD, int N, int ld, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                       const int *__restrict__ Lcol, const double *__restrict__ Lx,
-                                                       const double *__restrict__ D, double *__restrict__ S0) {
-  const int64_t e = Lp[cD] + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e < Lp[N]) {
-    const int k = Lcol[e] - cD, i = Li[e] - cD;
-    const double v = Lx[e];
-    S0[(size_t)i + (size_t)k * ld] = v;
-    S0[(size_t)k + (size_t)i * ld] = v;
-  }
-  const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (d < N - cD) S0[(size_t)d * (ld + 1)] = D[cD + d];
-}
-// wavefront w of the launch: column cols[c0 + w] of L, its entries in the rows of the block into row w of the two panels
-__global__ __launch_bounds__(kBlock) void k_dense_chunk(int c0, int ncols, int cD, int ld, const int *__restrict__ cols,
-                                                        const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                        const double *__restrict__ Lx, const double *__restrict__ D,
-                                                        double *__restrict__ Wp, double *__restrict__ Cp) {
-  const int lane = threadIdx.x & 63, w = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-  if (w >= kGjK || c0 + w >= ncols) return;
-  const int j = cols[c0 + w];
-  const double dj = D[j];
-  for (int64_t e = Lp[j] + lane; e < Lp[j + 1]; e += 64) {
-    const int i = Li[e];
-    if (i < cD) continue;
-    const double v = Lx[e];
-    Wp[(size_t)w * ld + (i - cD)] = v * dj;
-    Cp[(size_t)w * ld + (i - cD)] = v;
-  }
-}
-// upper triangle := transpose of the lower one, tile by tile through LDS (both sides contiguous)
-__global__ __launch_bounds__(256) void k_gj_mirror(int ld, double *__restrict__ S) {
-  const int I = blockIdx.y, J = blockIdx.x;
-  if (J >= I) return;
-  __shared__ double tile[64][65];
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) { const int r = e & 63, c = e >> 6; tile[c][r] = S[(size_t)(I * 64 + r) + (size_t)(J * 64 + c) * ld]; }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) { const int r = e & 63, c = e >> 6; S[(size_t)(J * 64 + r) + (size_t)(I * 64 + c) * ld] = tile[r][c]; }
-}
-__global__ __launch_bounds__(kBlock) void k_gj_pad(int kD, int ld, double *__restrict__ S) {
-  const int i = kD + blockIdx.x * kBlock + threadIdx.x;
-  if (i < ld) S[(size_t)i * (ld + 1)] = 1.0;
-}
-__global__ __launch_bounds__(kBlock) void k_gather_csr(int64_t nnz, const int64_t *__restrict__ Rmap, const double *__restrict__ Lx,
-                                                       double *__restrict__ Rx) {
-  int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q < nnz) Rx[q] = Lx[Rmap[q]];
-}
+#include "direct_factor_kernels.hpp"
+#include "direct_dense_kernels.hpp"
+#include "direct_level_kernels.hpp"
+#include "direct_sn_kernels.hpp"
 
-// sum of val[q] * b[idx[q]] over q = q0, q0 + stride, ... < q1: four gathers in flight per lane, added in the order of the plain
-// loop (a plain loop is one dependent index -> value round trip per entry)
-__device__ __forceinline__ double gather_dot(int64_t q0, int64_t q1, int stride, const int *__restrict__ idx, const double *__restrict__ val,
-                                             const double *b) {
-  double acc = 0.0;
-  int64_t q = q0;
-  for (; q + 3 * (int64_t)stride < q1; q += 4 * (int64_t)stride) {
-    const int j0 = idx[q], j1 = idx[q + stride], j2 = idx[q + 2 * (int64_t)stride], j3 = idx[q + 3 * (int64_t)stride];
-    const double x0 = val[q], x1 = val[q + stride], x2 = val[q + 2 * (int64_t)stride], x3 = val[q + 3 * (int64_t)stride];
-    const double b0 = b[j0], b1 = b[j1], b2 = b[j2], b3 = b[j3];
-    acc += x0 * b0; acc += x1 * b1; acc += x2 * b2; acc += x3 * b3;
-  }
-  for (; q < q1; q += stride) acc += val[q] * b[idx[q]];
-  return acc;
-}
-// ------------------------------------------------------------------ K3 / K4: level-scheduled triangular solves
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_fwd_level(int r0, int r1, const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                      const double *__restrict__ Rx, double *__restrict__ b) {
-  const int lane = threadIdx.x & (G - 1);
-  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
-  if (row >= r1) return;
-  double acc = gather_dot(Rp[row] + lane, Rp[row + 1], G, Rj, Rx, b);
-#pragma unroll
-  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) b[row] -= acc;
-}
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_bwd_level(int r0, int r1, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                      const double *__restrict__ Lx, const double *__restrict__ Dinv,
-                                                      double *__restrict__ b) {
-  const int lane = threadIdx.x & (G - 1);
-  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / G);
-  if (row >= r1) return;
-  double acc = gather_dot(Lp[row] + lane, Lp[row + 1], G, Li, Lx, b);
-#pragma unroll
-  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) b[row] = b[row] * Dinv[row] - acc;
-}
-// Chains of narrow levels inside one workgroup (barrier between levels); 4 lanes per row, or a whole
-// wavefront per row when the level has at most 16 rows.  A row of a chain splits at Rsplit[row] into the
-// entries whose columns lie before the chain (all of them solved when the chain starts: k_fwd_far takes
-// them for every row of the chain at once, T threads per row) and the entries inside the chain (the only part
-// that is sequential).  With a dense trailing block -- a few dense constraint rows -- the first part is the
-// long one: 10^4 entries per row against 10^2 inside the chain.
-template <int T>
-__global__ __launch_bounds__(kBlock) void k_fwd_far(int r0, int r1, const int64_t *__restrict__ Rp, const int64_t *__restrict__ Rsplit,
-                                                    const int *__restrict__ Rj, const double *__restrict__ Rx, double *__restrict__ b,
-                                                    double *__restrict__ out) {  // out != nullptr: out[row - r0] instead of b[row]
-  __shared__ double part[kBlock / 64];
-  const int lane = threadIdx.x & (T - 1);
-  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
-  double acc = row < r1 ? gather_dot(Rp[row] + lane, Rsplit[row], T, Rj, Rx, b) : 0.0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (T == 64) {
-    if (lane == 0 && row < r1) { if (out) out[row - r0] = b[row] - acc; else b[row] -= acc; }
-  } else {  // T == kBlock: one row per workgroup
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0 && row < r1) {
-      double t = 0.0;
-      for (int w = 0; w < kBlock / 64; w++) t += part[w];
-      if (out) out[row - r0] = b[row] - t; else b[row] -= t;
-    }
-  }
-}
-// Backward counterpart: the entries of column k of L with rows above the chain [c0, c1) (solved earlier in the
-// backward pass) are taken for all pivots of the chain at once, together with the D^-1 scaling:
-// b[k] = b[k] / d_k - sum_{i >= c1} L_ik b[i]; the chain then only walks the entries inside it.
-template <int T>
-__global__ __launch_bounds__(kBlock) void k_bwd_far(int r0, int r1, const int64_t *__restrict__ Lsplit, const int64_t *__restrict__ Lp,
-                                                    const int *__restrict__ Li, const double *__restrict__ Lx,
-                                                    const double *__restrict__ Dinv, double *__restrict__ b) {
-  __shared__ double part[kBlock / 64];
-  const int lane = threadIdx.x & (T - 1);
-  const int row = r0 + (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) / T);
-  double acc = row < r1 ? gather_dot(Lsplit[row] + lane, Lp[row + 1], T, Li, Lx, b) : 0.0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (T == 64) {
-    if (lane == 0 && row < r1) b[row] = b[row] * Dinv[row] - acc;
-  } else {
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0 && row < r1) {
-      double t = 0.0;
-      for (int w = 0; w < kBlock / 64; w++) t += part[w];
-      b[row] = b[row] * Dinv[row] - t;
-    }
-  }
-}
-// LDS-resident chains.  A chain is cut so that its pivots [c0, c1) and its level table fit in LDS (build_schedule):
-// the segment of the solution lives there for the whole chain and the workgroup never touches global memory on the
-// critical path: row r belongs to wavefront (r - c0) mod 16 for good, so a wavefront knows its next row ahead of time and
-// fetches its bounds and first 128 entries right after finishing the current one, levels before they are
-// needed; the barrier between levels only waits for LDS traffic (s_waitcnt lgkmcnt(0); s_barrier -- the plain
-// __syncthreads would also drain those prefetches).  Per level that leaves an LDS gather, a wavefront reduction
-// and the barrier: ~0.15 us instead of ~2 us of dependent global round trips.
-constexpr int kChainLdsRows = 8192, kChainLdsLevels = 8192;
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// Two rows ahead: the bounds of the row after next (so that fetching the entries of the next row never waits for
-// its own bounds), one row ahead: bounds and first G U entries of the next row (U = 2, 4 or 8 by the
-// longest row inside the chain: a dense trailing block has rows as long as the block).
-template <int U>
-struct RowPrefetch {
-  int64_t q0, q1;    // entries of the next row inside the chain
-  int64_t nq0, nq1;  // the same for the row after it
-  double v[U];
-  int c[U];
-};
-// G lanes share a row (64: a wavefront per row -- long rows of a dense block; 16 or 4: several short rows per wavefront)
-template <int U, int G>
-__device__ __forceinline__ void prefetch_entries(RowPrefetch<U> &p, const int *__restrict__ idx, const double *__restrict__ val, int lane) {
-  p.q0 = p.nq0; p.q1 = p.nq1;
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int64_t a = p.q0 + G * u + lane;
-    p.v[u] = a < p.q1 ? val[a] : 0.0;
-    p.c[u] = a < p.q1 ? idx[a] : -1;
-  }
-}
-template <int U, int G>
-__global__ __launch_bounds__(kChainThreads) void k_fwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
-                                                                 const int64_t *__restrict__ Rsplit, const int64_t *__restrict__ Rp,
-                                                                 const int *__restrict__ Rj, const double *__restrict__ Rx,
-                                                                 double *__restrict__ b) {
-  __shared__ double bl[kChainLdsRows];
-  __shared__ int lp[kChainLdsLevels + 1];
-  constexpr int kStride = kChainThreads / G;  // rows in flight: one per group of G lanes
-  const int c0 = level_ptr[l0], c1 = level_ptr[l1];
-  for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) bl[i] = b[c0 + i];
-  for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
-  const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
-  int next = c0 + grp;
-  RowPrefetch<U> pf;
-  pf.nq0 = pf.nq1 = 0;
-#pragma unroll
-  for (int u = 0; u < U; u++) { pf.v[u] = 0.0; pf.c[u] = -1; }
-  pf.q0 = pf.q1 = 0;
-  if (next < c1) { pf.nq0 = Rsplit[next]; pf.nq1 = Rp[next + 1]; prefetch_entries<U, G>(pf, Rj, Rx, lane); }
-  if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
-  __syncthreads();
-  for (int l = 0; l < l1 - l0; l++) {
-    const int r1 = lp[l + 1];
-    while (__any(next < r1)) {  // the groups of a wavefront may differ by one row: idle ones ride along
-      const bool mine = next < r1;
-      double acc = 0.0;
-      if (mine) {
-#pragma unroll
-        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
-        for (int64_t q = pf.q0 + G * U + lane; q < pf.q1; q += G) acc += Rx[q] * bl[Rj[q] - c0];
-      }
-#pragma unroll
-      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (mine) {
-        if (lane == 0) bl[next - c0] -= acc;
-        next += kStride;
-        if (next < c1) prefetch_entries<U, G>(pf, Rj, Rx, lane);
-        if (next + kStride < c1) { pf.nq0 = Rsplit[next + kStride]; pf.nq1 = Rp[next + kStride + 1]; }
-      }
-    }
-    lds_barrier();
-  }
-  for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) b[c0 + i] = bl[i];
-}
-// backward: the column of L below pivot k is row k of L'; only its rows inside the chain are left (k_bwd_far took
-// the rest and the D^-1 scaling).  Pivots and levels descend.
-template <int U, int G>
-__global__ __launch_bounds__(kChainThreads) void k_bwd_chain_lds(int l0, int l1, const int *__restrict__ level_ptr,
-                                                                 const int64_t *__restrict__ Lp, const int64_t *__restrict__ Lsplit,
-                                                                 const int *__restrict__ Li, const double *__restrict__ Lx,
-                                                                 double *__restrict__ b) {
-  __shared__ double bl[kChainLdsRows];
-  __shared__ int lp[kChainLdsLevels + 1];
-  constexpr int kStride = kChainThreads / G;
-  const int c0 = level_ptr[l0], c1 = level_ptr[l1];
-  for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) bl[i] = b[c0 + i];
-  for (int i = threadIdx.x; i <= l1 - l0; i += kChainThreads) lp[i] = level_ptr[l0 + i];
-  const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
-  int next = c1 - 1 - grp;
-  RowPrefetch<U> pf;
-  pf.nq0 = pf.nq1 = 0;
-#pragma unroll
-  for (int u = 0; u < U; u++) { pf.v[u] = 0.0; pf.c[u] = -1; }
-  pf.q0 = pf.q1 = 0;
-  if (next >= c0) { pf.nq0 = Lp[next]; pf.nq1 = Lsplit[next]; prefetch_entries<U, G>(pf, Li, Lx, lane); }
-  if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lsplit[next - kStride]; }
-  __syncthreads();
-  for (int l = l1 - l0 - 1; l >= 0; l--) {
-    const int r0 = lp[l];
-    while (__any(next >= r0)) {
-      const bool mine = next >= r0;
-      double acc = 0.0;
-      if (mine) {
-#pragma unroll
-        for (int u = 0; u < U; u++) if (pf.c[u] >= 0) acc += pf.v[u] * bl[pf.c[u] - c0];
-        for (int64_t t = pf.q0 + G * U + lane; t < pf.q1; t += G) acc += Lx[t] * bl[Li[t] - c0];
-      }
-#pragma unroll
-      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      if (mine) {
-        if (lane == 0) bl[next - c0] -= acc;
-        next -= kStride;
-        if (next >= c0) prefetch_entries<U, G>(pf, Li, Lx, lane);
-        if (next - kStride >= c0) { pf.nq0 = Lp[next - kStride]; pf.nq1 = Lsplit[next - kStride]; }
-      }
-    }
-    lds_barrier();
-  }
-  for (int i = threadIdx.x; i < c1 - c0; i += kChainThreads) b[c0 + i] = bl[i];
-}
-__global__ __launch_bounds__(kBlock) void k_perm_in(int N, const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ bp) {
-  int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k < N) bp[k] = in[perm[k]];
-}
-// ADMM form: x~ = sol_x ; z~ = rhs_z + rho^-1 nu   (SURVEY.md A.2).  plain form: out = sol
-__global__ __launch_bounds__(kBlock) void k_perm_out(int N, int n, const int *__restrict__ pinv, const double *__restrict__ bp,
-                                                     const double *__restrict__ rho_inv, double *__restrict__ out) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o >= N) return;
-  double v = bp[pinv[o]];
-  if (rho_inv && o >= n) out[o] += rho_inv[o - n] * v; else out[o] = v;
-}
-
-// fused iteration ends (direct back-end): the right-hand side is written straight into the pivot order and the
-// ADMM update reads the solution through the inverse permutation, so an iteration is rhs | trisolves | update.
-__global__ __launch_bounds__(kBlock) void k_direct_rhs(int n, int m, double sigma, const int *__restrict__ pinv,
-                                                       const double *__restrict__ x, const double *__restrict__ q,
-                                                       const double *__restrict__ z, const double *__restrict__ rho_inv,
-                                                       const double *__restrict__ y, double *__restrict__ bp) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o < n) bp[pinv[o]] = sigma * x[o] - q[o];
-  else if (o < n + m) { int j = o - n; bp[pinv[o]] = z[j] - rho_inv[j] * y[j]; }
-}
-__global__ __launch_bounds__(kBlock) void k_direct_update(int n, int m, double alpha, const int *__restrict__ pinv,
-                                                          const double *__restrict__ bp, const double *__restrict__ rho,
-                                                          const double *__restrict__ rho_inv, const double *__restrict__ l,
-                                                          const double *__restrict__ u, double *__restrict__ x, double *__restrict__ z,
-                                                          double *__restrict__ y, double *__restrict__ delta_x,
-                                                          double *__restrict__ delta_y) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o < n) {
-    double xp = x[o];
-    double xn = alpha * bp[pinv[o]] + (1.0 - alpha) * xp;
-    x[o] = xn;
-    delta_x[o] = xn - xp;
-  } else if (o < n + m) {
-    int j = o - n;
-    double zp = z[j], yj = y[j], ri = rho_inv[j];
-    double zt = (zp - ri * yj) + ri * bp[pinv[o]];  // z~ = rhs_z + rho^-1 nu  
-    double zh = alpha * zt + (1.0 - alpha) * zp;
-    double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
-    z[j] = zn;
-    double dy = rho[j] * (zh - zn);
-    delta_y[j] = dy;
-    y[j] = yj + dy;
-  }
-}
-
-// The same two ends with the neighbouring level folded in (one thread per index; used when the rows of level 1 / the
-// columns of level 0 are short -- bound constraints, diagonal blocks): the right-hand side of a level-0 pivot is cheap
-// to recompute, so a level-1 row takes what it needs from the original vectors instead of waiting for a kernel that
-// writes them; and the update computes the solution of a level-0 pivot on the spot instead of reading it back.
-__device__ __forceinline__ double direct_rhs_value(int o, int n, double sigma, const double *__restrict__ x, const double *__restrict__ q,
-                                                   const double *__restrict__ z, const double *__restrict__ rho_inv,
-                                                   const double *__restrict__ y) {
-  if (o < n) return sigma * x[o] - q[o];
-  const int j = o - n;
-  return z[j] - rho_inv[j] * y[j];
-}
-__global__ __launch_bounds__(kBlock) void k_direct_rhs_fwd1(int n, int m, double sigma, const int *__restrict__ pinv, const int *__restrict__ perm,
-                                                            int l1_begin, int l1_end, const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                            const double *__restrict__ Rx, const double *__restrict__ x,
-                                                            const double *__restrict__ q, const double *__restrict__ z,
-                                                            const double *__restrict__ rho_inv, const double *__restrict__ y,
-                                                            double *__restrict__ bp) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o >= n + m) return;
-  const int k = pinv[o];
-  double v = direct_rhs_value(o, n, sigma, x, q, z, rho_inv, y);
-  if (k >= l1_begin && k < l1_end) {
-    double acc = 0.0;
-    for (int64_t t = Rp[k]; t < Rp[k + 1]; t++) acc += Rx[t] * direct_rhs_value(perm[Rj[t]], n, sigma, x, q, z, rho_inv, y);
-    v -= acc;
-  }
-  bp[k] = v;
-}
-__global__ __launch_bounds__(kBlock) void k_direct_bwd0_update(int n, int m, double alpha, const int *__restrict__ pinv, int l0_end,
-                                                               const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                               const double *__restrict__ Lx, const double *__restrict__ Dinv,
-                                                               const double *__restrict__ bp, const double *__restrict__ rho,
-                                                               const double *__restrict__ rho_inv, const double *__restrict__ l,
-                                                               const double *__restrict__ u, double *__restrict__ x, double *__restrict__ z,
-                                                               double *__restrict__ y, double *__restrict__ delta_x,
-                                                               double *__restrict__ delta_y) {
-  int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o >= n + m) return;
-  const int k = pinv[o];
-  double sol = bp[k];
-  if (k < l0_end) {  // level 0: the last backward step, done here
-    double acc = 0.0;
-    for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) acc += Lx[t] * bp[Li[t]];
-    sol = sol * Dinv[k] - acc;
-  }
-  if (o < n) {
-    double xp = x[o];
-    double xn = alpha * sol + (1.0 - alpha) * xp;
-    x[o] = xn;
-    delta_x[o] = xn - xp;
-  } else {
-    int j = o - n;
-    double zp = z[j], yj = y[j], ri = rho_inv[j];
-    double zt = (zp - ri * yj) + ri * sol;
-    double zh = alpha * zt + (1.0 - alpha) * zp;
-    double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
-    z[j] = zn;
-    double dy = rho[j] * (zh - zn);
-    delta_y[j] = dy;
-    y[j] = yj + dy;
-  }
-}
-
-// Two-level factors (every constraint row a leaf under the variable it bounds: lasso, box-constrained problems; KKT
-// systems whose fill-free elimination has height 1) need no level kernel at all -- the whole iteration is two launches:
-//   k_direct2_fwd         thread per level-1 pivot k: the right-hand sides of k and of its level-0 columns are
-//                         recomputed from (x, q, z, rho^-1, y) -- a level-0 right-hand side is never stored -- the
-//                         forward step and, level 1 being the top of the tree, the D^-1 scaling: bp[k] is final;
-//   k_direct2_bwd_update  thread per KKT index o: a level-0 pivot takes its right-hand side from the same vectors the
-//                         ADMM update reads anyway, does its backward step against the level-1 solutions and goes
-//                         straight into the update of x / z / y.
-// Same operations in the same order as k_direct_rhs_fwd1 | k_bwd_level | k_direct_bwd0_update: bit-identical iterates.
-__global__ __launch_bounds__(kBlock) void k_direct2_fwd(int n, int N, double sigma, const int *__restrict__ perm, int l1_begin,
-                                                        const int64_t *__restrict__ Rp, const int *__restrict__ Rj,
-                                                        const double *__restrict__ Rx, const double *__restrict__ Dinv,
-                                                        const double *__restrict__ x, const double *__restrict__ q,
-                                                        const double *__restrict__ z, const double *__restrict__ rho_inv,
-                                                        const double *__restrict__ y, double *__restrict__ bp) {
-  const int k = l1_begin + blockIdx.x * kBlock + threadIdx.x;
-  if (k >= N) return;
-  double v = direct_rhs_value(perm[k], n, sigma, x, q, z, rho_inv, y);
-  double acc = 0.0;
-  for (int64_t t = Rp[k]; t < Rp[k + 1]; t++) acc += Rx[t] * direct_rhs_value(perm[Rj[t]], n, sigma, x, q, z, rho_inv, y);
-  v -= acc;
-  bp[k] = v * Dinv[k] - 0.0;
-}
-__global__ __launch_bounds__(kBlock) void k_direct2_bwd_update(int n, int m, double sigma, double alpha, const int *__restrict__ pinv,
-                                                               int l1_begin, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
-                                                               const double *__restrict__ Lx, const double *__restrict__ Dinv,
-                                                               const double *__restrict__ bp, const double *__restrict__ q,
-                                                               const double *__restrict__ rho, const double *__restrict__ rho_inv,
-                                                               const double *__restrict__ l, const double *__restrict__ u,
-                                                               double *__restrict__ x, double *__restrict__ z, double *__restrict__ y,
-                                                               double *__restrict__ delta_x, double *__restrict__ delta_y) {
-  const int o = blockIdx.x * kBlock + threadIdx.x;
-  if (o >= n + m) return;
-  const int k = pinv[o];
-  const bool leaf = k < l1_begin;
-  double acc = 0.0, dk = 0.0;
-  if (leaf) {
-    for (int64_t t = Lp[k]; t < Lp[k + 1]; t++) acc += Lx[t] * bp[Li[t]];
-    dk = Dinv[k];
-  }
-  if (o < n) {
-    const double xp = x[o];
-    const double sol = leaf ? (sigma * xp - q[o]) * dk - acc : bp[k];
-    const double xn = alpha * sol + (1.0 - alpha) * xp;
-    x[o] = xn;
-    delta_x[o] = xn - xp;
-  } else {
-    const int j = o - n;
-    const double zp = z[j], yj = y[j], ri = rho_inv[j];
-    const double rhs = zp - ri * yj;
-    const double sol = leaf ? rhs * dk - acc : bp[k];
-    const double zt = rhs + ri * sol;  // z~ = rhs_z + rho^-1 nu  
-    const double zh = alpha * zt + (1.0 - alpha) * zp;
-    const double zn = fmin(fmax(zh + ri * yj, l[j]), u[j]);
-    z[j] = zn;
-    const double dy = rho[j] * (zh - zn);
-    delta_y[j] = dy;
-    y[j] = yj + dy;
-  }
-}
-
-
-// ------------------------------------------------------------------ supernodal triangular solves
-// (symbolic.hpp, Supernodes) One workgroup per supernode, one launch per level of the supernode graph.  With
-// W = L_JJ^-1 (unit lower triangular, dense s x s, stored twice: Wc[j*s+a] = W(a,j), Wr[j*s+a] = W(j,a)):
-//   forward   t = b_J - F_J y (entries of the rows of J outside its block),  y_J = W t
-//   backward  u = D_J^-1 y_J - G_J x (entries of the columns of J outside its block),  x_J = W' u
-// A deep elimination tree (nested dissection of a long banded problem: 300 pivot levels) is 15 such levels.
-constexpr int kSnMax = 64, kSnThreads = 256;
-constexpr int kSnBusyLevel = 2048;   // supernodes in a level from which its workgroups no longer fit the device at once
-constexpr int kSnWaveLevel = 16384;  // supernodes in a level from which each gets a wavefront instead of a workgroup (below: the device is not full either way and a workgroup finishes its supernode sooner)
-
-__global__ __launch_bounds__(kSnThreads) void k_sn_invert(const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                          const int64_t *__restrict__ wmap, const double *__restrict__ Lx,
-                                                          double *__restrict__ Wc, double *__restrict__ Wr) {
-  __shared__ double Ld[kSnMax * kSnMax], Wd[kSnMax * kSnMax];
-  const int J = blockIdx.x, s = ptr[J + 1] - ptr[J];
-  const int64_t w0 = woff[J];
-  // blocks are stored as packed lower triangles (round 4): wmap row-major (a (a + 1) / 2 + b, b <= a), the inverse twice --
-  // Wc column by column (what a forward row product walks with its lanes along the rows), Wr row by row (backward)
-  for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
-    const int i = e / s, k = e - i * s;
-    double v = 0.0;
-    if (k < i) { const int64_t t = wmap[w0 + (int64_t)i * (i + 1) / 2 + k]; if (t >= 0) v = Lx[t]; }
-    Ld[e] = v;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < s) {  // column j of the inverse by forward substitution: W(i,j) = -sum_{k=j}^{i-1} L(i,k) W(k,j)
-    const int j = threadIdx.x;
-    for (int i = 0; i < s; i++) {
-      double w = 0.0;
-      if (i == j) w = 1.0;
-      else if (i > j) {
-        for (int k = j; k < i; k++) w -= Ld[i * s + k] * Wd[k * s + j];
-      }
-      Wd[i * s + j] = w;
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < s * s; e += kSnThreads) {
-    const int j = e / s, a = e - j * s;
-    if (a >= j) Wc[w0 + (int64_t)j * s - (int64_t)j * (j - 1) / 2 + (a - j)] = Wd[a * s + j];  // W(a, j), column j from its diagonal down
-    if (a <= j) Wr[w0 + (int64_t)j * (j + 1) / 2 + a] = Wd[j * s + a];                           // W(j, a), row j up to its diagonal
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sn_gather(int64_t nf, const int64_t *__restrict__ Fpos, double *__restrict__ Fx, int64_t ng,
-                                                      const int64_t *__restrict__ Gpos, double *__restrict__ Gx, int N,
-                                                      const int *__restrict__ piv, const double *__restrict__ Dinv,
-                                                      double *__restrict__ Dinv_s, const double *__restrict__ Lx) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < nf) Fx[i] = Lx[Fpos[i]];
-  if (i < ng) Gx[i] = Lx[Gpos[i]];
-  if (i < N) Dinv_s[i] = Dinv[piv[i]];
-}
-
-// sum over j = j0, j0 + dj, ... < s of W(a, j) t[j] (forward: the packed columns, j <= a) or W(j, a) t[j] (backward: the packed
-// rows, j >= a) for row a of an s x s block; j is uniform over the lanes that call it together, four loads in flight
-template <bool kForward>
-__device__ __forceinline__ double sn_block_row(const double *__restrict__ Wj, const double *t, int s, int a, int j0, int dj) {
-  auto w = [&](int j) -> double {
-    if (kForward) return (a < s && j <= a) ? Wj[j * s - j * (j - 1) / 2 + (a - j)] : 0.0;
-    return (a < s && j >= a) ? Wj[j * (j + 1) / 2 + a] : 0.0;
-  };
-  double acc = 0.0;
-  int j = j0;
-  for (; j + 3 * dj < s; j += 4 * dj) {
-    const double w0 = w(j), w1 = w(j + dj), w2 = w(j + 2 * dj), w3 = w(j + 3 * dj);
-    acc += w0 * t[j]; acc += w1 * t[j + dj]; acc += w2 * t[j + 2 * dj]; acc += w3 * t[j + 3 * dj];
-  }
-  for (; j < s; j += dj) acc += w(j) * t[j];
-  return acc;
-}
-
-// LA lanes per row for the entries outside the block, 4 lanes per row for the block product
-template <int LA, bool kForward>
-__global__ __launch_bounds__(kSnThreads) void k_sn_level(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                         const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
-                                                         const double *__restrict__ Ex, const double *__restrict__ W,
-                                                         const double *__restrict__ Dinv_s, double *__restrict__ b) {
-  __shared__ double t[kSnMax];
-  __shared__ double part[kSnThreads / 64][kSnMax];
-  const int J = J0 + blockIdx.x, q0 = ptr[J], s = ptr[J + 1] - q0;
-  {
-    const int lane = threadIdx.x % LA;
-    for (int a = threadIdx.x / LA; a < s; a += kSnThreads / LA) {
-      const int q = q0 + a;
-      double acc = gather_dot(Ep[q] + lane, Ep[q + 1], LA, Ej, Ex, b);
-#pragma unroll
-      for (int o = LA / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
-    }
-  }
-  __syncthreads();
-  // The block product, round 5: lane = row a, the step index j is wavefront-uniform, so every load of the block is ONE
-  // contiguous piece (column j of the packed columns forward, row j of the packed rows backward) instead of 64 scattered
-  // doubles (four lanes per row, each walking its own row); the four wavefronts take every fourth j, their partial sums meet
-  // in LDS in a fixed order.
-  const double *Wj = W + woff[J];
-  const int wv = threadIdx.x >> 6, a = threadIdx.x & 63;
-  part[wv][a] = sn_block_row<kForward>(Wj, t, s, a, wv, kSnThreads / 64);
-  __syncthreads();
-  if (wv == 0 && a < s) b[q0 + a] = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
-}
-
-// The same step with a WAVEFRONT per supernode (four per workgroup), for levels of many small supernodes: level 0 of a
-// nested-dissection tree is the leaves -- 540 000 subtrees of five pivots on average for control-1e6 -- and a 256-thread
-// workgroup each leaves 250 of them idle (533 us for the forward level 0 of that problem).  Same arithmetic as k_sn_level.  The wavefront's t vector sits in its own slab of LDS; its writes are
-// drained (s_waitcnt) before its reads, no workgroup barrier.  (The caller gives wide levels a notch fewer lanes per row
-// than narrow ones -- rows in flight x latency is what bounds them -- so the order of a row's sum may differ between forms.)
-template <int LA, bool kForward, int GS>  // GS: lanes per supernode, 64 or 16 (supernodes of at most 16 pivots: four to a wavefront)
-__global__ __launch_bounds__(kSnThreads) void k_sn_level_w(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                           const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
-                                                           const double *__restrict__ Ex, const double *__restrict__ W,
-                                                           const double *__restrict__ Dinv_s, double *__restrict__ b) {
-  static_assert(LA <= GS, "the lanes of a row lie inside its supernode's group");
-  constexpr int NG = 64 / GS, TS = GS == 64 ? kSnMax : GS;
-  __shared__ double tt[kSnThreads / 64][NG][TS];
-  const int wv = threadIdx.x >> 6, l64 = threadIdx.x & 63, g = l64 / GS, gl = l64 % GS;
-  const int J = J0 + (blockIdx.x * (kSnThreads / 64) + wv) * NG + g;
-  const bool live = J < J1;  // dead groups run no loop; the lanes of a row (and of its shuffles) share a group: all in or all out
-  double *t = tt[wv][g];
-  const int q0 = live ? ptr[J] : 0, s = live ? ptr[J + 1] - q0 : 0;
-  {
-    const int lane = gl % LA;
-    for (int a = gl / LA; a < s; a += GS / LA) {
-      const int q = q0 + a;
-      double acc = gather_dot(Ep[q] + lane, Ep[q + 1], LA, Ej, Ex, b);
-#pragma unroll
-      for (int o = LA / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) t[a] = (kForward ? b[q] : b[q] * Dinv_s[q]) - acc;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's LDS writes are done before any of its lanes reads them
-  __builtin_amdgcn_wave_barrier();
-  const double *Wj = W + (live ? woff[J] : 0);
-  // lane = row, the step index uniform over the lanes of the supernode: contiguous loads of the block (see k_sn_level)
-  const double acc = sn_block_row<kForward>(Wj, t, s, gl, 0, 1);
-  if (gl < s) b[q0 + gl] = acc;
-}
-
-// The same two steps with the entries outside the block taken FLAT (round 5).  The forms above give every row LA lanes and
-// walk the rows of a supernode LA-th by LA-th: a level-3 supernode of control-1e6 (54 rows of 94 entries) is fourteen rounds of
-// {row pointers -> entries -> gathered solution -> shuffle sum} behind each other, 42 memory latencies for 60 KB -- the levels
-// are bound by that chain, not by bytes (3 TB/s).  The entries of the rows of a supernode are ONE contiguous stretch of the
-// lists (its rows are consecutive slots), so: every thread takes kSnFlatU entries of the stretch whatever their row -- full
-// wavefront loads of the index and value streams, kSnFlatU gathers in flight per lane -- and leaves the products in LDS; then
-// the rows add up their own piece of the chunk in entry order (four lanes per row taking every fourth entry, met in a fixed
-// order: the same sum on every run).  Two latencies per chunk of 2048 entries.
-constexpr int kSnFlatU = 8;
-template <bool kForward, int DK>
-__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, int k0, double &lo, double &hi);  // below
-template <bool kForward, bool kFold>
-__global__ __launch_bounds__(kSnThreads) void k_sn_level_f(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                           const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
-                                                           const double *__restrict__ Ex, const double *__restrict__ W,
-                                                           const double *__restrict__ Dinv_s, double *__restrict__ b) {
-  constexpr int C = kSnThreads * kSnFlatU;
-  __shared__ double prod[C];
-  __shared__ double t[kSnMax];
-  __shared__ double part[kSnThreads / 64][kSnMax];
-  const int J = J0 + blockIdx.x, q0 = ptr[J], s = ptr[J + 1] - q0;
-  const int tid = threadIdx.x, ra = tid >> 2, rk = tid & 3;  // row ra (kSnThreads / 4 = kSnMax of them), lane rk of its four
-  const int64_t E0 = Ep[q0], E1 = Ep[q0 + s];
-  int64_t r1 = 0, pos = 0;
-  double rhs = 0.0;
-  if (ra < s) {
-    pos = Ep[q0 + ra] + rk; r1 = Ep[q0 + ra + 1];
-    if (rk == 0) rhs = kForward ? b[q0 + ra] : b[q0 + ra] * Dinv_s[q0 + ra];
-  }
-  double acc = 0.0;
-  for (int64_t base = E0; base < E1; base += C) {
-    int idx[kSnFlatU];
-    double val[kSnFlatU], bv[kSnFlatU];
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) {
-      const int64_t e = base + u * kSnThreads + tid;
-      const bool ok = e < E1;
-      idx[u] = ok ? Ej[e] : -1;
-      val[u] = ok ? Ex[e] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) bv[u] = idx[u] >= 0 ? b[idx[u]] : 0.0;
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) prod[u * kSnThreads + tid] = val[u] * bv[u];
-    __syncthreads();
-    const int64_t end = r1 < base + C ? r1 : base + C;
-    for (; pos < end; pos += 4) acc += prod[pos - base];
-    __syncthreads();
-  }
-  {
-    const double a1 = __shfl_xor(acc, 1);
-    const double pair = (rk & 1) ? a1 + acc : acc + a1;  // (lane 0 + lane 1), (lane 2 + lane 3) -- the same operands in the same order on both lanes
-    const double other = __shfl_xor(pair, 2);
-    const double sum = (rk & 2) ? other + pair : pair + other;
-    if (rk == 0 && ra < s) t[ra] = rhs - sum;
-  }
-  __syncthreads();
-  const double *Wj = W + woff[J];
-  const int wv = tid >> 6, a = tid & 63;
-  if (kFold) {  // the block is stored folded (sn_block_fold): the eight half-wavefronts take every eighth step
-    double lo, hi;
-    sn_block_fold<kForward, 8>(Wj, t, s, a, 2 * wv + (a >> 5), lo, hi);
-    if (a < 32) { part[wv][a] = lo; part[wv][32 + a] = hi; }
-    __syncthreads();
-    const int h = (s + 1) >> 1;
-    if (wv == 0 && a < h) {
-      const double slo = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
-      const double shi = (part[0][32 + a] + part[1][32 + a]) + (part[2][32 + a] + part[3][32 + a]);
-      b[q0 + (kForward ? a : s - 1 - a)] = slo;
-      if (a != s - 1 - a) b[q0 + (kForward ? s - 1 - a : a)] = shi;
-    }
-    return;
-  }
-  part[wv][a] = sn_block_row<kForward>(Wj, t, s, a, wv, kSnThreads / 64);
-  __syncthreads();
-  if (wv == 0 && a < s) b[q0 + a] = (part[0][a] + part[1][a]) + (part[2][a] + part[3][a]);
-}
-// ... and with a wavefront per supernode (k_sn_level_w, GS = 64): lane = row for the sums, chunks of 64 x kSnFlatU entries in
-// the wavefront's own slab of LDS, no workgroup barrier (LDS operations of a wavefront complete in order)
-// kFold: the block is stored FOLDED (k_sn_fold below).  Reading the packed triangle piece by piece leaves half the lanes of
-// every load masked off and the memory system at 3.3 TB/s (tools/micro/block_stream.hip: 4.9 TB/s for 64 rows, 2.6 for 24;
-// folded 6.2 / 4.3).  Folded, lane a < h = ceil(s / 2) owns the TWO rows a and s - 1 - a (forward; columns backward): a + 1
-// and s - a entries, s + 1 together for every lane, stored step by step (entry k of lane a at k h + a).  The lanes 32..63
-// take the odd steps, so a wavefront load is steps k and k + 1: 2 h contiguous doubles, no lane masked (s = 64), and the block
-// is over in (s + 1) / 2 loads instead of s.  The two halves meet through one lane exchange, even steps + odd steps.
-// (DK: the steps are dealt to DK half-wavefronts -- 2: the two halves of one wavefront; 8: of the four wavefronts of a workgroup,
-// whose sums the caller adds up; k0: this half-wavefront's first step)
-template <bool kForward, int DK>
-__device__ __forceinline__ void sn_block_fold(const double *__restrict__ Wj, const double *t, int s, int gl, int k0, double &lo, double &hi) {
-  const int h = (s + 1) >> 1, a = gl & 31, par = gl >> 5;
-  lo = 0.0; hi = 0.0;
-  if (a < h) {
-    auto idx = [&](int k) { return kForward ? (k <= a ? k : k - a - 1) : (k <= a ? s - 1 - a + k : k - 1); };
-    int k = k0;
-    for (; k + 3 * DK <= s; k += 4 * DK) {
-      const double w0 = Wj[k * h + a], w1 = Wj[(k + DK) * h + a], w2 = Wj[(k + 2 * DK) * h + a], w3 = Wj[(k + 3 * DK) * h + a];
-      const double p0 = w0 * t[idx(k)], p1 = w1 * t[idx(k + DK)], p2 = w2 * t[idx(k + 2 * DK)], p3 = w3 * t[idx(k + 3 * DK)];
-      if (k <= a) lo += p0; else hi += p0;
-      if (k + DK <= a) lo += p1; else hi += p1;
-      if (k + 2 * DK <= a) lo += p2; else hi += p2;
-      if (k + 3 * DK <= a) lo += p3; else hi += p3;
-    }
-    for (; k <= s; k += DK) {
-      const double p0 = Wj[k * h + a] * t[idx(k)];
-      if (k <= a) lo += p0; else hi += p0;
-    }
-  }
-  const double lo2 = __shfl_xor(lo, 32), hi2 = __shfl_xor(hi, 32);
-  lo = par ? lo2 + lo : lo + lo2;
-  hi = par ? hi2 + hi : hi + hi2;
-}
-template <bool kForward, bool kFold>
-__global__ __launch_bounds__(kSnThreads) void k_sn_level_wf(int J0, int J1, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                            const int64_t *__restrict__ Ep, const int *__restrict__ Ej,
-                                                            const double *__restrict__ Ex, const double *__restrict__ W,
-                                                            const double *__restrict__ Dinv_s, double *__restrict__ b) {
-  constexpr int C = 64 * kSnFlatU;
-  __shared__ double prod_all[kSnThreads / 64][C];
-  __shared__ double tt[kSnThreads / 64][kSnMax];
-  const int wv = threadIdx.x >> 6, gl = threadIdx.x & 63;
-  const int J = J0 + blockIdx.x * (kSnThreads / 64) + wv;
-  if (J >= J1) return;  // no workgroup barrier below
-  double *prod = prod_all[wv], *t = tt[wv];
-  const int q0 = ptr[J], s = ptr[J + 1] - q0;
-  const int64_t E0 = Ep[q0], E1 = Ep[q0 + s];
-  int64_t r1 = 0, pos = 0;
-  double rhs = 0.0;
-  if (gl < s) {
-    pos = Ep[q0 + gl]; r1 = Ep[q0 + gl + 1];
-    rhs = kForward ? b[q0 + gl] : b[q0 + gl] * Dinv_s[q0 + gl];
-  }
-  double acc = 0.0;
-  for (int64_t base = E0; base < E1; base += C) {
-    int idx[kSnFlatU];
-    double val[kSnFlatU], bv[kSnFlatU];
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) {
-      const int64_t e = base + u * 64 + gl;
-      const bool ok = e < E1;
-      idx[u] = ok ? Ej[e] : -1;
-      val[u] = ok ? Ex[e] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) bv[u] = idx[u] >= 0 ? b[idx[u]] : 0.0;
-#pragma unroll
-    for (int u = 0; u < kSnFlatU; u++) prod[u * 64 + gl] = val[u] * bv[u];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    const int64_t end = r1 < base + C ? r1 : base + C;
-    for (; pos < end; pos++) acc += prod[pos - base];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (gl < s) t[gl] = rhs - acc;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  const double *Wj = W + woff[J];
-  if (kFold) {
-    double lo, hi;
-    sn_block_fold<kForward, 2>(Wj, t, s, gl, gl >> 5, lo, hi);
-    const int a = gl & 31, h = (s + 1) >> 1;
-    if (gl < h) {  // forward: lo is row a, hi row s - 1 - a; backward: lo is column s - 1 - a, hi column a
-      b[q0 + (kForward ? a : s - 1 - a)] = lo;
-      if (a != s - 1 - a) b[q0 + (kForward ? s - 1 - a : a)] = hi;
-    }
-    return;
-  }
-  const double out = sn_block_row<kForward>(Wj, t, s, gl, 0, 1);
-  if (gl < s) b[q0 + gl] = out;
-}
-// A packed block to its folded form, in place through LDS (after every numeric factorisation, for the supernodes the
-// wavefront form solves: LdlFactor::fold_blocks).  kForward: the block is packed by columns (Wc), else by rows (Wr).
-template <bool kForward>
-__global__ __launch_bounds__(64) void k_sn_fold(int J0, const int *__restrict__ ptr, const int64_t *__restrict__ woff, double *__restrict__ W) {
-  __shared__ double tri[kSnMax * (kSnMax + 1) / 2];
-  const int J = J0 + blockIdx.x, s = ptr[J + 1] - ptr[J], gl = threadIdx.x;
-  double *Wj = W + woff[J];
-  const int nel = s * (s + 1) / 2, h = (s + 1) >> 1;
-  for (int e = gl; e < nel; e += 64) tri[e] = Wj[e];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  auto at = [&](int r, int c) { return kForward ? tri[c * s - c * (c - 1) / 2 + (r - c)] : tri[r * (r + 1) / 2 + c]; };  // W(r, c), r >= c
-  for (int e = gl; e < (s + 1) * h; e += 64) {
-    const int k = e / h, a = e - k * h;
-    double v;
-    if (kForward) v = k <= a ? at(a, k) : (a != s - 1 - a ? at(s - 1 - a, k - a - 1) : 0.0);
-    else v = k <= a ? at(s - 1 - a + k, s - 1 - a) : (a != s - 1 - a ? at(k - 1, a) : 0.0);
-    Wj[e] = v;
-  }
-}
-
-// Backward step of the supernodes of ONE pivot that a level starts with (symbolic.hpp lvl_single; control-1e6: 388 258 of the
-// 496 738 leaves, one entry each): the block is the number 1, so x_q = D_q^-1 y_q - G_q x with a lane per pivot over
-// consecutive slots -- in k_sn_level_w they were a quarter wavefront each, 15 of 16 lanes idle.  (Forward they are skipped
-// at level 0 altogether: no entries outside the block, y_q = b_q.)
-__global__ __launch_bounds__(kBlock) void k_sn_single_bwd(int q0, int count, const int64_t *__restrict__ Gp, const int *__restrict__ Gi,
-                                                          const double *__restrict__ Gx, const double *__restrict__ Dinv_s,
-                                                          double *__restrict__ b) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= count) return;
-  const int q = q0 + i;
-  const double acc = gather_dot(Gp[q], Gp[q + 1], 1, Gi, Gx, b);
-  b[q] = b[q] * Dinv_s[q] - acc;
-}
-
-// The supernodes of level >= 1 in ONE launch per direction: workgroup = supernode, started in level order, each
-// waiting on a counter for the supernodes below it (forward: `pending[J]` children still running; backward: the
-// supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
-// their resting values when the launch ends, so a captured graph can replay it.  Workgroups are dispatched in
-// blockIdx order per XCD and a workgroup only waits on lower blockIdx values, so the lowest unfinished one is always
-// resident and never waits on an unscheduled one -- and the launch is only used when ALL its workgroups fit the device
-// at once (LdlFactor: occupancy x CUs >= grid), so on a device of its own nothing can wait on an unscheduled workgroup
-// whatever the dispatch order; a wait that still exceeds 200 ms (a shared, pre-empted device) sets *fault (mapped host
-// memory) and carries on: the host sees the flag at the next residual evaluation -- tested again once the read-back has
-// drained the stream -- and at the end of osqp_solve, switches the factor to one launch per level and runs the solve
-// again from a cold start (Engine::solve), so a broken assumption costs time, never a wrong or missing answer.
-constexpr long long kSnWaitTicks = 20000000LL;  // 200 ms of the 100 MHz wall clock (a legitimate wait is microseconds; a workgroup
-                                                 // pre-empted on a shared device can look like milliseconds)
-__device__ __forceinline__ int sn_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// sum of Ex[i] * b[Ej[i]] over i = i0 + lane, i0 + lane + la, ... < i1, four gathers in flight per lane
-template <bool kCoherent>
-__device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, int la, const int *__restrict__ Ej,
-                                            const double *__restrict__ Ex, const double *b) {
-  auto ld = [&](int j) { return kCoherent ? __hip_atomic_load(&b[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : b[j]; };
-  double acc = 0.0;
-  int64_t i = i0 + lane;
-  for (; i + 3 * (int64_t)la < i1; i += 4 * (int64_t)la) {
-    const int j0 = Ej[i], j1 = Ej[i + la], j2 = Ej[i + 2 * la], j3 = Ej[i + 3 * la];
-    const double x0 = Ex[i], x1 = Ex[i + la], x2 = Ex[i + 2 * la], x3 = Ex[i + 3 * la];
-    const double b0 = ld(j0), b1 = ld(j1), b2 = ld(j2), b3 = ld(j3);
-    acc += x0 * b0; acc += x1 * b1; acc += x2 * b2; acc += x3 * b3;
-  }
-  for (; i < i1; i += la) acc += Ex[i] * ld(Ej[i]);
-  return acc;
-}
-constexpr int kSnCap = 16;  // entries per lane whose index and value are in registers before the wait
-template <bool kForward, int NT>  // NT threads per supernode: 1024, or 512 when that lets the launch take one more level (twice the resident workgroups)
-__global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
-                                                            const int64_t *__restrict__ Ep, const int64_t *__restrict__ Es,
-                                                            const int *__restrict__ Ej, const double *__restrict__ Ex,
-                                                            const double *__restrict__ W, const double *__restrict__ Dinv_s,
-                                                            const int *__restrict__ up, const int *__restrict__ waits,
-                                                            int *__restrict__ sync, int *__restrict__ fault, double *b, int *ticket) {
-  __shared__ double t[kSnMax];
-  __shared__ double Wl[kSnMax * kSnMax];
-  __shared__ int Js;
-  // ticket != nullptr (round 5): PERSISTENT workgroups -- as many as the device holds -- take the supernodes of the launch in
-  // level order from a counter.  A workgroup that waits (forward: for children, backward: for its parent) waits on a
-  // supernode with an earlier ticket, i.e. one that some resident workgroup is working on or has finished: progress whatever
-  // the count, so the launch can take EVERY level above level 0 (control-1e6: 19 000 supernodes in 10 levels instead of the
-  // top 841 that fit the device at once; the plain launches of levels 1 - 3 were 6 x ~55 us of a 0.85 ms iteration).
-  for (int k = ticket ? -1 : (int)blockIdx.x;;) {
-  if (ticket) {
-    __syncthreads();  // everybody is past the previous supernode: t, Wl and Js are free
-    if (threadIdx.x == 0) Js = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    k = Js;
-    if (k >= count - J0) break;
-  }
-  const int J = kForward ? J0 + k : count - 1 - k;
-  const int P = up[J];
-  const int q0 = ptr[J], s = ptr[J + 1] - q0;
-  // all rows of the supernode at once: 64 / 32 / 16 (/ 8 with 512 threads) lanes per row
-  const int la = s <= NT / 64 ? 64 : (s <= NT / 32 ? 32 : (s <= NT / 16 ? 16 : NT / 64));
-  const int lane = threadIdx.x & (la - 1), a = threadIdx.x / la;
-  const bool mine = a < s;
-  const int q = q0 + (mine ? a : 0);
-  // Entries of b written inside this launch (slots of level >= 1) are stored and loaded at device scope, past the
-  // per-XCD L2s, so no cache write-back / invalidate is needed around the counters; everything else (level-0 slots, L,
-  // W) was written by earlier launches and is read through the caches.  Everything that does not depend on the wait
-  // happens before it: the part of each forward row that points at level 0, the indices and values of the rest (into
-  // registers), the inverted block (into LDS); behind the wait there is one round of loads of b, the two small
-  // products and the store.
-  double acc0 = (kForward && mine) ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
-  const int64_t i0 = (kForward ? Es[q] : Ep[q]) + lane, i1 = mine ? Ep[q + 1] : 0;
-  int jj[kSnCap];
-  double xx[kSnCap];
-#pragma unroll
-  for (int u = 0; u < kSnCap; u++) {
-    const int64_t i = i0 + (int64_t)u * la;
-    const bool in = i < i1;
-    jj[u] = in ? Ej[i] : q;  // padding: the row's own slot (a finite number) times zero
-    xx[u] = in ? Ex[i] : 0.0;
-  }
-  {
-    const double *Wj = W + woff[J];
-    for (int e = threadIdx.x; e < s * (s + 1) / 2; e += NT) Wl[e] = Wj[e];
-  }
-  const double own = mine ? (kForward ? b[q] : b[q] * Dinv_s[q]) : 0.0;
-  if (threadIdx.x == 0) {
-    const long long t0 = wall_clock64();
-    if (kForward) {
-      for (unsigned spins = 1; sn_load(&sync[J]) != 0; spins++) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
-      }
-      sync[J] = waits[J];  // resting value for the next solve (its children are all past their decrement)
-    } else if (P >= 0) {
-      for (unsigned spins = 1; sn_load(&sync[P]) == 0; spins++) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
-      }
-      __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-  {
-    double bb[kSnCap];
-#pragma unroll
-    for (int u = 0; u < kSnCap; u++) bb[u] = __hip_atomic_load(&b[jj[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < kSnCap; u++) acc += xx[u] * bb[u];
-    if (i0 + (int64_t)kSnCap * la < i1) acc += sn_gather<true>(i0 - lane + (int64_t)kSnCap * la, i1, lane, la, Ej, Ex, b);
-    acc += acc0;
-    for (int o = la >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0 && mine) t[a] = own - acc;
-  }
-  __syncthreads();
-  {
-    constexpr int LP = NT / 64;  // 64 rows x LP lanes
-    const int part = threadIdx.x & (LP - 1), r = threadIdx.x / LP;
-    double acc = 0.0;
-    if (r < s) {
-      if (kForward) { for (int j = part; j <= r; j += LP) acc += Wl[j * s - j * (j - 1) / 2 + (r - j)] * t[j]; }
-      else { for (int j = r + part; j < s; j += LP) acc += Wl[j * (j + 1) / 2 + r] * t[j]; }
-    }
-#pragma unroll
-    for (int o = LP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (part == 0 && r < s) __hip_atomic_store(&b[q0 + r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (kForward) { if (P >= 0) __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else if (waits[J] > 0) __hip_atomic_store(&sync[J], waits[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (!ticket) break;
-  }
-}
+namespace oq {
+namespace {
 
 struct Step { int kind; int a, b, G; int U = 2, L = 64; };  // L: lanes per row inside an LDS chain  // kind 0: single level, rows [a,b), G lanes per row; 1: chain of levels [a,b),
                                          // G threads per row for the part of its rows that lies before the chain
