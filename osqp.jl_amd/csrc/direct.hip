@@ -98,6 +98,7 @@ struct LdlFactor {
   DevBuf<double> mf_panel;
   DevBuf<int> mf_tiles;
   std::vector<int64_t> mfh_poff;
+  std::vector<char> mf_is_big;
   std::vector<int> mfh_tiles;
   int mf_big_count = 0, mf_big_fmax = 0;
   int mf_fmax = 0;
@@ -211,6 +212,7 @@ struct LdlFactor {
     if (sn) e.setup_mark("    supernodes on the device");
     build_mf();
     if (mf) e.setup_mark("    fronts");
+    setup_top();
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
@@ -396,6 +398,52 @@ struct LdlFactor {
     std::vector<int>().swap(T.Fj); std::vector<int>().swap(T.Gi);
   }
 
+  // ---- the top of the tree by front vectors (direct_sn_kernels.hpp, SnTop): the levels from which every supernode has a panel ----
+  int sn_top_Jt = -1, sn_top_level = -1;
+  DevBuf<int64_t> sn_Ftop;
+  DevBuf<int> sn_tchp, sn_tchl;
+  DevBuf<double> sn_uvec;
+  SnTop sn_top_args() const {
+    if (sn_top_Jt < 0 || !mf) return SnTop{-1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return SnTop{sn_top_Jt, sn_Ftop.get(), sn_tchp.get(), sn_tchl.get(), mf_bsz.get(), mf_reloff.get(), mf_rel.get(), mf_poff.get(), mf_panel.get(), sn_uvec.get()};
+  }
+  void setup_top() {
+    sn_top_Jt = -1; sn_top_level = -1;
+    if (!mf || !sn_tree || mf_big_count == 0) return;
+    if (getenv("OSQP_AMD_SNODE_TOP") && atoi(getenv("OSQP_AMD_SNODE_TOP")) == 0) return;  // A/B runs: rows gathered entry by entry everywhere
+    // the lowest level, not below the first level of the one-launch tree, from which every supernode has a panel and a border
+    // that fits the LDS the kernel has free (4096 doubles)
+    int Lt = T.nlev;
+    for (int L = T.nlev - 1; L >= std::max(1, sn_tree_L0); L--) {
+      bool all = true;
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1] && all; J++) all = mfh_poff[J + 1] > mfh_poff[J] && mfh_bsz[J] <= 4096;
+      if (!all) break;
+      Lt = L;
+    }
+    if (T.nlev - Lt < 2) return;  // a single level: nothing is handed over
+    hipStream_t s = e.stream;
+    const int Jt = T.lvl_ptr[Lt], q_top = T.ptr[Jt];
+    std::vector<int> tchp(T.count - Jt + 1, 0), tchl;
+    for (int J = Jt; J < T.count; J++) if (T.up[J] >= 0) tchp[T.up[J] - Jt + 1]++;
+    for (int k = 0; k < T.count - Jt; k++) tchp[k + 1] += tchp[k];
+    tchl.resize(tchp[T.count - Jt]);
+    {
+      std::vector<int> fill(tchp.begin(), tchp.end() - 1);
+      for (int J = Jt; J < T.count; J++) if (T.up[J] >= 0) tchl[fill[T.up[J] - Jt]++] = J;  // ascending: the order of the sums
+    }
+    sn_tchp.alloc(tchp.size()); sn_tchp.upload(tchp.data(), tchp.size(), s);
+    sn_tchl.alloc(std::max<size_t>(1, tchl.size())); sn_tchl.upload(tchl.data(), tchl.size(), s);
+    sn_Ftop.alloc(N);
+    OQ_LAUNCH(k_lean_split, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, (const int64_t *)sn_Fp.get(), (const int *)sn_Fj.get(), q_top, sn_Ftop.get());
+    sn_uvec.alloc(std::max<int64_t>(1, mfh_reloff[T.count]));
+    sn_uvec.zero(s);
+    e.sync();
+    sn_top_Jt = Jt; sn_top_level = Lt;
+    if (getenv("OSQP_AMD_SETUP_TRACE"))
+      fprintf(stderr, "[supernodes] top part by front vectors: levels %d .. %d (%d supernodes from %d on; the one-launch tree starts at level %d)\n", Lt,
+              T.nlev - 1, T.count - Jt, Jt, sn_tree_L0);
+  }
+
   // ---- the device side of a LEAN analysis (symbolic.hpp): from the unsorted rows of the pattern of L ----------------------
   // CSC arrays of L: the rows go up as they were found, every entry with its row id beside it, and one sort by (column, row)
   // -- the transposition the setup already runs on A (kernels.hip csr_from_coo: counting / LSD radix sort, rows of the
@@ -501,13 +549,25 @@ struct LdlFactor {
     // tests: OSQP_AMD_MF_MAX_FRONT sends smaller fronts through the global-memory kernels too (the zoo at test sizes has none beyond 192 rows)
     const int max_front = getenv("OSQP_AMD_MF_MAX_FRONT") ? std::min(kMfMaxFront, std::max(1, atoi(getenv("OSQP_AMD_MF_MAX_FRONT")))) : kMfMaxFront;
     const bool big_ok = !(getenv("OSQP_AMD_MF_BIG") && atoi(getenv("OSQP_AMD_MF_BIG")) == 0);  // 0: the round-5 behaviour (A/B runs)
+    // which fronts go through global memory: those beyond LDS, and -- so that the set is closed towards the root: the
+    // solves treat the top of the tree by front vectors (direct_sn_kernels.hpp, SnTop), which needs a resident panel for
+    // every supernode above a large front -- their ancestors (the last segments of a top separator: a few small fronts at the
+    // end of a chain of large ones)
+    mf_is_big.assign(count, 0);
+    for (int J = 0; J < count; J++) {
+      const int top = T.piv[T.ptr[J + 1] - 1], s_ = T.ptr[J + 1] - T.ptr[J];
+      if (s_ + (S.Lp[top + 1] - S.Lp[top]) > max_front) mf_is_big[J] = 1;
+    }
+    if (!(getenv("OSQP_AMD_MF_BIG_ANCESTORS") && atoi(getenv("OSQP_AMD_MF_BIG_ANCESTORS")) == 0))
+      for (int J = 0; J < count; J++)  // parents have larger numbers: one ascending pass
+        if (mf_is_big[J] && T.up[J] >= 0 && T.ptr[T.up[J] + 1] - T.ptr[T.up[J]] <= kMfbSmax) mf_is_big[T.up[J]] = 1;
     for (int J = 0; J < count; J++) {
       const int top = T.piv[T.ptr[J + 1] - 1], s_ = T.ptr[J + 1] - T.ptr[J];
       const int64_t b = S.Lp[top + 1] - S.Lp[top];
       // (round 6) a front beyond one workgroup's LDS is factorised out of global memory (mfront_big.hpp) instead of sending
       // the whole matrix back to the level-by-level factorisation; what still does: a front beyond the 16-bit row indices of
       // `rel` / `loc`, or a supernode of more pivots than the pivot block of that kernel holds
-      if (s_ + b > max_front) {
+      if (mf_is_big[J]) {
         if (s_ + b > 65000 || s_ > kMfbSmax || !big_ok) return false;
         mf_big_count++;
         mf_big_fmax = std::max(mf_big_fmax, s_ + (int)b);
@@ -543,7 +603,7 @@ struct LdlFactor {
       int bigcap = 0;
       for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
         const int f = T.ptr[J + 1] - T.ptr[J] + mfh_bsz[J];
-        if (f > max_front) { bigs.push_back(J); bigcap = std::max(bigcap, f); continue; }
+        if (mf_is_big[J]) { bigs.push_back(J); bigcap = std::max(bigcap, f); continue; }
         int c = 0;
         while (f > kMfClassCap[c]) c++;
         cls[c].push_back(J);
@@ -927,7 +987,7 @@ struct LdlFactor {
 #define OQ_SN_TREE(FWD)                                                                                                           \
   if (sn_tree_threads == 512) OQ_SN_TREE_N(FWD, 512); else OQ_SN_TREE_N(FWD, 1024)
 #define OQ_SN_TREE_N(FWD, NT_)                                                                                                    \
-  OQ_LAUNCH((k_sn_tree<FWD, NT_>), dim3(sn_tree_grid ? sn_tree_grid : T.count - T.lvl_ptr[sn_tree_L0]), dim3(NT_), 0, s, T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
+  OQ_LAUNCH((k_sn_tree<FWD, NT_>), dim3(sn_tree_grid ? sn_tree_grid : T.count - T.lvl_ptr[sn_tree_L0]), dim3(NT_), 0, s, sn_top_args(), T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)

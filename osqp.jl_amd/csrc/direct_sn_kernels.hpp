@@ -386,8 +386,28 @@ __device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, in
   return acc;
 }
 constexpr int kSnCap = 16;  // entries per lane whose index and value are in registers before the wait
+// The top of the tree by FRONT VECTORS (round 6).  The rows of the top separators of a 2-D structure hold thousands of entries
+// each (64 rows x ~2 000 entries: 8 MB of 64-byte sectors gathered by ONE compute unit per supernode, eleven supernodes in a chain
+// for the top separator of a 700 x 700 grid: 1.8 ms of a 2.7 ms iteration).  Where every supernode from some level on has a front
+// out of global memory (mfront_big.hpp: its panel Y = L21 D stays resident, column-major), the forward solve of those levels is
+// the multifrontal one: a supernode hands its parent ONE dense vector -- the contributions of its own columns and of the top
+// supernodes below it to its border rows, u = (children's vectors, extended) + L21 y -- and its rows gather only the entries that
+// point BELOW the top part.  The panel is read coalesced (0.3 MB instead of 8 MB a supernode), children in ascending order: a
+// fixed order of sums.
+struct SnTop {
+  int Jt;                   // first supernode of the top part (everything from here on has a panel); < 0: off
+  const int64_t *Et;        // per forward row: the first entry that points at a slot of the top part
+  const int *tchp, *tchl;   // children INSIDE the top part, per supernode J >= Jt: tchl[tchp[J - Jt] .. tchp[J - Jt + 1])
+  const int *bsz;           // border rows of a supernode
+  const int64_t *reloff;    // rel + reloff[J]: row of the PARENT's front for each border row of J; uvec + reloff[J]: its vector
+  const uint16_t *rel;
+  const int64_t *poff;      // panel of J: panel + poff[J], s columns of (s + b) doubles
+  const double *panel;
+  double *uvec;
+};
+
 template <bool kForward, int NT>  // NT threads per supernode: 1024, or 512 when that lets the launch take one more level (twice the resident workgroups)
-__global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
+__global__ __launch_bounds__(NT) void k_sn_tree(SnTop top, int J0, int count, const int *__restrict__ ptr, const int64_t *__restrict__ woff,
                                                             const int64_t *__restrict__ Ep, const int64_t *__restrict__ Es,
                                                             const int *__restrict__ Ej, const double *__restrict__ Ex,
                                                             const double *__restrict__ W, const double *__restrict__ Dinv_s,
@@ -395,6 +415,7 @@ __global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__
                                                             int *__restrict__ sync, int *__restrict__ fault, double *b, int *ticket) {
   __shared__ double t[kSnMax];
   __shared__ double Wl[kSnMax * kSnMax];
+  __shared__ double ysc[kSnMax];
   __shared__ int Js;
   // ticket != nullptr (round 5): PERSISTENT workgroups -- as many as the device holds -- take the supernodes of the launch in
   // level order from a counter.  A workgroup that waits (forward: for children, backward: for its parent) waits on a
@@ -424,7 +445,8 @@ __global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__
   // registers), the inverted block (into LDS); behind the wait there is one round of loads of b, the two small
   // products and the store.
   double acc0 = (kForward && mine) ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
-  const int64_t i0 = (kForward ? Es[q] : Ep[q]) + lane, i1 = mine ? Ep[q + 1] : 0;
+  const bool topmode = kForward && top.Jt >= 0 && J >= top.Jt;  // (uniform over the workgroup)
+  const int64_t i0 = (kForward ? Es[q] : Ep[q]) + lane, i1 = mine ? (topmode ? top.Et[q] : Ep[q + 1]) : 0;
   int jj[kSnCap];
   double xx[kSnCap];
 #pragma unroll
@@ -469,6 +491,18 @@ __global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__
     if (lane == 0 && mine) t[a] = own - acc;
   }
   __syncthreads();
+  if (topmode) {  // the children inside the top part: their vectors' entries at this supernode's pivots
+    for (int ci = top.tchp[J - top.Jt]; ci < top.tchp[J - top.Jt + 1]; ci++) {
+      const int c = top.tchl[ci], bc = top.bsz[c];
+      const uint16_t *rl = top.rel + top.reloff[c];
+      const double *uc = top.uvec + top.reloff[c];
+      for (int i = threadIdx.x; i < bc; i += NT) {
+        const int r = rl[i];
+        if (r < s) t[r] -= __hip_atomic_load(&uc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a child's rows are distinct)
+      }
+      __syncthreads();
+    }
+  }
   {
     constexpr int LP = NT / 64;  // 64 rows x LP lanes
     const int part = threadIdx.x & (LP - 1), r = threadIdx.x / LP;
@@ -479,7 +513,41 @@ __global__ __launch_bounds__(NT) void k_sn_tree(int J0, int count, const int *__
     }
 #pragma unroll
     for (int o = LP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (part == 0 && r < s) __hip_atomic_store(&b[q0 + r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (part == 0 && r < s) {
+      __hip_atomic_store(&b[q0 + r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (topmode) ysc[r] = acc * Dinv_s[q0 + r];  // L21 = Y D^-1: the panel holds Y
+    }
+  }
+  if (topmode) {
+    const int bj = top.bsz[J], f = s + bj;
+    if (bj > 0) {  // u = (children's vectors at this supernode's border rows) + L21 y; Wl is free once y is formed: it holds the sums
+      double *uv = Wl;
+      __syncthreads();
+      for (int i = threadIdx.x; i < bj; i += NT) uv[i] = 0.0;
+      __syncthreads();
+      for (int ci = top.tchp[J - top.Jt]; ci < top.tchp[J - top.Jt + 1]; ci++) {
+        const int c = top.tchl[ci], bc = top.bsz[c];
+        const uint16_t *rl = top.rel + top.reloff[c];
+        const double *uc = top.uvec + top.reloff[c];
+        for (int i = threadIdx.x; i < bc; i += NT) {
+          const int r = rl[i];
+          if (r >= s) uv[r - s] += __hip_atomic_load(&uc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+      const double *Pn = top.panel + top.poff[J] + s;
+      double *uj = top.uvec + top.reloff[J];
+      for (int i = threadIdx.x; i < bj; i += NT) {
+        double a0 = uv[i], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int p = 0;
+        for (; p + 3 < s; p += 4) {
+          a0 += Pn[(int64_t)p * f + i] * ysc[p]; a1 += Pn[(int64_t)(p + 1) * f + i] * ysc[p + 1];
+          a2 += Pn[(int64_t)(p + 2) * f + i] * ysc[p + 2]; a3 += Pn[(int64_t)(p + 3) * f + i] * ysc[p + 3];
+        }
+        for (; p < s; p++) a0 += Pn[(int64_t)p * f + i] * ysc[p];
+        __hip_atomic_store(&uj[i], (a0 + a1) + (a2 + a3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
   __syncthreads();
