@@ -51,6 +51,13 @@ __host__ __device__ inline size_t mfb_panel_lds(int fcap) {
   return sizeof(double) * (kMfbSmax * (kMfbSmax + 1) / 2 + kMfbSmax + (kMfbPanelThreads / 64) * kMfbRows * kMfbSmax + 64 * kMfbNarrowU) + sizeof(uint16_t) * ((size_t)fcap + 8 + 64 * kMfbNarrow);
 }
 
+// acc += (b of lane LN of the sixteen-lane row) * m.  volatile: the multiply-adds of a row that is only stored by some lanes must
+// not be sunk into that condition -- the broadcast reads the register of ANOTHER lane, which has to be executing
+template <int LN>
+__device__ __forceinline__ void mfb_fmac_bc(double &acc, double b, double m) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(m), "n"(LN));
+}
+
 __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
   extern __shared__ __attribute__((aligned(16))) double mfb_lds[];
   __shared__ int blk_pos, blk_bad;
@@ -252,24 +259,36 @@ __global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_panel(MfbArgs g) {
   //    Y(R, c) = x(c) + sum_{k < c} W(c, k) x(k),  W(c, k) = -F[cs(k) + c]
   //    A lane keeps ONE row: its s sums in registers, x(k) read once per k (a coalesced read of column k of the panel), the
   //    coefficients W(c, k) broadcast from LDS.
-  //    Both loops unrolled (k and c compile-time: the sums stay in registers, a coefficient is ONE ds_read at an immediate
-  //    offset from the column's base); columns c >= s of a narrower block are computed on garbage and never stored.
-  for (int R = s + tid; R < f; R += TF) {
-    double acc[kMfbSmax];
-    [&]<int... KS>(std::integer_sequence<int, KS...>) {
-      ([&] {
-        constexpr int K = KS;
-        if (K < s) {
-          const double xk = Pn[(int64_t)K * f + R];
-          const double *Fk = F + cs(K);
-          acc[K] = K == 0 ? xk : acc[K] + xk;
-          [&]<int... CS>(std::integer_sequence<int, CS...>) {
-            ((acc[K + 1 + CS] = K == 0 ? -Fk[K + 1 + CS] * xk : __builtin_fma(-Fk[K + 1 + CS], xk, acc[K + 1 + CS])), ...);
-          }(std::make_integer_sequence<int, kMfbSmax - 1 - K>{});
-        }
-      }(), ...);
-    }(std::make_integer_sequence<int, kMfbSmax>{});
-    [&]<int... CS>(std::integer_sequence<int, CS...>) { ((CS < s ? (void)(Pn[(int64_t)CS * f + R] = acc[CS]) : (void)0), ...); }(std::make_integer_sequence<int, kMfbSmax>{});
+  //    Both loops unrolled (k and c compile-time: the sums stay in registers).  The coefficients of a step -- column k of W below
+  //    its diagonal -- are the same for every row: sixteen of them sit in one register across a sixteen-lane row (ONE ds_read per
+  //    sixteen coefficients) and reach the multiply-add through the DPP broadcast (v_fmac_f64_dpp row_newbcast, the idiom of the
+  //    batched kernel), where a ds_read per coefficient made the LDS port the bound (85 us of a 310 us front).  Columns c >= s of
+  //    a narrower block are computed on whatever lies behind the block and never stored.
+  {
+    const int lane16 = ln & 15;
+    for (int R0 = s + wv * 64; R0 < f; R0 += NWV * 64) {
+      const int R = R0 + ln;
+      const bool valid = R < f;
+      double acc[kMfbSmax];
+#pragma unroll
+      for (int c = 0; c < kMfbSmax; c++) acc[c] = 0.0;
+      [&]<int... KS>(std::integer_sequence<int, KS...>) {
+        ([&] {
+          constexpr int K = KS;
+          if (K < s) {
+            const double xk = valid ? Pn[(int64_t)K * f + R] : 0.0;
+            acc[K] += xk;
+            constexpr int NBK = (kMfbSmax - 1 - K + 15) / 16;
+            double Bk[NBK > 0 ? NBK : 1];
+            const double *Fk = F + cs(K) + K + 1 + lane16;
+#pragma unroll
+            for (int mm = 0; mm < NBK; mm++) Bk[mm] = -Fk[16 * mm];
+            [&]<int... CS>(std::integer_sequence<int, CS...>) { (mfb_fmac_bc<CS & 15>(acc[K + 1 + CS], Bk[CS >> 4], xk), ...); }(std::make_integer_sequence<int, kMfbSmax - 1 - K>{});
+          }
+        }(), ...);
+      }(std::make_integer_sequence<int, kMfbSmax>{});
+      if (valid) [&]<int... CS>(std::integer_sequence<int, CS...>) { ((CS < s ? (void)(Pn[(int64_t)CS * f + R] = acc[CS]) : (void)0), ...); }(std::make_integer_sequence<int, kMfbSmax>{});
+    }
   }
   __threadfence_block();
   __syncthreads();

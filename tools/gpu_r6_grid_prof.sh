@@ -7,5 +7,5 @@ for w in ${1:-grid2d-5e5}; do
   rm -rf /tmp/prof_$w
   timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $w --no-cpu --traffic off --steps 100 --warmup 25 > $O/bench_prof_$w.json 2> $O/prof_$w.err
   python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $(find /tmp/prof_$w -name '*_results.db' | head -1) > $O/kernel_stats_$w.md 2>&1
-  head -40 $O/kernel_stats_$w.md
+  head -14 $O/kernel_stats_$w.md | cut -c1-200
 done
