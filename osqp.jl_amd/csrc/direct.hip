@@ -321,7 +321,12 @@ struct LdlFactor {
       // (or more) into the launch -- a plain launch per level and direction is ~50 us on control-1e6, a level inside the
       // launch a hand-over of a few microseconds
       sn_tree_threads = 1024;
-      if (sn_tree_L0 > 1 && !(getenv("OSQP_AMD_SNODE_TREE_512") && atoi(getenv("OSQP_AMD_SNODE_TREE_512")) == 0)) {
+      // (round 6: not where fronts go through global memory -- a 2-D structure: the supernodes at the top of such a tree carry
+      // long rows and borders of hundreds of rows, and sixteen lanes a row instead of eight count for more than a level gained:
+      // grid 700 x 700 597 -> 712 it/s, 1000 x 1000 321 -> 334; control-1e6, all fronts in LDS, keeps 512: 1 792 against 1 731)
+      const bool long_rows = mf_ok && mf_big_count > 0;
+      const bool try512 = getenv("OSQP_AMD_SNODE_TREE_512") ? atoi(getenv("OSQP_AMD_SNODE_TREE_512")) != 0 : !long_rows;
+      if (sn_tree_L0 > 1 && try512) {
         int pf = 0, pb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, (const void *)k_sn_tree<true, 512>, 512, 0));
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, (const void *)k_sn_tree<false, 512>, 512, 0));
