@@ -37,6 +37,7 @@ constexpr int kChainThreads = 1024;
 #include "direct_dense_kernels.hpp"
 #include "direct_level_kernels.hpp"
 #include "direct_sn_kernels.hpp"
+#include "direct_sndense_kernels.hpp"
 
 namespace oq {
 namespace {
@@ -103,6 +104,15 @@ struct LdlFactor {
   int mf_big_count = 0, mf_big_fmax = 0;
   int mf_fmax = 0;
   bool mf_ok = false;                 // the host plan exists (mf_plan): every front fits LDS
+  // a dense top block OVER the supernode partition (direct_sndense_kernels.hpp): the supernodes of the levels [snd_L0, T.nlev)
+  // = [snd_J0, T.count) = the slots [snd_q0, N), snd_K pivots (0: none), are not factorised by fronts and not solved level by
+  // level: their Schur complement is inverted explicitly (S0a, the block sweeps) and a solve multiplies by it once
+  int snd_L0 = -1, snd_J0 = -1, snd_q0 = 0, snd_K = 0;
+  int snd_nb = 0, snd_nv = 0, snd_ntiles = 0;   // boundary children, those of them that hand a front vector up, tiles of the lower triangle
+  bool snd_vec_mode = false;                     // the rows of D gather up to sn_Ftop and take the front vectors (the one-launch tree runs the top part)
+  double snd_skipped = 0.0;                      // entries of the rows of D that point into D (never read by a solve)
+  DevBuf<int> snd_bch, snd_bslot, snd_crange, snd_vch, snd_tiles, snd_trow_ptr, snd_trow_list, snd_pend_ptr;
+  DevBuf<int64_t> snd_boff, snd_pend_src, snd_Fd;
   bool lean_built = false;            // the index arrays of the factor were built on the device (lean_device_*)
   std::vector<int> mfh_bsz, mfh_snof, mfh_chp, mfh_chl, mfh_list;
   std::vector<int64_t> mfh_uoff, mfh_reloff;
@@ -213,6 +223,7 @@ struct LdlFactor {
     build_mf();
     if (mf) e.setup_mark("    fronts");
     setup_top();
+    setup_dense_top();
     {  // levels of few columns with long rows: work rows of N doubles each, at most 256 MB
       long_rows.assign(nlev, 0);
       size_t wmax = 0;
@@ -316,7 +327,9 @@ struct LdlFactor {
       HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true, 1024>, 1024, 0));
       HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false, 1024>, 1024, 0));
       const long long cap = (long long)std::min(per_cu_f, per_cu_b) * cus;
-      while (sn_tree_L0 < T.nlev && (long long)(T.count - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
+      // (a dense top over the supernodes, direct_sndense_kernels.hpp, takes the last levels out of the launch)
+      const int top_end = snd_K ? snd_L0 : T.nlev, j_end = snd_K ? snd_J0 : T.count;
+      while (sn_tree_L0 < top_end && (long long)(j_end - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
       // round 5: with 512 threads per supernode twice as many workgroups are resident; taken when that brings one more level
       // (or more) into the launch -- a plain launch per level and direction is ~50 us on control-1e6, a level inside the
       // launch a hand-over of a few microseconds
@@ -333,7 +346,7 @@ struct LdlFactor {
         long long cap2 = (long long)std::min(pf, pb) * cus;
         if (getenv("OSQP_AMD_SNODE_TREE_CAP")) cap2 = std::min<long long>(cap2, atoll(getenv("OSQP_AMD_SNODE_TREE_CAP")));  // (experiments: a later start)
         int L2 = 1;
-        while (L2 < T.nlev && (long long)(T.count - T.lvl_ptr[L2]) > cap2) L2++;
+        while (L2 < top_end && (long long)(j_end - T.lvl_ptr[L2]) > cap2) L2++;
         if (L2 < sn_tree_L0) { sn_tree_L0 = L2; sn_tree_threads = 512; }
         // persistent workgroups: every level above level 0 in the launch, whatever the count (k_sn_tree, ticket)
         // (measured on control-1e6: from level 1 on 1 165 -> 858 it/s -- the wide levels are throughput work that the plain
@@ -348,11 +361,11 @@ struct LdlFactor {
         // control T = 8000 5.09 -> 5.56 k, T = 30 000 2.50 -> 2.67 k, T = 800 unchanged.)
         if (persist_from >= 1 && persist_from < sn_tree_L0) {
           sn_tree_L0 = persist_from; sn_tree_threads = 512;
-          sn_tree_grid = (int)std::min<long long>(cap2, (long long)(T.count - T.lvl_ptr[sn_tree_L0]));
+          sn_tree_grid = (int)std::min<long long>(cap2, (long long)(j_end - T.lvl_ptr[sn_tree_L0]));
           sn_ticket.alloc(2);
         }
       }
-      if (T.nlev - sn_tree_L0 < 2) sn_tree = false;  // a single level (or none) left: nothing to fuse
+      if (top_end - sn_tree_L0 < 2) sn_tree = false;  // a single level (or none) left: nothing to fuse
     }
     // the split of the forward rows: where the entries that point at the first level of the one-launch tree (level 1
     // without it) begin -- children below that level have finished in earlier launches (not waited for), entries that
@@ -447,6 +460,130 @@ struct LdlFactor {
     if (getenv("OSQP_AMD_SETUP_TRACE"))
       fprintf(stderr, "[supernodes] top part by front vectors: levels %d .. %d (%d supernodes from %d on; the one-launch tree starts at level %d)\n", Lt,
               T.nlev - 1, T.count - Jt, Jt, sn_tree_L0);
+  }
+
+  // ---- the dense top over the supernodes (direct_sndense_kernels.hpp): device arrays, numeric part, its step of a solve -----
+  void setup_dense_top() {
+    if (!snd_K) return;
+    if (!mf) throw Error(6, "internal: a dense top over the supernodes without the multifrontal plan");
+    hipStream_t s = e.stream;
+    const int K = snd_K;
+    std::vector<int> bch;
+    std::vector<int64_t> boff{0};
+    for (int J = 0; J < snd_J0; J++)
+      if (T.up[J] >= snd_J0 && mfh_bsz[J] > 0) { bch.push_back(J); boff.push_back(boff.back() + mfh_bsz[J]); }
+    snd_nb = (int)bch.size();
+    auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    up32(snd_bch, bch); up64(snd_boff, boff);
+    std::vector<int> hs((size_t)boff.back());
+    snd_bslot.alloc(std::max<size_t>(1, hs.size()));
+    if (snd_nb) {
+      mf_err.zero(s);
+      OQ_LAUNCH(k_snd_slots, dim3(snd_nb), dim3(256), 0, s, (const int *)snd_bch.get(), (const int *)sn_ptr.get(), (const int *)sn_piv.get(),
+                (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int64_t *)snd_boff.get(), snd_bslot.get(), mf_err.get());
+      int err = 0;
+      mf_err.download(&err, 1, s);
+      snd_bslot.download(hs.data(), hs.size(), s);
+      e.sync();
+      if (err) throw Error(6, "internal: the dense top over the supernodes is not closed towards the root");
+    }
+    // per child: its range of slots; the one-row children (a pendant constraint row adds one number to one diagonal entry) as a
+    // list per slot; per tile row of 64 slots the other children that have a border row there -- all ascending by child
+    ldD = (K + 63) / 64 * 64;
+    const int nt = ldD / 64;
+    std::vector<int> crange(2 * (size_t)std::max(1, snd_nb)), pend_ptr((size_t)K + 1, 0), trow_ptr((size_t)nt + 1, 0), trow_list, tiles;
+    std::vector<int64_t> pend_src;
+    for (int k = 0; k < snd_nb; k++)
+      if (mfh_bsz[bch[k]] == 1) pend_ptr[(size_t)hs[boff[k]] + 1]++;
+    for (int c = 0; c < K; c++) pend_ptr[c + 1] += pend_ptr[c];
+    pend_src.resize((size_t)pend_ptr[K]);
+    {
+      std::vector<int> fill(pend_ptr.begin(), pend_ptr.end() - 1), seen((size_t)nt, -1);
+      std::vector<std::vector<int>> rows((size_t)nt);
+      for (int k = 0; k < snd_nb; k++) {
+        const int J = bch[k], b = mfh_bsz[J];
+        if (b == 1) { pend_src[fill[hs[boff[k]]]++] = mfh_uoff[J]; crange[2 * k] = INT_MAX; crange[2 * k + 1] = -1; continue; }
+        int mn = INT_MAX, mx = -1;
+        for (int i = 0; i < b; i++) {
+          const int r = hs[boff[k] + i];
+          mn = std::min(mn, r); mx = std::max(mx, r);
+          if (seen[r / 64] != k) { seen[r / 64] = k; rows[r / 64].push_back(k); }
+        }
+        crange[2 * k] = mn; crange[2 * k + 1] = mx;
+      }
+      for (int t = 0; t < nt; t++) { trow_ptr[t + 1] = trow_ptr[t] + (int)rows[t].size(); trow_list.insert(trow_list.end(), rows[t].begin(), rows[t].end()); }
+    }
+    for (int ti = 0; ti < nt; ti++)
+      for (int tj = 0; tj <= ti; tj++) { tiles.push_back(ti); tiles.push_back(tj); }
+    snd_ntiles = (int)(tiles.size() / 2);
+    up32(snd_crange, crange); up32(snd_pend_ptr, pend_ptr); up64(snd_pend_src, pend_src);
+    up32(snd_trow_ptr, trow_ptr); up32(snd_trow_list, trow_list); up32(snd_tiles, tiles);
+    // the boundary children inside the part of the tree that hands front vectors up (setup_top)
+    std::vector<int> vch;
+    if (sn_top_Jt >= 0 && sn_top_Jt < snd_J0)
+      for (int k = 0; k < snd_nb; k++) if (bch[k] >= sn_top_Jt) vch.push_back(k);
+    snd_nv = (int)vch.size();
+    up32(snd_vch, vch);
+    // where the entries of a forward row that point into D begin (what a row of D gathers when no front vectors arrive)
+    snd_Fd.alloc((size_t)N);
+    OQ_LAUNCH(k_lean_split, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, (const int64_t *)sn_Fp.get(), (const int *)sn_Fj.get(), snd_q0, snd_Fd.get());
+    {
+      std::vector<int64_t> fd((size_t)K);
+      HIP_CHECK(hipMemcpyAsync(fd.data(), snd_Fd.get() + snd_q0, (size_t)K * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      e.sync();
+      snd_skipped = 0.0;
+      for (int r = 0; r < K; r++) snd_skipped += (double)(T.Fp[(size_t)snd_q0 + r + 1] - fd[r]);
+    }
+    S0a.alloc((size_t)ldD * ldD);
+    gjT.alloc(kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD);
+    x2.alloc((size_t)K);
+    const size_t nbk = (size_t)ldD / kDsT;
+    dsP1.alloc(nbk * nbk * kDsT); dsP2.alloc(nbk * nbk * kDsT);
+    e.sync();
+    if (getenv("OSQP_AMD_SETUP_TRACE"))
+      fprintf(stderr, "[supernodes] dense top: levels %d .. %d (%d supernodes, %d pivots, %.1f MB of inverse), %d boundary children (%d one-row, %d with a front vector)\n",
+              snd_L0, T.nlev - 1, T.count - snd_J0, K, 8e-6 * (double)ldD * (double)ldD, snd_nb, pend_ptr[K], snd_nv);
+  }
+  // numeric: S = K_DD + the boundary children's update matrices, then -S^-1 by the block sweeps
+  void factor_dense_top(hipStream_t s) {
+    S0a.zero(s);
+    OQ_LAUNCH(k_snd_init, dim3(snd_K), dim3(64), 0, s, snd_q0, ldD, (const int *)sn_piv.get(), (const int *)mf_slot.get(), (const int64_t *)Lp.get(),
+              (const int *)Li.get(), (const double *)Lx.get(), (const double *)D.get(), (const int *)snd_pend_ptr.get(), (const int64_t *)snd_pend_src.get(),
+              (const double *)mf_U.get(), S0a.get());
+    if (snd_nb) {
+      SndExtArgs a{snd_tiles.get(), snd_trow_ptr.get(), snd_trow_list.get(), snd_bch.get(), mf_bsz.get(), mf_uoff.get(), snd_boff.get(),
+                   snd_bslot.get(), snd_crange.get(), mf_U.get(), S0a.get(), ldD};
+      OQ_LAUNCH(k_snd_extend, dim3(snd_ntiles), dim3(256), 0, s, a);
+    }
+    gj_invert(snd_K, s);
+  }
+  // x_D = S^-1 (b_D - what the levels below contribute), between the forward and the backward sweep of the levels below
+  void solve_dense_top(hipStream_t s, bool tree) {
+    const bool vec = tree && sn_top_Jt >= 0 && sn_top_Jt < snd_J0;  // the top part below D ran in the one-launch tree: its front vectors exist
+    OQ_LAUNCH(k_snd_rhs, dim3(blocks_for((int64_t)snd_K * 64)), dim3(kBlock), 0, s, snd_q0, snd_K, (const int64_t *)sn_Fp.get(),
+              (const int64_t *)(vec ? sn_Ftop.get() : snd_Fd.get()), (const int *)sn_Fj.get(), (const double *)sn_Fx.get(), (const double *)bp.get(), x2.get());
+    if (vec && snd_nv)
+      OQ_LAUNCH(k_snd_vec, dim3(1), dim3(1024), 0, s, snd_nv, (const int *)snd_vch.get(), (const int *)snd_bch.get(), (const int *)mf_bsz.get(),
+                (const int64_t *)mf_reloff.get(), (const int64_t *)snd_boff.get(), (const int *)snd_bslot.get(), (const double *)sn_uvec.get(), x2.get());
+    const int nb = ldD / kDsT;
+    OQ_LAUNCH(k_dense_apply_sym, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, snd_K, ldD, nb, (const double *)Sinv, (const double *)x2.get(), dsP1.get(), dsP2.get());
+    OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, snd_K, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + snd_q0);
+  }
+  // -S^-1 in place of the K x K array in S0a (leading dimension ldD, a multiple of 64; identity on the padding): block sweeps of
+  // kGjK pivots on the matrix cores
+  void gj_invert(int K, hipStream_t s) {
+    if (ldD > K) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - K)), dim3(kBlock), 0, s, K, ldD, S0a.get());
+    const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
+    // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
+    for (int p0 = 0; p0 < ldD; p0 += kGjK) {
+      OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, K, ldD, p0, S0a.get(), gjT.get(), status.get());
+      OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+      OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+    }
+    OQ_LAUNCH(k_gj_mirror, gu, dim3(256), 0, s, ldD, S0a.get());
+    Sinv = S0a.get();
   }
 
   // ---- the device side of a LEAN analysis (symbolic.hpp): from the unsorted rows of the pattern of L ----------------------
@@ -547,6 +684,7 @@ struct LdlFactor {
     const int mode = getenv("OSQP_AMD_MF") ? atoi(getenv("OSQP_AMD_MF")) : 1;
     if (mode == 0) return false;
     const int count = T.count;
+    snd_L0 = snd_J0 = -1; snd_q0 = 0; snd_K = 0;
     mfh_bsz.assign(count, 0); mfh_snof.assign(N, 0);
     mfh_uoff.assign(count + 1, 0); mfh_reloff.assign(count + 1, 0); mfh_poff.assign(count + 1, 0);
     mf_fmax = 0; mf_big_count = 0; mf_big_fmax = 0;
@@ -601,7 +739,8 @@ struct LdlFactor {
     mfh_list.clear();
     mfh_list.reserve(count);
     mf_launches.clear();
-    for (int L = 0; L < T.nlev; L++) {
+    choose_dense_top_over_supernodes();
+    for (int L = 0; L < (snd_K ? snd_L0 : T.nlev); L++) {  // (the supernodes of the dense top have no front)
       std::vector<int> cls[kMfClasses];
       int cap[kMfClasses] = {0};
       std::vector<int> bigs;
@@ -645,6 +784,23 @@ struct LdlFactor {
       }
     }
     return true;
+  }
+  // The dense top over the supernodes (direct_sndense_kernels.hpp): the largest set of whole top levels with at most
+  // OSQP_AMD_SN_DENSE_MAX pivots.  Taken by default where fronts go through global memory (a 2-D structure: the top levels are
+  // chains of large separators, ~300 us of factorisation and ~28 us of solve per level) and at least eight levels go; a tree whose
+  // fronts all fit LDS (the control family) keeps its one-launch top: six levels of small supernodes cost less than the product
+  // with a block of their thousands of pivots.  OSQP_AMD_SN_DENSE = 0 never, 2 whenever a level fits (tests: small problems).
+  void choose_dense_top_over_supernodes() {
+    snd_L0 = snd_J0 = -1; snd_q0 = 0; snd_K = 0;
+    const int mode = getenv("OSQP_AMD_SN_DENSE") ? atoi(getenv("OSQP_AMD_SN_DENSE")) : 1;
+    if (mode == 0 || T.nlev < 2) return;
+    const int kmax = getenv("OSQP_AMD_SN_DENSE_MAX") ? atoi(getenv("OSQP_AMD_SN_DENSE_MAX")) : 3072;
+    int L = T.nlev;
+    while (L - 1 >= 1 && N - T.ptr[T.lvl_ptr[L - 1]] <= kmax) L--;
+    if (L == T.nlev) return;
+    const int K = N - T.ptr[T.lvl_ptr[L]];
+    if (mode != 2 && (mf_big_count == 0 || T.nlev - L < 8 || K < 256)) return;
+    snd_L0 = L; snd_J0 = T.lvl_ptr[L]; snd_q0 = T.ptr[snd_J0]; snd_K = K;
   }
   // size classes of the fronts: rows at most 16 / 48 (16 lanes / a wavefront each, fixed slabs), then workgroups with the
   // slab of the launch's largest front -- cut at 64 / 80 / 96 / 128 rows so that a few large fronts do not take the occupancy
@@ -814,6 +970,7 @@ struct LdlFactor {
       OQ_LAUNCH(k_scatter_A, dim3(blocks_for(e.nnzA)), dim3(kBlock), 0, s, e.nnzA, AtoL.get(), e.At.val.get(), Lx.get());
     int p0 = 0, p1 = 0, half = 0;  // the previous level that went through work rows, and the half of W it used
     if (mf) run_mf(s);
+    if (mf && snd_K) factor_dense_top(s);
     for (int l = 0; l < (mf ? 0 : lD); l++) {
       const int c0 = S.level_ptr[l], c1 = S.level_ptr[l + 1];
       const int64_t entries = S.Lp[c1] - S.Lp[c0];
@@ -899,17 +1056,7 @@ struct LdlFactor {
     }
     if (factorizations == 0) e.setup_mark("  numeric: Schur complement of the block");
     if (kD >= kDenseBlocked) {  // block sweeps of kGjK pivots on the matrix cores, in place
-      if (ldD > kD) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - kD)), dim3(kBlock), 0, s, kD, ldD, S0a.get());
-      const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
-      // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
-      HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
-      for (int p0 = 0; p0 < ldD; p0 += kGjK) {
-        OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, kD, ldD, p0, S0a.get(), gjT.get(), status.get());
-        OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
-        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
-      }
-      OQ_LAUNCH(k_gj_mirror, gu, dim3(256), 0, s, ldD, S0a.get());
-      Sinv = S0a.get();
+      gj_invert(kD, s);
       return;
     }
     double *cur = S0a.get(), *nxt = S0b.get();
@@ -992,7 +1139,7 @@ struct LdlFactor {
 #define OQ_SN_TREE(FWD)                                                                                                           \
   if (sn_tree_threads == 512) OQ_SN_TREE_N(FWD, 512); else OQ_SN_TREE_N(FWD, 1024)
 #define OQ_SN_TREE_N(FWD, NT_)                                                                                                    \
-  OQ_LAUNCH((k_sn_tree<FWD, NT_>), dim3(sn_tree_grid ? sn_tree_grid : T.count - T.lvl_ptr[sn_tree_L0]), dim3(NT_), 0, s, sn_top_args(), T.lvl_ptr[sn_tree_L0], T.count, sn_ptr.get(),    \
+  OQ_LAUNCH((k_sn_tree<FWD, NT_>), dim3(sn_tree_grid ? sn_tree_grid : sn_j_end() - T.lvl_ptr[sn_tree_L0]), dim3(NT_), 0, s, sn_top_args(), T.lvl_ptr[sn_tree_L0], sn_j_end(), sn_ptr.get(),    \
             sn_woff.get(), FWD ? sn_Fp.get() : sn_Gp.get(), FWD ? sn_Fsplit.get() : sn_Gp.get(), FWD ? sn_Fj.get() : sn_Gi.get(),      \
             FWD ? sn_Fx.get() : sn_Gx.get(), FWD ? sn_Wc.get() : sn_Wr.get(), sn_Dinv.get(), sn_up.get(), sn_waits.get(),          \
             FWD ? sn_pending.get() : sn_ready.get(), sn_fault, bp.get(), sn_tree_grid ? sn_ticket.get() + (FWD ? 0 : 1) : (int *)nullptr)
@@ -1015,7 +1162,7 @@ struct LdlFactor {
         lvl_fold[L] = (cnt >= sn_wave_min_fixed ? T.lvl_ptr[L + 1] > mid : sn_fold_wg) && !(sn_tree && L >= sn_tree_L0);
       }
     }
-    for (int L = 0; L < T.nlev; L++) {
+    for (int L = 0; L < sn_l_end(); L++) {  // (the blocks of a dense top are never formed)
       const int cnt = T.lvl_ptr[L + 1] - T.lvl_ptr[L];
       const int mid = cnt >= sn_wave_min_fixed ? T.lvl_ptr[L] + T.lvl_small[L] : T.lvl_ptr[L];
       if (!lvl_fold[L]) continue;
@@ -1027,17 +1174,22 @@ struct LdlFactor {
   const bool sn_singles = !(getenv("OSQP_AMD_SNODE_SINGLE") && atoi(getenv("OSQP_AMD_SNODE_SINGLE")) == 0);
   // OSQP_AMD_SNODE_WAVE_MIN (tests): supernodes in a level from which the wavefront / quarter-wavefront form is used
   static int sn_wave_min() { const char *v = getenv("OSQP_AMD_SNODE_WAVE_MIN"); return v ? atoi(v) : kSnWaveLevel; }
+  int sn_l_end() const { return snd_K ? snd_L0 : T.nlev; }   // levels / supernodes below the dense top (all of them without one)
+  int sn_j_end() const { return snd_K ? snd_J0 : T.count; }
   void run_supernodes() {
     hipStream_t s = e.stream;
-    const int plain = sn_tree ? sn_tree_L0 : T.nlev;  // levels [0, plain): one launch each; the rest: one launch per direction
+    const bool tree = sn_tree && sn_tree_L0 < sn_l_end();
+    const int plain = tree ? sn_tree_L0 : sn_l_end();  // levels [0, plain): one launch each; the rest: one launch per direction
     for (int L = 0; L < plain; L++) switch (sn_lanes_f[L]) {
       case 1: OQ_SN_LEVEL(1, true, L); break;
       case 4: OQ_SN_LEVEL(4, true, L); break;
       case 16: OQ_SN_LEVEL(16, true, L); break;
       default: OQ_SN_LEVEL(64, true, L); break;
     }
-    if (sn_tree && sn_tree_grid) HIP_CHECK(hipMemsetAsync(sn_ticket.get(), 0, 2 * sizeof(int), s));
-    if (sn_tree) { OQ_SN_TREE(true); OQ_SN_TREE(false); }
+    if (tree && sn_tree_grid) HIP_CHECK(hipMemsetAsync(sn_ticket.get(), 0, 2 * sizeof(int), s));
+    if (tree) { OQ_SN_TREE(true); }
+    if (snd_K) solve_dense_top(s, tree);
+    if (tree) { OQ_SN_TREE(false); }
     for (int L = plain - 1; L >= 0; L--) switch (sn_lanes_b[L]) {
       case 1: OQ_SN_LEVEL(1, false, L); break;
       case 4: OQ_SN_LEVEL(4, false, L); break;
@@ -1125,6 +1277,13 @@ struct LdlFactor {
   }
 
   double trisolve_bytes() const {
+    // (a dense top over the supernodes: the entries of its rows that point into it and its blocks are not read, the lower triangle
+    // of its inverse is -- once, not per direction)
+    if (sn && snd_K) {
+      const double blocks = 8.0 * (double)(T.woff[T.count] - T.woff[snd_J0]);
+      return 2.0 * (12.0 * ((double)T.Fp[N] - snd_skipped) + 8.0 * (double)T.wdoubles - blocks + 8.0 * ((double)N + 1.0)) + 40.0 * (double)N +
+             4.0 * (double)snd_K * (double)snd_K;
+    }
     if (sn) return 2.0 * (12.0 * (double)T.Fp[N] + 8.0 * (double)T.wdoubles + 8.0 * ((double)N + 1.0)) + 40.0 * (double)N;
     return 2.0 * (12.0 * (double)S.nnzL + 4.0 * ((double)N + 1.0)) + 40.0 * (double)N;
   }
@@ -1226,7 +1385,7 @@ struct Direct : Linsys {
   double supernode_levels() const override { return F->sn ? (double)F->T.nlev : 0.0; }
   double multifrontal() const override { return F->mf ? 1.0 : 0.0; }
   double lean_setup() const override { return F->lean_built ? 1.0 : 0.0; }
-  double dense_block() const override { return (double)F->kD; }
+  double dense_block() const override { return (double)(F->kD ? F->kD : F->snd_K); }
   double trisolve_bytes() const override { return F->trisolve_bytes(); }
   double factorizations() const override { return (double)F->factorizations; }
   float time_solve(int reps) override {

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NT) void k_sn_tree(SnTop top, int J0, int count, co
         if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
       }
       sync[J] = waits[J];  // resting value for the next solve (its children are all past their decrement)
-    } else if (P >= 0) {
+    } else if (P >= 0 && P < count) {  // (a parent beyond the launch -- in the dense top, direct_sndense_kernels.hpp -- has its solution in b already)
       for (unsigned spins = 1; sn_load(&sync[P]) == 0; spins++) {
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 255u) == 0 && wall_clock64() - t0 > kSnWaitTicks) { *fault = 1; break; }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT) void k_sn_tree(SnTop top, int J0, int count, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the device-coherent level
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (kForward) { if (P >= 0) __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (kForward) { if (P >= 0 && P < count) __hip_atomic_fetch_sub(&sync[P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     else if (waits[J] > 0) __hip_atomic_store(&sync[J], waits[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!ticket) break;

@@ -275,3 +275,50 @@ def test_lone_leaves_outside_the_blocks(product_lib, monkeypatch, case):
             assert np.max(np.abs(v - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (case, leaf, k, np.max(np.abs(v - ref)))
     if case == "control-400":
         assert levels["1"] >= levels["0"]  # (the leaves are a level of their own below the subtrees)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["lds-fronts", "global-fronts", "global-fronts-no-tree"])
+@pytest.mark.parametrize("kmax", [24, 150])
+@pytest.mark.parametrize("case", ["control-400", "grid2d-40", "portfolio", "random-200"])
+def test_dense_top_over_the_supernodes_gives_the_level_factor(product_lib, monkeypatch, case, kmax, variant):
+    """Round 6: a dense top block OVER the supernode partition (csrc/direct_sndense_kernels.hpp): the supernodes of the last
+    levels are not factorised by fronts -- their Schur complement is assembled from the boundary children's update matrices,
+    inverted by the block sweeps, and a solve multiplies by it once instead of walking the chain of those levels in both
+    directions.  Forced on small problems (OSQP_AMD_SN_DENSE=2, at most `kmax` pivots), below LDS fronts, below fronts out of
+    global memory whose top part hands front vectors up (the one-launch tree), and with one launch per level (no vectors):
+    the KKT solves must be those of the level-by-level factor, before and after a rho update, and the inertia count must
+    still add up (setup succeeds)."""
+    make, smax = CASES[case]
+    prob = make()
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(min(smax, 16)))
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(15).standard_normal(n + mm)
+    sols, dense = {}, {}
+    for mode in ("level", "dense"):
+        monkeypatch.setenv("OSQP_AMD_MF", "0" if mode == "level" else "1")
+        monkeypatch.setenv("OSQP_AMD_SN_DENSE", "0" if mode == "level" else "2")
+        monkeypatch.setenv("OSQP_AMD_SN_DENSE_MAX", str(kmax))
+        if mode == "dense" and variant != "lds-fronts":
+            monkeypatch.setenv("OSQP_AMD_MF_MAX_FRONT", "12")
+        if mode == "dense" and variant == "global-fronts-no-tree":
+            monkeypatch.setenv("OSQP_AMD_SNODE_TREE", "0")
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        st = oq.stats(m)
+        assert st[19] >= 1 and st[22] == float(mode == "dense"), (st[19], st[22])
+        dense[mode] = st[25]
+        first = _kkt_solve(m, rhs)
+        oq.update_settings(m, rho=0.731)
+        second = _kkt_solve(m, rhs)
+        third = _kkt_solve(m, rhs)
+        assert np.array_equal(second, third)  # (the counters of the one-launch tree are back at rest; a fixed order of sums)
+        sols[mode] = (first, second)
+        oq.clean(m)
+    assert dense["level"] == 0 and 1 <= dense["dense"] <= kmax, dense
+    for k in range(2):
+        a, b = sols["level"][k], sols["dense"][k]
+        assert np.all(np.isfinite(b))
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (case, k, np.max(np.abs(a - b)), np.max(np.abs(a)))
+    assert np.max(np.abs(sols["dense"][0] - sols["dense"][1])) > 1e-6
