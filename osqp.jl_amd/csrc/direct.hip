@@ -517,6 +517,38 @@ struct LdlFactor {
     for (int ti = 0; ti < nt; ti++)
       for (int tj = 0; tj <= ti; tj++) { tiles.push_back(ti); tiles.push_back(tj); }
     snd_ntiles = (int)(tiles.size() / 2);
+    {  // block pattern of S and of everything its elimination fills: the cliques of the fronts of the supernodes of D (their own
+       // slots and their border rows; a boundary child's border lies inside its parent's front) -- what gj_symbolic starts from
+      std::vector<int> dl;
+      std::vector<int64_t> doff{0};
+      for (int J = snd_J0; J < T.count; J++) if (mfh_bsz[J] > 0) { dl.push_back(J); doff.push_back(doff.back() + mfh_bsz[J]); }
+      std::vector<int> ds((size_t)doff.back());
+      if (!dl.empty()) {
+        DevBuf<int> d_dl, d_ds(std::max<size_t>(1, ds.size()));
+        DevBuf<int64_t> d_doff;
+        up32(d_dl, dl); up64(d_doff, doff);
+        mf_err.zero(s);
+        OQ_LAUNCH(k_snd_slots, dim3((int)dl.size()), dim3(256), 0, s, (const int *)d_dl.get(), (const int *)sn_ptr.get(), (const int *)sn_piv.get(),
+                  (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int64_t *)d_doff.get(), d_ds.get(), mf_err.get());
+        int err = 0;
+        mf_err.download(&err, 1, s);
+        d_ds.download(ds.data(), ds.size(), s);
+        e.sync();
+        if (err) throw Error(6, "internal: a front of the dense top reaches below it");
+      }
+      std::vector<char> pat((size_t)nt * nt, 0);
+      std::vector<int> blk;
+      size_t di = 0;
+      for (int J = snd_J0; J < T.count; J++) {
+        blk.clear();
+        for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) blk.push_back((q - snd_q0) / 64);
+        if (mfh_bsz[J] > 0) { for (int64_t i = doff[di]; i < doff[di + 1]; i++) blk.push_back(ds[(size_t)i] / 64); di++; }
+        std::sort(blk.begin(), blk.end());
+        blk.erase(std::unique(blk.begin(), blk.end()), blk.end());
+        for (int a : blk) for (int b : blk) pat[(size_t)a * nt + b] = 1;
+      }
+      gj_symbolic(pat, nt, s);
+    }
     up32(snd_crange, crange); up32(snd_pend_ptr, pend_ptr); up64(snd_pend_src, pend_src);
     up32(snd_trow_ptr, trow_ptr); up32(snd_trow_list, trow_list); up32(snd_tiles, tiles);
     // the boundary children inside the part of the tree that hands front vectors up (setup_top)
@@ -572,15 +604,53 @@ struct LdlFactor {
   }
   // -S^-1 in place of the K x K array in S0a (leading dimension ldD, a multiple of 64; identity on the padding): block sweeps of
   // kGjK pivots on the matrix cores
+  // Block pattern of the sweeps (round 6).  The Schur complement of a dense top over the supernodes is block-sparse -- two
+  // separators on either side of a third never meet until that one is eliminated -- and a sweep step on pivot block k changes
+  // only the tiles (i, j) whose blocks i and j are both coupled with k (everything else is multiplied by the zeros of the
+  // panels): R_k = { i : S_ik != 0 } + k, then S_ij becomes nonzero for all i, j in R_k -- the in-place inverse of the blocks
+  // already swept included.  Simulated once at setup on the 64 x 64 block pattern (`pat`, symmetric, nt x nt); the step lists
+  // go to the device.  Skipping a tile skips a subtraction of exact zeros: the same bits as the full sweeps.
+  std::vector<int> gj_rptr, gj_tptr;
+  DevBuf<int> gj_rows, gj_tiles;
+  bool gj_sparse = false;
+  void gj_symbolic(std::vector<char> &pat, int nt, hipStream_t s) {
+    std::vector<int> rows, tiles;
+    gj_rptr.assign(1, 0); gj_tptr.assign(1, 0);
+    for (int k = 0; k < nt; k++) {
+      std::vector<int> R;
+      for (int i = 0; i < nt; i++) if (i == k || pat[(size_t)i * nt + k]) R.push_back(i);
+      for (int i : R) for (int j : R) pat[(size_t)i * nt + j] = 1;
+      rows.insert(rows.end(), R.begin(), R.end());
+      for (int i : R) for (int j : R) if (j <= i) { tiles.push_back(i); tiles.push_back(j); }
+      gj_rptr.push_back((int)rows.size()); gj_tptr.push_back((int)(tiles.size() / 2));
+    }
+    gj_rows.alloc(std::max<size_t>(1, rows.size())); gj_rows.upload(rows.data(), rows.size(), s);
+    gj_tiles.alloc(std::max<size_t>(1, tiles.size())); gj_tiles.upload(tiles.data(), tiles.size(), s);
+    e.sync();
+    gj_sparse = true;
+    if (getenv("OSQP_AMD_SETUP_TRACE"))
+      fprintf(stderr, "[supernodes] dense top: block sweeps touch %.1f %% of the tiles of a full sweep (%d steps)\n",
+              100.0 * (double)(tiles.size() / 2) / ((double)nt * (double)nt * (double)(nt + 1) / 2.0), nt);
+  }
   void gj_invert(int K, hipStream_t s) {
+    const bool sparse = gj_sparse && !(getenv("OSQP_AMD_GJ_SPARSE") && atoi(getenv("OSQP_AMD_GJ_SPARSE")) == 0);  // 0: full sweeps (A/B, test)
     if (ldD > K) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - K)), dim3(kBlock), 0, s, K, ldD, S0a.get());
     const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
     // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
+    const bool in_registers = !(getenv("OSQP_AMD_GJ_PIVOT_LDS") && atoi(getenv("OSQP_AMD_GJ_PIVOT_LDS")) == 1);  // 1: the round-5 form (A/B, test)
     for (int p0 = 0; p0 < ldD; p0 += kGjK) {
+      if (in_registers) OQ_LAUNCH(k_gj_pivot_r, dim3(1), dim3(kGjPivotRThreads), 0, s, K, ldD, p0, S0a.get(), gjT.get(), status.get());
+      else
       OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, K, ldD, p0, S0a.get(), gjT.get(), status.get());
-      OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
-      OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+      if (sparse) {  // only the blocks coupled with the pivot block (gj_symbolic): the others see zeros in the panels
+        const int k = p0 / kGjK, nr = gj_rptr[k + 1] - gj_rptr[k], ntl = gj_tptr[k + 1] - gj_tptr[k];
+        OQ_LAUNCH(k_gj_panel, dim3(nr), dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)gj_rows.get() + gj_rptr[k]);
+        OQ_LAUNCH(k_gj_update, dim3(ntl), dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)gj_tiles.get() + 2 * (size_t)gj_tptr[k]);
+        continue;
+      }
+      OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
+      OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
     }
     OQ_LAUNCH(k_gj_mirror, gu, dim3(256), 0, s, ldD, S0a.get());
     Sinv = S0a.get();
@@ -834,6 +904,7 @@ struct LdlFactor {
     const int lds = (int)(mf_slab_doubles(mf_fmax) * sizeof(double));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<512>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     if (mf_big_count)
       HIP_CHECK(hipFuncSetAttribute((const void *)k_mfb_panel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((int)mfb_panel_lds(mf_big_fmax), 65536)));
     if (getenv("OSQP_AMD_SETUP_TRACE")) {
@@ -855,8 +926,16 @@ struct LdlFactor {
         if (l.tile_count) OQ_LAUNCH(k_mfb_update, dim3(l.tile_count), dim3(256), 0, s, g);
       } else if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
       else if (l.cls == 1) OQ_LAUNCH(k_mf_front<64>, dim3((l.count + 3) / 4), dim3(kMfBlock), 4 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);
-      else if (l.count <= kMfWideCount) OQ_LAUNCH(k_mf_front<1024>, dim3(l.count), dim3(1024), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
-      else OQ_LAUNCH(k_mf_front<256>, dim3(l.count), dim3(kMfBlock), mf_slab_doubles(l.fcap) * sizeof(double), s, a);
+      else {
+        // threads per front by what the slab leaves of a compute unit (160 KB of LDS): a slab beyond 80 KB is alone there whatever
+        // its workgroup size -- 1024 threads instead of four wavefronts on an otherwise empty unit (round 6: grid 700 x 700, 653
+        // fronts of up to 187 rows in one launch, 821 us) --, one beyond 40 KB shares it with one other: 512
+        const size_t slab = mf_slab_doubles(l.fcap) * sizeof(double);
+        const int wide = getenv("OSQP_AMD_MF_WIDE") ? atoi(getenv("OSQP_AMD_MF_WIDE")) : 1;  // 0: the round-5 rule (A/B)
+        if (l.count <= kMfWideCount || (wide && slab > 80 * 1024)) OQ_LAUNCH(k_mf_front<1024>, dim3(l.count), dim3(1024), slab, s, a);
+        else if (wide && slab > 40 * 1024) OQ_LAUNCH(k_mf_front<512>, dim3(l.count), dim3(512), slab, s, a);
+        else OQ_LAUNCH(k_mf_front<256>, dim3(l.count), dim3(kMfBlock), slab, s, a);
+      }
     }
   }
 
@@ -1040,7 +1119,7 @@ struct LdlFactor {
         gjW.zero(s); gjC.zero(s);
         OQ_LAUNCH(k_dense_chunk, dim3(blocks_for((int64_t)kGjK * 64)), dim3(kBlock), 0, s, c0, schur_ncols, cD, ldD, (const int *)schur_cols.get(), Lp.get(),
                   Li.get(), Lx.get(), D.get(), gjW.get(), gjC.get());
-        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, -kGjK, S0a.get(), gjT.get(), gjW.get(), gjC.get());
+        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, -kGjK, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
       }
     }
     for (int b0 = cD; b0 < N && schur_ncols == 0; b0 += bw) {

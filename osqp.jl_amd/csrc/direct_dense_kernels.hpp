@@ -228,15 +228,63 @@ __global__ __launch_bounds__(kGjPivotThreads) void k_gj_pivot(int kD, int ld, in
   for (int e = t; e < kGjK * kGjK; e += kGjPivotThreads) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = buf[cur][i][j]; }
   if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
 }
+// The same sweeps with the block in REGISTERS (round 6: the pivot kernel is the one serial piece of a step -- a single workgroup,
+// 64 dependent pivots -- and in LDS with a barrier and twelve LDS operations per element and pivot it took 67 us of a ~100 us
+// step; a dense top of 2 900 pivots is 46 steps).  256 threads: thread (c, h) holds rows 16 h .. 16 h + 15 of column c.  Per
+// pivot p (unrolled: every register index and the pivot's lane are compile-time constants): the pivot row comes through LDS
+// (written by the wavefront that holds it, one barrier per pivot, two buffers), the pivot column of a wavefront's own rows
+// is in ITS lane p -- sixteen v_readlane, no LDS --, and every element is swept by the very expression of the LDS form
+// (sweep_value): the same bits.
+constexpr int kGjPivotRThreads = 256;
+__device__ __forceinline__ double gj_readlane(double x, int lane) {
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+__global__ __launch_bounds__(kGjPivotRThreads) void k_gj_pivot_r(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
+                                                                 int *__restrict__ status) {
+  __shared__ double tile[kGjK][kGjK + 1];  // tile[j][i] = element (i, j)
+  __shared__ double rowp[2][kGjK];
+  const int t = threadIdx.x, c = t & 63, h = t >> 6;
+  for (int e = t; e < kGjK * kGjK; e += kGjPivotRThreads) { const int i = e % kGjK, j = e / kGjK; tile[j][i] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
+  __syncthreads();
+  double v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) v[k] = tile[c][16 * h + k];
+  int pos = 0, bad = 0;
+#pragma unroll
+  for (int p = 0; p < kGjK; p++) {
+    const int hp = p >> 4, rp = p & 15;
+    if (h == hp) rowp[p & 1][c] = v[rp];
+    __syncthreads();
+    const double xpj = rowp[p & 1][c], piv = rowp[p & 1][p], ip = 1.0 / piv;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const double xip = gj_readlane(v[k], p);
+      v[k] = sweep_value(k == rp && h == hp, c == p, v[k], xip, xpj, ip);
+    }
+    if (p0 + p < kD) { if (piv == 0.0 || piv != piv) bad = 1; else if (piv > 0.0) pos++; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; k++) tile[c][16 * h + k] = v[k];
+  __syncthreads();
+  for (int e = t; e < kGjK * kGjK; e += kGjPivotRThreads) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = tile[j][i]; }
+  if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
+}
 // thread per column j of the array: W[k][j] = sum_l G[k][l] S[p0 + l][j], C[k][j] = S[p0 + k][j]  (G = -T)
+// (`cols` != nullptr, round 6: the launch covers only the listed column blocks -- the ones coupled with the pivot block in a
+// block-sparse array, direct.hip gj_symbolic -- and the update below only the tiles between them)
 __global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *__restrict__ S, const double *__restrict__ T,
-                                                  double *__restrict__ Wp, double *__restrict__ Cp) {
+                                                  double *__restrict__ Wp, double *__restrict__ Cp, const int *__restrict__ cols) {
   __shared__ double G[kGjK][kGjK];
   for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e % kGjK][e / kGjK] = -T[e];
   __syncthreads();
   // 64 columns per workgroup, its four wavefronts a quarter of the panel's rows each (round 5: a thread per column and all
   // kGjK rows left the 6000-column panel of equality_qp on 24 compute units, 86 us per step)
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
+  const int j = (cols ? cols[blockIdx.x] : (int)blockIdx.x) * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
   if (j >= ld) return;
   double s[kGjK];
   // element (p0 + l, j) from the LOWER triangle (round 5: the sweeps keep only that one current, the mirror is written once at
@@ -256,8 +304,8 @@ __global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
 // workgroup (I, J), I >= J: the 64 x 64 tile of rows I, columns J and its mirror; wavefront w its 32 x 32 quadrant
 __global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__restrict__ S, const double *__restrict__ T,
-                                                   const double *__restrict__ Wp, const double *__restrict__ Cp) {
-  const int I = blockIdx.y, J = blockIdx.x;
+                                                   const double *__restrict__ Wp, const double *__restrict__ Cp, const int *__restrict__ tiles) {
+  const int I = tiles ? tiles[2 * blockIdx.x] : (int)blockIdx.y, J = tiles ? tiles[2 * blockIdx.x + 1] : (int)blockIdx.x;
   if (J > I) return;
   __shared__ double tr[4][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1;

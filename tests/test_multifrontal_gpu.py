@@ -322,3 +322,30 @@ def test_dense_top_over_the_supernodes_gives_the_level_factor(product_lib, monke
         assert np.all(np.isfinite(b))
         assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (case, k, np.max(np.abs(a - b)), np.max(np.abs(a)))
     assert np.max(np.abs(sols["dense"][0] - sols["dense"][1])) > 1e-6
+
+
+@pytest.mark.gpu
+def test_pivot_block_in_registers_is_the_lds_sweep(product_lib, monkeypatch):
+    """Round 6: the pivot block of a block Gauss-Jordan step swept in registers (csrc/direct_dense_kernels.hpp k_gj_pivot_r:
+    pivot row through LDS, pivot column by v_readlane) uses the expression of the LDS form element by element: the inverse --
+    hence every KKT solve -- has the same bits.  Through the dense top over the supernodes (always block sweeps, 3 steps here).
+    So do the sweeps restricted to the tiles the block pattern says can change (direct.hip gj_symbolic): what they skip are
+    subtractions of exact zeros."""
+    prob = qp_zoo.grid2d(40)
+    monkeypatch.setenv("OSQP_AMD_SNODE", "2")
+    monkeypatch.setenv("OSQP_AMD_SNODE_MAX", "16")
+    monkeypatch.setenv("OSQP_AMD_SN_DENSE", "2")
+    monkeypatch.setenv("OSQP_AMD_SN_DENSE_MAX", "150")
+    n, mm = prob["P"].shape[0], prob["A"].shape[0]
+    rhs = np.random.default_rng(16).standard_normal(n + mm)
+    sols = {}
+    for lds, sparse in (("0", "1"), ("1", "1"), ("0", "0")):
+        monkeypatch.setenv("OSQP_AMD_GJ_PIVOT_LDS", lds)
+        monkeypatch.setenv("OSQP_AMD_GJ_SPARSE", sparse)  # 0: every tile in every step (the block pattern of the sweeps not used)
+        m = oq.Model(product_lib)
+        oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
+        assert oq.stats(m)[25] > 64
+        sols[lds, sparse] = _kkt_solve(m, rhs)
+        oq.clean(m)
+    assert np.all(np.isfinite(sols["0", "1"]))
+    assert np.array_equal(sols["0", "1"], sols["1", "1"]) and np.array_equal(sols["0", "1"], sols["0", "0"])

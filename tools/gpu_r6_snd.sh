@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r06_snd; mkdir -p $O
 export TMPDIR=/tmp OSQP_AMD_BENCH_CPU_FULL=0 OSQP_AMD_BENCH_OTHERS=0
-timeout 1200 python -m pytest tests/test_multifrontal_gpu.py -m gpu -q -x -k "dense_top" > $O/pytest.log 2>&1
+timeout 1200 python -m pytest tests/test_multifrontal_gpu.py -m gpu -q -x -k "dense_top or pivot_block" > $O/pytest.log 2>&1
 tail -15 $O/pytest.log
 run() {
   w=$1; shift

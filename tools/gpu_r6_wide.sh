@@ -1,0 +1,26 @@
+# round 6: fronts of large slabs with 1024 / 512 threads (A/B against the round-5 rule), grid + control refactorisation, dense-top size sweep
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r06_snd; mkdir -p $O
+export TMPDIR=/tmp OSQP_AMD_BENCH_CPU_FULL=0 OSQP_AMD_BENCH_OTHERS=0
+timeout 1200 python -m pytest tests/test_multifrontal_gpu.py -m gpu -q -x -k "multifrontal_factor_is or fronts_beyond" 2>&1 | tail -3
+for w in 1 0; do
+  REFACTOR_GRID=1 OSQP_AMD_MF_WIDE=$w timeout 600 python tools/refactor_time.py --child 700 2>&1 | grep "T=" | sed "s/^/wide=$w /"
+  OSQP_AMD_MF_WIDE=$w OSQP_AMD_MF=1 timeout 600 python tools/refactor_time.py --child 8000 2>&1 | grep "T=" | sed "s/^/wide=$w /"
+done | tee $O/wide_ab.txt
+run() {
+  w=$1; shift
+  env "$@" OSQP_AMD_SETUP_TRACE=1 timeout 900 python bench.py --workload $w --no-cpu --traffic off --steps 100 --warmup 25 2> $O/trace.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$w $*: %.1f it/s  %.4f ms/step  to eps %.4f s  iters %d  frac %.3f step %.3f setup %.2f' % (d['value'], d['ms_per_step'], d['time_to_eps_s'], d['iters_to_eps'], d['roofline']['frac'], d['roofline']['step']['frac'], d['setup_s']))"
+  grep "dense top" $O/trace.txt
+}
+for k in 4300 6000 8000; do
+  run grid2d-5e5 OSQP_AMD_SN_DENSE_MAX=$k
+  REFACTOR_GRID=1 OSQP_AMD_SN_DENSE_MAX=$k timeout 600 python tools/refactor_time.py --child 700 2>&1 | grep "T="
+done | tee $O/sweep2.txt
+for k in 3072 4300 6000; do
+  run grid2d-1e6 OSQP_AMD_SN_DENSE_MAX=$k
+  REFACTOR_GRID=1 OSQP_AMD_SN_DENSE_MAX=$k timeout 600 python tools/refactor_time.py --child 1000 2>&1 | grep "T="
+done | tee $O/sweep3.txt
+run control-1e6 A=1
