@@ -113,6 +113,7 @@ struct LdlFactor {
   double snd_skipped = 0.0;                      // entries of the rows of D that point into D (never read by a solve)
   DevBuf<int> snd_bch, snd_bslot, snd_crange, snd_vch, snd_tiles, snd_trow_ptr, snd_trow_list, snd_pend_ptr;
   DevBuf<int64_t> snd_boff, snd_pend_src, snd_Fd;
+  DevBuf<int> snd_dpos, snd_dinv;                // slot - snd_q0 -> row / column of the dense array, and back
   bool lean_built = false;            // the index arrays of the factor were built on the device (lean_device_*)
   std::vector<int> mfh_bsz, mfh_snof, mfh_chp, mfh_chl, mfh_list;
   std::vector<int64_t> mfh_uoff, mfh_reloff;
@@ -475,13 +476,42 @@ struct LdlFactor {
     snd_nb = (int)bch.size();
     auto up32 = [&](DevBuf<int> &d, const std::vector<int> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
     auto up64 = [&](DevBuf<int64_t> &d, const std::vector<int64_t> &h) { d.alloc(std::max<size_t>(1, h.size())); d.upload(h.data(), h.size(), s); };
+    // the order of the pivots inside the dense array: the supernodes of D in postorder of their tree (children ascending), so that
+    // the segments of a separator -- a chain -- and then whole subtrees are contiguous; OSQP_AMD_SN_DENSE_ORDER=0: slot order
+    std::vector<int> dpos((size_t)K), dinv((size_t)K);
+    {
+      const int nd = T.count - snd_J0;
+      std::vector<int> order;
+      order.reserve(nd);
+      if (getenv("OSQP_AMD_SN_DENSE_ORDER") && atoi(getenv("OSQP_AMD_SN_DENSE_ORDER")) == 0) { for (int J = snd_J0; J < T.count; J++) order.push_back(J); }
+      else {
+        std::vector<int> chp((size_t)nd + 1, 0), chl, stack, next((size_t)nd, 0);
+        for (int J = snd_J0; J < T.count; J++) if (T.up[J] >= snd_J0) chp[(size_t)(T.up[J] - snd_J0) + 1]++;
+        for (int k = 0; k < nd; k++) chp[k + 1] += chp[k];
+        chl.resize((size_t)chp[nd]);
+        { std::vector<int> f(chp.begin(), chp.end() - 1); for (int J = snd_J0; J < T.count; J++) if (T.up[J] >= snd_J0) chl[(size_t)f[T.up[J] - snd_J0]++] = J; }
+        for (int R = snd_J0; R < T.count; R++) {
+          if (T.up[R] >= snd_J0) continue;  // (roots of the forest of D: up = -1)
+          stack.push_back(R);
+          while (!stack.empty()) {
+            const int J = stack.back(), k = J - snd_J0;
+            if (next[k] < chp[k + 1] - chp[k]) stack.push_back(chl[(size_t)chp[k] + next[k]++]);
+            else { order.push_back(J); stack.pop_back(); }
+          }
+        }
+      }
+      if ((int)order.size() != nd) throw Error(6, "internal: the supernodes of the dense top are not a forest");
+      int pos = 0;
+      for (int J : order) for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) { dpos[(size_t)(q - snd_q0)] = pos; dinv[(size_t)pos] = q - snd_q0; pos++; }
+    }
+    up32(snd_dpos, dpos); up32(snd_dinv, dinv);
     up32(snd_bch, bch); up64(snd_boff, boff);
     std::vector<int> hs((size_t)boff.back());
     snd_bslot.alloc(std::max<size_t>(1, hs.size()));
     if (snd_nb) {
       mf_err.zero(s);
       OQ_LAUNCH(k_snd_slots, dim3(snd_nb), dim3(256), 0, s, (const int *)snd_bch.get(), (const int *)sn_ptr.get(), (const int *)sn_piv.get(),
-                (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int64_t *)snd_boff.get(), snd_bslot.get(), mf_err.get());
+                (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int *)snd_dpos.get(), (const int64_t *)snd_boff.get(), snd_bslot.get(), mf_err.get());
       int err = 0;
       mf_err.download(&err, 1, s);
       snd_bslot.download(hs.data(), hs.size(), s);
@@ -529,7 +559,7 @@ struct LdlFactor {
         up32(d_dl, dl); up64(d_doff, doff);
         mf_err.zero(s);
         OQ_LAUNCH(k_snd_slots, dim3((int)dl.size()), dim3(256), 0, s, (const int *)d_dl.get(), (const int *)sn_ptr.get(), (const int *)sn_piv.get(),
-                  (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int64_t *)d_doff.get(), d_ds.get(), mf_err.get());
+                  (const int64_t *)Lp.get(), (const int *)Li.get(), (const int *)mf_slot.get(), snd_q0, (const int *)snd_dpos.get(), (const int64_t *)d_doff.get(), d_ds.get(), mf_err.get());
         int err = 0;
         mf_err.download(&err, 1, s);
         d_ds.download(ds.data(), ds.size(), s);
@@ -541,7 +571,7 @@ struct LdlFactor {
       size_t di = 0;
       for (int J = snd_J0; J < T.count; J++) {
         blk.clear();
-        for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) blk.push_back((q - snd_q0) / 64);
+        for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) blk.push_back(dpos[(size_t)(q - snd_q0)] / 64);
         if (mfh_bsz[J] > 0) { for (int64_t i = doff[di]; i < doff[di + 1]; i++) blk.push_back(ds[(size_t)i] / 64); di++; }
         std::sort(blk.begin(), blk.end());
         blk.erase(std::unique(blk.begin(), blk.end()), blk.end());
@@ -580,7 +610,7 @@ struct LdlFactor {
   // numeric: S = K_DD + the boundary children's update matrices, then -S^-1 by the block sweeps
   void factor_dense_top(hipStream_t s) {
     S0a.zero(s);
-    OQ_LAUNCH(k_snd_init, dim3(snd_K), dim3(64), 0, s, snd_q0, ldD, (const int *)sn_piv.get(), (const int *)mf_slot.get(), (const int64_t *)Lp.get(),
+    OQ_LAUNCH(k_snd_init, dim3(snd_K), dim3(64), 0, s, snd_q0, ldD, (const int *)sn_piv.get(), (const int *)mf_slot.get(), (const int *)snd_dpos.get(), (const int64_t *)Lp.get(),
               (const int *)Li.get(), (const double *)Lx.get(), (const double *)D.get(), (const int *)snd_pend_ptr.get(), (const int64_t *)snd_pend_src.get(),
               (const double *)mf_U.get(), S0a.get());
     if (snd_nb) {
@@ -593,14 +623,15 @@ struct LdlFactor {
   // x_D = S^-1 (b_D - what the levels below contribute), between the forward and the backward sweep of the levels below
   void solve_dense_top(hipStream_t s, bool tree) {
     const bool vec = tree && sn_top_Jt >= 0 && sn_top_Jt < snd_J0;  // the top part below D ran in the one-launch tree: its front vectors exist
-    OQ_LAUNCH(k_snd_rhs, dim3(blocks_for((int64_t)snd_K * 64)), dim3(kBlock), 0, s, snd_q0, snd_K, (const int64_t *)sn_Fp.get(),
+    OQ_LAUNCH(k_snd_rhs, dim3(blocks_for((int64_t)snd_K * 64)), dim3(kBlock), 0, s, snd_q0, snd_K, (const int *)snd_dpos.get(), (const int64_t *)sn_Fp.get(),
               (const int64_t *)(vec ? sn_Ftop.get() : snd_Fd.get()), (const int *)sn_Fj.get(), (const double *)sn_Fx.get(), (const double *)bp.get(), x2.get());
     if (vec && snd_nv)
       OQ_LAUNCH(k_snd_vec, dim3(1), dim3(1024), 0, s, snd_nv, (const int *)snd_vch.get(), (const int *)snd_bch.get(), (const int *)mf_bsz.get(),
                 (const int64_t *)mf_reloff.get(), (const int64_t *)snd_boff.get(), (const int *)snd_bslot.get(), (const double *)sn_uvec.get(), x2.get());
     const int nb = ldD / kDsT;
     OQ_LAUNCH(k_dense_apply_sym, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, snd_K, ldD, nb, (const double *)Sinv, (const double *)x2.get(), dsP1.get(), dsP2.get());
-    OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, snd_K, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + snd_q0);
+    OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, snd_K, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + snd_q0,
+              (const int *)snd_dinv.get());
   }
   // -S^-1 in place of the K x K array in S0a (leading dimension ldD, a multiple of 64; identity on the padding): block sweeps of
   // kGjK pivots on the matrix cores
@@ -864,7 +895,7 @@ struct LdlFactor {
     snd_L0 = snd_J0 = -1; snd_q0 = 0; snd_K = 0;
     const int mode = getenv("OSQP_AMD_SN_DENSE") ? atoi(getenv("OSQP_AMD_SN_DENSE")) : 1;
     if (mode == 0 || T.nlev < 2) return;
-    const int kmax = getenv("OSQP_AMD_SN_DENSE_MAX") ? atoi(getenv("OSQP_AMD_SN_DENSE_MAX")) : 3072;
+    const int kmax = getenv("OSQP_AMD_SN_DENSE_MAX") ? atoi(getenv("OSQP_AMD_SN_DENSE_MAX")) : 4300;
     int L = T.nlev;
     while (L - 1 >= 1 && N - T.ptr[T.lvl_ptr[L - 1]] <= kmax) L--;
     if (L == T.nlev) return;
@@ -1308,7 +1339,7 @@ struct LdlFactor {
       if (dsP1.n) {  // the blocked inverse: symmetric, padded to whole tiles -- the product reads its lower triangle only
         const int nb = ldD / kDsT;
         OQ_LAUNCH(k_dense_apply_sym, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, kD, ldD, nb, (const double *)Sinv, (const double *)x2.get(), dsP1.get(), dsP2.get());
-        OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, kD, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + cD);
+        OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, kD, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + cD, (const int *)nullptr);
       } else
         OQ_LAUNCH(k_dense_apply, dim3(blocks_for((int64_t)kD * 64)), dim3(kBlock), 0, s, kD, ldD, Sinv, x2.get(), bp.get() + cD);
     }

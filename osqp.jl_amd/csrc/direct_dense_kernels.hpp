@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void k_dense_apply_sym(int kD, int ld, int nb,
 }
 // out[a] = -(sum over the tiles below and on the diagonal of a's column block + sum over the tiles left of the diagonal of a's
 // row block), the four wavefronts of a workgroup taking every fourth term, met in a fixed order
+// (`omap` != nullptr: entry a goes to out[omap[a]] -- the dense top over the supernodes keeps its pivots in an order of its own)
 __global__ __launch_bounds__(256) void k_dense_sym_reduce(int kD, int nb, const double *__restrict__ P1, const double *__restrict__ P2,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, const int *__restrict__ omap) {
   __shared__ double part[4][kDsT];
   const int B = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double acc = 0.0;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_dense_sym_reduce(int kD, int nb, const 
   part[wv][lane] = acc;
   __syncthreads();
   const int a = B * kDsT + lane;
-  if (wv == 0 && a < kD) out[a] = -((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+  if (wv == 0 && a < kD) out[omap ? omap[a] : a] = -((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int kD, int ld, const double *__restrict__ S, const double *__restrict__ v,
                                                         double *__restrict__ out) {

@@ -26,9 +26,13 @@ namespace oq {
 namespace {
 
 // setup: slot (relative to q0) of every border row of every boundary child; block per child
+// (the rows and columns of S are the pivots of D in an order of their own, `dpos`: slot - q0 -> position -- the separators one
+// after the other, children before parents, instead of interleaved level by level as the slots are: the block pattern of the
+// sweeps, direct.hip gj_symbolic, is only sparse when a 64-block holds ONE separator's pivots)
 __global__ __launch_bounds__(256) void k_snd_slots(const int *__restrict__ bch, const int *__restrict__ ptr, const int *__restrict__ piv,
                                                    const int64_t *__restrict__ Lp, const int *__restrict__ Li, const int *__restrict__ slot,
-                                                   int q0, const int64_t *__restrict__ boff, int *__restrict__ bslot, int *__restrict__ err) {
+                                                   int q0, const int *__restrict__ dpos, const int64_t *__restrict__ boff,
+                                                   int *__restrict__ bslot, int *__restrict__ err) {
   const int k = blockIdx.x, J = bch[k];
   const int top = piv[ptr[J + 1] - 1];
   const int64_t t0 = Lp[top];
@@ -36,24 +40,24 @@ __global__ __launch_bounds__(256) void k_snd_slots(const int *__restrict__ bch, 
   for (int i = threadIdx.x; i < b; i += 256) {
     const int r = slot[Li[t0 + i]] - q0;
     if (r < 0) atomicOr(err, 8);  // a border row of a child of D below D: the set would not be upward closed
-    bslot[boff[k] + i] = r;
+    bslot[boff[k] + i] = r < 0 ? 0 : dpos[r];
   }
 }
 
 // entries of K in the columns of D (they sit in Lx / D after the scatter kernels of the assembly: no front touches these
 // columns), both triangles; the one-row children of a pivot onto its diagonal entry, in ascending order.  Wavefront per slot.
 __global__ __launch_bounds__(64) void k_snd_init(int q0, int ld, const int *__restrict__ piv, const int *__restrict__ slot,
-                                                 const int64_t *__restrict__ Lp, const int *__restrict__ Li, const double *__restrict__ Lx,
-                                                 const double *__restrict__ D, const int *__restrict__ pend_ptr,
+                                                 const int *__restrict__ dpos, const int64_t *__restrict__ Lp, const int *__restrict__ Li,
+                                                 const double *__restrict__ Lx, const double *__restrict__ D, const int *__restrict__ pend_ptr,
                                                  const int64_t *__restrict__ pend_src, const double *__restrict__ U, double *__restrict__ S) {
-  const int c = blockIdx.x, k = piv[q0 + c];
+  const int k = piv[q0 + blockIdx.x], c = dpos[blockIdx.x];
   if (threadIdx.x == 0) {
     double d = D[k];
     for (int p = pend_ptr[c]; p < pend_ptr[c + 1]; p++) d += U[pend_src[p]];
     S[(size_t)c * (ld + 1)] = d;
   }
   for (int64_t e = Lp[k] + threadIdx.x; e < Lp[k + 1]; e += 64) {
-    const int r = slot[Li[e]] - q0;
+    const int r = dpos[slot[Li[e]] - q0];
     const double v = Lx[e];
     S[(size_t)r + (size_t)c * ld] = v;
     S[(size_t)c + (size_t)r * ld] = v;
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256) void k_snd_extend(SndExtArgs a) {
 
 // t = b_D - (entries of the row before `Fd`: what lies below the part that hands front vectors up -- or below D itself);
 // wavefront per row of D
-__global__ __launch_bounds__(kBlock) void k_snd_rhs(int q0, int K, const int64_t *__restrict__ Fp, const int64_t *__restrict__ Fd,
-                                                    const int *__restrict__ Fj, const double *__restrict__ Fx,
+__global__ __launch_bounds__(kBlock) void k_snd_rhs(int q0, int K, const int *__restrict__ dpos, const int64_t *__restrict__ Fp,
+                                                    const int64_t *__restrict__ Fd, const int *__restrict__ Fj, const double *__restrict__ Fx,
                                                     const double *__restrict__ b, double *__restrict__ t) {
   const int lane = threadIdx.x & 63;
   const int r = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_snd_rhs(int q0, int K, const int64_t
   double acc = gather_dot(Fp[q] + lane, Fd[q], 64, Fj, Fx, b);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) t[r] = b[q] - acc;
+  if (lane == 0) t[dpos[r]] = b[q] - acc;
 }
 // ... minus the front vectors of the boundary children inside the top part, child after child (ONE workgroup: a fixed order of
 // sums; the rows of one child are distinct)
