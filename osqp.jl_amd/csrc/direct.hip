@@ -246,7 +246,7 @@ struct LdlFactor {
         const bool blocked = kD >= kDenseBlocked;
         ldD = blocked ? (kD + 63) / 64 * 64 : kD;
         S0a.alloc((size_t)ldD * ldD);
-        if (blocked) { gjT.alloc(kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD); }
+        if (blocked) { gjT.alloc(2 * kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD); }
         else S0b.alloc((size_t)kD * kD);
         schur_ncols = 0;
         if (blocked && !S.Li.empty() && !(getenv("OSQP_AMD_SCHUR_DENSE") && atoi(getenv("OSQP_AMD_SCHUR_DENSE")) == 0)) {
@@ -598,7 +598,7 @@ struct LdlFactor {
       for (int r = 0; r < K; r++) snd_skipped += (double)(T.Fp[(size_t)snd_q0 + r + 1] - fd[r]);
     }
     S0a.alloc((size_t)ldD * ldD);
-    gjT.alloc(kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD);
+    gjT.alloc(2 * kGjK * kGjK); gjW.alloc((size_t)kGjK * ldD); gjC.alloc((size_t)kGjK * ldD);
     x2.alloc((size_t)K);
     const size_t nbk = (size_t)ldD / kDsT;
     dsP1.alloc(nbk * nbk * kDsT); dsP2.alloc(nbk * nbk * kDsT);
@@ -642,17 +642,22 @@ struct LdlFactor {
   // already swept included.  Simulated once at setup on the 64 x 64 block pattern (`pat`, symmetric, nt x nt); the step lists
   // go to the device.  Skipping a tile skips a subtraction of exact zeros: the same bits as the full sweeps.
   std::vector<int> gj_rptr, gj_tptr;
+  std::vector<char> gj_next;
   DevBuf<int> gj_rows, gj_tiles;
   bool gj_sparse = false;
   void gj_symbolic(std::vector<char> &pat, int nt, hipStream_t s) {
     std::vector<int> rows, tiles;
-    gj_rptr.assign(1, 0); gj_tptr.assign(1, 0);
+    gj_rptr.assign(1, 0); gj_tptr.assign(1, 0); gj_next.clear();
     for (int k = 0; k < nt; k++) {
       std::vector<int> R;
       for (int i = 0; i < nt; i++) if (i == k || pat[(size_t)i * nt + k]) R.push_back(i);
       for (int i : R) for (int j : R) pat[(size_t)i * nt + j] = 1;
       rows.insert(rows.end(), R.begin(), R.end());
-      for (int i : R) for (int j : R) if (j <= i) { tiles.push_back(i); tiles.push_back(j); }
+      // (the next pivot tile is left to the workgroup that sweeps it inside this step's launch, k_gj_update: gj_next says whether
+      // this step changes it at all; a launch without that workgroup -- OSQP_AMD_GJ_FUSE=0 -- must not use these lists: see gj_invert)
+      char nextc = 0;
+      for (int i : R) for (int j : R) if (j <= i) { if (i == k + 1 && j == k + 1) { nextc = 1; continue; } tiles.push_back(i); tiles.push_back(j); }
+      gj_next.push_back(nextc);
       gj_rptr.push_back((int)rows.size()); gj_tptr.push_back((int)(tiles.size() / 2));
     }
     gj_rows.alloc(std::max<size_t>(1, rows.size())); gj_rows.upload(rows.data(), rows.size(), s);
@@ -664,24 +669,37 @@ struct LdlFactor {
               100.0 * (double)(tiles.size() / 2) / ((double)nt * (double)nt * (double)(nt + 1) / 2.0), nt);
   }
   void gj_invert(int K, hipStream_t s) {
-    const bool sparse = gj_sparse && !(getenv("OSQP_AMD_GJ_SPARSE") && atoi(getenv("OSQP_AMD_GJ_SPARSE")) == 0);  // 0: full sweeps (A/B, test)
+    const bool in_registers = !(getenv("OSQP_AMD_GJ_PIVOT_LDS") && atoi(getenv("OSQP_AMD_GJ_PIVOT_LDS")) == 1);   // 1: the round-5 pivot kernel (A/B, test)
+    const bool fuse = in_registers && !(getenv("OSQP_AMD_GJ_FUSE") && atoi(getenv("OSQP_AMD_GJ_FUSE")) == 0);      // 0: the pivot block a launch of its own
+    // (the tile lists leave the next pivot tile to the fused workgroup: without it, full sweeps)
+    const bool sparse = gj_sparse && fuse && !(getenv("OSQP_AMD_GJ_SPARSE") && atoi(getenv("OSQP_AMD_GJ_SPARSE")) == 0);  // 0: full sweeps (A/B, test)
     if (ldD > K) OQ_LAUNCH(k_gj_pad, dim3(blocks_for(ldD - K)), dim3(kBlock), 0, s, K, ldD, S0a.get());
-    const dim3 gp(blocks_for(ldD, 64)), gu(ldD / 64, ldD / 64);
-    // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
-    const bool in_registers = !(getenv("OSQP_AMD_GJ_PIVOT_LDS") && atoi(getenv("OSQP_AMD_GJ_PIVOT_LDS")) == 1);  // 1: the round-5 form (A/B, test)
-    for (int p0 = 0; p0 < ldD; p0 += kGjK) {
-      if (in_registers) OQ_LAUNCH(k_gj_pivot_r, dim3(1), dim3(kGjPivotRThreads), 0, s, K, ldD, p0, S0a.get(), gjT.get(), status.get());
-      else
-      OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, K, ldD, p0, S0a.get(), gjT.get(), status.get());
-      if (sparse) {  // only the blocks coupled with the pivot block (gj_symbolic): the others see zeros in the panels
-        const int k = p0 / kGjK, nr = gj_rptr[k + 1] - gj_rptr[k], ntl = gj_tptr[k + 1] - gj_tptr[k];
-        OQ_LAUNCH(k_gj_panel, dim3(nr), dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)gj_rows.get() + gj_rptr[k]);
-        OQ_LAUNCH(k_gj_update, dim3(ntl), dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)gj_tiles.get() + 2 * (size_t)gj_tptr[k]);
-        continue;
+    const int nt = ldD / 64;
+    const dim3 gu(nt, nt);
+    auto pivot = [&](int p0, double *Tk) {
+      if (in_registers) OQ_LAUNCH(k_gj_pivot_r, dim3(1), dim3(kGjPivotRThreads), 0, s, K, ldD, p0, (const double *)S0a.get(), Tk, status.get());
+      else {
+        // per device, not per process (the library serves several devices): set on every factorisation, as build_mf does
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_gj_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * kGjK * (kGjK + 1))));
+        OQ_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjPivotThreads), sizeof(double) * 2 * kGjK * (kGjK + 1), s, K, ldD, p0, (const double *)S0a.get(), Tk, status.get());
       }
-      OQ_LAUNCH(k_gj_panel, gp, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
-      OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, p0, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
+    };
+    for (int k = 0; k < nt; k++) {
+      const int p0 = k * kGjK;
+      double *Tk = gjT.get() + (size_t)(k & 1) * kGjK * kGjK, *Tn = gjT.get() + (size_t)((k + 1) & 1) * kGjK * kGjK;
+      if (k == 0 || !fuse) pivot(p0, Tk);
+      const int next = (fuse && k + 1 < nt) ? (sparse ? (gj_next[k] ? 2 : 1) : 2) : 0;
+      if (sparse) {  // only the blocks coupled with the pivot block (gj_symbolic): the others see zeros in the panels
+        const int nr = gj_rptr[k + 1] - gj_rptr[k], ntl = gj_tptr[k + 1] - gj_tptr[k];
+        OQ_LAUNCH(k_gj_panel, dim3(nr), dim3(256), 0, s, ldD, p0, (const double *)S0a.get(), (const double *)Tk, gjW.get(), gjC.get(), (const int *)gj_rows.get() + gj_rptr[k]);
+        OQ_LAUNCH(k_gj_update, dim3(ntl + (next ? 1 : 0)), dim3(256), 0, s, ldD, p0, S0a.get(), (const double *)Tk, (const double *)gjW.get(), (const double *)gjC.get(),
+                  (const int *)gj_tiles.get() + 2 * (size_t)gj_tptr[k], ntl, next, Tn, K, status.get());
+      } else {
+        const int ntl = nt * (nt + 1) / 2;
+        OQ_LAUNCH(k_gj_panel, dim3(nt), dim3(256), 0, s, ldD, p0, (const double *)S0a.get(), (const double *)Tk, gjW.get(), gjC.get(), (const int *)nullptr);
+        OQ_LAUNCH(k_gj_update, dim3(ntl + (next ? 1 : 0)), dim3(256), 0, s, ldD, p0, S0a.get(), (const double *)Tk, (const double *)gjW.get(), (const double *)gjC.get(),
+                  (const int *)nullptr, ntl, next, Tn, K, status.get());
+      }
     }
     OQ_LAUNCH(k_gj_mirror, gu, dim3(256), 0, s, ldD, S0a.get());
     Sinv = S0a.get();
@@ -1150,7 +1168,8 @@ struct LdlFactor {
         gjW.zero(s); gjC.zero(s);
         OQ_LAUNCH(k_dense_chunk, dim3(blocks_for((int64_t)kGjK * 64)), dim3(kBlock), 0, s, c0, schur_ncols, cD, ldD, (const int *)schur_cols.get(), Lp.get(),
                   Li.get(), Lx.get(), D.get(), gjW.get(), gjC.get());
-        OQ_LAUNCH(k_gj_update, gu, dim3(256), 0, s, ldD, -kGjK, S0a.get(), gjT.get(), gjW.get(), gjC.get(), (const int *)nullptr);
+        OQ_LAUNCH(k_gj_update, dim3((ldD / 64) * (ldD / 64 + 1) / 2), dim3(256), 0, s, ldD, -kGjK, S0a.get(), (const double *)gjT.get(), (const double *)gjW.get(),
+                  (const double *)gjC.get(), (const int *)nullptr, (ldD / 64) * (ldD / 64 + 1) / 2, 0, (double *)nullptr, kD, status.get());
       }
     }
     for (int b0 = cD; b0 < N && schur_ncols == 0; b0 += bw) {

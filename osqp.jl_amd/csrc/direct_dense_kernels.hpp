@@ -244,16 +244,15 @@ __device__ __forceinline__ double gj_readlane(double x, int lane) {
   u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
   return u.d;
 }
-__global__ __launch_bounds__(kGjPivotRThreads) void k_gj_pivot_r(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
-                                                                 int *__restrict__ status) {
-  __shared__ double tile[kGjK][kGjK + 1];  // tile[j][i] = element (i, j)
-  __shared__ double rowp[2][kGjK];
+// The diagonal tile is bit-symmetric (assembled and updated that way) and the sweeps keep it so -- the mirror of an element is the
+// same expression with the two factors of its product swapped -- so thread (c, h) reads ITS elements (16 h + k, c) from the places of
+// their mirrors (c, 16 h + k), the lanes along the contiguous direction, and writes T the same way: no transposition through LDS.
+__device__ __forceinline__ void gj_pivot_sweep(int kD, int ld, int p0, const double *S, double *__restrict__ T, int *__restrict__ status,
+                                               double (*rowp)[kGjK]) {
   const int t = threadIdx.x, c = t & 63, h = t >> 6;
-  for (int e = t; e < kGjK * kGjK; e += kGjPivotRThreads) { const int i = e % kGjK, j = e / kGjK; tile[j][i] = S[(size_t)(p0 + i) + (size_t)(p0 + j) * ld]; }
-  __syncthreads();
   double v[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) v[k] = tile[c][16 * h + k];
+  for (int k = 0; k < 16; k++) v[k] = S[(size_t)(p0 + c) + (size_t)(p0 + 16 * h + k) * ld];
   int pos = 0, bad = 0;
 #pragma unroll
   for (int p = 0; p < kGjK; p++) {
@@ -268,12 +267,14 @@ __global__ __launch_bounds__(kGjPivotRThreads) void k_gj_pivot_r(int kD, int ld,
     }
     if (p0 + p < kD) { if (piv == 0.0 || piv != piv) bad = 1; else if (piv > 0.0) pos++; }
   }
-  __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; k++) tile[c][16 * h + k] = v[k];
-  __syncthreads();
-  for (int e = t; e < kGjK * kGjK; e += kGjPivotRThreads) { const int i = e % kGjK, j = e / kGjK; T[i + j * kGjK] = tile[j][i]; }
+  for (int k = 0; k < 16; k++) T[c + (16 * h + k) * kGjK] = v[k];
   if (t == 0) { if (bad) atomicOr(&status[0], 1); atomicAdd(&status[1], pos); }
+}
+__global__ __launch_bounds__(kGjPivotRThreads) void k_gj_pivot_r(int kD, int ld, int p0, const double *__restrict__ S, double *__restrict__ T,
+                                                                 int *__restrict__ status) {
+  __shared__ double rowp[2][kGjK];
+  gj_pivot_sweep(kD, ld, p0, S, T, status, rowp);
 }
 // thread per column j of the array: W[k][j] = sum_l G[k][l] S[p0 + l][j], C[k][j] = S[p0 + k][j]  (G = -T)
 // (`cols` != nullptr, round 6: the launch covers only the listed column blocks -- the ones coupled with the pivot block in a
@@ -281,34 +282,42 @@ __global__ __launch_bounds__(kGjPivotRThreads) void k_gj_pivot_r(int kD, int ld,
 __global__ __launch_bounds__(256) void k_gj_panel(int ld, int p0, const double *__restrict__ S, const double *__restrict__ T,
                                                   double *__restrict__ Wp, double *__restrict__ Cp, const int *__restrict__ cols) {
   __shared__ double G[kGjK][kGjK];
-  for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e % kGjK][e / kGjK] = -T[e];
+  for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) G[e / kGjK][e % kGjK] = -T[e];  // (T is bit-symmetric, gj_pivot_sweep: no transposition, no bank conflicts)
   __syncthreads();
   // 64 columns per workgroup, its four wavefronts a quarter of the panel's rows each (round 5: a thread per column and all
   // kGjK rows left the 6000-column panel of equality_qp on 24 compute units, 86 us per step)
-  const int j = (cols ? cols[blockIdx.x] : (int)blockIdx.x) * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
-  if (j >= ld) return;
+  const int jb = cols ? cols[blockIdx.x] : (int)blockIdx.x, c = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const int j0 = jb * 64, j = j0 + c;
+  if (j0 >= ld) return;
+  // the 64 x 64 piece S(p0 + l, j0 + c) from the LOWER triangle (round 5: the sweeps keep only that one current, the mirror is
+  // written once at the end; a diagonal tile is whole): left of the pivot block it sits in its own place, rows contiguous;
+  // right of it in the place of its mirror, columns contiguous.  Round 6: brought to LDS with the lanes along the contiguous
+  // direction either way (a thread per column reading its 64 rows was 64 cache lines per load instruction on the left side:
+  // 21 us a step of a 4 160-pivot block) -- slot (l, c ^ l): no bank conflicts for lanes along l or along c.
+  __shared__ double tile[kGjK * kGjK];
+  if (j0 <= p0) {
+    for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) { const int l = e & 63, cc = e >> 6; tile[l * 64 + (cc ^ l)] = S[(size_t)(p0 + l) + (size_t)(j0 + cc) * ld]; }
+  } else {
+    for (int e = threadIdx.x; e < kGjK * kGjK; e += 256) { const int cc = e & 63, l = e >> 6; tile[l * 64 + (cc ^ l)] = S[(size_t)(j0 + cc) + (size_t)(p0 + l) * ld]; }
+  }
+  __syncthreads();
   double s[kGjK];
-  // element (p0 + l, j) from the LOWER triangle (round 5: the sweeps keep only that one current, the mirror is written once at
-  // the end): its own place for j <= p0 + l, the place of (j, p0 + l) otherwise -- which is also the contiguous read
-  auto at = [&](int r) -> double { return j <= r ? S[(size_t)r + (size_t)j * ld] : S[(size_t)j + (size_t)r * ld]; };
 #pragma unroll
-  for (int l = 0; l < kGjK; l++) s[l] = at(p0 + l);
+  for (int l = 0; l < kGjK; l++) s[l] = tile[l * 64 + (c ^ l)];
 #pragma unroll 4
   for (int k = kq * (kGjK / 4); k < (kq + 1) * (kGjK / 4); k++) {
     double w = 0.0;
 #pragma unroll
     for (int l = 0; l < kGjK; l++) w = __builtin_fma(G[k][l], s[l], w);
     Wp[(size_t)k * ld + j] = w;
-    Cp[(size_t)k * ld + j] = at(p0 + k);  // (from the cache: s[k] with a run-time k would be a scratch access)
+    Cp[(size_t)k * ld + j] = tile[k * 64 + (c ^ k)];
   }
 }
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
 // workgroup (I, J), I >= J: the 64 x 64 tile of rows I, columns J and its mirror; wavefront w its 32 x 32 quadrant
-__global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__restrict__ S, const double *__restrict__ T,
-                                                   const double *__restrict__ Wp, const double *__restrict__ Cp, const int *__restrict__ tiles) {
-  const int I = tiles ? tiles[2 * blockIdx.x] : (int)blockIdx.y, J = tiles ? tiles[2 * blockIdx.x + 1] : (int)blockIdx.x;
+__device__ __forceinline__ void gj_tile_update(int I, int J, int ld, int p0, double *S, const double *__restrict__ T,
+                                               const double *__restrict__ Wp, const double *__restrict__ Cp, double (*tr)[16][17]) {
   if (J > I) return;
-  __shared__ double tr[4][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1;
   if (I == J && wi < wj) return;  // the upper quadrant of a diagonal tile is the mirror of the lower one
   const int lr = lane >> 4, lc = lane & 15;
@@ -355,6 +364,37 @@ __global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *__res
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
     }
+}
+// The launch of a step: a workgroup per tile -- from a list (`tiles`: the tiles the block pattern says can change, direct.hip
+// gj_symbolic) or, without one, every tile on and below the diagonal by its running number -- and, with `next` != 0, ONE MORE
+// workgroup that prepares the NEXT step while the others stream the array (round 6: the pivot block was a launch of its own, a
+// single workgroup for 38 us between two updates of ~35 us): it owns the next pivot tile (I = J = p0 / 64 + 1; the other
+// workgroups leave it alone), brings it up to date (next == 2; next == 1: this step does not touch it), sweeps it in registers
+// and leaves -G in Tnext.
+__global__ __launch_bounds__(256) void k_gj_update(int ld, int p0, double *S, const double *__restrict__ T, const double *__restrict__ Wp,
+                                                   const double *__restrict__ Cp, const int *__restrict__ tiles, int ntiles, int next,
+                                                   double *__restrict__ Tnext, int kD, int *__restrict__ status) {
+  __shared__ double tr[4][16][17];
+  __shared__ double rowp[2][kGjK];
+  const int nextb = p0 / kGjK + 1;
+  if (next && blockIdx.x == 0) {  // (the FIRST workgroup of the launch: it is the longest one -- started last it trailed the launch by its whole length)
+    if (next == 2) gj_tile_update(nextb, nextb, ld, p0, S, T, Wp, Cp, tr);
+    __threadfence_block();
+    __syncthreads();
+    gj_pivot_sweep(kD, ld, nextb * kGjK, S, Tnext, status, rowp);
+    return;
+  }
+  int I, J;
+  const int t = (int)blockIdx.x - (next ? 1 : 0);
+  if (tiles) { I = tiles[2 * t]; J = tiles[2 * t + 1]; }
+  else {  // tile t of the lower triangle, row by row: I (I + 1) / 2 + J
+    I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    while (I * (I + 1) / 2 > t) I--;
+    J = t - I * (I + 1) / 2;
+  }
+  if (next && I == nextb && J == nextb) return;
+  gj_tile_update(I, J, ld, p0, S, T, Wp, Cp, tr);
 }
 // ---- the Schur complement of a LARGE dense block on the matrix cores (round 5) ---------------------------------------------
 // S0 = K22 - L21 D1 L21' entry by entry is a sparse dot product per entry of the block (k_dense_entries: 3.6e7 wavefronts for

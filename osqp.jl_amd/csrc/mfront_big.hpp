@@ -26,7 +26,7 @@ namespace {
 #ifdef OQ_MFB_PROFILE  // experiment build: wall-clock stamps (100 MHz) per phase of k_mfb_panel, printed by launches of one front
 #define MFB_T0 long long mt0 = wall_clock64(), macc[12] = {0};
 #define MFB_T(k) { __syncthreads(); long long mt1 = wall_clock64(); macc[k] += mt1 - mt0; mt0 = mt1; }
-#define MFB_PRINT if (a.count == 1 && tid == 0) printf("mfb f %d s %d children %d: zero %lld scatter %lld narrow %lld wide %lld ldl %lld lx %lld inv %lld w %lld y %lld lxp %lld (x10 ns)\n", f, s, c1 - c0, macc[0], macc[1], macc[2], macc[3], macc[4], macc[5], macc[6], macc[7], macc[8], macc[9]);
+#define MFB_PRINT if (blockIdx.x == 0 && tid == 0) printf("mfb f %d s %d children %d: zero %lld scatter %lld narrow %lld wide %lld ldl %lld lx %lld inv %lld w %lld y %lld lxp %lld (x10 ns)\n", f, s, c1 - c0, macc[0], macc[1], macc[2], macc[3], macc[4], macc[5], macc[6], macc[7], macc[8], macc[9]);
 #else
 #define MFB_T0
 #define MFB_T(k)

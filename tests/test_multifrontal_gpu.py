@@ -339,13 +339,16 @@ def test_pivot_block_in_registers_is_the_lds_sweep(product_lib, monkeypatch):
     n, mm = prob["P"].shape[0], prob["A"].shape[0]
     rhs = np.random.default_rng(16).standard_normal(n + mm)
     sols = {}
-    for lds, sparse in (("0", "1"), ("1", "1"), ("0", "0")):
+    for lds, sparse, fuse in (("0", "1", "1"), ("1", "1", "1"), ("0", "0", "1"), ("0", "1", "0")):
         monkeypatch.setenv("OSQP_AMD_GJ_PIVOT_LDS", lds)
         monkeypatch.setenv("OSQP_AMD_GJ_SPARSE", sparse)  # 0: every tile in every step (the block pattern of the sweeps not used)
+        monkeypatch.setenv("OSQP_AMD_GJ_FUSE", fuse)      # 0: the pivot block swept by a launch of its own, not inside the previous update
         m = oq.Model(product_lib)
         oq.setup(m, linsys_solver="direct", verbose=False, adaptive_rho=False, **prob)
         assert oq.stats(m)[25] > 64
-        sols[lds, sparse] = _kkt_solve(m, rhs)
+        sols[lds, sparse, fuse] = _kkt_solve(m, rhs)
         oq.clean(m)
-    assert np.all(np.isfinite(sols["0", "1"]))
-    assert np.array_equal(sols["0", "1"], sols["1", "1"]) and np.array_equal(sols["0", "1"], sols["0", "0"])
+    ref = sols["0", "1", "1"]
+    assert np.all(np.isfinite(ref))
+    for key, v in sols.items():
+        assert np.array_equal(ref, v), key
