@@ -111,8 +111,8 @@ struct LdlFactor {
   int snd_nb = 0, snd_nv = 0, snd_ntiles = 0;   // boundary children, those of them that hand a front vector up, tiles of the lower triangle
   bool snd_vec_mode = false;                     // the rows of D gather up to sn_Ftop and take the front vectors (the one-launch tree runs the top part)
   double snd_skipped = 0.0;                      // entries of the rows of D that point into D (never read by a solve)
-  DevBuf<int> snd_bch, snd_bslot, snd_crange, snd_vch, snd_tiles, snd_trow_ptr, snd_trow_list, snd_pend_ptr;
-  DevBuf<int64_t> snd_boff, snd_pend_src, snd_Fd;
+  DevBuf<int> snd_bch, snd_bslot, snd_crange, snd_vptr, snd_tiles, snd_trow_ptr, snd_trow_list, snd_pend_ptr;
+  DevBuf<int64_t> snd_boff, snd_pend_src, snd_Fd, snd_vsrc;
   DevBuf<int> snd_dpos, snd_dinv;                // slot - snd_q0 -> row / column of the dense array, and back
   bool lean_built = false;            // the index arrays of the factor were built on the device (lean_device_*)
   std::vector<int> mfh_bsz, mfh_snof, mfh_chp, mfh_chl, mfh_list;
@@ -586,7 +586,15 @@ struct LdlFactor {
     if (sn_top_Jt >= 0 && sn_top_Jt < snd_J0)
       for (int k = 0; k < snd_nb; k++) if (bch[k] >= sn_top_Jt) vch.push_back(k);
     snd_nv = (int)vch.size();
-    up32(snd_vch, vch);
+    {  // per row of the dense array: where its entries of those vectors sit in uvec, children ascending
+      std::vector<int> vptr((size_t)K + 1, 0);
+      for (int k : vch) for (int i = 0; i < mfh_bsz[bch[k]]; i++) vptr[(size_t)hs[boff[k] + i] + 1]++;
+      for (int a = 0; a < K; a++) vptr[a + 1] += vptr[a];
+      std::vector<int64_t> vsrc((size_t)vptr[K]);
+      std::vector<int> fill(vptr.begin(), vptr.end() - 1);
+      for (int k : vch) for (int i = 0; i < mfh_bsz[bch[k]]; i++) vsrc[(size_t)fill[hs[boff[k] + i]]++] = mfh_reloff[bch[k]] + i;
+      up32(snd_vptr, vptr); up64(snd_vsrc, vsrc);
+    }
     // where the entries of a forward row that point into D begin (what a row of D gathers when no front vectors arrive)
     snd_Fd.alloc((size_t)N);
     OQ_LAUNCH(k_lean_split, dim3(blocks_for(N)), dim3(kBlock), 0, s, N, (const int64_t *)sn_Fp.get(), (const int *)sn_Fj.get(), snd_q0, snd_Fd.get());
@@ -624,10 +632,8 @@ struct LdlFactor {
   void solve_dense_top(hipStream_t s, bool tree) {
     const bool vec = tree && sn_top_Jt >= 0 && sn_top_Jt < snd_J0;  // the top part below D ran in the one-launch tree: its front vectors exist
     OQ_LAUNCH(k_snd_rhs, dim3(blocks_for((int64_t)snd_K * 64)), dim3(kBlock), 0, s, snd_q0, snd_K, (const int *)snd_dpos.get(), (const int64_t *)sn_Fp.get(),
-              (const int64_t *)(vec ? sn_Ftop.get() : snd_Fd.get()), (const int *)sn_Fj.get(), (const double *)sn_Fx.get(), (const double *)bp.get(), x2.get());
-    if (vec && snd_nv)
-      OQ_LAUNCH(k_snd_vec, dim3(1), dim3(1024), 0, s, snd_nv, (const int *)snd_vch.get(), (const int *)snd_bch.get(), (const int *)mf_bsz.get(),
-                (const int64_t *)mf_reloff.get(), (const int64_t *)snd_boff.get(), (const int *)snd_bslot.get(), (const double *)sn_uvec.get(), x2.get());
+              (const int64_t *)(vec ? sn_Ftop.get() : snd_Fd.get()), (const int *)sn_Fj.get(), (const double *)sn_Fx.get(), (const double *)bp.get(),
+              (const int *)(vec && snd_nv ? snd_vptr.get() : nullptr), (const int64_t *)snd_vsrc.get(), (const double *)sn_uvec.get(), x2.get());
     const int nb = ldD / kDsT;
     OQ_LAUNCH(k_dense_apply_sym, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, snd_K, ldD, nb, (const double *)Sinv, (const double *)x2.get(), dsP1.get(), dsP2.get());
     OQ_LAUNCH(k_dense_sym_reduce, dim3(nb), dim3(256), 0, s, snd_K, nb, (const double *)dsP1.get(), (const double *)dsP2.get(), bp.get() + snd_q0,

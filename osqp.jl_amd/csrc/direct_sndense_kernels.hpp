@@ -127,33 +127,33 @@ __global__ __launch_bounds__(256) void k_snd_extend(SndExtArgs a) {
     }
 }
 
-// t = b_D - (entries of the row before `Fd`: what lies below the part that hands front vectors up -- or below D itself);
-// wavefront per row of D
+// t = b_D - (entries of the row before `Fd`: what lies below the part that hands front vectors up -- or below D itself)
+//         - (the entries of the boundary children's front vectors that belong to this row, children in ascending order:
+//            `vptr` / `vsrc`, positions in uvec; vptr == nullptr: no vectors);
+// wavefront per row of D.  (The vectors were subtracted child after child by ONE workgroup at first -- a fixed order of sums --
+// which cost 21 us of a 500 us iteration for twenty children: twenty dependent trips to memory.  A row's own list has the same
+// order and a handful of entries, loaded by as many lanes at once.)
 __global__ __launch_bounds__(kBlock) void k_snd_rhs(int q0, int K, const int *__restrict__ dpos, const int64_t *__restrict__ Fp,
                                                     const int64_t *__restrict__ Fd, const int *__restrict__ Fj, const double *__restrict__ Fx,
-                                                    const double *__restrict__ b, double *__restrict__ t) {
+                                                    const double *__restrict__ b, const int *__restrict__ vptr, const int64_t *__restrict__ vsrc,
+                                                    const double *__restrict__ uvec, double *__restrict__ t) {
   const int lane = threadIdx.x & 63;
   const int r = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
   if (r >= K) return;
-  const int q = q0 + r;
+  const int q = q0 + r, a = dpos[r];
   double acc = gather_dot(Fp[q] + lane, Fd[q], 64, Fj, Fx, b);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) t[dpos[r]] = b[q] - acc;
-}
-// ... minus the front vectors of the boundary children inside the top part, child after child (ONE workgroup: a fixed order of
-// sums; the rows of one child are distinct)
-__global__ __launch_bounds__(1024) void k_snd_vec(int nv, const int *__restrict__ vch, const int *__restrict__ bch, const int *__restrict__ bsz,
-                                                  const int64_t *__restrict__ reloff, const int64_t *__restrict__ boff,
-                                                  const int *__restrict__ bslot, const double *__restrict__ uvec, double *t) {
-  for (int v = 0; v < nv; v++) {
-    const int k = vch[v], J = bch[k], b = bsz[J];
-    const double *uc = uvec + reloff[J];
-    const int *bs = bslot + boff[k];
-    for (int i = threadIdx.x; i < b; i += 1024) t[bs[i]] -= uc[i];
-    __threadfence_block();
-    __syncthreads();
+  double v = b[q] - acc;
+  if (vptr) {
+    const int v0 = vptr[a], nv = vptr[a + 1] - v0;
+    for (int base = 0; base < nv; base += 64) {
+      const double u = base + lane < nv ? uvec[vsrc[v0 + base + lane]] : 0.0;
+      const int cnt = nv - base < 64 ? nv - base : 64;
+      for (int i = 0; i < cnt; i++) v -= __shfl(u, i, 64);
+    }
   }
+  if (lane == 0) t[a] = v;
 }
 
 }  // namespace
