@@ -93,11 +93,13 @@ struct LdlFactor {
   DevBuf<int64_t> mf_uoff, mf_reloff;
   DevBuf<uint16_t> mf_rel, mf_loc;
   DevBuf<double> mf_U;
-  struct MfLaunch { int cls, off, count, fcap; int tile_off = 0, tile_count = 0; };  // cls kMfBig: the fronts beyond LDS (mfront_big.hpp)
+  struct MfLaunch { int cls, off, count, fcap; int tile_off = 0, tile_count = 0, chunk_off = 0, chunk_count = 0; };  // cls kMfBig: the fronts beyond LDS (mfront_big.hpp)
   std::vector<MfLaunch> mf_launches;  // in level order
   DevBuf<int64_t> mf_poff;            // panel scratch of the big fronts
   DevBuf<double> mf_panel;
-  DevBuf<int> mf_tiles;
+  DevBuf<int64_t> mf_ct0;
+  DevBuf<int> mf_tiles, mf_chunks, mf_wide, mf_nwide;  // (chunks: 64-row pieces of the big fronts' panels, k_mfb_rows)
+  std::vector<int> mfh_chunks;
   std::vector<int64_t> mfh_poff;
   std::vector<char> mf_is_big;
   std::vector<int> mfh_tiles;
@@ -813,7 +815,7 @@ struct LdlFactor {
     mfh_bsz.assign(count, 0); mfh_snof.assign(N, 0);
     mfh_uoff.assign(count + 1, 0); mfh_reloff.assign(count + 1, 0); mfh_poff.assign(count + 1, 0);
     mf_fmax = 0; mf_big_count = 0; mf_big_fmax = 0;
-    mfh_tiles.clear();
+    mfh_tiles.clear(); mfh_chunks.clear();
     // tests: OSQP_AMD_MF_MAX_FRONT sends smaller fronts through the global-memory kernels too (the zoo at test sizes has none beyond 192 rows)
     const int max_front = getenv("OSQP_AMD_MF_MAX_FRONT") ? std::min(kMfMaxFront, std::max(1, atoi(getenv("OSQP_AMD_MF_MAX_FRONT")))) : kMfMaxFront;
     const bool big_ok = !(getenv("OSQP_AMD_MF_BIG") && atoi(getenv("OSQP_AMD_MF_BIG")) == 0);  // 0: the round-5 behaviour (A/B runs)
@@ -904,6 +906,10 @@ struct LdlFactor {
             for (int tj = 0; tj <= ti; tj++) { mfh_tiles.push_back(i); mfh_tiles.push_back(ti); mfh_tiles.push_back(tj); }
         }
         l.tile_count = (int)(mfh_tiles.size() / 3) - l.tile_off;
+        l.chunk_off = (int)(mfh_chunks.size() / 2);
+        for (int i = 0; i < (int)bigs.size(); i++)
+          for (int ch = 0; ch < (mfh_bsz[bigs[i]] + 63) / 64; ch++) { mfh_chunks.push_back(i); mfh_chunks.push_back(ch); }
+        l.chunk_count = (int)(mfh_chunks.size() / 2) - l.chunk_off;
         mf_launches.push_back(l);
         mfh_list.insert(mfh_list.end(), bigs.begin(), bigs.end());
       }
@@ -944,7 +950,9 @@ struct LdlFactor {
     up32(mf_bsz, mfh_bsz); up32(mf_chp, mfh_chp); up32(mf_chl, mfh_chl); up32(mf_list, mfh_list);
     up64(mf_uoff, mfh_uoff); up64(mf_reloff, mfh_reloff);
     mf_rel.alloc(std::max<int64_t>(1, mfh_reloff[count])); mf_loc.alloc(std::max<int64_t>(1, S.nnzL)); mf_U.alloc(std::max<int64_t>(1, mfh_uoff[count]));
-    up64(mf_poff, mfh_poff); up32(mf_tiles, mfh_tiles);
+    up64(mf_poff, mfh_poff); up32(mf_tiles, mfh_tiles); up32(mf_chunks, mfh_chunks);
+    mf_wide.alloc(std::max<size_t>(1, mfh_chl.size())); mf_nwide.alloc((size_t)count);
+    mf_ct0.alloc(std::max<size_t>(1, (mfh_chunks.size() / 2) * kMfbSmax));
     mf_panel.alloc(std::max<int64_t>(1, mfh_poff[count]));
     mf_err.alloc(1); mf_err.zero(s);
     OQ_LAUNCH(k_mf_rel, dim3(blocks_for(count)), dim3(kBlock), 0, s, count, sn_ptr.get(), sn_piv.get(), sn_up.get(), mf_snof.get(), mf_slot.get(),
@@ -956,12 +964,25 @@ struct LdlFactor {
     mf_err.download(&err, 1, s);
     e.sync();
     if (err) throw Error(6, "internal: the fronts of the supernodes do not cover the pattern of L (code " + std::to_string(err) + ")");
+    for (const MfLaunch &l : mf_launches)  // where the 64-row pieces of the big fronts begin in the columns of L (k_mfb_rows)
+      if (l.cls == kMfBig && l.chunk_count) {
+        MfArgs a{mf_list.get() + l.off, l.count, l.fcap, sn_ptr.get(), sn_piv.get(), mf_bsz.get(), mf_uoff.get(), mf_reloff.get(), mf_rel.get(),
+                 mf_chp.get(), mf_chl.get(), Lp.get(), mf_loc.get(), Lx.get(), D.get(), Dinv.get(), mf_U.get(), status.get(),
+                 sn_Wc.get(), sn_Wr.get(), sn_woff.get()};
+        MfbSplitArgs sa{MfbArgs{a, mf_poff.get(), mf_panel.get(), nullptr}, mf_wide.get(), mf_nwide.get(), mf_chunks.get() + 2 * (size_t)l.chunk_off,
+                        mf_ct0.get() + (size_t)l.chunk_off * kMfbSmax};
+        OQ_LAUNCH(k_mfb_chunk_t0, dim3(blocks_for((int64_t)l.chunk_count * kMfbSmax, 256)), dim3(256), 0, s, l.chunk_count, sa);
+      }
+    e.sync();
     const int lds = (int)(mf_slab_doubles(mf_fmax) * sizeof(double));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_front<512>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, 65536)));
-    if (mf_big_count)
+    if (mf_big_count) {
       HIP_CHECK(hipFuncSetAttribute((const void *)k_mfb_panel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((int)mfb_panel_lds(mf_big_fmax), 65536)));
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_mfb_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((int)mfb_panel_lds(0), 65536)));
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_mfb_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kMfbSmax * 64 * sizeof(double))));
+    }
     if (getenv("OSQP_AMD_SETUP_TRACE")) {
       for (const MfLaunch &l : mf_launches) fprintf(stderr, "[fronts] class %d: %d fronts, slab for %d rows\n", l.cls, l.count, l.fcap);
       fprintf(stderr, "[fronts] beyond LDS: %d fronts (largest %d rows), %.1f MB of panels, update matrices of all fronts %.1f MB\n", mf_big_count,
@@ -970,6 +991,7 @@ struct LdlFactor {
     std::vector<int>().swap(mfh_snof); std::vector<int>().swap(mfh_list); std::vector<int>().swap(mfh_chl);
     mf = true;
   }
+  const bool mfb_split = !(getenv("OSQP_AMD_MFB_SPLIT") && atoi(getenv("OSQP_AMD_MFB_SPLIT")) == 0);  // 0: one workgroup per big front (A/B, tests)
   void run_mf(hipStream_t s) {
     for (const MfLaunch &l : mf_launches) {
       MfArgs a{mf_list.get() + l.off, l.count, l.fcap, sn_ptr.get(), sn_piv.get(), mf_bsz.get(), mf_uoff.get(), mf_reloff.get(), mf_rel.get(),
@@ -977,6 +999,11 @@ struct LdlFactor {
                sn_Wc.get(), sn_Wr.get(), sn_woff.get()};
       if (l.cls == kMfBig) {
         MfbArgs g{a, mf_poff.get(), mf_panel.get(), mf_tiles.get() + 3 * (size_t)l.tile_off};
+        if (mfb_split) {  // the pivot blocks, then the panels in 64-row pieces (mfront_big.hpp)
+          MfbSplitArgs sa{g, mf_wide.get(), mf_nwide.get(), mf_chunks.get() + 2 * (size_t)l.chunk_off, mf_ct0.get() + (size_t)l.chunk_off * kMfbSmax};
+          OQ_LAUNCH(k_mfb_pivot, dim3(l.count), dim3(kMfbPanelThreads), mfb_panel_lds(0), s, sa);
+          if (l.chunk_count) OQ_LAUNCH(k_mfb_rows, dim3(l.chunk_count), dim3(256), 2 * kMfbSmax * 64 * sizeof(double), s, sa);
+        } else
         OQ_LAUNCH(k_mfb_panel, dim3(l.count), dim3(kMfbPanelThreads), mfb_panel_lds(l.fcap), s, g);
         if (l.tile_count) OQ_LAUNCH(k_mfb_update, dim3(l.tile_count), dim3(256), 0, s, g);
       } else if (l.cls == 0) OQ_LAUNCH(k_mf_front<16>, dim3((l.count + 15) / 16), dim3(kMfBlock), 16 * mf_slab_doubles(l.fcap) * sizeof(double), s, a);

@@ -327,6 +327,282 @@ __device__ __forceinline__ int mfb_lower(const uint16_t *v, int n, int key) {
   return l;
 }
 
+// ---- the same front in TWO launches (round 6, second pass) ---------------------------------------------------------------
+// One workgroup per front is one compute unit per front: the phases that scale with the front's rows -- zero, scatter,
+// the wide children's gathers, Y, the panel's columns of L: 190 of the 270 us of a 659-row front -- run on one of 256 units
+// while a launch of the top levels holds nine to forty fronts.  Only the 64 x 64 pivot block is serial.  So:
+//   k_mfb_pivot  one workgroup per front: the pivot block alone (assembly, LDL', inverse), W = L11^-1 left in the unused
+//                block rows of the front's panel scratch (rows < s of its s columns), the children that reach below the block
+//                listed for the second launch;
+//   k_mfb_rows   one workgroup per 64 ROWS of a front's panel: the piece X (64 rows x s columns) assembled in LDS -- entries of
+//                K found by bisection in the columns of L (rows ascend within a column), the listed children gathered through
+//                per-child inverse maps of the piece, one thread per entry, children in ascending order --, Y = X W' with the
+//                four wavefronts taking every fourth column (coefficients broadcast from LDS, plain fused multiply-adds: the DPP
+//                broadcast of the one-launch form runs at a quarter of that rate for 64-bit operands), Y to the panel scratch
+//                and Y D^-1 to the columns of L.
+// OSQP_AMD_MFB_SPLIT=0 keeps the one-launch form (A/B, tests).
+struct MfbSplitArgs {
+  MfbArgs g;
+  int *wide;                  // per front: the children that reach below the pivot block, at wide + chp[J] (ascending)
+  int *nwide;                 // ... how many
+  const int *chunks;          // k_mfb_rows: (index into a.list, 64-row piece) per workgroup
+  int64_t *ct0;               // per piece and column c < 64: where the rows of the piece begin in column c of L (set once: k_mfb_chunk_t0)
+};
+
+__global__ __launch_bounds__(kMfbPanelThreads) void k_mfb_pivot(MfbSplitArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) double mfb_lds[];
+  __shared__ int blk_pos, blk_bad, n_wide;
+  __shared__ int h_bc[64], h_first[64], h_last[64];
+  __shared__ long long h_uoff[64], h_roff[64];
+  __shared__ double h_val[64];
+  const MfbArgs &g = sa.g;
+  const MfArgs &a = g.a;
+  constexpr int TF = kMfbPanelThreads, NWV = TF / 64, RW = 32, CW = TF / RW;
+  const int tid = threadIdx.x, wv = tid / 64, ln = tid % 64, ta = tid % RW, tb = tid / RW;
+  const int J = a.list[blockIdx.x];
+  const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0, b = a.bsz[J], f = s + b;
+  double *F = mfb_lds;                                   // pivot block, packed lower triangle of order s
+  double *dv = F + kMfbSmax * (kMfbSmax + 1) / 2;        // reciprocal pivots
+  double *stU = dv + kMfbSmax + NWV * kMfbRows * kMfbSmax;
+  uint16_t *stR = (uint16_t *)(stU + 64 * kMfbNarrowU);
+  double *Pn = g.panel + g.poff[J];
+  auto cs = [&](int j) { return j * (2 * s - j - 1) / 2; };
+  if (tid == 0) { blk_pos = 0; blk_bad = 0; n_wide = 0; }
+  for (int e = tid; e < s * (s + 1) / 2; e += TF) F[e] = 0.0;
+  __syncthreads();
+  // 1. the entries of K inside the pivot block (the rows of a column ascend: the block's come first)
+  for (int c = tid / 32; c < s; c += TF / 32) {
+    const int k = a.piv[q0 + c], cc = cs(c);
+    if (tid % 32 == 0) F[cc + c] = a.D[k];
+    const int64_t t1 = a.Lp[k + 1];
+    for (int64_t t = a.Lp[k] + tid % 32; t < t1; t += 32) {
+      const int r = a.loc[t];
+      if (r >= s) break;
+      F[cc + r] = a.Lx[t];
+    }
+  }
+  __syncthreads();
+  // 2. extend-add of the children into the pivot block (as k_mfb_panel), the children that reach below it listed
+  const int c0 = a.chp[J], c1 = a.chp[J + 1];
+  for (int cbase = c0; cbase < c1; cbase += 64) {
+    const int nc = c1 - cbase < 64 ? c1 - cbase : 64;
+    __syncthreads();
+    if (tid < nc) {
+      const int cn = a.chl[cbase + tid], bc = a.bsz[cn];
+      const long long uo = a.uoff[cn], ro = a.reloff[cn];
+      h_bc[tid] = bc; h_uoff[tid] = uo; h_roff[tid] = ro;
+      h_first[tid] = bc ? a.rel[ro] : 0; h_last[tid] = bc ? a.rel[ro + bc - 1] : 0;
+      h_val[tid] = bc == 1 ? a.U[uo] : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int nw = n_wide;
+      for (int k = 0; k < nc; k++)
+        if (h_bc[k] >= 2 && h_first[k] < s && h_last[k] >= s) sa.wide[c0 + nw++] = a.chl[cbase + k];
+      n_wide = nw;
+    }
+    {
+      const int k = tid / 8, l = tid % 8;
+      if (k < nc) {
+        const int bc = h_bc[k];
+        if (bc >= 2 && bc <= kMfbNarrow && h_last[k] < s) {
+          if (l < bc) stR[k * kMfbNarrow + l] = a.rel[h_roff[k] + l];
+          for (int e = l; e < bc * (bc + 1) / 2; e += 8) stU[k * kMfbNarrowU + e] = a.U[h_uoff[k] + e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < s) {
+      double d = F[cs(tid) + tid];
+      for (int k = 0; k < nc; k++) if (h_bc[k] == 1 && h_first[k] == tid) d += h_val[k];
+      F[cs(tid) + tid] = d;
+    }
+    __syncthreads();
+    for (int k = 0; k < nc; k++) {
+      const int bc = h_bc[k];
+      if (!(bc >= 2 && bc <= kMfbNarrow && h_last[k] < s)) continue;
+      const uint16_t *rl = stR + k * kMfbNarrow;
+      const double *Uc = stU + k * kMfbNarrowU;
+      for (int bb = 0; bb < bc; bb++) {
+        const int tc = rl[bb];
+        if ((tc & (NWV - 1)) != wv) continue;
+        const int r = bb + ln;
+        if (r < bc) F[cs(tc) + rl[r]] += Uc[bb * (2 * bc - bb - 1) / 2 + r];
+      }
+    }
+    for (int k = 0; k < nc; k++) {
+      const int bc = h_bc[k];
+      if (bc <= 1 || (bc <= kMfbNarrow && h_last[k] < s) || h_first[k] >= s) continue;
+      const double *Uc = a.U + h_uoff[k];
+      const uint16_t *rl = a.rel + h_roff[k];
+      for (int bb = 0; bb < bc; bb++) {
+        const int tc = rl[bb];
+        if (tc >= s) break;
+        if ((tc & (NWV - 1)) != wv) continue;
+        const int cb = cs(tc), ub = bb * (2 * bc - bb - 1) / 2;
+        for (int r = bb + ln; r < bc; r += 64) { const int tr = rl[r]; if (tr < s) F[cb + tr] += Uc[ub + r]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) sa.nwide[J] = n_wide;
+  // 3. the pivots, right-looking inside the block
+  for (int p = 0; p < s; p++) {
+    const int cp = cs(p);
+    const double d = F[cp + p];
+    const double dinv = 1.0 / d;
+    if (tid == 0) { dv[p] = dinv; if ((d == 0.0) || (d != d)) blk_bad = 1; }
+    for (int j = p + 1 + tb; j < s; j += CW) {
+      const double w = F[cp + j] * dinv;
+      const int cj = cs(j);
+      for (int i = j + ta; i < s; i += RW) F[cj + i] -= F[cp + i] * w;
+    }
+    __syncthreads();
+  }
+  // 4. pivots and the block's columns of L to D / Dinv / Lx
+  int pos = 0;
+  for (int c = tid / 16; c < s; c += TF / 16) {
+    const int k = a.piv[q0 + c], cc = cs(c);
+    const double dinv = dv[c];
+    if (tid % 16 == 0) { const double d = F[cc + c]; a.D[k] = d; a.Dinv[k] = dinv; pos += d > 0.0; }
+    for (int64_t t = a.Lp[k] + tid % 16; t < a.Lp[k + 1]; t += 16) { const int r = a.loc[t]; if (r >= s) break; a.Lx[t] = F[cc + r] * dinv; }
+  }
+  __syncthreads();
+  // 5. W = L11^-1 in place (mfront.hpp step 6): B = -W below the diagonal
+  for (int j = tb; j < s; j += CW) {
+    const int cj = cs(j);
+    const double dj = dv[j];
+    for (int i = j + 1 + ta; i < s; i += RW) F[cj + i] *= dj;
+  }
+  __syncthreads();
+  for (int p = 1; p + 1 < s; p++) {
+    const int cp = cs(p);
+    for (int c = tb; c < p; c += CW) {
+      const int cc = cs(c);
+      const double w = F[cc + p];
+      for (int i = p + 1 + ta; i < s; i += RW) F[cc + i] -= F[cp + i] * w;
+    }
+    __syncthreads();
+  }
+  // 6. W to the arrays of the solves, and -- whole, zeros above the diagonal -- to the block rows of the panel scratch for k_mfb_rows
+  for (int j = tb; j < s; j += CW) {
+    const int cj = cs(j), cw = j * (2 * s - j - 1) / 2;
+    for (int i = ta; i < s; i += RW) {
+      const double v = i == j ? 1.0 : (i > j ? -F[cj + i] : 0.0);
+      Pn[(int64_t)j * f + i] = v;
+      if (a.Wc && i >= j) { a.Wc[a.woff[J] + cw + i] = v; a.Wr[a.woff[J] + i * (i + 1) / 2 + j] = v; }
+    }
+  }
+  if (pos) atomicAdd(&blk_pos, pos);
+  __syncthreads();
+  if (tid == 0) {
+    if (blk_bad) atomicOr(&a.status[0], 1);
+    if (blk_pos) atomicAdd(&a.status[1], blk_pos);
+  }
+}
+
+// first position in [t0, t1) whose 16-bit value is >= key (ascending list)
+__device__ __forceinline__ int64_t mfb_lower64(const uint16_t *v, int64_t t0, int64_t t1, int key) {
+  while (t0 < t1) { const int64_t mid = (t0 + t1) >> 1; if ((int)v[mid] < key) t0 = mid + 1; else t1 = mid; }
+  return t0;
+}
+
+// setup: thread per (piece, column): first entry of column c of L whose row of the front is >= the piece's first row (a bisection
+// of ~11 dependent loads -- done inside k_mfb_rows, sixteen columns per wavefront one after the other, it was most of its 100 us)
+__global__ __launch_bounds__(256) void k_mfb_chunk_t0(int nchunks, MfbSplitArgs sa) {
+  const MfArgs &a = sa.g.a;
+  const int i = blockIdx.x * 256 + threadIdx.x, w = i / kMfbSmax, c = i % kMfbSmax;
+  if (w >= nchunks) return;
+  const int J = a.list[sa.chunks[2 * w]], ch = sa.chunks[2 * w + 1];
+  const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0;
+  if (c >= s) { sa.ct0[i] = 0; return; }
+  const int k = a.piv[q0 + c];
+  sa.ct0[i] = mfb_lower64(a.loc, a.Lp[k], a.Lp[k + 1], s + ch * 64);
+}
+
+__global__ __launch_bounds__(256) void k_mfb_rows(MfbSplitArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) double mfb_rows_lds[];  // 2 x 32 KB (above the static limit together with the maps)
+  double *X = mfb_rows_lds;                  // the piece: X[c * 64 + r], row r of the piece, column c of the panel
+  double *Wl = mfb_rows_lds + kMfbSmax * 64; // W(c, k) at Wl[k * 64 + c] (zeros above the diagonal, rows / columns beyond s zero)
+  __shared__ double dinv[kMfbSmax];
+  __shared__ long long tlo[kMfbSmax], thi[kMfbSmax];
+  __shared__ unsigned short invR[64], invC[kMfbSmax];
+  __shared__ int bnd[3];
+  const MfbArgs &g = sa.g;
+  const MfArgs &a = g.a;
+  const int tid = threadIdx.x, wv = tid / 64, ln = tid % 64;
+  const int li = sa.chunks[2 * blockIdx.x], ch = sa.chunks[2 * blockIdx.x + 1];
+  const int J = a.list[li];
+  const int q0 = a.ptr[J], s = a.ptr[J + 1] - q0, b = a.bsz[J], f = s + b;
+  const int R0 = s + ch * 64, nr = f - R0 < 64 ? f - R0 : 64;
+  double *Pn = g.panel + g.poff[J];
+  for (int e = tid; e < kMfbSmax * 64; e += 256) {
+    const int k = e / 64, c = e % 64;
+    X[e] = 0.0;
+    Wl[e] = (k < s && c < s) ? Pn[(int64_t)k * f + c] : 0.0;
+  }
+  if (tid < kMfbSmax) dinv[tid] = tid < s ? a.Dinv[a.piv[q0 + tid]] : 0.0;
+  __syncthreads();
+  // 1. the entries of K in the piece: in column c of L the entries of the rows R0 .. R0 + 64 are one run (the rows ascend)
+  if (tid < s) {  // (the pieces of a front follow each other in the list: the next piece's start is this one's end)
+    const bool last = R0 + 64 >= f;
+    tlo[tid] = sa.ct0[(int64_t)blockIdx.x * kMfbSmax + tid];
+    thi[tid] = last ? a.Lp[a.piv[q0 + tid] + 1] : sa.ct0[((int64_t)blockIdx.x + 1) * kMfbSmax + tid];
+  }
+  __syncthreads();
+  for (int c = wv; c < s; c += 4)
+    for (int64_t t = tlo[c] + ln; t < thi[c]; t += 64) X[c * 64 + (a.loc[t] - R0)] = a.Lx[t];
+  // 2. the children that reach below the pivot block, ascending: entry (R, C) of the piece is U_child(row of R, row of C)
+  const int c0 = a.chp[J], nw = sa.nwide[J];
+  for (int w = 0; w < nw; w++) {
+    const int cn = sa.wide[c0 + w], bc = a.bsz[cn];
+    const uint16_t *rl = a.rel + a.reloff[cn];
+    if ((int)rl[bc - 1] < R0) continue;  // (uniform over the workgroup)
+    __syncthreads();                     // (the previous child's maps and bounds are no longer read)
+    if (tid < 3) bnd[tid] = mfb_lower(rl, bc, tid == 0 ? R0 : (tid == 1 ? R0 + 64 : s));  // three bisections side by side
+    if (tid < 64) invR[tid] = 0xFFFF;
+    if (tid < kMfbSmax) invC[tid] = 0xFFFF;
+    __syncthreads();
+    const int i0 = bnd[0], i1 = bnd[1], ncol = bnd[2];
+    if (i0 == i1) continue;
+    for (int i = i0 + tid; i < i1; i += 256) invR[rl[i] - R0] = (unsigned short)i;
+    for (int i = tid; i < ncol; i += 256) invC[rl[i]] = (unsigned short)i;
+    __syncthreads();
+    const double *Uc = a.U + a.uoff[cn];
+    const unsigned ir = invR[ln];
+    if (ir != 0xFFFFu)
+      for (int C = wv; C < s; C += 4) {
+        const unsigned ic = invC[C];
+        if (ic != 0xFFFFu) X[C * 64 + ln] += Uc[(int64_t)ic * (2 * bc - (int64_t)ic - 1) / 2 + ir];
+      }
+  }
+  __syncthreads();
+  // 3. Y = X W': lane = row of the piece, the wavefront's columns c = wv + 4 j; the sums over k ascending
+  double acc[kMfbSmax / 4];
+#pragma unroll
+  for (int j = 0; j < kMfbSmax / 4; j++) acc[j] = 0.0;
+  for (int k = 0; k < s; k++) {
+    const double xk = X[k * 64 + ln];
+    const double *wk = Wl + k * 64 + wv;
+#pragma unroll
+    for (int j = 0; j < kMfbSmax / 4; j++) acc[j] = __builtin_fma(wk[4 * j], xk, acc[j]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kMfbSmax / 4; j++) X[(wv + 4 * j) * 64 + ln] = acc[j];
+  __syncthreads();
+  // 4. Y to the panel scratch (what k_mfb_update and the solves' top part read), Y D^-1 to the columns of L
+  for (int e = tid; e < s * 64; e += 256) {
+    const int c = e / 64, r = e % 64;
+    if (r < nr) Pn[(int64_t)c * f + R0 + r] = X[e];
+  }
+  for (int c = wv; c < s; c += 4) {
+    const double di = dinv[c];
+    for (int64_t t = tlo[c] + ln; t < thi[c]; t += 64) a.Lx[t] = X[c * 64 + (a.loc[t] - R0)] * di;
+  }
+}
+
+
 constexpr int kMfbPass = 32;  // pivots of the rank-s product staged per pass (two slabs of 32 x 64 doubles: 32 KB of LDS)
 
 __global__ __launch_bounds__(256) void k_mfb_update(MfbArgs g) {

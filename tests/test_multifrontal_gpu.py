@@ -75,16 +75,19 @@ def test_multifrontal_factor_is_the_level_factor(product_lib, monkeypatch, case)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", ["1", "0"])
 @pytest.mark.parametrize("max_front", [8, 40])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_fronts_beyond_lds_give_the_level_factor(product_lib, monkeypatch, case, max_front):
+def test_fronts_beyond_lds_give_the_level_factor(product_lib, monkeypatch, case, max_front, split):
     """Round 6: fronts of more rows than one workgroup's LDS holds are factorised out of global memory (csrc/mfront_big.hpp:
     pivot block in LDS, panel and update matrix in global tiles) instead of sending the whole matrix back to the level-by-level
     factorisation.  The zoo at test sizes has no front beyond 192 rows, so the threshold is lowered (OSQP_AMD_MF_MAX_FRONT): every
     front above `max_front` rows -- parents and children of LDS fronts among them -- takes the global-memory path, and the KKT
-    solves must be those of the level-by-level factor, before and after a rho update."""
+    solves must be those of the level-by-level factor, before and after a rho update.  `split`: the pivot blocks in one launch and
+    the panels in 64-row pieces in a second (k_mfb_pivot + k_mfb_rows, the default) or one workgroup per front (k_mfb_panel)."""
     make, smax = CASES[case]
     prob = make()
+    monkeypatch.setenv("OSQP_AMD_MFB_SPLIT", split)
     monkeypatch.setenv("OSQP_AMD_SNODE", "2")
     monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
     n, mm = prob["P"].shape[0], prob["A"].shape[0]
