@@ -432,6 +432,11 @@ struct LdlFactor {
     sn_top_Jt = -1; sn_top_level = -1;
     if (!mf || !sn_tree || mf_big_count == 0) return;
     if (getenv("OSQP_AMD_SNODE_TOP") && atoi(getenv("OSQP_AMD_SNODE_TOP")) == 0) return;  // A/B runs: rows gathered entry by entry everywhere
+    // Under a dense top (direct_sndense_kernels.hpp) the long chains of large separators -- what the front vectors were built for --
+    // are gone from the launch, and for the levels that remain the plain gathers are the faster form (grid 700 x 700: 2 083 -> 2 409
+    // it/s, 1000 x 1000: 920 -> 1 036 without the vectors: a supernode's hand-over is two loops over its children with a barrier
+    // each and a panel product by one workgroup): off unless asked for (OSQP_AMD_SNODE_TOP=1; the tests of the vector path do)
+    if (snd_K && !(getenv("OSQP_AMD_SNODE_TOP") && atoi(getenv("OSQP_AMD_SNODE_TOP")) == 1)) return;
     // the lowest level, not below the first level of the one-launch tree, from which every supernode has a panel and a border
     // that fits the LDS the kernel has free (4096 doubles)
     int Lt = T.nlev;

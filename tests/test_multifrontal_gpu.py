@@ -305,6 +305,7 @@ def test_dense_top_over_the_supernodes_gives_the_level_factor(product_lib, monke
         monkeypatch.setenv("OSQP_AMD_SN_DENSE_MAX", str(kmax))
         if mode == "dense" and variant != "lds-fronts":
             monkeypatch.setenv("OSQP_AMD_MF_MAX_FRONT", "12")
+            monkeypatch.setenv("OSQP_AMD_SNODE_TOP", "1")  # (front vectors below a dense top are opt-in: the rows of D must take them)
         if mode == "dense" and variant == "global-fronts-no-tree":
             monkeypatch.setenv("OSQP_AMD_SNODE_TREE", "0")
         m = oq.Model(product_lib)
