@@ -54,6 +54,15 @@ __device__ __forceinline__ void mf_sync() {
   }
 }
 
+#ifdef OQ_MF_PROFILE  // experiment build: wall-clock stamps (100 MHz) per phase of k_mf_front, printed by the first front of a launch
+#define MF_T0 long long mt0 = wall_clock64(), macc[8] = {0};
+#define MF_T(k) { __syncthreads(); long long mt1 = wall_clock64(); macc[k] += mt1 - mt0; mt0 = mt1; }
+#define MF_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("mf TF %d count %d f %d s %d children %d: zero+K %lld extend %lld pivots %lld U %lld L %lld W %lld Wout %lld (x10 ns)\n", TF, a.count, f, s, a.chp[J + 1] - a.chp[J], macc[0], macc[1], macc[2], macc[3], macc[4], macc[5], macc[6]);
+#else
+#define MF_T0
+#define MF_T(k)
+#define MF_PRINT
+#endif
 constexpr int kMfBlock = 256;
 __host__ __device__ inline size_t mf_slab_doubles(int fcap) { return (size_t)fcap * (fcap + 1) / 2 + (size_t)(fcap < 64 ? fcap : 64); }
 
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
   double *F = mf_lds + (size_t)fr * mf_slab_doubles(a.fcap);
   double *dv = F + (size_t)a.fcap * (a.fcap + 1) / 2;  // reciprocal pivots
   auto cs = [&](int j) { return j * (2 * f - j - 1) / 2; };
+  MF_T0
   if (threadIdx.x == 0) blk_pos = 0;
   for (int e = tid; e < f * (f + 1) / 2; e += TF) F[e] = 0.0;
   mf_sync<TF>();
@@ -86,11 +96,56 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
     for (int64_t t = a.Lp[k] + tid % G; t < a.Lp[k + 1]; t += G) F[cc + a.loc[t]] = a.Lx[t];
   }
   mf_sync<TF>();
+  MF_T(0)
   // 2. extend-add of the children's update matrices.  No barrier between children: a target column belongs to ONE wavefront
   //    (column mod 4 of the front for the workgroup form; the only wavefront otherwise), and the LDS operations of a wavefront
   //    run in program order, so every entry of the front receives its children's terms in ascending order of the children --
   //    a fixed order of sums without the child-after-child barriers that made a front with 58 children ~100 us of latency.
-  {
+  if constexpr (TF >= 256) {
+    // (round 6) A front of a problem with a constraint row per variable has one ONE-ROW child per pivot -- 58 children for the 84-row
+    // fronts of the control family, 70 for a 119-row front of a grid -- and walking them one after the other was four dependent trips
+    // to memory each: 59 of the 183 us of such a front, as much as its pivots.  As in k_mfb_panel: the headers of up to 64 children
+    // at a time come to LDS in one round, a one-row child is one number added to the diagonal entry of its row (the row's thread adds
+    // them up in the order of the children), the others follow with their headers at hand.  (Fixed order of sums: the one-row
+    // children of a batch first, then the others, ascending.)
+    __shared__ int h_bc[64], h_first[64];
+    __shared__ long long h_uoff[64], h_roff[64];
+    __shared__ double h_val[64];
+    constexpr int NWV = TF / 64;
+    const int wvf = tid / 64, ln = tid % 64;
+    const int c0 = a.chp[J], c1 = a.chp[J + 1];
+    for (int cbase = c0; cbase < c1; cbase += 64) {
+      const int nc = c1 - cbase < 64 ? c1 - cbase : 64;
+      __syncthreads();
+      if (tid < nc) {
+        const int cn = a.chl[cbase + tid], bc = a.bsz[cn];
+        const long long uo = a.uoff[cn], ro = a.reloff[cn];
+        h_bc[tid] = bc; h_uoff[tid] = uo; h_roff[tid] = ro;
+        h_first[tid] = bc ? a.rel[ro] : 0;
+        h_val[tid] = bc == 1 ? a.U[uo] : 0.0;
+      }
+      __syncthreads();
+      if (tid < f) {
+        double d = F[cs(tid) + tid];
+        for (int k = 0; k < nc; k++) if (h_bc[k] == 1 && h_first[k] == tid) d += h_val[k];
+        F[cs(tid) + tid] = d;
+      }
+      __syncthreads();
+      for (int k = 0; k < nc; k++) {
+        const int bc = h_bc[k];
+        if (bc <= 1) continue;
+        const double *Uc = a.U + h_uoff[k];
+        const uint16_t *rl = a.rel + h_roff[k];
+        for (int bb = 0; bb < bc; bb++) {
+          const int tc = rl[bb];
+          if ((tc & (NWV - 1)) != wvf) continue;
+          const int cb = cs(tc), ub = bb * (2 * bc - bb - 1) / 2;
+          for (int r = bb + ln; r < bc; r += 64) F[cb + rl[r]] += Uc[ub + r];
+        }
+      }
+    }
+    mf_sync<TF>();
+  } else {
     constexpr int NWV = TF >= 64 ? TF / 64 : 1;                 // wavefronts of the front
     constexpr int LW = TF >= 64 ? 64 : TF;                      // lanes that share the rows of one child column
     const int wvf = TF >= 64 ? tid / 64 : 0, ln = tid % LW;
@@ -112,6 +167,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
     }
     mf_sync<TF>();
   }
+  MF_T(1)
   // 3. the pivots of the supernode: right-looking over the columns of the panel
   int bad = 0;
   for (int p = 0; p < s; p++) {
@@ -139,6 +195,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
     }
     mf_sync<TF>();
   }
+  MF_T(2)
   // 4. update matrix: U(r, c) = F(s + r, s + c) - sum_p F(s + r, p) dinv_p F(s + c, p), sums in registers
   if (b > 0) {
     double *Uj = a.U + a.uoff[J];
@@ -158,6 +215,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
       }
     }
   }
+  MF_T(3)
   // 5. the columns of L, the pivots, the inertia
   int pos = 0;
   for (int c = tid / G; c < s; c += TF / G) {
@@ -169,6 +227,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
   // 6. W = L_JJ^-1 in place.  With B = -W below the diagonal, eliminating column p of the unit lower triangular block from
   //    the rows below it is   B(i, c) -= B(i, p) B(p, c),  c < p < i   (B(i, p) is still the entry of L when step p reads it:
   //    it only becomes a target in later steps) -- every update of a step is independent, one barrier per step.
+  MF_T(4)
   if (a.Wc) {
     mf_sync<TF>();
     for (int j = tb; j < s; j += CW) {
@@ -192,6 +251,7 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
       }
       mf_sync<TF>();
     }
+    MF_T(5)
     double *Wc = a.Wc + (live ? a.woff[J] : 0), *Wr = a.Wr + (live ? a.woff[J] : 0);
     for (int j = tb; j < s; j += CW) {
       const int cj = cs(j), cw = j * (2 * s - j - 1) / 2;
@@ -202,6 +262,8 @@ __global__ __launch_bounds__(TF > kMfBlock ? TF : kMfBlock) void k_mf_front(MfAr
       }
     }
   }
+  MF_T(6)
+  MF_PRINT
   if (bad) atomicOr(&a.status[0], 1);
   if (pos) atomicAdd(&blk_pos, pos);
   __syncthreads();
