@@ -130,7 +130,28 @@ def grid2d(g=24, seed=7, diag=0.1):
     return dict(P=P, q=q, A=A, l=-b, u=b)
 
 
-ZOO = {"grid2d": grid2d, "control": control, "portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
+def grid3d(g=10, seed=8, diag=0.1, coupled_rows=True):
+    """A QP on a g x g x g grid (separators of ~g^2 nodes: fronts far beyond one workgroup's LDS already at g = 12): P = the 7-point
+    Laplacian + diag * I; constraints: a box on every variable and -- `coupled_rows` -- a band on the difference of every pair of
+    neighbours along the first axis (rows of A with two entries: the KKT graph is not just the grid with pendant nodes)."""
+    rng = np.random.default_rng(seed)
+    n = g ** 3
+    T = sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+    I = sp.eye(g)
+    P = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + diag * sp.eye(n)).tocsc()
+    q = rng.standard_normal(n)
+    rows = [sp.eye(n, format="csr")]
+    lo, up = [-(0.5 + rng.random(n))], [0.5 + rng.random(n)]
+    if coupled_rows:
+        D = sp.diags([-np.ones(g - 1), np.ones(g - 1)], [0, 1], shape=(g - 1, g))
+        G = sp.kron(sp.kron(D, I), I).tocsr()
+        rows.append(G)
+        lo.append(-0.3 * np.ones(G.shape[0])); up.append(0.3 * np.ones(G.shape[0]))
+    A = sp.vstack(rows).tocsc()
+    return dict(P=P, q=q, A=A, l=np.concatenate(lo), u=np.concatenate(up))
+
+
+ZOO = {"grid2d": grid2d, "grid3d": grid3d, "control": control, "portfolio": portfolio, "svm": svm, "huber": huber, "lasso_data": lasso_data, "equality_qp": equality_qp}
 
 
 def kkt_check(prob, x, y, eps):

@@ -42,6 +42,7 @@ CASES = {
     "random-60": (lambda: _random_problem(np.random.default_rng(5), 60, 90, 0.08), 64),
     "random-200": (lambda: _random_problem(np.random.default_rng(6), 200, 150, 0.02), 24),
     "grid2d-40": (lambda: qp_zoo.grid2d(40), 64),
+    "grid3d-9": (lambda: qp_zoo.grid3d(9), 32),
 }
 
 
@@ -283,7 +284,7 @@ def test_lone_leaves_outside_the_blocks(product_lib, monkeypatch, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["lds-fronts", "global-fronts", "global-fronts-no-tree"])
 @pytest.mark.parametrize("kmax", [24, 150])
-@pytest.mark.parametrize("case", ["control-400", "grid2d-40", "portfolio", "random-200"])
+@pytest.mark.parametrize("case", ["control-400", "grid2d-40", "grid3d-9", "portfolio", "random-200"])
 def test_dense_top_over_the_supernodes_gives_the_level_factor(product_lib, monkeypatch, case, kmax, variant):
     """Round 6: a dense top block OVER the supernode partition (csrc/direct_sndense_kernels.hpp): the supernodes of the last
     levels are not factorised by fronts -- their Schur complement is assembled from the boundary children's update matrices,
