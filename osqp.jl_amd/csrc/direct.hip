@@ -301,8 +301,21 @@ struct LdlFactor {
     if (const char *v = getenv("OSQP_AMD_SNODE_MAX")) smax = std::max(1, std::min(kSnMax, atoi(v)));
     build_supernodes(S, smax, T, false, lean);  // lean: the partition, list lengths as upper bounds from the counts
     sn = mode == 2 || supernodes_pay(S, T, kChainRows, lD, kD, kSnThreads);
-    if (!sn) { T = Supernodes(); return; }
-    mf_ok = mf_plan();
+    bool planned = false;
+    if (!sn) {
+      // (round 6) second look with the plan of the fronts: where it puts a dense top over the partition -- a 2-D / 3-D structure: the
+      // long chains of large separators at the top, which the model above charges level by level, are ONE product -- the solve is
+      // modelled with it; and a level schedule that would carry a dense block of thousands of pivots above a deep tree pays for
+      // that block's Schur complement at every refactorisation (a 50 x 50 x 50 grid: 12 277 pivots, 0.9 s; by fronts: 22 ms)
+      mf_ok = mf_plan();
+      planned = true;
+      if (mf_ok && snd_K > 0) {
+        const double with_top = supernode_solve_cost_us(T, kSnThreads, snd_L0) + (double)snd_K * (double)snd_K * 4.0 / 4.0e6 + 30.0;
+        sn = with_top < level_solve_cost_us(S, kChainRows, lD, kD) || kD >= 2048;
+      }
+    }
+    if (!sn) { T = Supernodes(); mf_ok = false; snd_L0 = snd_J0 = -1; snd_q0 = 0; snd_K = 0; return; }
+    if (!planned) mf_ok = mf_plan();
     if (!mf_ok && !lean) supernode_wmap(S, T);  // k_sn_invert gathers the blocks through it; the fronts invert theirs in place
   }
 
@@ -848,13 +861,15 @@ struct LdlFactor {
         mf_big_fmax = std::max(mf_big_fmax, s_ + (int)b);
         mfh_poff[J + 1] = (int64_t)(s_ + b) * s_;
       } else mf_fmax = std::max(mf_fmax, s_ + (int)b);
-      mfh_bsz[J] = (int)b;
-      mfh_uoff[J + 1] = mfh_uoff[J] + b * (b + 1) / 2;
+      mfh_bsz[J] = (int)b;  // (where its update matrix lives: place_update_matrices, once the dense top is known)
       mfh_reloff[J + 1] = mfh_reloff[J] + b;
       for (int q = T.ptr[J]; q < T.ptr[J + 1]; q++) mfh_snof[T.piv[q]] = J;
     }
     for (int J = 0; J < count; J++) mfh_poff[J + 1] += mfh_poff[J];
-    {  // the update matrices of all supernodes are resident at once, beside the factor: they have to fit what the device has free
+    choose_dense_top_over_supernodes();
+    place_update_matrices();
+    {  // the update matrices (as placed: the large ones share memory over their lifetimes), beside the factor: they have to fit what
+       // the device has free
       size_t free_b = 0, total_b = 0;
       const int64_t need = 8 * (mfh_uoff[count] + mfh_poff[count]);
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -871,7 +886,6 @@ struct LdlFactor {
     mfh_list.clear();
     mfh_list.reserve(count);
     mf_launches.clear();
-    choose_dense_top_over_supernodes();
     for (int L = 0; L < (snd_K ? snd_L0 : T.nlev); L++) {  // (the supernodes of the dense top have no front)
       std::vector<int> cls[kMfClasses];
       int cap[kMfClasses] = {0};
@@ -921,6 +935,64 @@ struct LdlFactor {
     }
     return true;
   }
+  // Where the update matrices live (round 6).  Up to now every supernode had its own place for the whole factorisation: the sum
+  // of b (b + 1) / 2 over all fronts -- fine for chains and 2-D structures (0.3 GB on control-1e6, 1.1 GB on a 1000 x 1000 grid),
+  // beyond the 2^32-double limit of the plan on a 50 x 50 x 50 grid (borders of 4 000 rows: 60 - 190 MB per front, ~5e9 doubles
+  // in all), which sent the whole matrix back to the level-by-level factorisation: 1.07 s per refactorisation.  An update matrix
+  // is written in the launches of its supernode's level and read in the launches of its parent's level, nowhere else: the LARGE
+  // ones (>= kMfShareMin doubles; a few thousand at most) are placed by their lifetimes -- level by level: place the level's own,
+  // then release those whose parent sits on this level (first fit over a free list, neighbours merged) --, the small ones keep
+  // a place of their own (their sum is small, and a million of them through a free list would be a quadratic plan).
+  // mfh_uoff[J] = offset of supernode J, mfh_uoff[count] = doubles in all.  The supernodes of a dense top have no update matrix;
+  // their boundary children's live to the end (the dense array is assembled after the last level).
+  static constexpr int64_t kMfShareMin = 16384;
+  void place_update_matrices() {
+    const int count = T.count;
+    const bool share = !(getenv("OSQP_AMD_MF_SHARE_U") && atoi(getenv("OSQP_AMD_MF_SHARE_U")) == 0);  // 0: every update matrix a place of its own (A/B, tests)
+    const int j_end = snd_K ? snd_J0 : count;
+    const int64_t share_min = getenv("OSQP_AMD_MF_SHARE_MIN") ? std::max(1, atoi(getenv("OSQP_AMD_MF_SHARE_MIN"))) : kMfShareMin;  // (tests: small problems)
+    auto size_of = [&](int J) { return J < j_end ? (int64_t)mfh_bsz[J] * (mfh_bsz[J] + 1) / 2 : (int64_t)0; };
+    int64_t base = 0;
+    for (int J = 0; J < count; J++) {
+      const int64_t sz = size_of(J);
+      mfh_uoff[J] = base;
+      if (!share || sz < share_min) base += sz;
+    }
+    if (!share) { mfh_uoff[count] = base; return; }
+    // the large ones: [offset, size) blocks above `base`
+    std::vector<std::pair<int64_t, int64_t>> free_list;  // sorted by offset
+    int64_t top = base;
+    std::vector<std::vector<int>> dies((size_t)T.nlev);   // per level: the large update matrices whose parent sits there
+    std::vector<int> level_of((size_t)count, 0);
+    for (int L = 0; L < T.nlev; L++) for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) level_of[J] = L;
+    for (int L = 0; L < T.nlev; L++) {
+      for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1] && J < j_end; J++) {
+        const int64_t sz = size_of(J);
+        if (sz < share_min) continue;
+        size_t k = 0;
+        while (k < free_list.size() && free_list[k].second < sz) k++;
+        if (k < free_list.size()) {
+          mfh_uoff[J] = free_list[k].first;
+          if (free_list[k].second == sz) free_list.erase(free_list.begin() + (long)k);
+          else { free_list[k].first += sz; free_list[k].second -= sz; }
+        } else if (!free_list.empty() && free_list.back().first + free_list.back().second == top) {  // grow the last free block at the top
+          mfh_uoff[J] = free_list.back().first;
+          top = free_list.back().first + sz;
+          free_list.pop_back();
+        } else { mfh_uoff[J] = top; top += sz; }
+        const int P = T.up[J];
+        if (P >= 0 && P < j_end) dies[level_of[P]].push_back(J);  // (a parent in the dense top: read after the last level -- never released)
+      }
+      for (int J : dies[L]) {
+        std::pair<int64_t, int64_t> blk(mfh_uoff[J], size_of(J));
+        auto it = std::lower_bound(free_list.begin(), free_list.end(), blk);
+        it = free_list.insert(it, blk);
+        if (it + 1 != free_list.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; free_list.erase(it + 1); }
+        if (it != free_list.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; free_list.erase(it); }
+      }
+    }
+    mfh_uoff[count] = top;
+  }
   // The dense top over the supernodes (direct_sndense_kernels.hpp): the largest set of whole top levels with at most
   // OSQP_AMD_SN_DENSE_MAX pivots.  Taken by default where fronts go through global memory (a 2-D structure: the top levels are
   // chains of large separators, ~300 us of factorisation and ~28 us of solve per level) and at least eight levels go; a tree whose
@@ -933,6 +1005,13 @@ struct LdlFactor {
     const int kmax = getenv("OSQP_AMD_SN_DENSE_MAX") ? atoi(getenv("OSQP_AMD_SN_DENSE_MAX")) : 4300;
     int L = T.nlev;
     while (L - 1 >= 1 && N - T.ptr[T.lvl_ptr[L - 1]] <= kmax) L--;
+    // ... and on while the next level down is still a chain (at most four supernodes: a level of pure latency in the solves and of
+    // a handful of workgroups in the factorisation), up to 8 192 pivots: the separators of a 3-D structure are planes -- a
+    // 50 x 50 x 50 grid has 63 levels of one supernode each above 4 247 pivots and is still at 1.5 supernodes a level at 7 817
+    // (293 -> 694 it/s for 22 -> 32 ms of refactorisation); a 700 x 700 grid is at eleven a level below its 4 137 and stops there.
+    // (Not when the size was asked for explicitly.)
+    if (!getenv("OSQP_AMD_SN_DENSE_MAX"))
+      while (L - 1 >= 1 && T.lvl_ptr[L] - T.lvl_ptr[L - 1] <= 4 && N - T.ptr[T.lvl_ptr[L - 1]] <= 8192) L--;
     if (L == T.nlev) return;
     const int K = N - T.ptr[T.lvl_ptr[L]];
     if (mode != 2 && (mf_big_count == 0 || T.nlev - L < 8 || K < 256)) return;

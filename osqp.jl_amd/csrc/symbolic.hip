@@ -1080,9 +1080,9 @@ double level_solve_cost_us(const Symbolic &Y, int chain_rows, int dense_max, int
   return us;
 }
 
-double supernode_solve_cost_us(const Supernodes &T, int threads) {
+double supernode_solve_cost_us(const Supernodes &T, int threads, int levels) {
   double cost = 0.0;
-  for (int L = 0; L < T.nlev; L++) {
+  for (int L = 0; L < (levels >= 0 ? std::min(levels, T.nlev) : T.nlev); L++) {
     double worst = 0.0;
     for (int J = T.lvl_ptr[L]; J < T.lvl_ptr[L + 1]; J++) {
       const int q0 = T.ptr[J], q1 = T.ptr[J + 1];

@@ -119,7 +119,8 @@ double level_solve_cost_us(const Symbolic &Y, int chain_rows, int dense_max, int
 double level_solve_cost_us(const Symbolic &Y, int chain_rows, int lD, int kD);
 // ... and by supernodes: two launches per direction, inside them one hand-over between workgroups per level; the
 // slowest workgroup of each level walks its entries outside the blocks and its block with `threads` threads.
-double supernode_solve_cost_us(const Supernodes &T, int threads);
+// (levels >= 0: only the first `levels` levels -- what is left below a dense top over the partition, direct_sndense_kernels.hpp)
+double supernode_solve_cost_us(const Supernodes &T, int threads, int levels = -1);
 bool supernodes_pay(const Symbolic &S, const Supernodes &T, int chain_rows, int lD, int kD, int threads);
 
 }  // namespace oq

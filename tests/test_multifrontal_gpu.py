@@ -47,10 +47,16 @@ CASES = {
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("share_min", ["", "3"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_multifrontal_factor_is_the_level_factor(product_lib, monkeypatch, case):
+def test_multifrontal_factor_is_the_level_factor(product_lib, monkeypatch, case, share_min):
+    """`share_min`: update matrices of at least that many entries share memory over their lifetimes (written at their supernode's
+    level, read at the parent's; csrc/direct.hip place_update_matrices -- by default from 16 384 entries on, which no problem of
+    test size reaches; 3 = every update matrix beyond one row)."""
     make, smax = CASES[case]
     prob = make()
+    if share_min:
+        monkeypatch.setenv("OSQP_AMD_MF_SHARE_MIN", share_min)
     monkeypatch.setenv("OSQP_AMD_SNODE", "2")
     monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
     n, mm = prob["P"].shape[0], prob["A"].shape[0]
@@ -89,6 +95,7 @@ def test_fronts_beyond_lds_give_the_level_factor(product_lib, monkeypatch, case,
     make, smax = CASES[case]
     prob = make()
     monkeypatch.setenv("OSQP_AMD_MFB_SPLIT", split)
+    monkeypatch.setenv("OSQP_AMD_MF_SHARE_MIN", "3" if max_front == 8 else "100000000")  # (shared update matrices under the big fronts too)
     monkeypatch.setenv("OSQP_AMD_SNODE", "2")
     monkeypatch.setenv("OSQP_AMD_SNODE_MAX", str(smax))
     n, mm = prob["P"].shape[0], prob["A"].shape[0]
@@ -304,6 +311,7 @@ def test_dense_top_over_the_supernodes_gives_the_level_factor(product_lib, monke
         monkeypatch.setenv("OSQP_AMD_MF", "0" if mode == "level" else "1")
         monkeypatch.setenv("OSQP_AMD_SN_DENSE", "0" if mode == "level" else "2")
         monkeypatch.setenv("OSQP_AMD_SN_DENSE_MAX", str(kmax))
+        monkeypatch.setenv("OSQP_AMD_MF_SHARE_MIN", "3" if kmax == 24 else "100000000")  # (boundary children's update matrices are never released)
         if mode == "dense" and variant != "lds-fronts":
             monkeypatch.setenv("OSQP_AMD_MF_MAX_FRONT", "12")
             monkeypatch.setenv("OSQP_AMD_SNODE_TOP", "1")  # (front vectors below a dense top are opt-in: the rows of D must take them)
