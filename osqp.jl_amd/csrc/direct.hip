@@ -144,7 +144,11 @@ struct LdlFactor {
     // asked (the min-degree analysis of such a graph only finds the chain: 2 - 3 s at 2.7e6 nodes), and min-degree is the
     // second opinion when the dissection comes out deep
     bool nd_by_depth = false;
-    if (first_ordering < 0 && e.hP.cols + mr_ >= 200000) nd_by_depth = kkt_graph_depth(e.hP, e.hA, row_map, mr_) >= 400;
+    // (round 6: "long" is a level structure of 100 levels or more -- 400 until then: a 50 x 50 x 50 grid is 150 deep, and its
+    // minimum-degree analysis was 2.2 of its 3.8 s of setup only to be replaced by the dissection; random sparsity at this size is
+    // 10 - 20 deep.  A dissection that comes out badly is still replaced below.  OSQP_AMD_ND_DEPTH overrides.)
+    const int nd_depth = getenv("OSQP_AMD_ND_DEPTH") ? atoi(getenv("OSQP_AMD_ND_DEPTH")) : 100;
+    if (first_ordering < 0 && e.hP.cols + mr_ >= 200000) nd_by_depth = kkt_graph_depth(e.hP, e.hA, row_map, mr_) >= nd_depth;
     if (first_ordering < 0) first_ordering = nd_by_depth ? 1 : 0;
     // Round 5: a large long problem (the class nested dissection goes first on) gets a LEAN analysis -- numbering, tree,
     // levels, counts and the unsorted rows of the pattern -- and, when the factor is a supernodal one with fronts that fit

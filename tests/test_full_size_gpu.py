@@ -112,6 +112,38 @@ def test_grid2d_700_matches_oracle_at_full_size(product_lib, oracle_lib, monkeyp
     assert pri <= 2.0 * eps_pri and dua <= 2.0 * eps_dua, (pri, eps_pri, dua, eps_dua)
 
 
+def test_grid3d_36_matches_oracle(product_lib, oracle_lib, monkeypatch):
+    """Round 6: a second structure nobody tuned for -- a 36 x 36 x 36 grid QP (tests/qp_zoo.py grid3d: 7-point Laplacian, a box
+    on every variable and a band on the difference of neighbours along one axis: rows of A with two entries; N = 1.4e5 pivots,
+    separators are planes of ~1 300 nodes, fronts of ~2 000 rows).  Default settings of the direct back-end: the multifrontal
+    factorisation with its fronts out of global memory, update matrices placed by lifetimes, a dense top over the supernode
+    partition (stats[25]) -- and the CPU oracle's solve: same status, the same iteration count, x / y to 1e-6 of scale."""
+    import qp_zoo
+
+    monkeypatch.delenv("OSQP_AMD_FIRST_ORDERING", raising=False)
+    prob = qp_zoo.grid3d(36)
+    res = []
+    for lib, ls in ((product_lib, "direct"), (oracle_lib, "qdldl")):
+        m = oq.Model(lib)
+        oq.setup(m, linsys_solver=ls, **prob, **bench.SETTINGS)
+        if lib is product_lib:
+            st = oq.stats(m)
+            assert st[0] == 0 and st[19] > 2 and st[22] == 1.0 and st[25] >= 512, (st[0], st[19], st[22], st[25])
+        res.append(oq.solve(m))
+        if lib is product_lib:
+            oq.update_settings(m, rho=0.3)
+            res.append(oq.solve(m))
+        oq.clean(m)
+    rp, rp2, ro = res
+    assert rp.info.status == ro.info.status == rp2.info.status == "Solved"
+    assert rp.info.iter == ro.info.iter, (rp.info.iter, ro.info.iter)
+    assert np.max(np.abs(rp.x - ro.x)) <= 1e-6 * max(1.0, np.max(np.abs(ro.x)))
+    assert np.max(np.abs(rp.y - ro.y)) <= 1e-6 * max(1.0, np.max(np.abs(ro.y)))
+    assert np.max(np.abs(rp2.x - ro.x)) <= 2e-4 * max(1.0, np.max(np.abs(ro.x)))
+    pri, eps_pri, dua, eps_dua = qp_zoo.kkt_check(prob, rp.x, rp.y, 1e-4)
+    assert pri <= 2.0 * eps_pri and dua <= 2.0 * eps_dua, (pri, eps_pri, dua, eps_dua)
+
+
 @pytest.mark.parametrize("name", ["rand-1e5", "lasso-5e5"])
 def test_bench_config_matches_oracle_at_full_size(product_lib, oracle_lib, name):
     kind, n, k, linsys = bench.WORKLOADS[name]
