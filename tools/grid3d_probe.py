@@ -15,7 +15,7 @@ import qp_zoo  # noqa: E402
 g = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 40
 prob = qp_zoo.grid3d(g)
 n, m = prob["P"].shape[0], prob["A"].shape[0]
-opts = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, max_iter=4000)
+opts = dict(verbose=False, eps_abs=1e-4, eps_rel=1e-4, max_iter=4000, adaptive_rho_interval=50)
 mdl = oq.Model(oq.load_library())
 t0 = time.perf_counter()
 oq.setup(mdl, linsys_solver="direct", **opts, **prob)
@@ -24,6 +24,12 @@ st = oq.stats(mdl)
 t0 = time.perf_counter()
 r = oq.solve(mdl)
 solve = time.perf_counter() - t0
+oq.update_settings(mdl, rho=0.1)
+t0 = time.perf_counter()
+r2 = oq.solve(mdl)
+solve2 = time.perf_counter() - t0
+st2 = oq.stats(mdl)
+print("second solve (warm): %d iterations in %.4f s = %.0f it/s; tree restarts so far %d; bytes of a solve %.3g" % (r2.info.iter, solve2, r2.info.iter / max(solve2, 1e-9), st2[21], st2[11]))
 ts = []
 for k in range(12):
     t0 = time.perf_counter()
