@@ -112,10 +112,9 @@ void finish_setup(OSQPWorkspace *w) {
   w->info->rho_estimate = e.st.rho;
   w->first_run = 1;
   w->summary_printed = 0;
-  if (e.st.verbose)
-    printf("[osqp-amd] n = %d, m = %d, nnz(triu P) = %lld, nnz(A) = %lld, linsys = %s, device %d, rank %d of %d\n", e.ng, e.mg,
-           (long long)e.nnzPtriu, (long long)e.nnzA, e.lin->kind() == 0 ? "direct LDL' (HIP)" : "PCG (HIP)", e.device, e.rank(),
-           e.comm ? e.comm->world : 1);
+  if (e.st.verbose && e.comm)  // (a single device: the setup banner of Engine::setup says it all; a row block adds where it sits)
+    printf("[osqp-amd] row block of rank %d of %d on device %d: n = %d, m = %d (global), linsys = %s\n", e.rank(), e.comm->world, e.device, e.ng, e.mg,
+           e.lin->kind() == 0 ? "direct LDL' (HIP)" : "PCG (HIP)");
 }
 
 void destroy(OSQPWorkspace *w) {

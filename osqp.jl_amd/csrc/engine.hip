@@ -604,6 +604,28 @@ void Engine::finish_setup(DevBuf<double> &q_, DevBuf<double> &l_, DevBuf<double>
   compact_matrices();
   setup_mark("compaction (late)");
   sync();
+  // The setup banner of a verbose run (the reference's default is verbose = true, and libosqp prints its settings there with
+  // "linear system solver = qdldl"): what a drop-in caller otherwise only finds in osqp_amd_get_stats -- WHICH back-end the
+  // default setting resolved to, and in which form the factor is.
+  if (st.verbose && rank() == 0) {
+    const char *asked = st.linsys_solver == 0 ? "qdldl" : (st.linsys_solver == 1 ? "mkl pardiso" : (st.linsys_solver == AMD_PCG_SOLVER ? "amd pcg" : "amd direct"));
+    printf("-----------------------------------------------------------------\n");
+    printf("  OSQP ADMM engine for AMD MI355X (libosqp v0.6.2 interface)\n");
+    printf("-----------------------------------------------------------------\n");
+    printf("problem:  variables n = %d, constraints m = %d\n          nnz(P) + nnz(A) = %lld\n", n, m, (long long)(nnzPtriu + nnzA));
+    if (lin->kind() == 0) {
+      printf("settings: linear system solver = %s -> direct (LDL' on the device)\n", asked);
+      printf("          nnz(L) = %.0f, %d levels", lin->nnzL(), (int)lin->levels());
+      if (lin->supernode_levels() > 0) printf(" (%d supernode levels%s)", (int)lin->supernode_levels(), lin->multifrontal() > 0 ? ", multifrontal factorisation" : "");
+      if (lin->dense_block() > 0) printf(", dense top block of %d pivots", (int)lin->dense_block());
+      printf("\n");
+    } else
+      printf("settings: linear system solver = %s -> indirect (preconditioned CG%s)\n", asked,
+             st.linsys_solver == AMD_PCG_SOLVER ? "" : ": the factor of this problem would not fit / its KKT matrix is beyond the direct back-end's limit");
+    printf("          eps_abs = %.1e, eps_rel = %.1e, rho = %.2e%s, sigma = %.2e, alpha = %.2f, max_iter = %lld\n", st.eps_abs, st.eps_rel, st.rho,
+           st.adaptive_rho ? " (adaptive)" : "", st.sigma, st.alpha, (long long)st.max_iter);
+    printf("          scaling: %s, polish: %s, warm start: %s\n\n", st.scaling ? "on" : "off", st.polish ? "on" : "off", st.warm_start ? "on" : "off");
+  }
 }
 
 // 64-bit indices of the caller, as they arrive in a staging buffer, to the 32-bit arrays of the engine; an index outside
