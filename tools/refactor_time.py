@@ -29,9 +29,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         oq.update_settings(m, rho=0.1 + 0.01 * (k % 5))
         ts.append(time.perf_counter() - t0)
     ts = sorted(ts[4:])
+    t0 = time.perf_counter()
     r = oq.solve(m)
-    print("T=%d N=%d nnzL=%d levels=%d sn_levels=%d mf=%d setup %.3f s  refactor median %.3f ms min %.3f ms  (%s, %d it)" % (
-        T, prob["P"].shape[0] + prob["A"].shape[0], st[4], st[5], st[19], st[22], setup, 1e3 * ts[len(ts) // 2], 1e3 * ts[0], r.info.status, r.info.iter))
+    solve = time.perf_counter() - t0
+    print("T=%d N=%d nnzL=%d levels=%d sn_levels=%d mf=%d setup %.3f s  refactor median %.3f ms min %.3f ms  (%s, %d it, %.0f it/s)" % (
+        T, prob["P"].shape[0] + prob["A"].shape[0], st[4], st[5], st[19], st[22], setup, 1e3 * ts[len(ts) // 2], 1e3 * ts[0], r.info.status, r.info.iter, r.info.iter / solve))
     sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == "grid":
