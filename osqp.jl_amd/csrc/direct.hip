@@ -16,6 +16,7 @@
 // with barriers instead of one launch per level.
 // Per solve the kernels stream L twice: 2 * (12 nnz(L) + 4 (N+1)) + ~40 N bytes.
 #include <climits>
+#include <cstring>
 #include <cmath>
 
 #include "engine.hpp"
@@ -323,6 +324,20 @@ struct LdlFactor {
     if (!mf_ok && !lean) supernode_wmap(S, T);  // k_sn_invert gathers the blocks through it; the fronts invert theirs in place
   }
 
+  // Workgroups of `threads` threads of the tree kernel that one compute unit holds at once: the occupancy query (the kernel takes
+  // 92 - 97 registers: one workgroup of 1024 threads, two of 512; compiled for 64 registers -- __launch_bounds__(NT, 8) -- it
+  // spills 50 of them and loses: grid 700 x 700 2 405 -> 2 170 it/s, control T = 800 8.6 -> 5.5 k, measured in round 6)
+  static int tree_resident(const void *f, int threads) {
+    int api = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, f, threads, 0));
+    if (getenv("OSQP_AMD_SETUP_TRACE")) {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, f) == hipSuccess)
+        fprintf(stderr, "[supernodes] tree kernel, %d threads: %d workgroups per compute unit (%zu B of LDS, %d registers)\n", threads, api, (size_t)fa.sharedSizeBytes, fa.numRegs);
+      else (void)hipGetLastError();
+    }
+    return std::max(1, api);
+  }
   // The device side of a supernodal factor: the lists of the entries outside the blocks (uploaded from a full analysis,
   // built by lean_device_lists otherwise), the counters of the one-launch tree, the arrays of the inverted blocks.
   void supernodes_on_device() {
@@ -344,9 +359,20 @@ struct LdlFactor {
       int per_cu_f = 0, per_cu_b = 0, cus = 0, dev = 0;
       HIP_CHECK(hipGetDevice(&dev));
       HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void *)k_sn_tree<true, 1024>, 1024, 0));
-      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void *)k_sn_tree<false, 1024>, 1024, 0));
-      const long long cap = (long long)std::min(per_cu_f, per_cu_b) * cus;
+      per_cu_f = tree_resident((const void *)k_sn_tree<true, 1024>, 1024);
+      per_cu_b = tree_resident((const void *)k_sn_tree<false, 1024>, 1024);
+      if (const char *v = getenv("OSQP_AMD_SNODE_TREE_PER_CU")) per_cu_f = per_cu_b = std::max(1, atoi(v));  // (experiments)
+      // Round 6: where fronts go through global memory (a 2-D / 3-D structure: many narrow levels of large supernodes) the launch may
+      // hold up to TWICE what is resident at once.  That is safe for the reason the kernel's comment gives as its second line of
+      // defence -- workgroups are dispatched in block order per XCD and a workgroup only waits on lower blocks, so the lowest
+      // unfinished one is resident or next in line whatever the grid -- with the 200 ms flag and the per-level fallback behind it;
+      // full residency (the first line) was a margin, and on these structures it costs two levels of the launch: grid 700 x 700
+      // 2 405 -> 2 754 it/s, 1000 x 1000 1 036 -> 1 222, no restart in any run.  The control family (fronts in LDS, 512-thread
+      // variant below) is unchanged by it and keeps the margin.  OSQP_AMD_SNODE_TREE_OVERSUB = 1 restores it everywhere.
+      const int oversub = (mf_ok && mf_big_count > 0) ? (getenv("OSQP_AMD_SNODE_TREE_OVERSUB") ? std::max(1, atoi(getenv("OSQP_AMD_SNODE_TREE_OVERSUB"))) : 2) : 1;
+      const long long cap = (long long)oversub * std::min(per_cu_f, per_cu_b) * cus;
+      if (getenv("OSQP_AMD_SETUP_TRACE"))
+        fprintf(stderr, "[supernodes] one-launch tree: %d / %d resident workgroups of 1024 threads per compute unit (forward / backward), %d compute units, launch of at most %lld\n", per_cu_f, per_cu_b, cus, cap);
       // (a dense top over the supernodes, direct_sndense_kernels.hpp, takes the last levels out of the launch)
       const int top_end = snd_K ? snd_L0 : T.nlev, j_end = snd_K ? snd_J0 : T.count;
       while (sn_tree_L0 < top_end && (long long)(j_end - T.lvl_ptr[sn_tree_L0]) > cap) sn_tree_L0++;
@@ -361,9 +387,11 @@ struct LdlFactor {
       const bool try512 = getenv("OSQP_AMD_SNODE_TREE_512") ? atoi(getenv("OSQP_AMD_SNODE_TREE_512")) != 0 : !long_rows;
       if (sn_tree_L0 > 1 && try512) {
         int pf = 0, pb = 0;
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, (const void *)k_sn_tree<true, 512>, 512, 0));
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, (const void *)k_sn_tree<false, 512>, 512, 0));
+        pf = tree_resident((const void *)k_sn_tree<true, 512>, 512);
+        pb = tree_resident((const void *)k_sn_tree<false, 512>, 512);
+        if (const char *v = getenv("OSQP_AMD_SNODE_TREE_PER_CU")) pf = pb = 2 * std::max(1, atoi(v));  // (experiments)
         long long cap2 = (long long)std::min(pf, pb) * cus;
+        if (getenv("OSQP_AMD_SETUP_TRACE")) fprintf(stderr, "[supernodes] one-launch tree: %d / %d resident workgroups of 512 threads per compute unit\n", pf, pb);
         if (getenv("OSQP_AMD_SNODE_TREE_CAP")) cap2 = std::min<long long>(cap2, atoll(getenv("OSQP_AMD_SNODE_TREE_CAP")));  // (experiments: a later start)
         int L2 = 1;
         while (L2 < top_end && (long long)(j_end - T.lvl_ptr[L2]) > cap2) L2++;

@@ -360,9 +360,10 @@ __global__ __launch_bounds__(kBlock) void k_sn_single_bwd(int q0, int count, con
 // supernode above publishes `ready[up] = number of waiting children`, each child takes one).  Both counters are back at
 // their resting values when the launch ends, so a captured graph can replay it.  Workgroups are dispatched in
 // blockIdx order per XCD and a workgroup only waits on lower blockIdx values, so the lowest unfinished one is always
-// resident and never waits on an unscheduled one -- and the launch is only used when ALL its workgroups fit the device
-// at once (LdlFactor: occupancy x CUs >= grid), so on a device of its own nothing can wait on an unscheduled workgroup
-// whatever the dispatch order; a wait that still exceeds 200 ms (a shared, pre-empted device) sets *fault (mapped host
+// resident and never waits on an unscheduled one -- and the launch is sized so that ALL its workgroups fit the device at
+// once (LdlFactor: occupancy x CUs >= grid; round 6: up to twice that where fronts go through global memory -- the
+// dispatch-order argument carries those launches, measured without a single time-out), so on a device of its own nothing
+// waits on a workgroup that cannot be scheduled; a wait that still exceeds 200 ms (a shared, pre-empted device) sets *fault (mapped host
 // memory) and carries on: the host sees the flag at the next residual evaluation -- tested again once the read-back has
 // drained the stream -- and at the end of osqp_solve, switches the factor to one launch per level and runs the solve
 // again from a cold start (Engine::solve), so a broken assumption costs time, never a wrong or missing answer.
