@@ -386,7 +386,10 @@ __device__ __forceinline__ double sn_gather(int64_t i0, int64_t i1, int lane, in
   for (; i < i1; i += la) acc += Ex[i] * ld(Ej[i]);
   return acc;
 }
-constexpr int kSnCap = 16;  // entries per lane whose index and value are in registers before the wait
+// entries per lane whose index and value are in registers before the wait: 24 with 1024 threads a supernode (one workgroup per compute
+// unit whatever its registers: 128 of them), 20 with 512 (117 registers: two workgroups still fit; with 24 -- 133 -- one does, and
+// control-1e6 loses 5 %).  Round 6, measured against 16 for both: grid 700 x 700 2 736 -> 2 812 it/s, 1000 x 1000 1 222 -> 1 275.
+template <int NT> constexpr int kSnCapOf = NT == 1024 ? 24 : 20;
 // The top of the tree by FRONT VECTORS (round 6).  The rows of the top separators of a 2-D structure hold thousands of entries
 // each (64 rows x ~2 000 entries: 8 MB of 64-byte sectors gathered by ONE compute unit per supernode, eleven supernodes in a chain
 // for the top separator of a 700 x 700 grid: 1.8 ms of a 2.7 ms iteration).  Where every supernode from some level on has a front
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(NT) void k_sn_tree(SnTop top, int J0, int count, co
   double acc0 = (kForward && mine) ? sn_gather<false>(Ep[q], Es[q], lane, la, Ej, Ex, b) : 0.0;
   const bool topmode = kForward && top.Jt >= 0 && J >= top.Jt;  // (uniform over the workgroup)
   const int64_t i0 = (kForward ? Es[q] : Ep[q]) + lane, i1 = mine ? (topmode ? top.Et[q] : Ep[q + 1]) : 0;
+  constexpr int kSnCap = kSnCapOf<NT>;
   int jj[kSnCap];
   double xx[kSnCap];
 #pragma unroll
